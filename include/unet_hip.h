@@ -1,0 +1,194 @@
+/*
+ * unet_hip.h -- C ABI of the MI355X (gfx950) U-Net segmentation engine.
+ *
+ * The reference (deadskull7/One-Stop-for-COVID-19-...) has NO native/FFI boundary of its
+ * own: its hot path is Keras calls inside two Python runners.  Each entry point below
+ * therefore cites the Keras call site it replaces (paths relative to
+ * /root/reference/Scripts/; T1 = task1_preprocessing_plus_unet_with_comments.py,
+ * T3 = task3_lung_segmentation_unet.py, which is line-for-line the same graph/recipe).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no C++/torch types cross the boundary.
+ *   - every function returns int32 status: 0 = ok, <0 = error (unet_last_error(ctx)).
+ *   - the CALLER owns every tensor buffer (device memory, fp32, NHWC = Keras channels_last).
+ *     `ld*` arguments are the pixel stride in floats, so an op can read/write a channel
+ *     slice of a wider NHWC buffer (zero-copy skip concatenation, T1:887).
+ *   - all launches are asynchronous on the passed hipStream_t (`void* stream`); no hidden
+ *     synchronisation, no allocation, no global mutable state besides the ctx.
+ *   - there is NO CPU fallback: without a gfx950 device unet_ctx_create fails.
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_ABI_VERSION 1
+
+typedef struct unet_ctx unet_ctx;
+typedef struct unet_model unet_model;
+
+/* status codes */
+enum { UNET_OK = 0, UNET_E_ARG = -1, UNET_E_HIP = -2, UNET_E_SHAPE = -3, UNET_E_STATE = -4, UNET_E_NODEV = -5 };
+
+/* conv algorithm selector (all are HIP kernels; NAIVE exists as an on-device cross-check) */
+enum { UNET_ALGO_AUTO = 0, UNET_ALGO_NAIVE = 1, UNET_ALGO_MFMA = 2 };
+
+int32_t unet_abi_version(void);
+int32_t unet_ctx_create(int32_t device_id, unet_ctx** out);
+void unet_ctx_destroy(unet_ctx* ctx);
+const char* unet_last_error(const unet_ctx* ctx);
+/* 1 = op-level timing with hipEvents (bench.py roofline leg); adds a sync per op */
+int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
+
+/* ------------------------------------------------------------------------------------
+ * Op level.  Replaces: Conv2D(C,(3,3),activation='relu',padding='same')   T1:859-911
+ *   y[n,i,j,o] = act(b[o] + sum_{a,b,c} x[n,i+a-1,j+b-1,c] * w[a,b,c,o]);  w is HWIO.
+ * ---------------------------------------------------------------------------------- */
+int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
+                         int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
+                         int32_t relu, int32_t algo, void* stream);
+/* dx = conv3x3(dy, flip/transposed w); if relu_src != NULL, dx *= (relu_src > 0): the ReLU
+ * mask of the layer that PRODUCED x is fused here (backward of T1:859-860 pairs).
+ * wt_ws: 9*cin*cout floats of scratch for the transformed weights. */
+int32_t unet_conv3x3_bwd_data(unet_ctx*, const float* dy, const float* w, const float* relu_src,
+                              float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd,
+                              int32_t cin, int32_t cout, int32_t algo, void* stream);
+/* dw[a,b,c,o] = sum x[n,i+a-1,j+b-1,c]*dy[n,i,j,o];  db[o] = sum dy.  dy already ReLU-masked.
+ * ws: split-K scratch (unet_conv3x3_bwd_weights_ws_bytes). dw/db are OVERWRITTEN. */
+size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout);
+int32_t unet_conv3x3_bwd_weights(unet_ctx*, const float* x, const float* dy, float* dw, float* db,
+                                 void* ws, size_t ws_bytes, int32_t n, int32_t h, int32_t wd,
+                                 int32_t cin, int32_t cout, int32_t algo, void* stream);
+
+/* Replaces: Conv2DTranspose(C,(2,2),strides=(2,2),padding='same') + concatenate([u,c])
+ * T1:886-887 (and 893-894, 900-901, 907-908).  Kernel layout [2,2,Cout,Cin] (Keras).
+ *   u[n,2i+a,2j+b,o] = bias[o] + sum_c x[n,i,j,c] * w[a,b,o,c]
+ * y is written with pixel stride ldy (the first Cout channels of the concat buffer). */
+int32_t unet_convT2x2_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
+                          int32_t ldy, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
+                          int32_t algo, void* stream);
+int32_t unet_convT2x2_bwd_data(unet_ctx*, const float* dy, int32_t lddy, const float* w,
+                               const float* relu_src, float* dx, int32_t n, int32_t h, int32_t wd,
+                               int32_t cin, int32_t cout, int32_t algo, void* stream);
+int32_t unet_convT2x2_bwd_weights(unet_ctx*, const float* x, const float* dy, int32_t lddy,
+                                  float* dw, float* db, int32_t n, int32_t h, int32_t wd,
+                                  int32_t cin, int32_t cout, int32_t algo, void* stream);
+
+/* Replaces: BatchNormalization()  T1:861,867,873,879,888,895,902,909 (eps 1e-3, momentum .99)
+ * Training forward = stats -> [optional cross-rank all-reduce of `sums`] -> finalize -> apply.
+ *   sums: double[2*C] = (sum x, sum x^2), ACCUMULATED (zero it first: unet_zero).
+ *   bnp : float[4*C]  = scale, shift, mean, invstd.
+ *   count = elements per channel over the GLOBAL batch (n*h*w*world). */
+int32_t unet_bn_stats(unet_ctx*, const float* x, int32_t ldx, double* sums, int64_t pixels,
+                      int32_t c, void* stream);
+int32_t unet_bn_finalize_train(unet_ctx*, const double* sums, double count, const float* gamma,
+                               const float* beta, float* moving_mean, float* moving_var,
+                               float* bnp, int32_t c, void* stream);
+int32_t unet_bn_finalize_infer(unet_ctx*, const float* gamma, const float* beta,
+                               const float* moving_mean, const float* moving_var, float* bnp,
+                               int32_t c, void* stream);
+int32_t unet_bn_apply(unet_ctx*, const float* x, int32_t ldx, const float* bnp, float* y,
+                      int32_t ldy, int64_t pixels, int32_t c, void* stream);
+/* backward: sums = double[2*C] (sum dy, sum dy*xhat), accumulated.  param_grads writes
+ * dgamma/dbeta from the LOCAL sums (call before any cross-rank reduction of sums).
+ * apply: dx = scale*(dy - sum_dy/count - xhat*sum_dyxhat/count) [* (x>0) if relu_mask]. */
+int32_t unet_bn_bwd_stats(unet_ctx*, const float* dy, int32_t lddy, const float* x, int32_t ldx,
+                          const float* bnp, double* sums, int64_t pixels, int32_t c, void* stream);
+int32_t unet_bn_bwd_param_grads(unet_ctx*, const double* sums, float* dgamma, float* dbeta,
+                                int32_t c, void* stream);
+int32_t unet_bn_bwd_apply(unet_ctx*, const float* dy, int32_t lddy, const float* x, int32_t ldx,
+                          const float* bnp, const double* sums, double count, int32_t relu_mask,
+                          float* dx, int32_t lddx, int64_t pixels, int32_t c, void* stream);
+
+/* Replaces: MaxPooling2D((2,2)) + Dropout(0.25)  T1:862-863 (868-869, 874-875, 880-881).
+ * rate 0 => plain pool.  Dropout keep-mask = counter-based RNG keyed by (seed, element index);
+ * the backward recomputes it.  Ties in the max go to the first element in (di,dj) order.
+ * bwd: dx[slice] (+)= routed gradient; accumulate=1 adds to what is already in dx (skip grad). */
+int32_t unet_maxpool2x2_dropout_fwd(unet_ctx*, const float* x, int32_t ldx, float* y, int32_t n,
+                                    int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
+                                    void* stream);
+int32_t unet_maxpool2x2_dropout_bwd(unet_ctx*, const float* x, int32_t ldx, const float* dy,
+                                    float* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd,
+                                    int32_t c, float rate, uint64_t seed, int32_t accumulate,
+                                    void* stream);
+
+/* Replaces: Conv2D(1,(1,1),activation='sigmoid') T1:913 fused with the reductions of
+ * bce_dice_loss / dice_coeff T1:784-799.  p = sigmoid(b + x.w).  If y_true != NULL,
+ * loss_sums (double[4], accumulated) += (sum bce_elem, sum t*p, sum t, sum p). */
+int32_t unet_head_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* p,
+                      const float* y_true, double* loss_sums, int64_t pixels, int32_t cin,
+                      void* stream);
+/* loss_out float[2] = (bce_dice_loss, dice_coeff) from (globally reduced) sums; count = GLOBAL
+ * number of label elements. */
+int32_t unet_loss_finalize(unet_ctx*, const double* loss_sums, double count, float* loss_out,
+                           void* stream);
+/* backward of loss + sigmoid + 1x1 conv: dx = dz*w*(x>0), dw = sum dz*x, db = sum dz,
+ * dz = dL/dp * p(1-p) with dL/dp from the GLOBAL sums.  dw/db (cin+1 floats) are ACCUMULATED. */
+int32_t unet_head_bwd(unet_ctx*, const float* x, const float* w, const float* p, const float* y_true,
+                      const double* loss_sums, double count, float* dx, float* dw, float* db,
+                      int64_t pixels, int32_t cin, void* stream);
+
+/* Replaces: Adam(lr=0.0005) step of model.fit T1:1053,1059 -- Keras-2.3 form:
+ *   m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps), lr_t=lr*sqrt(1-b2^t)/(1-b1^t)
+ * (lr_t computed by the caller).  One launch over the flat parameter buffer. */
+int32_t unet_adam_keras(unet_ctx*, float* p, const float* g, float* m, float* v, int64_t count,
+                        float lr_t, float b1, float b2, float eps, float grad_scale, void* stream);
+
+/* Replaces: sm.metrics.IOUScore/FScore/Precision/Recall(threshold=t) evaluate sweeps
+ * T1:1205-1211, 1259-1265, 1313-1319: out double[T*3] += (sum gt*pr, sum pr, sum gt), pr=(p>t). */
+int32_t unet_seg_metrics_sweep(unet_ctx*, const float* p, const float* gt, const float* thresholds,
+                               int32_t nthr, double* out, int64_t count, void* stream);
+
+int32_t unet_zero(unet_ctx*, void* ptr, size_t bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Model level.  Replaces the Keras Model built at T1:853-916 and driven by
+ * compile/fit/evaluate/predict (T1:1053-1061, 1101, 1137).  A model is a fixed-shape plan:
+ * three op programs (training forward, backward, inference forward) over caller-owned
+ * flat buffers.  Programs can be run in [begin,end) slices so a data-parallel host can put
+ * collectives between ops (sync points) and overlap gradient all-reduce with backward.
+ * ---------------------------------------------------------------------------------- */
+enum { UNET_PROG_FWD_TRAIN = 0, UNET_PROG_BWD = 1, UNET_PROG_FWD_INFER = 2 };
+
+typedef struct unet_sync_point {
+  int32_t after_op;   /* run ops [.., after_op] then reduce */
+  int32_t kind;       /* 0 = bn fwd sums, 1 = loss sums, 2 = bn bwd sums, 3 = grad bucket ready */
+  void* ptr;          /* device pointer of the doubles (kinds 0-2) / floats (kind 3) to SUM-reduce */
+  int64_t count;      /* number of elements */
+} unet_sync_point;
+
+int32_t unet_model_create(unet_ctx*, int32_t in_ch, int32_t n, int32_t h, int32_t w,
+                          int32_t world_size, int32_t conv_algo, unet_model** out);
+void unet_model_destroy(unet_model*);
+int64_t unet_model_param_count(const unet_model*);   /* trainable floats (7,762,401 for in_ch=1) */
+int64_t unet_model_state_count(const unet_model*);   /* BN moving mean/var floats (2,880) */
+size_t unet_model_workspace_bytes(const unet_model*, int32_t training);
+/* offsets (in floats) of a named tensor inside the flat param / state buffers; name as in
+ * Keras order: "c1a/kernel", "bn1/gamma", "bn1/mean", "u6/kernel", "out/bias", ... */
+int32_t unet_model_tensor_info(const unet_model*, const char* name, int32_t* is_state,
+                               int64_t* offset, int64_t* count);
+int32_t unet_model_bind(unet_model*, float* params, float* grads, float* adam_m, float* adam_v,
+                        float* bn_state, void* workspace, size_t workspace_bytes);
+int32_t unet_model_set_io(unet_model*, const float* x, const float* y_true, float* p_out);
+int32_t unet_model_set_dropout(unet_model*, float rate, uint64_t seed);
+int32_t unet_model_num_ops(const unet_model*, int32_t prog);
+int32_t unet_model_sync_points(const unet_model*, int32_t prog, unet_sync_point* out, int32_t cap);
+int32_t unet_model_run(unet_model*, int32_t prog, int32_t begin, int32_t end, void* stream);
+/* device pointer to float[2] = (loss, dice_coeff) of the last forward with y_true bound */
+const float* unet_model_loss_ptr(const unet_model*);
+/* intermediate activation / gradient taps for tests ("c1a","bn1","p1","u6","cat6",...) */
+int32_t unet_model_tap(const unet_model*, const char* name, int32_t grad, const float** ptr,
+                       int32_t* ld, int32_t* n, int32_t* h, int32_t* w, int32_t* c);
+/* profiling: per-op name and accumulated milliseconds since last reset (profiling on) */
+int32_t unet_model_op_info(const unet_model*, int32_t prog, int32_t op, const char** name,
+                           double* flops, double* bytes, double* ms, int64_t* calls);
+int32_t unet_model_reset_timers(unet_model*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H */

@@ -1,0 +1,130 @@
+"""ctypes binding of the C ABI declared in include/unet_hip.h (libunet_hip.so, gfx950).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible the
+product raises -- it never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+ABI_VERSION = 1
+
+ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2
+PROG_FWD_TRAIN, PROG_BWD, PROG_FWD_INFER = 0, 1, 2
+SYNC_BN_FWD, SYNC_LOSS, SYNC_BN_BWD, SYNC_GRAD_BUCKET = 0, 1, 2, 3
+
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+i32, i64, u64, f32, f64, sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
+
+
+class SyncPoint(C.Structure):
+    _fields_ = [("after_op", i32), ("kind", i32), ("ptr", vp), ("count", i64)]
+
+
+# name -> (restype, argtypes); pointers to device memory are passed as void* integers
+_PROTOS = {
+    "unet_abi_version": (i32, []),
+    "unet_ctx_create": (i32, [i32, C.POINTER(vp)]),
+    "unet_ctx_destroy": (None, [vp]),
+    "unet_last_error": (C.c_char_p, [vp]),
+    "unet_ctx_set_profiling": (i32, [vp, i32]),
+    "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_conv3x3_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "unet_conv3x3_bwd_weights": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_convT2x2_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_convT2x2_bwd_data": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_convT2x2_bwd_weights": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_bn_stats": (i32, [vp, vp, i32, vp, i64, i32, vp]),
+    "unet_bn_finalize_train": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, i32, vp]),
+    "unet_bn_finalize_infer": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
+    "unet_bn_apply": (i32, [vp, vp, i32, vp, vp, i32, i64, i32, vp]),
+    "unet_bn_bwd_stats": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, i32, vp]),
+    "unet_bn_bwd_param_grads": (i32, [vp, vp, vp, vp, i32, vp]),
+    "unet_bn_bwd_apply": (i32, [vp, vp, i32, vp, i32, vp, vp, f64, i32, vp, i32, i64, i32, vp]),
+    "unet_maxpool2x2_dropout_fwd": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_maxpool2x2_dropout_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, u64, i32, vp]),
+    "unet_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "unet_loss_finalize": (i32, [vp, vp, f64, vp, vp]),
+    "unet_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, i64, i32, vp]),
+    "unet_adam_keras": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
+    "unet_seg_metrics_sweep": (i32, [vp, vp, vp, vp, i32, vp, i64, vp]),
+    "unet_zero": (i32, [vp, vp, sz, vp]),
+    "unet_model_create": (i32, [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
+    "unet_model_destroy": (None, [vp]),
+    "unet_model_param_count": (i64, [vp]),
+    "unet_model_state_count": (i64, [vp]),
+    "unet_model_workspace_bytes": (sz, [vp, i32]),
+    "unet_model_tensor_info": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]),
+    "unet_model_bind": (i32, [vp, vp, vp, vp, vp, vp, vp, sz]),
+    "unet_model_set_io": (i32, [vp, vp, vp, vp]),
+    "unet_model_set_dropout": (i32, [vp, f32, u64]),
+    "unet_model_num_ops": (i32, [vp, i32]),
+    "unet_model_sync_points": (i32, [vp, i32, C.POINTER(SyncPoint), i32]),
+    "unet_model_run": (i32, [vp, i32, i32, i32, vp]),
+    "unet_model_loss_ptr": (vp, [vp]),
+    "unet_model_tap": (i32, [vp, C.c_char_p, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
+                             C.POINTER(i32), C.POINTER(i32)]),
+    "unet_model_op_info": (i32, [vp, i32, i32, C.POINTER(C.c_char_p), f64p, f64p, f64p, C.POINTER(i64)]),
+    "unet_model_reset_timers": (i32, [vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lib = None
+
+
+class UNetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libunet_hip.so and attach prototypes.  Raises UNetHipError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UNetHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C <package>/csrc`). There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.unet_abi_version() != ABI_VERSION:
+        raise UNetHipError(f"ABI mismatch: library {lib.unet_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One unet_ctx per device."""
+    _cache = {}
+
+    def __init__(self, device: int):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.unet_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise UNetHipError(
+                f"unet_ctx_create(device={device}) failed with status {rc}: no gfx950 (MI355X) device visible. "
+                "This engine has no CPU fallback.")
+        self.handle = h
+        self.device = device
+
+    @classmethod
+    def get(cls, device: int) -> "Context":
+        if device not in cls._cache:
+            cls._cache[device] = cls(device)
+        return cls._cache[device]
+
+    def check(self, rc: int, what: str = ""):
+        if rc != 0:
+            msg = self.lib.unet_last_error(self.handle)
+            raise UNetHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

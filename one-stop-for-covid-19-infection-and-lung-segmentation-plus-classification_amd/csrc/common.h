@@ -1,0 +1,85 @@
+// Shared host/device helpers for the gfx950 U-Net engine (internal; the public surface is
+// include/unet_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/unet_hip.h"
+
+struct unet_ctx {
+  int device = 0;
+  int num_cu = 256;
+  int profiling = 0;
+  std::string err;
+};
+
+#define UNET_FAIL(ctx, code, ...)                         \
+  do {                                                    \
+    char _b[512];                                         \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);                \
+    if (ctx) (ctx)->err = _b;                             \
+    return (code);                                        \
+  } while (0)
+
+#define UNET_CHECK_LAUNCH(ctx, what)                                              \
+  do {                                                                            \
+    hipError_t _e = hipGetLastError();                                            \
+    if (_e != hipSuccess) UNET_FAIL(ctx, UNET_E_HIP, "%s: %s", what, hipGetErrorString(_e)); \
+  } while (0)
+
+#define UNET_HIP(ctx, expr)                                                       \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) UNET_FAIL(ctx, UNET_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Philox-4x32-10 counter RNG (dropout keep-mask): counter = element-quad index, key = seed.
+__device__ __forceinline__ uint4 philox4x32(uint64_t ctr, uint64_t seed) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+
+// internal launchers shared between the op-level ABI and the model programs -------------
+// (definitions in the .hip files; all return a unet status code)
+int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask,
+                            float* y, int n, int h, int wd, int cin, int cout, int relu, hipStream_t s);
+int32_t k_conv3x3_c1_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int n, int h,
+                         int wd, int cout, int relu, hipStream_t s);
+int32_t k_flip_transpose_w3x3(unet_ctx*, const float* w, float* wt, int cin, int cout, hipStream_t s);
+int32_t k_conv3x3_naive_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, int n, int h,
+                              int wd, int cin, int cout, hipStream_t s);
+int32_t k_convT_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n,
+                          int h, int wd, int cin, int cout, hipStream_t s);
+int32_t k_convT_naive_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx,
+                            int n, int h, int wd, int cin, int cout, hipStream_t s);
+int32_t k_convT_naive_wgrad(unet_ctx*, const float* x, const float* dy, int lddy, float* dw, float* db, int n,
+                            int h, int wd, int cin, int cout, hipStream_t s);
+// MFMA paths (kernels_conv_mfma.hip); return UNET_E_SHAPE if the shape is unsupported
+bool mfma_conv3x3_supported(int cin, int cout);
+int32_t k_conv3x3_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask,
+                           float* y, int n, int h, int wd, int cin, int cout, int relu, hipStream_t s);
+size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
+int32_t k_conv3x3_mfma_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws,
+                             size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);

@@ -1,0 +1,236 @@
+// Direct (non-MFMA) HIP convolution kernels: the Cin=1 first layer (HBM-bound, final form),
+// plus straightforward one-output-per-thread kernels for 3x3 conv / 2x2 transposed conv and
+// their gradients.  The direct kernels serve (1) shapes the MFMA kernels do not cover and
+// (2) as an on-device cross-check of the MFMA path (UNET_ALGO_NAIVE).  They are HIP kernels,
+// not a CPU fallback.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+// y[pix][co] = act(b[co] + sum_{tap,ci} x[pix+tap][ci] * w[tap][ci][co]); lanes run along co.
+template <bool RELU, bool MASK>
+__global__ __launch_bounds__(TPB) void conv3x3_naive_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ mask,
+                                                            float* __restrict__ y, int N, int H, int W, int Cin, int Cout) {
+  const long long total = (long long)N * H * W * Cout;
+  for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
+    int co = (int)(idx % Cout); long long pix = idx / Cout;
+    int j = (int)(pix % W); long long t = pix / W; int i = (int)(t % H); long long n = t / H;
+    float acc = bias ? bias[co] : 0.0f;
+    for (int a = 0; a < 3; ++a) {
+      int ii = i + a - 1; if (ii < 0 || ii >= H) continue;
+      for (int b = 0; b < 3; ++b) {
+        int jj = j + b - 1; if (jj < 0 || jj >= W) continue;
+        const float* xp = x + ((n * H + ii) * W + jj) * (long long)Cin;
+        const float* wp = w + (long long)((a * 3 + b) * Cin) * Cout + co;
+        for (int ci = 0; ci < Cin; ++ci) acc = fmaf(xp[ci], wp[(long long)ci * Cout], acc);
+      }
+    }
+    if (RELU) acc = fmaxf(acc, 0.0f);
+    if (MASK) acc = mask[idx] > 0.0f ? acc : 0.0f;
+    y[idx] = acc;
+  }
+}
+
+// First layer, Cin = 1 (c1a, T1:859): HBM-bound (AI ~2 F/B).  8 lanes per pixel, each lane owns
+// 4 output channels with its 9x4 weights in registers; a wave writes 8 pixels = 1 KiB contiguous.
+template <bool RELU>
+__global__ __launch_bounds__(TPB) void conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int N, int H, int W, int Cout) {
+  const int lpp = Cout >> 2;
+  const int sub = threadIdx.x % lpp;
+  float4 wr[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wr[t] = *reinterpret_cast<const float4*>(w + t * Cout + sub * 4);
+  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + sub * 4) : make_float4(0, 0, 0, 0);
+  const long long pixels = (long long)N * H * W;
+  const long long g0 = ((long long)blockIdx.x * TPB + threadIdx.x) / lpp, gs = ((long long)gridDim.x * TPB) / lpp;
+  for (long long p = g0; p < pixels; p += gs) {
+    int j = (int)(p % W); long long t = p / W; int i = (int)(t % H);
+    float4 acc = b4;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int ii = i + a - 1;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        int jj = j + b - 1;
+        float v = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? x[p + (a - 1) * W + (b - 1)] : 0.0f;
+        const float4 k = wr[a * 3 + b];
+        acc.x = fmaf(v, k.x, acc.x); acc.y = fmaf(v, k.y, acc.y); acc.z = fmaf(v, k.z, acc.z); acc.w = fmaf(v, k.w, acc.w);
+      }
+    }
+    if (RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(y + p * Cout + sub * 4) = acc;
+  }
+}
+
+// wt[t'][co][ci] = w[8-t'][ci][co]: weights of the data-gradient convolution.
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin, int Cout) {
+  const int total = 9 * Cin * Cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int ci = i % Cin; int r = i / Cin; int co = r % Cout; int t = r / Cout;
+    wt[i] = w[((8 - t) * Cin + ci) * Cout + co];
+  }
+}
+
+// dw[tap][ci][co] = sum_pix x[pix+tap][ci]*dy[pix][co]; grid.y splits the pixel range, float atomics.
+// The bias gradient rides along as a virtual row (r == 9*Cin): db[co] = sum_pix dy[pix][co].
+__global__ __launch_bounds__(TPB) void conv3x3_naive_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* dw, float* db, int N, int H, int W, int Cin, int Cout) {
+  const int rows = 9 * Cin + 1;
+  const long long total = (long long)rows * Cout;
+  const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int co = (int)(idx % Cout); const int r = (int)(idx / Cout);
+  const long long pixels = (long long)N * H * W;
+  const long long chunk = (pixels + gridDim.y - 1) / gridDim.y;
+  const long long p0 = chunk * blockIdx.y, p1 = (p0 + chunk < pixels) ? p0 + chunk : pixels;
+  float acc = 0.0f;
+  if (r == 9 * Cin) {
+    for (long long p = p0; p < p1; ++p) acc += dy[p * Cout + co];
+    atomicAdd(db + co, acc);
+    return;
+  }
+  const int ci = r % Cin, tap = r / Cin, da = tap / 3 - 1, dbb = tap % 3 - 1;
+  for (long long p = p0; p < p1; ++p) {
+    int j = (int)(p % W); long long t = p / W; int i = (int)(t % H);
+    int ii = i + da, jj = j + dbb;
+    if (ii < 0 || ii >= H || jj < 0 || jj >= W) continue;
+    acc = fmaf(x[(p + da * W + dbb) * Cin + ci], dy[p * Cout + co], acc);
+  }
+  atomicAdd(dw + (long long)r * Cout + co, acc);
+}
+
+// ---- transposed conv 2x2 stride 2 (kernel [2][2][Cout][Cin]) --------------------------
+__global__ __launch_bounds__(TPB) void convT_naive_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int ldy,
+                                                              int N, int h, int wd, int Cin, int Cout) {
+  const int Ho = 2 * h, Wo = 2 * wd;
+  const long long total = (long long)N * Ho * Wo * Cout;
+  for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
+    int o = (int)(idx % Cout); long long pix = idx / Cout;
+    int xo = (int)(pix % Wo); long long t = pix / Wo; int yo = (int)(t % Ho); long long n = t / Ho;
+    int i = yo >> 1, a = yo & 1, j = xo >> 1, b = xo & 1;
+    const float* xp = x + ((n * h + i) * wd + j) * (long long)Cin;
+    const float* wp = w + ((long long)((a * 2 + b) * Cout + o)) * Cin;
+    float acc = bias ? bias[o] : 0.0f;
+    for (int c = 0; c < Cin; ++c) acc = fmaf(xp[c], wp[c], acc);
+    y[pix * ldy + o] = acc;
+  }
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(TPB) void convT_naive_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
+                                                                const float* __restrict__ mask, float* __restrict__ dx,
+                                                                int N, int h, int wd, int Cin, int Cout) {
+  const int Wo = 2 * wd, Ho = 2 * h;
+  const long long total = (long long)N * h * wd * Cin;
+  for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
+    int c = (int)(idx % Cin); long long pix = idx / Cin;
+    int j = (int)(pix % wd); long long t = pix / wd; int i = (int)(t % h); long long n = t / h;
+    float acc = 0.0f;
+    for (int ab = 0; ab < 4; ++ab) {
+      const float* gp = dy + ((n * Ho + 2 * i + (ab >> 1)) * Wo + 2 * j + (ab & 1)) * (long long)lddy;
+      const float* wp = w + (long long)ab * Cout * Cin + c;
+      for (int o = 0; o < Cout; ++o) acc = fmaf(gp[o], wp[(long long)o * Cin], acc);
+    }
+    if (MASK) acc = mask[idx] > 0.0f ? acc : 0.0f;
+    dx[idx] = acc;
+  }
+}
+
+// dw[ab][o][c] = sum_{n,i,j} dy[n,2i+a,2j+b,o]*x[n,i,j,c];  db[o] = sum dy (virtual column c == Cin, ab == 0 rows
+// of every ab so each output pixel is counted once).
+__global__ __launch_bounds__(TPB) void convT_naive_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int lddy,
+                                                                float* dw, float* db, int N, int h, int wd, int Cin, int Cout) {
+  const long long total = (long long)4 * Cout * (Cin + 1);
+  const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % (Cin + 1)); long long r = idx / (Cin + 1); const int o = (int)(r % Cout); const int ab = (int)(r / Cout);
+  const int Wo = 2 * wd, Ho = 2 * h;
+  const long long pixels = (long long)N * h * wd;
+  const long long chunk = (pixels + gridDim.y - 1) / gridDim.y;
+  const long long p0 = chunk * blockIdx.y, p1 = (p0 + chunk < pixels) ? p0 + chunk : pixels;
+  float acc = 0.0f;
+  for (long long p = p0; p < p1; ++p) {
+    int j = (int)(p % wd); long long t = p / wd; int i = (int)(t % h); long long n = t / h;
+    float g = dy[((n * Ho + 2 * i + (ab >> 1)) * Wo + 2 * j + (ab & 1)) * (long long)lddy + o];
+    acc = (c == Cin) ? acc + g : fmaf(g, x[p * Cin + c], acc);
+  }
+  if (c == Cin) atomicAdd(db + o, acc);
+  else atomicAdd(dw + ((long long)ab * Cout + o) * Cin + c, acc);
+}
+
+inline int grid_for(long long items, int cap = 4096) {
+  long long b = cdiv64(items, TPB);
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+}  // namespace
+
+int32_t k_conv3x3_naive_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, float* y,
+                            int n, int h, int wd, int cin, int cout, int relu, hipStream_t s) {
+  long long total = (long long)n * h * wd * cout;
+  dim3 g(grid_for(total, 1 << 20)), b(TPB);
+  if (relu && mask) hipLaunchKernelGGL((conv3x3_naive_kernel<true, true>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
+  else if (relu) hipLaunchKernelGGL((conv3x3_naive_kernel<true, false>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
+  else if (mask) hipLaunchKernelGGL((conv3x3_naive_kernel<false, true>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
+  else hipLaunchKernelGGL((conv3x3_naive_kernel<false, false>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
+  UNET_CHECK_LAUNCH(ctx, "conv3x3_naive_fwd"); return UNET_OK;
+}
+
+int32_t k_conv3x3_c1_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd,
+                         int cout, int relu, hipStream_t s) {
+  if ((cout & 3) || TPB % (cout / 4)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1: cout=%d unsupported", cout);
+  long long threads = (long long)n * h * wd * (cout / 4);
+  dim3 g(grid_for(threads / 2 + 1, 2048)), b(TPB);
+  if (relu) hipLaunchKernelGGL(conv3x3_c1_kernel<true>, g, b, 0, s, x, w, bias, y, n, h, wd, cout);
+  else hipLaunchKernelGGL(conv3x3_c1_kernel<false>, g, b, 0, s, x, w, bias, y, n, h, wd, cout);
+  UNET_CHECK_LAUNCH(ctx, "conv3x3_c1_fwd"); return UNET_OK;
+}
+
+int32_t k_flip_transpose_w3x3(unet_ctx* ctx, const float* w, float* wt, int cin, int cout, hipStream_t s) {
+  hipLaunchKernelGGL(flip_transpose_kernel, dim3(grid_for(9LL * cin * cout, 2048)), dim3(TPB), 0, s, w, wt, cin, cout);
+  UNET_CHECK_LAUNCH(ctx, "flip_transpose"); return UNET_OK;
+}
+
+int32_t k_conv3x3_naive_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, int n, int h, int wd,
+                              int cin, int cout, hipStream_t s) {
+  UNET_HIP(ctx, hipMemsetAsync(dw, 0, sizeof(float) * 9 * cin * cout, s));
+  UNET_HIP(ctx, hipMemsetAsync(db, 0, sizeof(float) * cout, s));
+  long long outs = (long long)(9 * cin + 1) * cout, pixels = (long long)n * h * wd;
+  int gx = (int)cdiv64(outs, TPB);
+  long long want = (1 << 18) / (outs < 1 ? 1 : outs) + 1;    // aim for ~256K threads in flight
+  int gy = (int)std::min<long long>(std::max<long long>(want, 1), std::max<long long>(pixels / 64, 1));
+  hipLaunchKernelGGL(conv3x3_naive_wgrad_kernel, dim3(gx, gy), dim3(TPB), 0, s, x, dy, dw, db, n, h, wd, cin, cout);
+  UNET_CHECK_LAUNCH(ctx, "conv3x3_naive_wgrad"); return UNET_OK;
+}
+
+int32_t k_convT_naive_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h,
+                          int wd, int cin, int cout, hipStream_t s) {
+  long long total = (long long)n * 4 * h * wd * cout;
+  hipLaunchKernelGGL(convT_naive_fwd_kernel, dim3(grid_for(total, 1 << 20)), dim3(TPB), 0, s, x, w, bias, y, ldy, n, h, wd, cin, cout);
+  UNET_CHECK_LAUNCH(ctx, "convT_naive_fwd"); return UNET_OK;
+}
+
+int32_t k_convT_naive_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n,
+                            int h, int wd, int cin, int cout, hipStream_t s) {
+  long long total = (long long)n * h * wd * cin;
+  dim3 g(grid_for(total, 1 << 20)), b(TPB);
+  if (mask) hipLaunchKernelGGL(convT_naive_dgrad_kernel<true>, g, b, 0, s, dy, lddy, w, mask, dx, n, h, wd, cin, cout);
+  else hipLaunchKernelGGL(convT_naive_dgrad_kernel<false>, g, b, 0, s, dy, lddy, w, mask, dx, n, h, wd, cin, cout);
+  UNET_CHECK_LAUNCH(ctx, "convT_naive_dgrad"); return UNET_OK;
+}
+
+int32_t k_convT_naive_wgrad(unet_ctx* ctx, const float* x, const float* dy, int lddy, float* dw, float* db, int n, int h,
+                            int wd, int cin, int cout, hipStream_t s) {
+  UNET_HIP(ctx, hipMemsetAsync(dw, 0, sizeof(float) * 4 * cin * cout, s));
+  UNET_HIP(ctx, hipMemsetAsync(db, 0, sizeof(float) * cout, s));
+  long long outs = 4LL * cout * (cin + 1), pixels = (long long)n * h * wd;
+  int gx = (int)cdiv64(outs, TPB);
+  long long want = (1 << 18) / outs + 1;
+  int gy = (int)std::min<long long>(std::max<long long>(want, 1), std::max<long long>(pixels / 64, 1));
+  hipLaunchKernelGGL(convT_naive_wgrad_kernel, dim3(gx, gy), dim3(TPB), 0, s, x, dy, lddy, dw, db, n, h, wd, cin, cout);
+  UNET_CHECK_LAUNCH(ctx, "convT_naive_wgrad"); return UNET_OK;
+}

@@ -1,0 +1,492 @@
+// HBM-bound kernels of the U-Net hot path for gfx950: BatchNorm (stats / apply / backward),
+// 2x2 max-pool + dropout, 1x1 sigmoid head fused with the BCE+Dice reductions and its
+// backward, Keras-form Adam, thresholded segmentation metric sums.
+// All tensors NHWC fp32; every global access is a 16-byte (float4) lane access on a
+// channel-contiguous run, so a wave touches whole 128-B lines.  `ld` = pixel stride in
+// floats (channel slices of the zero-copy concat buffers).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident blocks; grid-stride beyond that
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm statistics.  MODE 0: (sum x, sum x^2).  MODE 1: (sum dy, sum dy*xhat).
+// lanes-per-pixel lpp = C/4; a block covers ppb = 256/lpp pixels per iteration.
+// fp32 per-thread partials (<= a few hundred terms each), block tree, fp64 global atomics.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__ a, int lda,
+                                                       const float* __restrict__ x, int ldx,
+                                                       const float* __restrict__ bnp, double* sums,
+                                                       long long pixels, int C) {
+  const int lpp = C >> 2, ppb = TPB / lpp;
+  const int tid = threadIdx.x, q = tid % lpp, pl = tid / lpp;
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = s1;
+  float4 mean = s1, istd = s1;
+  if (MODE == 1) { mean = ld4(bnp + 2 * C + q * 4); istd = ld4(bnp + 3 * C + q * 4); }
+  if (pl < ppb) {
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < pixels; p += (long long)gridDim.x * ppb) {
+      float4 v = ld4(a + p * lda + q * 4);
+      if (MODE == 0) {
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+      } else {
+        float4 xv = ld4(x + p * ldx + q * 4);
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * (xv.x - mean.x) * istd.x; s2.y += v.y * (xv.y - mean.y) * istd.y;
+        s2.z += v.z * (xv.z - mean.z) * istd.z; s2.w += v.w * (xv.w - mean.w) * istd.w;
+      }
+    }
+  }
+  __shared__ float4 sh1[TPB], sh2[TPB];
+  sh1[tid] = s1; sh2[tid] = s2;
+  __syncthreads();
+  if (tid < lpp) {
+    for (int k = 1; k < ppb; ++k) {
+      float4 u = sh1[tid + k * lpp], w = sh2[tid + k * lpp];
+      s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w;
+      s2.x += w.x; s2.y += w.y; s2.z += w.z; s2.w += w.w;
+    }
+    double* d1 = sums + q * 4; double* d2 = sums + C + q * 4;
+    atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y);
+    atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
+    atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y);
+    atomicAdd(d2 + 2, (double)s2.z); atomicAdd(d2 + 3, (double)s2.w);
+  }
+}
+
+__global__ void bn_finalize_train_kernel(const double* sums, double count, const float* gamma,
+                                         const float* beta, float* mm, float* mv, float* bnp, int C,
+                                         float momentum, float eps) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;
+  if (var < 0) var = 0;
+  float istd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc = gamma[c] * istd;
+  bnp[c] = sc; bnp[C + c] = beta[c] - (float)mean * sc; bnp[2 * C + c] = (float)mean; bnp[3 * C + c] = istd;
+  double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+  mm[c] = mm[c] * momentum + (float)mean * (1.0f - momentum);
+  mv[c] = mv[c] * momentum + (float)unbiased * (1.0f - momentum);
+}
+
+__global__ void bn_finalize_infer_kernel(const float* gamma, const float* beta, const float* mm,
+                                         const float* mv, float* bnp, int C, float eps) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float istd = 1.0f / sqrtf(mv[c] + eps);
+  float sc = gamma[c] * istd;
+  bnp[c] = sc; bnp[C + c] = beta[c] - mm[c] * sc; bnp[2 * C + c] = mm[c]; bnp[3 * C + c] = istd;
+}
+
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, int ldx,
+                                                       const float* __restrict__ bnp,
+                                                       float* __restrict__ y, int ldy,
+                                                       long long pixels, int C) {
+  const int lpp = C >> 2;
+  const long long total = pixels * lpp;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    int q = (int)(i % lpp); long long p = i / lpp;
+    float4 v = ld4(x + p * ldx + q * 4), sc = ld4(bnp + q * 4), sh = ld4(bnp + C + q * 4);
+    st4(y + p * ldy + q * 4, make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y),
+                                          fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)));
+  }
+}
+
+__global__ void bn_bwd_param_grads_kernel(const double* sums, float* dgamma, float* dbeta, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c];
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy,
+                                                           const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ bnp,
+                                                           const double* __restrict__ sums, double inv_count,
+                                                           float* __restrict__ dx, int lddx,
+                                                           long long pixels, int C) {
+  const int lpp = C >> 2;
+  const long long total = pixels * lpp;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    int q = (int)(i % lpp); long long p = i / lpp;
+    float4 g = ld4(dy + p * lddy + q * 4), xv = ld4(x + p * ldx + q * 4);
+    float4 sc = ld4(bnp + q * 4), mean = ld4(bnp + 2 * C + q * 4), istd = ld4(bnp + 3 * C + q * 4);
+    const double* s1 = sums + q * 4; const double* s2 = sums + C + q * 4;
+    float r[4];
+    const float gg[4] = {g.x, g.y, g.z, g.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float ss[4] = {sc.x, sc.y, sc.z, sc.w}, mm[4] = {mean.x, mean.y, mean.z, mean.w};
+    const float ii[4] = {istd.x, istd.y, istd.z, istd.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float k1 = (float)(s1[k] * inv_count), k2 = (float)(s2[k] * inv_count);
+      float xh = (xx[k] - mm[k]) * ii[k];
+      float v = ss[k] * (gg[k] - k1 - xh * k2);
+      if (MASK) v = xx[k] > 0.0f ? v : 0.0f;
+      r[k] = v;
+    }
+    st4(dx + p * lddx + q * 4, make_float4(r[0], r[1], r[2], r[3]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 2x2 max-pool (+ inverted dropout).  One thread = one pooled pixel x 4 channels.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 keep_scale(long long idx, float rate, uint64_t seed) {
+  uint4 r = philox4x32((uint64_t)idx, seed);
+  float s = 1.0f / (1.0f - rate);
+  return make_float4(u32_to_unit(r.x) >= rate ? s : 0.f, u32_to_unit(r.y) >= rate ? s : 0.f,
+                     u32_to_unit(r.z) >= rate ? s : 0.f, u32_to_unit(r.w) >= rate ? s : 0.f);
+}
+
+__global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                       float* __restrict__ y, int N, int H, int W, int C,
+                                                       float rate, uint64_t seed) {
+  const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo * lpp;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    int q = (int)(i % lpp); long long p = i / lpp;
+    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    const float* b = x + ((n * H + 2 * io) * W + 2 * jo) * (long long)ldx + q * 4;
+    float4 a0 = ld4(b), a1 = ld4(b + ldx), a2 = ld4(b + (long long)W * ldx), a3 = ld4(b + (long long)(W + 1) * ldx);
+    float4 m = make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)), fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
+                           fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)), fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
+    if (rate > 0.0f) { float4 k = keep_scale(i, rate, seed); m.x *= k.x; m.y *= k.y; m.z *= k.z; m.w *= k.w; }
+    st4(y + p * C + q * 4, m);
+  }
+}
+
+__device__ __forceinline__ int argmax4(float a, float b, float c, float d) {
+  int k = 0; float m = a;
+  if (b > m) { m = b; k = 1; }
+  if (c > m) { m = c; k = 2; }
+  if (d > m) { m = d; k = 3; }
+  return k;
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__ x, int ldx,
+                                                       const float* __restrict__ dy, float* dx, int lddx,
+                                                       int N, int H, int W, int C, float rate, uint64_t seed) {
+  const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo * lpp;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    int q = (int)(i % lpp); long long p = i / lpp;
+    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    long long pix = (n * H + 2 * io) * W + 2 * jo;
+    const float* b = x + pix * ldx + q * 4;
+    float4 a0 = ld4(b), a1 = ld4(b + ldx), a2 = ld4(b + (long long)W * ldx), a3 = ld4(b + (long long)(W + 1) * ldx);
+    float4 g = ld4(dy + p * C + q * 4);
+    if (rate > 0.0f) { float4 k = keep_scale(i, rate, seed); g.x *= k.x; g.y *= k.y; g.z *= k.z; g.w *= k.w; }
+    int kx = argmax4(a0.x, a1.x, a2.x, a3.x), ky = argmax4(a0.y, a1.y, a2.y, a3.y);
+    int kz = argmax4(a0.z, a1.z, a2.z, a3.z), kw = argmax4(a0.w, a1.w, a2.w, a3.w);
+    float* o = dx + pix * lddx + q * 4;
+    const long long offs[4] = {0, lddx, (long long)W * lddx, (long long)(W + 1) * lddx};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 v = make_float4(kx == k ? g.x : 0.f, ky == k ? g.y : 0.f, kz == k ? g.z : 0.f, kw == k ? g.w : 0.f);
+      if (ACC) { float4 e = ld4(o + offs[k]); v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+      st4(o + offs[k], v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 1x1 conv + sigmoid head fused with the loss reductions; and its backward.
+// lpp = cin/4 lanes per pixel (power of two <= 64), xor-shuffle dot product.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float bce_elem(float p, float t, float* pc_out, bool* inrange) {
+  const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+  float pc = fminf(fmaxf(p, lo), hi);
+  *pc_out = pc; *inrange = (p >= lo) && (p <= hi);
+  float z = logf(pc / (1.0f - pc));
+  return fmaxf(z, 0.0f) - z * t + log1pf(expf(-fabsf(z)));
+}
+
+__global__ __launch_bounds__(TPB) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ pout,
+                                                       const float* __restrict__ yt, double* sums,
+                                                       long long pixels, int cin) {
+  const int lpp = cin >> 2;
+  const int sub = threadIdx.x & (lpp - 1);
+  const float4 wv = ld4(w + sub * 4);
+  const float b = bias[0];
+  float sb = 0, stp = 0, st = 0, sp = 0;
+  const long long gt0 = ((long long)blockIdx.x * TPB + threadIdx.x) / lpp;
+  const long long gstride = ((long long)gridDim.x * TPB) / lpp;
+  const long long iters = (pixels + gstride - 1) / gstride;   // uniform trip count: shuffles stay converged
+  for (long long it = 0; it < iters; ++it) {
+    long long p = gt0 + it * gstride;
+    bool ok = p < pixels;
+    float4 v = ok ? ld4(x + p * cin + sub * 4) : make_float4(0, 0, 0, 0);
+    float d = v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+    for (int o = lpp >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (ok && sub == 0) {
+      float pr = 1.0f / (1.0f + expf(-(d + b)));
+      pout[p] = pr;
+      if (yt) {
+        float t = yt[p], pc; bool inr;
+        sb += bce_elem(pr, t, &pc, &inr); stp += t * pr; st += t; sp += pr;
+      }
+    }
+  }
+  if (yt) {
+    __shared__ float red[4][TPB / 64];
+    sb = wave_sum(sb); stp = wave_sum(stp); st = wave_sum(st); sp = wave_sum(sp);
+    int wv_ = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv_] = sb; red[1][wv_] = stp; red[2][wv_] = st; red[3][wv_] = sp; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      float s = 0;
+      for (int k = 0; k < TPB / 64; ++k) s += red[threadIdx.x][k];
+      atomicAdd(sums + threadIdx.x, (double)s);
+    }
+  }
+}
+
+__global__ void loss_finalize_kernel(const double* sums, double count, float* out) {
+  double dice = (2.0 * sums[1] + 1.0) / (sums[2] + sums[3] + 1.0);
+  out[0] = (float)(0.5 * (sums[0] / count) + 0.5 * (1.0 - dice));
+  out[1] = (float)dice;
+}
+
+__global__ __launch_bounds__(TPB) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ pin, const float* __restrict__ yt,
+                                                       const double* __restrict__ sums, double inv_count,
+                                                       float* __restrict__ dx, float* dw, float* db,
+                                                       long long pixels, int cin) {
+  const int lpp = cin >> 2;
+  const int sub = threadIdx.x & (lpp - 1);
+  const float4 wv = ld4(w + sub * 4);
+  const double S = sums[2] + sums[3] + 1.0;
+  const float dice = (float)((2.0 * sums[1] + 1.0) / S), invS = (float)(1.0 / S);
+  const float hb = (float)(0.5 * inv_count);
+  float4 aw = make_float4(0, 0, 0, 0); float ab = 0;
+  const long long gt0 = ((long long)blockIdx.x * TPB + threadIdx.x) / lpp;
+  const long long gstride = ((long long)gridDim.x * TPB) / lpp;
+  for (long long p = gt0; p < pixels; p += gstride) {
+    float pr = pin[p], t = yt[p], pc; bool inr;
+    (void)bce_elem(pr, t, &pc, &inr);
+    float dLdp = (inr ? hb * (pc - t) / (pc * (1.0f - pc)) : 0.0f) - 0.5f * (2.0f * t - dice) * invS;
+    float dz = dLdp * pr * (1.0f - pr);
+    float4 v = ld4(x + p * cin + sub * 4);
+    st4(dx + p * cin + sub * 4, make_float4(v.x > 0 ? dz * wv.x : 0.f, v.y > 0 ? dz * wv.y : 0.f,
+                                            v.z > 0 ? dz * wv.z : 0.f, v.w > 0 ? dz * wv.w : 0.f));
+    aw.x += dz * v.x; aw.y += dz * v.y; aw.z += dz * v.z; aw.w += dz * v.w;
+    if (sub == 0) ab += dz;
+  }
+  // reduce lanes sharing `sub` inside the wave, then the 4 waves through LDS
+  for (int o = lpp; o < 64; o <<= 1) {
+    aw.x += __shfl_xor(aw.x, o, 64); aw.y += __shfl_xor(aw.y, o, 64);
+    aw.z += __shfl_xor(aw.z, o, 64); aw.w += __shfl_xor(aw.w, o, 64);
+    ab += __shfl_xor(ab, o, 64);
+  }
+  __shared__ float4 rw[TPB / 64][64]; __shared__ float rb[TPB / 64];
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+  if (lane < lpp) rw[wv_][lane] = aw;
+  if (lane == 0) rb[wv_] = ab;
+  __syncthreads();
+  if (threadIdx.x < lpp) {
+    float4 s = rw[0][threadIdx.x];
+    for (int k = 1; k < TPB / 64; ++k) { float4 u = rw[k][threadIdx.x]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
+    atomicAdd(dw + threadIdx.x * 4 + 0, s.x); atomicAdd(dw + threadIdx.x * 4 + 1, s.y);
+    atomicAdd(dw + threadIdx.x * 4 + 2, s.z); atomicAdd(dw + threadIdx.x * 4 + 3, s.w);
+  }
+  if (threadIdx.x == 0) { float s = 0; for (int k = 0; k < TPB / 64; ++k) s += rb[k]; atomicAdd(db, s); }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   float lr_t, float b1, float b2, float eps, float gs) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+    float4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
+    float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x * gs, gg.y * gs, gg.z * gs, gg.w * gs};
+    float M[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      M[k] = b1 * M[k] + (1.0f - b1) * G[k];
+      V[k] = b2 * V[k] + (1.0f - b2) * G[k] * G[k];
+      P[k] = P[k] - lr_t * M[k] / (sqrtf(V[k]) + eps);
+    }
+    st4(p + i * 4, make_float4(P[0], P[1], P[2], P[3]));
+    st4(m + i * 4, make_float4(M[0], M[1], M[2], M[3]));
+    st4(v + i * 4, make_float4(V[0], V[1], V[2], V[3]));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    long long i = (n4 << 2) + threadIdx.x;
+    float G = g[i] * gs, M = b1 * m[i] + (1.0f - b1) * G, V = b2 * v[i] + (1.0f - b2) * G * G;
+    m[i] = M; v[i] = V; p[i] = p[i] - lr_t * M / (sqrtf(V) + eps);
+  }
+}
+
+constexpr int THR_CHUNK = 8;
+__global__ __launch_bounds__(TPB) void metrics_sweep_kernel(const float* __restrict__ p, const float* __restrict__ gt,
+                                                            const float* __restrict__ thr, int nthr, double* out,
+                                                            long long n) {
+  const int t0 = blockIdx.y * THR_CHUNK;
+  float th[THR_CHUNK], tp[THR_CHUNK], pr[THR_CHUNK], sg = 0;
+#pragma unroll
+  for (int k = 0; k < THR_CHUNK; ++k) { th[k] = (t0 + k < nthr) ? thr[t0 + k] : 2.0f; tp[k] = 0; pr[k] = 0; }
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    float pv = p[i], g = gt[i];
+    sg += g;
+#pragma unroll
+    for (int k = 0; k < THR_CHUNK; ++k) { bool on = pv > th[k]; tp[k] += on ? g : 0.f; pr[k] += on ? 1.f : 0.f; }
+  }
+  __shared__ float red[2 * THR_CHUNK + 1][TPB / 64];
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < THR_CHUNK; ++k) {
+    float a = wave_sum(tp[k]), b = wave_sum(pr[k]);
+    if (lane == 0) { red[2 * k][wv_] = a; red[2 * k + 1][wv_] = b; }
+  }
+  sg = wave_sum(sg);
+  if (lane == 0) red[2 * THR_CHUNK][wv_] = sg;
+  __syncthreads();
+  if (threadIdx.x < 2 * THR_CHUNK + 1) {
+    float s = 0;
+    for (int k = 0; k < TPB / 64; ++k) s += red[threadIdx.x][k];
+    if (threadIdx.x == 2 * THR_CHUNK) {
+      for (int k = 0; k < THR_CHUNK; ++k) if (t0 + k < nthr) atomicAdd(out + (t0 + k) * 3 + 2, (double)s);
+    } else {
+      int k = threadIdx.x >> 1;
+      if (t0 + k < nthr) atomicAdd(out + (t0 + k) * 3 + (threadIdx.x & 1), (double)s);
+    }
+  }
+}
+
+inline int grid_for(long long work_items) {
+  long long b = cdiv64(work_items, TPB);
+  return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
+}
+inline bool bn_c_ok(int c) { return c >= 4 && (c % 4) == 0 && (c / 4) <= TPB; }
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int32_t unet_bn_stats(unet_ctx* ctx, const float* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) {
+  if (!x || !sums || !bn_c_ok(c) || ldx < c || (ldx & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: bad args c=%d ldx=%d", c, ldx);
+  int ppb = TPB / (c / 4);
+  int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), MAX_BLOCKS); if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(bn_stats_kernel<0>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, nullptr, 0, nullptr, sums, (long long)pixels, c);
+  UNET_CHECK_LAUNCH(ctx, "bn_stats"); return UNET_OK;
+}
+
+int32_t unet_bn_finalize_train(unet_ctx* ctx, const double* sums, double count, const float* gamma, const float* beta,
+                               float* mm, float* mv, float* bnp, int32_t c, void* stream) {
+  if (!sums || !gamma || !beta || !mm || !mv || !bnp || c < 1 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "bn_finalize_train: bad args");
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((c + 127) / 128), dim3(128), 0, as_stream(stream), sums, count, gamma, beta, mm, mv, bnp, c, 0.99f, 1e-3f);
+  UNET_CHECK_LAUNCH(ctx, "bn_finalize_train"); return UNET_OK;
+}
+
+int32_t unet_bn_finalize_infer(unet_ctx* ctx, const float* gamma, const float* beta, const float* mm, const float* mv,
+                               float* bnp, int32_t c, void* stream) {
+  if (!gamma || !beta || !mm || !mv || !bnp || c < 1) UNET_FAIL(ctx, UNET_E_ARG, "bn_finalize_infer: bad args");
+  hipLaunchKernelGGL(bn_finalize_infer_kernel, dim3((c + 127) / 128), dim3(128), 0, as_stream(stream), gamma, beta, mm, mv, bnp, c, 1e-3f);
+  UNET_CHECK_LAUNCH(ctx, "bn_finalize_infer"); return UNET_OK;
+}
+
+int32_t unet_bn_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy, int64_t pixels,
+                      int32_t c, void* stream) {
+  if (!x || !bnp || !y || !bn_c_ok(c) || ldx < c || ldy < c || ((ldx | ldy) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_apply: bad args");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, y, ldy, (long long)pixels, c);
+  UNET_CHECK_LAUNCH(ctx, "bn_apply"); return UNET_OK;
+}
+
+int32_t unet_bn_bwd_stats(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp,
+                          double* sums, int64_t pixels, int32_t c, void* stream) {
+  if (!dy || !x || !bnp || !sums || !bn_c_ok(c) || ((ldx | lddy) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_stats: bad args");
+  int ppb = TPB / (c / 4);
+  int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), MAX_BLOCKS); if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, sums, (long long)pixels, c);
+  UNET_CHECK_LAUNCH(ctx, "bn_bwd_stats"); return UNET_OK;
+}
+
+int32_t unet_bn_bwd_param_grads(unet_ctx* ctx, const double* sums, float* dgamma, float* dbeta, int32_t c, void* stream) {
+  if (!sums || !dgamma || !dbeta || c < 1) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_param_grads: bad args");
+  hipLaunchKernelGGL(bn_bwd_param_grads_kernel, dim3((c + 127) / 128), dim3(128), 0, as_stream(stream), sums, dgamma, dbeta, c);
+  UNET_CHECK_LAUNCH(ctx, "bn_bwd_param_grads"); return UNET_OK;
+}
+
+int32_t unet_bn_bwd_apply(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp,
+                          const double* sums, double count, int32_t relu_mask, float* dx, int32_t lddx, int64_t pixels,
+                          int32_t c, void* stream) {
+  if (!dy || !x || !bnp || !sums || !dx || !bn_c_ok(c) || count < 1 || ((ldx | lddy | lddx) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_apply: bad args");
+  int grid = grid_for(pixels * (c / 4));
+  if (relu_mask) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, sums, 1.0 / count, dx, lddx, (long long)pixels, c);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, sums, 1.0 / count, dx, lddx, (long long)pixels, c);
+  UNET_CHECK_LAUNCH(ctx, "bn_bwd_apply"); return UNET_OK;
+}
+
+int32_t unet_maxpool2x2_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, float* y, int32_t n, int32_t h, int32_t wd,
+                                    int32_t c, float rate, uint64_t seed, void* stream) {
+  if (!x || !y || (c & 3) || (h & 1) || (wd & 1) || ldx < c || (ldx & 3) || rate < 0 || rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "maxpool fwd: bad args (h,w even; c%%4==0)");
+  long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, y, n, h, wd, c, rate, seed);
+  UNET_CHECK_LAUNCH(ctx, "maxpool fwd"); return UNET_OK;
+}
+
+int32_t unet_maxpool2x2_dropout_bwd(unet_ctx* ctx, const float* x, int32_t ldx, const float* dy, float* dx, int32_t lddx,
+                                    int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
+                                    int32_t accumulate, void* stream) {
+  if (!x || !dy || !dx || (c & 3) || (h & 1) || (wd & 1) || ((ldx | lddx) & 3) || rate < 0 || rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd: bad args");
+  long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  int grid = grid_for(total);
+  if (accumulate) hipLaunchKernelGGL(pool_bwd_kernel<true>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
+  else hipLaunchKernelGGL(pool_bwd_kernel<false>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
+  UNET_CHECK_LAUNCH(ctx, "maxpool bwd"); return UNET_OK;
+}
+
+int32_t unet_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* p, const float* y_true,
+                      double* loss_sums, int64_t pixels, int32_t cin, void* stream) {
+  if (!x || !w || !bias || !p || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || (y_true && !loss_sums)) UNET_FAIL(ctx, UNET_E_ARG, "head_fwd: bad args (cin/4 must be a power of two <= 64)");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for(pixels * (cin / 4) / 4)), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels, cin);
+  UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
+}
+
+int32_t unet_loss_finalize(unet_ctx* ctx, const double* loss_sums, double count, float* loss_out, void* stream) {
+  if (!loss_sums || !loss_out || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "loss_finalize: bad args");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, as_stream(stream), loss_sums, count, loss_out);
+  UNET_CHECK_LAUNCH(ctx, "loss_finalize"); return UNET_OK;
+}
+
+int32_t unet_head_bwd(unet_ctx* ctx, const float* x, const float* w, const float* p, const float* y_true,
+                      const double* loss_sums, double count, float* dx, float* dw, float* db, int64_t pixels, int32_t cin,
+                      void* stream) {
+  if (!x || !w || !p || !y_true || !loss_sums || !dx || !dw || !db || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "head_bwd: bad args");
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(grid_for(pixels * (cin / 4) / 4)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin);
+  UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
+}
+
+int32_t unet_adam_keras(unet_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float b1,
+                        float b2, float eps, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "adam: bad args");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count / 4 + 1)), dim3(TPB), 0, as_stream(stream), p, g, m, v, (long long)count, lr_t, b1, b2, eps, grad_scale);
+  UNET_CHECK_LAUNCH(ctx, "adam"); return UNET_OK;
+}
+
+int32_t unet_seg_metrics_sweep(unet_ctx* ctx, const float* p, const float* gt, const float* thresholds, int32_t nthr,
+                               double* out, int64_t count, void* stream) {
+  if (!p || !gt || !thresholds || !out || nthr < 1 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "metrics_sweep: bad args");
+  int gx = (int)std::min<int64_t>(cdiv64(count, TPB * 8), 1024); if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(metrics_sweep_kernel, dim3(gx, (nthr + THR_CHUNK - 1) / THR_CHUNK), dim3(TPB), 0, as_stream(stream), p, gt, thresholds, nthr, out, (long long)count);
+  UNET_CHECK_LAUNCH(ctx, "metrics_sweep"); return UNET_OK;
+}
+
+int32_t unet_zero(unet_ctx* ctx, void* ptr, size_t bytes, void* stream) {
+  if (!ptr) UNET_FAIL(ctx, UNET_E_ARG, "zero: null");
+  UNET_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, as_stream(stream)));
+  return UNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,634 @@
+// Context, op-level convolution entry points and the model-level op programs of the gfx950
+// U-Net engine.  The graph mirrors the Keras model of the reference,
+// /root/reference/Scripts/task1_preprocessing_plus_unet_with_comments.py:853-916
+// (== task3_lung_segmentation_unet.py:850-913): 4 encoder blocks Conv-Conv-BN-[skip]-Pool-Dropout,
+// bottleneck Conv-Conv, 4 decoder blocks ConvT-concat([up,skip])-BN-Conv-Conv, 1x1 sigmoid head.
+//
+// HBM layout: every activation is a dense NHWC fp32 tensor carved from ONE caller-owned
+// workspace; the skip concatenation is zero-copy: encoder BN k writes channels [C,2C) and the
+// decoder ConvT writes channels [0,C) of the same [N,S,S,2C] "cat" buffer (ld = 2C).
+// Parameters / gradients / Adam moments are flat buffers in Keras get_weights() order, so
+// Adam is one launch and gradient buckets for all-reduce are contiguous ranges.
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// =========================================================================================
+// context
+// =========================================================================================
+extern "C" {
+
+int32_t unet_abi_version(void) { return UNET_ABI_VERSION; }
+
+int32_t unet_ctx_create(int32_t device_id, unet_ctx** out) {
+  if (!out) return UNET_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return UNET_E_NODEV;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return UNET_E_NODEV;
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return UNET_E_NODEV;  // gfx950-only code objects
+  unet_ctx* c = new unet_ctx();
+  c->device = device_id;
+  c->num_cu = prop.multiProcessorCount;
+  *out = c;
+  return UNET_OK;
+}
+
+void unet_ctx_destroy(unet_ctx* ctx) { delete ctx; }
+const char* unet_last_error(const unet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on) { if (!ctx) return UNET_E_ARG; ctx->profiling = on; return UNET_OK; }
+
+}  // extern "C"
+
+// =========================================================================================
+// convolution dispatch (shared by the op-level ABI and the model programs)
+// =========================================================================================
+static bool use_mfma(int algo, int cin, int cout) {
+  if (algo == UNET_ALGO_NAIVE) return false;
+  return mfma_conv3x3_supported(cin, cout);
+}
+
+static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask,
+                                    float* y, int n, int h, int wd, int cin, int cout, int relu, int algo, hipStream_t s) {
+  if (algo == UNET_ALGO_MFMA && !mfma_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 mfma: cin=%d cout=%d unsupported", cin, cout);
+  if (use_mfma(algo, cin, cout)) return k_conv3x3_mfma_fwd(ctx, x, w, bias, mask, y, n, h, wd, cin, cout, relu, s);
+  if (cin == 1 && !mask && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0)
+    return k_conv3x3_c1_fwd(ctx, x, w, bias, y, n, h, wd, cout, relu, s);
+  return k_conv3x3_naive_fwd(ctx, x, w, bias, mask, y, n, h, wd, cin, cout, relu, s);
+}
+
+static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
+                                      size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
+  if (use_mfma(algo, cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout))
+    return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
+  if (algo == UNET_ALGO_MFMA) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 wgrad mfma: unsupported shape or workspace too small");
+  return k_conv3x3_naive_wgrad(ctx, x, dy, dw, db, n, h, wd, cin, cout, s);
+}
+
+extern "C" {
+
+int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t h,
+                         int32_t wd, int32_t cin, int32_t cout, int32_t relu, int32_t algo, void* stream) {
+  if (!ctx || !x || !w || !y || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: bad args");
+  return conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, y, n, h, wd, cin, cout, relu, algo, as_stream(stream));
+}
+
+int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* relu_src, float* dx, float* wt_ws,
+                              int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+  if (!ctx || !dy || !w || !dx || !wt_ws || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data: bad args");
+  int32_t r = k_flip_transpose_w3x3(ctx, w, wt_ws, cin, cout, as_stream(stream));
+  if (r) return r;
+  // data gradient = 3x3 convolution of dy (cout channels) with wt -> cin channels
+  return conv3x3_fwd_dispatch(ctx, dy, wt_ws, nullptr, relu_src, dx, n, h, wd, cout, cin, 0, algo, as_stream(stream));
+}
+
+size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
+  return mfma_conv3x3_supported(cin, cout) ? mfma_wgrad_ws_bytes(n, h, wd, cin, cout) : 0;
+}
+
+int32_t unet_conv3x3_bwd_weights(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                                 int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+  if (!ctx || !x || !dy || !dw || !db || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_weights: bad args");
+  return conv3x3_wgrad_dispatch(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, algo, as_stream(stream));
+}
+
+int32_t unet_convT2x2_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t ldy, int32_t n,
+                          int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+  if (!ctx || !x || !w || !y || ldy < cout || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "convT_fwd: bad args");
+  (void)algo;
+  return k_convT_naive_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
+}
+
+int32_t unet_convT2x2_bwd_data(unet_ctx* ctx, const float* dy, int32_t lddy, const float* w, const float* relu_src, float* dx,
+                               int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+  if (!ctx || !dy || !w || !dx || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_data: bad args");
+  (void)algo;
+  return k_convT_naive_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
+}
+
+int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy, int32_t lddy, float* dw, float* db, int32_t n,
+                                  int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+  if (!ctx || !x || !dy || !dw || !db || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_weights: bad args");
+  (void)algo;
+  return k_convT_naive_wgrad(ctx, x, dy, lddy, dw, db, n, h, wd, cin, cout, as_stream(stream));
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// model
+// =========================================================================================
+namespace {
+
+struct Layer { std::string name; int kind; int cin, cout; };   // kind 0 conv3, 1 convT, 2 bn, 3 conv1
+struct TInfo { int is_state; int64_t off, count; };
+struct Buf { size_t off = 0; int ld = 0, n = 0, h = 0, w = 0, c = 0; size_t chan_off = 0; };   // float offsets into workspace
+
+struct Op {
+  std::string name;
+  std::function<int32_t(hipStream_t)> run;
+  double flops = 0, bytes = 0, ms = 0;
+  int64_t calls = 0;
+};
+
+}  // namespace
+
+struct unet_model {
+  unet_ctx* ctx = nullptr;
+  int in_ch = 1, N = 0, H = 0, W = 0, world = 1, algo = 0;
+  std::vector<Layer> layers;
+  std::map<std::string, TInfo> tinfo;
+  int64_t n_params = 0, n_state = 0;
+  // bound buffers
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *state = nullptr;
+  char* ws = nullptr; size_t ws_bytes = 0;
+  const float *x = nullptr, *yt = nullptr; float* pout = nullptr;
+  float drop_rate = 0.0f; uint64_t drop_seed = 0;
+  // workspace plan (offsets in floats)
+  std::map<std::string, Buf> act, grad;
+  size_t ws_floats_infer = 0, ws_floats_train = 0;
+  size_t off_bn_sums = 0, bn_sums_doubles = 0;       // all fwd BN sums (double), then loss sums (4 doubles)
+  size_t off_bn_bsums = 0;                            // all bwd BN sums (double)
+  std::map<std::string, size_t> bn_sum_off, bn_bsum_off, bnp_off;   // per-BN offsets (doubles / floats)
+  size_t off_loss_sums = 0, off_loss_out = 0, off_wt = 0, off_wgrad_ws = 0; size_t wgrad_ws_bytes = 0;
+  std::vector<Op> prog[3];
+  std::vector<unet_sync_point> sync[3];
+  struct SyncRef { int after_op, kind; bool in_ws; size_t off_bytes; int64_t count; };
+  std::vector<SyncRef> syncref[3];
+
+  float* wsf(size_t off) const { return reinterpret_cast<float*>(ws) + off; }
+  double* wsd(size_t off_floats) const { return reinterpret_cast<double*>(reinterpret_cast<float*>(ws) + off_floats); }
+  float* P(const std::string& n) const { auto& t = tinfo.at(n); return (t.is_state ? state : params) + t.off; }
+  float* G(const std::string& n) const { auto& t = tinfo.at(n); return grads + t.off; }
+  const float* A(const std::string& n) const { auto& b = act.at(n); return wsf(b.off + b.chan_off); }
+  float* Aw(const std::string& n) const { auto& b = act.at(n); return wsf(b.off + b.chan_off); }
+  float* D(const std::string& n) const { auto& b = grad.at(n); return wsf(b.off + b.chan_off); }
+};
+
+namespace {
+
+const int ENC[4] = {32, 64, 128, 256};
+
+void build_layers(unet_model* m) {
+  auto& L = m->layers;
+  int cprev = m->in_ch;
+  for (int k = 1; k <= 4; ++k) {
+    int c = ENC[k - 1];
+    L.push_back({"c" + std::to_string(k) + "a", 0, cprev, c});
+    L.push_back({"c" + std::to_string(k) + "b", 0, c, c});
+    L.push_back({"bn" + std::to_string(k), 2, c, c});
+    cprev = c;
+  }
+  L.push_back({"c5a", 0, 256, 512});
+  L.push_back({"c5b", 0, 512, 512});
+  cprev = 512;
+  const int dec[4] = {256, 128, 64, 32};
+  for (int k = 6; k <= 9; ++k) {
+    int c = dec[k - 6];
+    L.push_back({"u" + std::to_string(k), 1, cprev, c});
+    L.push_back({"bn" + std::to_string(k), 2, 2 * c, 2 * c});
+    L.push_back({"c" + std::to_string(k) + "a", 0, 2 * c, c});
+    L.push_back({"c" + std::to_string(k) + "b", 0, c, c});
+    cprev = c;
+  }
+  L.push_back({"out", 3, 32, 1});
+  int64_t po = 0, so = 0;
+  for (auto& l : L) {
+    if (l.kind == 2) {
+      m->tinfo[l.name + "/gamma"] = {0, po, l.cout}; po += l.cout;
+      m->tinfo[l.name + "/beta"] = {0, po, l.cout}; po += l.cout;
+      m->tinfo[l.name + "/mean"] = {1, so, l.cout}; so += l.cout;
+      m->tinfo[l.name + "/var"] = {1, so, l.cout}; so += l.cout;
+    } else {
+      int64_t kn = (l.kind == 0 ? 9 : l.kind == 1 ? 4 : 1) * (int64_t)l.cin * l.cout;
+      m->tinfo[l.name + "/kernel"] = {0, po, kn}; po += kn;
+      m->tinfo[l.name + "/bias"] = {0, po, l.cout}; po += l.cout;
+    }
+  }
+  m->n_params = po; m->n_state = so;
+}
+
+struct Carver {
+  size_t cur = 0;
+  size_t take(size_t floats) { size_t o = cur; cur += (floats + 63) & ~size_t(63); return o; }
+};
+
+Buf mk(Carver& cv, int n, int h, int w, int c) { Buf b; b.off = cv.take((size_t)n * h * w * c); b.ld = c; b.n = n; b.h = h; b.w = w; b.c = c; return b; }
+Buf slice(const Buf& b, int c0, int c) { Buf s = b; s.chan_off = c0; s.c = c; return s; }
+
+void plan_workspace(unet_model* m) {
+  Carver cv;
+  const int N = m->N;
+  // --- small scratch first ---
+  size_t nd = 0;
+  for (auto& l : m->layers) if (l.kind == 2) { m->bn_sum_off[l.name] = nd; nd += 2 * (size_t)l.cout; }
+  m->bn_sums_doubles = nd;
+  m->off_bn_sums = cv.take((nd + 4) * 2);                 // doubles -> 2 floats each; +4 loss sums
+  m->off_loss_sums = m->off_bn_sums + nd * 2;
+  size_t nb = 0;
+  for (auto& l : m->layers) if (l.kind == 2) { m->bn_bsum_off[l.name] = nb; nb += 2 * (size_t)l.cout; }
+  m->off_bn_bsums = cv.take(nb * 2);
+  for (auto& l : m->layers) if (l.kind == 2) m->bnp_off[l.name] = cv.take(4 * (size_t)l.cout);
+  m->off_loss_out = cv.take(64);
+  // --- activations ---
+  int S = m->H, T = m->W;
+  for (int k = 1; k <= 4; ++k) {
+    int c = ENC[k - 1];
+    std::string ks = std::to_string(k), dk = std::to_string(10 - k);
+    m->act["c" + ks + "a"] = mk(cv, N, S, T, c);
+    m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
+    Buf cat = mk(cv, N, S, T, 2 * c);
+    m->act["cat" + dk] = cat;
+    m->act["u" + dk] = slice(cat, 0, c);
+    m->act["bn" + ks] = slice(cat, c, c);
+    m->act["p" + ks] = mk(cv, N, S / 2, T / 2, c);
+    S /= 2; T /= 2;
+  }
+  m->act["c5a"] = mk(cv, N, S, T, 512);
+  m->act["c5b"] = mk(cv, N, S, T, 512);
+  const int dec[4] = {256, 128, 64, 32};
+  for (int k = 6; k <= 9; ++k) {
+    int c = dec[k - 6]; S *= 2; T *= 2;
+    std::string ks = std::to_string(k);
+    m->act["bn" + ks] = mk(cv, N, S, T, 2 * c);
+    m->act["c" + ks + "a"] = mk(cv, N, S, T, c);
+    m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
+  }
+  m->ws_floats_infer = cv.cur;
+  // --- training extras: gradient twins + weight scratch ---
+  for (auto& kv : m->act) {
+    const std::string& nm = kv.first; const Buf& b = kv.second;
+    if (nm.rfind("cat", 0) == 0) {
+      Buf g = mk(cv, b.n, b.h, b.w, b.c);
+      m->grad[nm] = g;
+    }
+  }
+  for (auto& kv : m->act) {
+    const std::string& nm = kv.first; const Buf& b = kv.second;
+    if (nm.rfind("cat", 0) == 0) continue;
+    if (b.chan_off != 0 || b.ld != b.c) {                       // slices of a cat buffer: u<k>, bn<1..4>
+      std::string catname;
+      if (nm[0] == 'u') catname = "cat" + nm.substr(1);
+      else catname = "cat" + std::to_string(10 - std::stoi(nm.substr(2)));
+      m->grad[nm] = slice(m->grad.at(catname), (int)b.chan_off, b.c);
+    } else {
+      m->grad[nm] = mk(cv, b.n, b.h, b.w, b.c);
+    }
+  }
+  size_t wt = 0, wgb = 0;
+  int S2 = m->H, T2 = m->W;
+  (void)S2; (void)T2;
+  for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)9 * l.cin * l.cout);
+  m->off_wt = cv.take(wt);
+  // wgrad split-K workspace: max over conv layers at their spatial sizes
+  {
+    int s = m->H, t = m->W, idx = 0;
+    for (auto& l : m->layers) {
+      (void)idx;
+      if (l.kind != 0) continue;
+      // spatial size of this conv layer
+      int lvl;
+      if (l.name == "c5a" || l.name == "c5b") lvl = 4;
+      else { int k = l.name[1] - '0'; lvl = (k <= 4) ? k - 1 : 9 - k; }
+      int hs = s >> lvl, ts = t >> lvl;
+      if (mfma_conv3x3_supported(l.cin, l.cout)) wgb = std::max(wgb, mfma_wgrad_ws_bytes(m->N, hs, ts, l.cin, l.cout));
+    }
+  }
+  m->wgrad_ws_bytes = wgb;
+  m->off_wgrad_ws = cv.take((wgb + 3) / 4);
+  m->ws_floats_train = cv.cur;
+}
+
+// ---- algorithmic flop / byte model -------------------------------
+double nel(const Buf& b) { return (double)b.n * b.h * b.w * b.c; }
+
+#define ADD_OP(vec, nm, fl, by, ...)                          \
+  do {                                                        \
+    Op _o; _o.name = (nm); _o.flops = (fl); _o.bytes = (by);  \
+    _o.run = [=](hipStream_t s) -> int32_t __VA_ARGS__;       \
+    (vec).push_back(std::move(_o));                           \
+  } while (0)
+
+void build_programs(unet_model* m) {
+  unet_ctx* ctx = m->ctx;
+  const int N = m->N, algo = m->algo;
+  const double gcount = (double)m->world;     // multiplies per-rank element counts into global counts
+  auto& FT = m->prog[UNET_PROG_FWD_TRAIN];
+  auto& FI = m->prog[UNET_PROG_FWD_INFER];
+  auto& BW = m->prog[UNET_PROG_BWD];
+  const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
+
+  // ------------------------------------------------------------------ forward (train / infer)
+  for (int training = 1; training >= 0; --training) {
+    auto& F = training ? FT : FI;
+    auto& SY = m->syncref[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
+    ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
+    auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
+      const Buf ob = m->act.at(name);
+      double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
+      double by = 4.0 * ((double)ob.n * ob.h * ob.w * (cin + cout) + 9.0 * cin * cout);
+      ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
+        const float* xin = in.empty() ? m->x : m->A(in);
+        return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, m->Aw(name), ob.n, ob.h, ob.w, cin, cout, 1, algo, s);
+      });
+    };
+    auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c) {
+      const Buf ib = m->act.at(in), ob = m->act.at(out);
+      const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
+      const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
+      if (training) {
+        ADD_OP(F, "bn_stats:" + name, 0, 4.0 * pixels * c, { return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s); });
+        SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
+        ADD_OP(F, "bn_finalize:" + name, 0, 0, {
+          return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
+                                        m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
+        });
+      } else {
+        ADD_OP(F, "bn_finalize_infer:" + name, 0, 0, {
+          return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
+        });
+      }
+      ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s); });
+    };
+    std::string prev = "";
+    int cprev = m->in_ch;
+    for (int k = 1; k <= 4; ++k) {
+      int c = ENC[k - 1]; std::string ks = std::to_string(k);
+      conv("c" + ks + "a", prev, cprev, c);
+      conv("c" + ks + "b", "c" + ks + "a", c, c);
+      bn("bn" + ks, "c" + ks + "b", "bn" + ks, c);
+      const Buf ib = m->act.at("bn" + ks);
+      const std::string pin = "bn" + ks, pout = "p" + ks;
+      const int tr = training;
+      ADD_OP(F, "pool:" + pout, 0, 4.0 * 1.25 * nel(ib), {
+        return unet_maxpool2x2_dropout_fwd(ctx, m->A(pin), ib.ld, m->Aw(pout), ib.n, ib.h, ib.w, ib.c, tr ? m->drop_rate : 0.0f,
+                                           m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
+      });
+      prev = pout; cprev = c;
+    }
+    conv("c5a", "p4", 256, 512);
+    conv("c5b", "c5a", 512, 512);
+    prev = "c5b"; cprev = 512;
+    const int dec[4] = {256, 128, 64, 32};
+    for (int k = 6; k <= 9; ++k) {
+      int c = dec[k - 6]; std::string ks = std::to_string(k);
+      const Buf ib = m->act.at(prev), ub = m->act.at("u" + ks);
+      const std::string uin = prev, un = "u" + ks; const int ci = cprev;
+      ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * ci * c * nel(ib) / ib.c, 4.0 * (nel(ib) + nel(ub)), {
+        return unet_convT2x2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, algo, s);
+      });
+      bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c);
+      conv("c" + ks + "a", "bn" + ks, 2 * c, c);
+      conv("c" + ks + "b", "c" + ks + "a", c, c);
+      prev = "c" + ks + "b"; cprev = c;
+    }
+    const Buf hb = m->act.at("c9b");
+    const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
+    ADD_OP(F, "head_fwd", 2.0 * 32 * hp, 4.0 * hp * 34, {
+      if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_fwd: p_out not set (unet_model_set_io)");
+      return unet_head_fwd(ctx, m->A("c9b"), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt, m->yt ? m->wsd(m->off_loss_sums) : nullptr, hp, hb.c, s);
+    });
+    SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
+    ADD_OP(F, "loss_finalize", 0, 0, {
+      if (!m->yt) return UNET_OK;
+      return unet_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsf(m->off_loss_out), s);
+    });
+  }
+
+  // ------------------------------------------------------------------ backward
+  {
+    auto& SY = m->syncref[UNET_PROG_BWD];
+    size_t nb = 0;
+    for (auto& kv : m->bn_bsum_off) nb = std::max(nb, kv.second);
+    size_t bs_bytes = 0;
+    for (auto& l : m->layers) if (l.kind == 2) bs_bytes += 2 * (size_t)l.cout * sizeof(double);
+    ADD_OP(BW, "zero_bwd_sums", 0, 0, {
+      int32_t r = unet_zero(ctx, m->wsf(m->off_bn_bsums), bs_bytes, s);
+      if (r) return r;
+      return unet_zero(ctx, m->G("out/kernel"), (size_t)(m->tinfo.at("out/kernel").count + 1) * sizeof(float), s);
+    });
+    const Buf hb = m->act.at("c9b");
+    const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
+    ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, 4.0 * hp * 66, {
+      if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
+      return unet_head_bwd(ctx, m->A("c9b"), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, m->D("c9b"),
+                           m->G("out/kernel"), m->G("out/bias"), hp, hb.c, s);
+    });
+    // conv backward: wgrad (x, dy) then dgrad (dy -> dx, optional relu mask = activation that produced x)
+    auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, bool mask_in) {
+      const Buf ob = m->act.at(name);
+      const double px = (double)ob.n * ob.h * ob.w;
+      ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+        const float* xin = in.empty() ? m->x : m->A(in);
+        return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
+                                      ob.n, ob.h, ob.w, cin, cout, algo, s);
+      });
+      if (want_dx) {
+        ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cout + cin + (mask_in ? cin : 0)) + 9.0 * cin * cout), {
+          return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), mask_in ? m->A(in) : nullptr, m->D(in), m->wsf(m->off_wt), ob.n, ob.h, ob.w,
+                                       cin, cout, algo, s);
+        });
+      }
+    };
+    // bn backward: dy tensor `dyname` (grad buffer), x tensor `xname` (act), output grad `dxname`
+    auto bn_bwd = [&](const std::string& name, const std::string& dyname, const std::string& xname, const std::string& dxname, int c, int mask) {
+      const Buf gb = m->grad.at(dyname), xb = m->act.at(xname), db = m->grad.at(dxname);
+      const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
+      const size_t so = m->bn_bsum_off.at(name), bo = m->bnp_off.at(name);
+      ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
+        int32_t r = unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
+        if (r) return r;
+        return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
+      });
+      SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
+      ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
+        return unet_bn_bwd_apply(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, mask, m->D(dxname),
+                                 db.ld, pixels, c, s);
+      });
+    };
+    auto bucket = [&](const std::string& first, const std::string& last_tensor) {
+      const TInfo a = m->tinfo.at(first), b = m->tinfo.at(last_tensor);
+      SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off});
+    };
+    const int dec[4] = {256, 128, 64, 32};
+    for (int k = 9; k >= 6; --k) {
+      int c = dec[k - 6]; std::string ks = std::to_string(k);
+      std::string prev = (k == 6) ? "c5b" : "c" + std::to_string(k - 1) + "b";
+      int cprev = (k == 6) ? 512 : dec[k - 7];
+      conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
+      conv_bwd("c" + ks + "a", "bn" + ks, 2 * c, c, true, false);
+      bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0);
+      const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
+      const std::string un = "u" + ks;
+      ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, 4.0 * (nel(ib) + nel(ug)), {
+        return unet_convT2x2_bwd_weights(ctx, m->A(prev), m->D(un), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), ib.n, ib.h, ib.w, cprev, c, algo, s);
+      });
+      ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, 4.0 * (2 * nel(ib) + nel(ug)), {
+        return unet_convT2x2_bwd_data(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->A(prev), m->D(prev), ib.n, ib.h, ib.w, cprev, c, algo, s);
+      });
+      if (k == 7) bucket("u7/kernel", "out/bias");
+      if (k == 6) bucket("u6/kernel", "c6b/bias");
+    }
+    conv_bwd("c5b", "c5a", 512, 512, true, true);
+    conv_bwd("c5a", "p4", 256, 512, true, false);
+    bucket("c5a/kernel", "c5b/bias");
+    for (int k = 4; k >= 1; --k) {
+      int c = ENC[k - 1]; std::string ks = std::to_string(k);
+      const Buf xb = m->act.at("bn" + ks), gb = m->grad.at("bn" + ks);
+      const std::string bnn = "bn" + ks, pn = "p" + ks;
+      ADD_OP(BW, "pool_bwd:" + pn, 0, 4.0 * 3.25 * nel(xb), {
+        return unet_maxpool2x2_dropout_bwd(ctx, m->A(bnn), xb.ld, m->D(pn), m->D(bnn), gb.ld, xb.n, xb.h, xb.w, xb.c, m->drop_rate,
+                                           m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, 1, s);
+      });
+      bn_bwd(bnn, bnn, "c" + ks + "b", "c" + ks + "b", c, 1);
+      conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
+      int cprev = (k == 1) ? m->in_ch : ENC[k - 2];
+      conv_bwd("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cprev, c, k > 1, false);
+    }
+    bucket("c1a/kernel", "bn4/beta");
+  }
+}
+
+void resolve_sync(unet_model* m) {
+  for (int p = 0; p < 3; ++p) {
+    m->sync[p].clear();
+    for (auto& r : m->syncref[p]) {
+      unet_sync_point sp;
+      sp.after_op = r.after_op; sp.kind = r.kind; sp.count = r.count;
+      sp.ptr = r.in_ws ? (void*)(m->ws ? m->ws + r.off_bytes : nullptr) : (void*)(m->grads ? (char*)m->grads + r.off_bytes : nullptr);
+      m->sync[p].push_back(sp);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t unet_model_create(unet_ctx* ctx, int32_t in_ch, int32_t n, int32_t h, int32_t w, int32_t world_size, int32_t conv_algo,
+                          unet_model** out) {
+  if (!ctx || !out) return UNET_E_ARG;
+  *out = nullptr;
+  if (in_ch < 1 || n < 1 || h < 16 || w < 16 || (h % 16) || (w % 16) || world_size < 1)
+    UNET_FAIL(ctx, UNET_E_SHAPE, "model_create: need n>=1 and h,w multiples of 16 (4 pool levels, T1:862-880); got n=%d h=%d w=%d", n, h, w);
+  unet_model* m = new unet_model();
+  m->ctx = ctx; m->in_ch = in_ch; m->N = n; m->H = h; m->W = w; m->world = world_size; m->algo = conv_algo;
+  build_layers(m);
+  plan_workspace(m);
+  build_programs(m);
+  *out = m;
+  return UNET_OK;
+}
+
+void unet_model_destroy(unet_model* m) { delete m; }
+int64_t unet_model_param_count(const unet_model* m) { return m ? m->n_params : 0; }
+int64_t unet_model_state_count(const unet_model* m) { return m ? m->n_state : 0; }
+size_t unet_model_workspace_bytes(const unet_model* m, int32_t training) {
+  if (!m) return 0;
+  return (training ? m->ws_floats_train : m->ws_floats_infer) * sizeof(float);
+}
+
+int32_t unet_model_tensor_info(const unet_model* m, const char* name, int32_t* is_state, int64_t* offset, int64_t* count) {
+  if (!m || !name) return UNET_E_ARG;
+  auto it = m->tinfo.find(name);
+  if (it == m->tinfo.end()) return UNET_E_ARG;
+  if (is_state) *is_state = it->second.is_state;
+  if (offset) *offset = it->second.off;
+  if (count) *count = it->second.count;
+  return UNET_OK;
+}
+
+int32_t unet_model_bind(unet_model* m, float* params, float* grads, float* adam_m, float* adam_v, float* bn_state, void* workspace,
+                        size_t workspace_bytes) {
+  if (!m || !params || !bn_state || !workspace) UNET_FAIL(m ? m->ctx : nullptr, UNET_E_ARG, "model_bind: null buffer");
+  size_t need = (grads ? m->ws_floats_train : m->ws_floats_infer) * sizeof(float);
+  if (workspace_bytes < need) UNET_FAIL(m->ctx, UNET_E_ARG, "model_bind: workspace %zu < %zu bytes", workspace_bytes, need);
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(params) & 15)) UNET_FAIL(m->ctx, UNET_E_ARG, "model_bind: buffers must be 256-B (workspace) / 16-B aligned");
+  m->params = params; m->grads = grads; m->adam_m = adam_m; m->adam_v = adam_v; m->state = bn_state;
+  m->ws = static_cast<char*>(workspace); m->ws_bytes = workspace_bytes;
+  resolve_sync(m);
+  return UNET_OK;
+}
+
+int32_t unet_model_set_io(unet_model* m, const float* x, const float* y_true, float* p_out) {
+  if (!m) return UNET_E_ARG;
+  m->x = x; m->yt = y_true; m->pout = p_out;
+  return UNET_OK;
+}
+
+int32_t unet_model_set_dropout(unet_model* m, float rate, uint64_t seed) {
+  if (!m || rate < 0 || rate >= 1) return UNET_E_ARG;
+  m->drop_rate = rate; m->drop_seed = seed;
+  return UNET_OK;
+}
+
+int32_t unet_model_num_ops(const unet_model* m, int32_t prog) { return (!m || prog < 0 || prog > 2) ? UNET_E_ARG : (int32_t)m->prog[prog].size(); }
+
+int32_t unet_model_sync_points(const unet_model* m, int32_t prog, unet_sync_point* out, int32_t cap) {
+  if (!m || prog < 0 || prog > 2) return UNET_E_ARG;
+  int n = (int)m->sync[prog].size();
+  if (out) for (int i = 0; i < n && i < cap; ++i) out[i] = m->sync[prog][i];
+  return n;
+}
+
+int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, void* stream) {
+  if (!m || prog < 0 || prog > 2) return UNET_E_ARG;
+  unet_ctx* ctx = m->ctx;
+  auto& P = m->prog[prog];
+  if (begin < 0 || end > (int)P.size() || begin > end) UNET_FAIL(ctx, UNET_E_ARG, "model_run: bad op range [%d,%d) of %zu", begin, end, P.size());
+  if (!m->ws || !m->params) UNET_FAIL(ctx, UNET_E_STATE, "model_run: buffers not bound");
+  if (prog == UNET_PROG_BWD && !m->grads) UNET_FAIL(ctx, UNET_E_STATE, "model_run: backward needs a grads buffer");
+  if (!m->x) UNET_FAIL(ctx, UNET_E_STATE, "model_run: input not set");
+  hipStream_t s = as_stream(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profiling) { UNET_HIP(ctx, hipEventCreate(&e0)); UNET_HIP(ctx, hipEventCreate(&e1)); }
+  for (int i = begin; i < end; ++i) {
+    if (ctx->profiling) UNET_HIP(ctx, hipEventRecord(e0, s));
+    int32_t r = P[i].run(s);
+    if (r) { ctx->err = P[i].name + ": " + ctx->err; return r; }
+    if (ctx->profiling) {
+      UNET_HIP(ctx, hipEventRecord(e1, s));
+      UNET_HIP(ctx, hipEventSynchronize(e1));
+      float ms = 0; UNET_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+      P[i].ms += ms; P[i].calls += 1;
+    }
+  }
+  if (ctx->profiling) { hipEventDestroy(e0); hipEventDestroy(e1); }
+  return UNET_OK;
+}
+
+const float* unet_model_loss_ptr(const unet_model* m) { return (m && m->ws) ? m->wsf(m->off_loss_out) : nullptr; }
+
+int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, const float** ptr, int32_t* ld, int32_t* n, int32_t* h,
+                       int32_t* w, int32_t* c) {
+  if (!m || !name || !m->ws) return UNET_E_ARG;
+  auto& mp = grad ? m->grad : m->act;
+  auto it = mp.find(name);
+  if (it == mp.end()) return UNET_E_ARG;
+  const Buf& b = it->second;
+  if (ptr) *ptr = m->wsf(b.off + b.chan_off);
+  if (ld) *ld = b.ld; if (n) *n = b.n; if (h) *h = b.h; if (w) *w = b.w; if (c) *c = b.c;
+  return UNET_OK;
+}
+
+int32_t unet_model_op_info(const unet_model* m, int32_t prog, int32_t op, const char** name, double* flops, double* bytes, double* ms,
+                           int64_t* calls) {
+  if (!m || prog < 0 || prog > 2 || op < 0 || op >= (int)m->prog[prog].size()) return UNET_E_ARG;
+  const Op& o = m->prog[prog][op];
+  if (name) *name = o.name.c_str();
+  if (flops) *flops = o.flops; if (bytes) *bytes = o.bytes; if (ms) *ms = o.ms; if (calls) *calls = o.calls;
+  return UNET_OK;
+}
+
+int32_t unet_model_reset_timers(unet_model* m) {
+  if (!m) return UNET_E_ARG;
+  for (auto& P : m->prog) for (auto& o : P) { o.ms = 0; o.calls = 0; }
+  return UNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+"""Injectable data for the runners: synthetic CT slices + masks and the hold-out split.
+
+The reference acquires data with pip/Kaggle/Drive (T1:8-136) and pre-processes NIfTI volumes
+(T1:163-686) into ``cts, infections : float [N,224,224,1] in [0,1]`` (uint8/255, T1:520, 678,
+soft bilinear-resized labels T1:488).  None of that is on the hot path; here the arrays are
+injected (``.npy``/arrays) or synthesised with the same value structure.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def synthetic_ct(n: int, size: int = 512, seed: int = 0):
+    """x,y float32 [n,size,size,1].  Image = 0.1 background + 4 random 2-D Gaussians + N(0,.02)
+    noise, clipped, quantised to k/255.  Mask = union of 1-3 random ellipses (1-10 % area each),
+    Gaussian-blurred (sigma 1 px) and quantised to k/255 (soft labels like T1:488)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    xs = np.empty((n, size, size, 1), np.float32)
+    ys = np.empty((n, size, size, 1), np.float32)
+    r = np.arange(-3, 4, dtype=np.float32)
+    g1 = np.exp(-0.5 * r * r); g1 /= g1.sum()
+    for i in range(n):
+        img = np.full((size, size), 0.1, np.float32)
+        for _ in range(4):
+            cx, cy = rng.uniform(0.1, 0.9, 2); s = rng.uniform(0.05, 0.3); a = rng.uniform(0.2, 0.8)
+            img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+        img += rng.normal(0, 0.02, img.shape).astype(np.float32)
+        xs[i, :, :, 0] = np.round(np.clip(img, 0, 1) * 255) / 255
+        m = np.zeros((size, size), np.float32)
+        for _ in range(rng.integers(1, 4)):
+            cx, cy = rng.uniform(0.2, 0.8, 2)
+            area = rng.uniform(0.01, 0.10); ratio = rng.uniform(0.5, 2.0)
+            ra = math.sqrt(area * ratio / math.pi); rb = math.sqrt(area / ratio / math.pi)
+            th = rng.uniform(0, math.pi)
+            u = (xx - cx) * math.cos(th) + (yy - cy) * math.sin(th)
+            v = -(xx - cx) * math.sin(th) + (yy - cy) * math.cos(th)
+            m = np.maximum(m, ((u / ra) ** 2 + (v / rb) ** 2 <= 1).astype(np.float32))
+        mp = np.pad(m, 3, mode="edge")                              # separable 7-tap Gaussian blur
+        m = sum(g1[k] * mp[k:k + size, 3:3 + size] for k in range(7))
+        mp = np.pad(m, 3, mode="edge")
+        m = sum(g1[k] * mp[3:3 + size, k:k + size] for k in range(7))
+        ys[i, :, :, 0] = np.round(np.clip(m, 0, 1) * 255) / 255
+    return xs, ys
+
+
+def train_test_split(x, y, test_size: float = 0.3, random_state: int = 42):
+    """sklearn.model_selection.train_test_split(x, y, test_size=0.3, random_state=42) as called
+    at T1:762 -- restated (ShuffleSplit): n_test = ceil(test_size*n); perm = RandomState(seed)
+    .permutation(n); test = perm[:n_test]; train = perm[n_test:].  Returns x_tr, x_va, y_tr, y_va."""
+    n = len(x)
+    n_test = int(math.ceil(test_size * n))
+    n_train = n - n_test
+    if n_train < 1 or n_test < 1:
+        raise ValueError(f"train_test_split: n={n} too small for test_size={test_size}")
+    perm = np.random.RandomState(random_state).permutation(n)
+    te, tr = perm[:n_test], perm[n_test:n_test + n_train]
+    return x[tr], x[te], y[tr], y[te]

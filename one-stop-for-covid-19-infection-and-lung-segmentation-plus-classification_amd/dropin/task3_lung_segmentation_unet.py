@@ -1,0 +1,18 @@
+"""Drop-in for the reference module of the same name (Scripts/task3_lung_segmentation_unet.py:6): exports exactly
+`runner_lung_segmentation`, so the reference's app.py (`from task3_lung_segmentation_unet import *`, app.py:7-12)
+works unchanged with this directory on sys.path.  Import has no side effects."""
+import os as _os, sys as _sys
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+if _ROOT not in _sys.path:
+    _sys.path.insert(0, _ROOT)
+
+__all__ = ["runner_lung_segmentation"]
+
+
+def runner_lung_segmentation(**kw):
+    from covidseg_amd.runners import runner_lung_segmentation as _impl
+    return _impl(**kw)
+
+
+if __name__ == "__main__":
+    runner_lung_segmentation()

@@ -1,0 +1,252 @@
+"""HIP engine: owns the flat parameter / gradient / Adam / workspace buffers (torch-ROCm is
+used ONLY as device allocator, stream owner and process-group bootstrap) and drives the op
+programs of libunet_hip.so.  One process per GPU; gradients and the few batch-global
+reductions (BatchNorm sums, Dice sums) go through torch.distributed (RCCL over xGMI).
+
+Replaces the Keras model object the reference builds at
+task1_preprocessing_plus_unet_with_comments.py:853-916 and trains at T1:1053-1061.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .weights import weight_shapes
+
+ADAM_LR, ADAM_B1, ADAM_B2, ADAM_EPS = 5e-4, 0.9, 0.999, 1e-7     # Adam(lr=0.0005), T1:1053
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class HipUNet:
+    """Backend used by keras_like.UNetModel.  All tensors NHWC fp32 on one MI355X."""
+
+    def __init__(self, h: int, w: int, in_ch: int = 1, device: int | None = None, conv_algo: int = _lib.ALGO_AUTO,
+                 process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.UNetHipError("HipUNet: no GPU visible to torch (torch.cuda.is_available() is False); "
+                                    "the hot path has no CPU fallback")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.dev = torch.device("cuda", self.device_index)
+        self.ctx = _lib.Context.get(self.device_index)
+        self.h, self.w, self.in_ch, self.algo = h, w, in_ch, conv_algo
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        self.sync_bn = sync_bn
+        self.dropout_rate, self.seed, self.lr = float(dropout_rate), int(seed), float(lr)
+        self.step = 0
+        self._plans = {}
+        self._ws = None
+        # flat buffers sized from a probe plan
+        probe = self._create_plan(1)
+        self.n_params = self.lib.unet_model_param_count(probe)
+        self.n_state = self.lib.unet_model_state_count(probe)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.dev)
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.dev)
+        self._tinfo = OrderedDict()
+        for name, shape in weight_shapes(in_ch).items():
+            st, off, cnt = C.c_int32(), C.c_int64(), C.c_int64()
+            self.ctx.check(self.lib.unet_model_tensor_info(probe, name.encode(), C.byref(st), C.byref(off), C.byref(cnt)), "tensor_info")
+            assert cnt.value == int(np.prod(shape)), (name, cnt.value, shape)
+            self._tinfo[name] = (bool(st.value), off.value, cnt.value, shape)
+        self.lib.unet_model_destroy(probe)
+        self._comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+
+    # ------------------------------------------------------------------ plans / buffers
+    def _create_plan(self, n):
+        m = _lib.vp()
+        self.ctx.check(self.lib.unet_model_create(self.ctx.handle, self.in_ch, n, self.h, self.w,
+                                                  self.world if self.sync_bn else 1, self.algo, C.byref(m)), "model_create")
+        return m
+
+    def _plan(self, n: int):
+        torch = _torch()
+        if n not in self._plans:
+            m = self._create_plan(n)
+            need = self.lib.unet_model_workspace_bytes(m, 1)
+            self._plans[n] = {"m": m, "bytes": need, "bound_ws": None}
+        p = self._plans[n]
+        if self._ws is None or self._ws.numel() < p["bytes"]:
+            self._ws = torch.empty(p["bytes"], dtype=torch.uint8, device=self.dev)
+        if p["bound_ws"] != self._ws.data_ptr():
+            self.ctx.check(self.lib.unet_model_bind(p["m"], self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                                    self.adam_v.data_ptr(), self.state.data_ptr(), self._ws.data_ptr(),
+                                                    self._ws.numel()), "model_bind")
+            p["bound_ws"] = self._ws.data_ptr()
+            p["sync"] = {}
+            for prog in (0, 1, 2):
+                cnt = self.lib.unet_model_sync_points(p["m"], prog, None, 0)
+                arr = (_lib.SyncPoint * max(cnt, 1))()
+                self.lib.unet_model_sync_points(p["m"], prog, arr, cnt)
+                p["sync"][prog] = [(arr[i].after_op, arr[i].kind, arr[i].ptr, arr[i].count) for i in range(cnt)]
+        return p
+
+    def _stream(self):
+        return _torch().cuda.current_stream(self.dev).cuda_stream
+
+    def _ws_view_f64(self, ptr, count):
+        off = ptr - self._ws.data_ptr()
+        return self._ws[off:off + 8 * count].view(_torch().float64)
+
+    # ------------------------------------------------------------------ weights
+    def set_weights(self, weights):
+        torch = _torch()
+        for name, (is_state, off, cnt, shape) in self._tinfo.items():
+            a = np.ascontiguousarray(np.asarray(weights[name], np.float32).reshape(-1))
+            assert a.size == cnt, name
+            (self.state if is_state else self.params)[off:off + cnt].copy_(torch.from_numpy(a))
+
+    def get_weights(self):
+        p, s = self.params.cpu().numpy(), self.state.cpu().numpy()
+        return OrderedDict((name, (s if st else p)[off:off + cnt].reshape(shape).copy())
+                           for name, (st, off, cnt, shape) in self._tinfo.items())
+
+    def get_grads(self):
+        g = self.grads.cpu().numpy()
+        return OrderedDict((name, g[off:off + cnt].reshape(shape).copy())
+                           for name, (st, off, cnt, shape) in self._tinfo.items() if not st)
+
+    def reset_optimizer(self):
+        self.adam_m.zero_(); self.adam_v.zero_(); self.step = 0
+
+    # ------------------------------------------------------------------ running programs
+    def _to_dev(self, a):
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            return a.to(self.dev, torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)
+
+    def _run(self, plan, prog, overlap_grads=False):
+        lib, m = self.lib, plan["m"]
+        nops = lib.unet_model_num_ops(m, prog)
+        if self.world == 1:
+            self.ctx.check(lib.unet_model_run(m, prog, 0, nops, self._stream()), "model_run")
+            return
+        import torch.distributed as dist
+        torch = _torch()
+        begin = 0
+        for after_op, kind, ptr, count in plan["sync"][prog]:
+            if kind in (_lib.SYNC_BN_FWD, _lib.SYNC_BN_BWD) and not self.sync_bn:
+                continue
+            if kind == _lib.SYNC_LOSS and not self.sync_bn:
+                continue
+            self.ctx.check(lib.unet_model_run(m, prog, begin, after_op + 1, self._stream()), "model_run")
+            begin = after_op + 1
+            if kind == _lib.SYNC_GRAD_BUCKET:
+                off = (ptr - self.grads.data_ptr()) // 4
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev)
+                    dist.all_reduce(self.grads[off:off + count], op=dist.ReduceOp.SUM, group=self.pg)
+            else:
+                dist.all_reduce(self._ws_view_f64(ptr, count), op=dist.ReduceOp.SUM, group=self.pg)
+        self.ctx.check(lib.unet_model_run(m, prog, begin, nops, self._stream()), "model_run")
+        if prog == _lib.PROG_BWD:
+            torch.cuda.current_stream(self.dev).wait_stream(self._comm_stream)
+
+    def _loss_tensor(self, plan):
+        torch = _torch()
+        ptr = self.lib.unet_model_loss_ptr(plan["m"])
+        off = ptr - self._ws.data_ptr()
+        return self._ws[off:off + 8].view(torch.float32)
+
+    def forward_backward(self, x, y, training_dropout=True):
+        """fwd (training mode) + loss + bwd on one batch; gradients land in self.grads.
+        Returns a device tensor [loss, dice_coeff] (no host sync)."""
+        torch = _torch()
+        xd, yd = self._to_dev(x), self._to_dev(y)
+        n = xd.shape[0]
+        plan = self._plan(n)
+        if not hasattr(self, "_p_train") or self._p_train.numel() != n * self.h * self.w:
+            self._p_train = torch.empty(n * self.h * self.w, dtype=torch.float32, device=self.dev)
+        rate = self.dropout_rate if training_dropout else 0.0
+        self.ctx.check(self.lib.unet_model_set_dropout(plan["m"], rate, self.seed * 1000003 + self.step), "set_dropout")
+        self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr(), self._p_train.data_ptr()), "set_io")
+        self._keep = (xd, yd)
+        self._run(plan, _lib.PROG_FWD_TRAIN)
+        self._run(plan, _lib.PROG_BWD)
+        return self._loss_tensor(plan)
+
+    def adam_step(self):
+        self.step += 1
+        t = self.step
+        lr_t = self.lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+        self.ctx.check(self.lib.unet_adam_keras(self.ctx.handle, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                                self.adam_v.data_ptr(), self.n_params, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1.0,
+                                                self._stream()), "adam")
+
+    def train_batch(self, x, y, training_dropout=True):
+        """One optimizer step (model.fit inner loop, T1:1059).  Returns device tensor [loss, dice]."""
+        out = self.forward_backward(x, y, training_dropout).clone()
+        self.adam_step()
+        return out
+
+    def predict_batch(self, x, y=None):
+        """Inference forward (moving BN stats, no dropout).  Returns (p [n,h,w,1] device tensor,
+        [loss, dice] device tensor or None)."""
+        torch = _torch()
+        xd = self._to_dev(x)
+        n = xd.shape[0]
+        plan = self._plan(n)
+        p = torch.empty((n, self.h, self.w, 1), dtype=torch.float32, device=self.dev)
+        yd = self._to_dev(y) if y is not None else None
+        self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr() if yd is not None else None, p.data_ptr()), "set_io")
+        self._keep = (xd, yd)
+        self._run(plan, _lib.PROG_FWD_INFER)
+        return p, (self._loss_tensor(plan).clone() if yd is not None else None)
+
+    def threshold_sums(self, p, y, thresholds):
+        """[T,3] float64 (sum gt*pr, sum pr, sum gt) with pr = p > t  (sm.metrics, T1:1206-1207)."""
+        torch = _torch()
+        yd = self._to_dev(y)
+        th = torch.tensor(np.asarray(thresholds, np.float32), device=self.dev)
+        out = torch.zeros((len(thresholds), 3), dtype=torch.float64, device=self.dev)
+        self.ctx.check(self.lib.unet_seg_metrics_sweep(self.ctx.handle, p.data_ptr(), yd.data_ptr(), th.data_ptr(), len(thresholds),
+                                                       out.data_ptr(), p.numel(), self._stream()), "metrics_sweep")
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.pg)
+        return out
+
+    def tap(self, n, name, grad=False):
+        """Copy of an intermediate activation / gradient of the last run (tests)."""
+        torch = _torch()
+        plan = self._plan(n)
+        ptr, ld, nn, hh, ww, cc = _lib.vp(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.ctx.check(self.lib.unet_model_tap(plan["m"], name.encode(), int(grad), C.byref(ptr), C.byref(ld), C.byref(nn), C.byref(hh),
+                                               C.byref(ww), C.byref(cc)), f"tap({name})")
+        off = ptr.value - self._ws.data_ptr()
+        pix = nn.value * hh.value * ww.value
+        flat = self._ws[off:off + 4 * ((pix - 1) * ld.value + cc.value)].view(torch.float32)
+        v = torch.as_strided(flat, (pix, cc.value), (ld.value, 1))
+        return v.reshape(nn.value, hh.value, ww.value, cc.value).cpu().numpy()
+
+    def op_profile(self, n, prog):
+        """[(name, flops, bytes, ms, calls)] accumulated while ctx profiling was on."""
+        plan = self._plan(n)
+        out = []
+        for i in range(self.lib.unet_model_num_ops(plan["m"], prog)):
+            nm, fl, by, ms, calls = C.c_char_p(), C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+            self.lib.unet_model_op_info(plan["m"], prog, i, C.byref(nm), C.byref(fl), C.byref(by), C.byref(ms), C.byref(calls))
+            out.append((nm.value.decode(), fl.value, by.value, ms.value, calls.value))
+        return out
+
+    def set_profiling(self, on: bool, n: int | None = None):
+        self.ctx.check(self.lib.unet_ctx_set_profiling(self.ctx.handle, int(on)), "set_profiling")
+        if n is not None:
+            self.lib.unet_model_reset_timers(self._plan(n)["m"])

@@ -1,0 +1,149 @@
+"""Host-side mirror of the Keras surface the reference's runners consume
+(task1_preprocessing_plus_unet_with_comments.py): Model construction T1:853-916,
+``compile`` T1:1053, ``fit`` T1:1059-1061 with two ModelCheckpoint(save_best_only) slots
+T1:1044-1047, ``load_weights``/``save_weights``/``to_json`` T1:1073-1093, ``evaluate`` T1:1101,
+threshold sweeps with segmentation_models metrics T1:1196-1330, ``predict`` T1:1137.
+
+The arithmetic runs in a *backend* (default: engine.HipUNet on an MI355X).  The backend is an
+explicit constructor argument so host logic can be unit-tested; there is no implicit fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import weights as W
+
+SM_SMOOTH = 1e-5
+
+
+def sm_scores(tp, spr, sgt, smooth=SM_SMOOTH):
+    """segmentation_models FScore(beta=1) / IOUScore / Precision / Recall from batch sums
+    (gt is NOT thresholded: soft labels, as in the reference)."""
+    tp, spr, sgt = (np.asarray(a, np.float64) for a in (tp, spr, sgt))
+    fp, fn = spr - tp, sgt - tp
+    return {"dice": (2 * tp + smooth) / (2 * tp + fn + fp + smooth), "iou": (tp + smooth) / (sgt + spr - tp + smooth),
+            "precision": (tp + smooth) / (tp + fp + smooth), "recall": (tp + smooth) / (tp + fn + smooth)}
+
+
+def _host(v):
+    """device tensor / array / tuple -> numpy float64 array"""
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v, np.float64)
+
+
+class History:
+    def __init__(self):
+        self.history = {"loss": [], "dice_coeff": [], "val_loss": [], "val_dice_coeff": []}
+
+
+class UNetModel:
+    def __init__(self, input_size: int = 224, in_ch: int = 1, backend=None, seed: int = 0, **backend_kw):
+        self.h = self.w = int(input_size)
+        self.in_ch = in_ch
+        if backend is None:
+            from .engine import HipUNet                      # raises loudly without GPU / library
+            backend = HipUNet(self.h, self.w, in_ch, seed=seed, **backend_kw)
+        self.backend = backend
+        self.backend.set_weights(W.init_weights(seed, in_ch))
+        self.compiled = False
+        self.verbose = 1
+
+    # --- Keras-shaped surface ---------------------------------------------------------
+    def count_params(self):
+        return W.count_params(self.in_ch)[0]
+
+    def summary(self, print_fn=print):
+        total, train = W.count_params(self.in_ch)
+        for n, k, ci, co in W.layer_table(self.in_ch):
+            print_fn(f"{n:6s} {k:6s} {ci:4d} -> {co:4d}")
+        print_fn(f"Total params: {total:,}\nTrainable params: {train:,}\nNon-trainable params: {total - train:,}")
+
+    def compile(self, lr: float = 0.0005, loss: str = "bce_dice_loss", metrics=("dice_coeff",)):
+        """model.compile(optimizer=Adam(lr), loss=bce_dice_loss, metrics=[dice_coeff]) T1:1053.
+        Re-compiling keeps the weights and resets the optimizer state (as Keras does, T1:1208)."""
+        if loss != "bce_dice_loss":
+            raise ValueError("only bce_dice_loss (T1:797-799) is implemented on the hot path")
+        self.backend.lr = float(lr)
+        self.backend.reset_optimizer()
+        self.compiled = True
+
+    def get_weights(self):
+        return self.backend.get_weights()
+
+    def set_weights(self, w):
+        self.backend.set_weights(w)
+
+    def save_weights(self, path):
+        W.save_weights(path, self.backend.get_weights(), self.in_ch)
+
+    def load_weights(self, path):
+        self.backend.set_weights(W.load_weights(path, self.in_ch))
+
+    def to_json(self):
+        return W.to_json(self.h, self.w, self.in_ch)
+
+    def fit(self, x, y, batch_size=32, epochs=1, validation_data=None, checkpoint_dice=None, checkpoint_loss=None,
+            shuffle=True, shuffle_seed=0, dropout=True):
+        """model.fit(...) T1:1059-1061.  Per epoch: shuffle, bs-`batch_size` steps with a short
+        last batch, loss = sample-weighted mean of batch losses, dice_coeff = mean of per-batch
+        values; then a full validation pass; ModelCheckpoint(save_best_only) on val_dice_coeff
+        (max) and val_loss (min) T1:1046-1047."""
+        assert self.compiled, "call compile() first"
+        hist = History()
+        n = len(x)
+        best_dice, best_loss = -np.inf, np.inf
+        rng = np.random.RandomState(shuffle_seed)
+        for ep in range(epochs):
+            order = rng.permutation(n) if shuffle else np.arange(n)
+            outs, sizes = [], []
+            for i in range(0, n, batch_size):
+                idx = order[i:i + batch_size]
+                outs.append(self.backend.train_batch(x[idx], y[idx], dropout))
+                sizes.append(len(idx))
+            vals = np.stack([_host(o) for o in outs])                     # one host sync per epoch
+            hist.history["loss"].append(float(np.average(vals[:, 0], weights=sizes)))
+            hist.history["dice_coeff"].append(float(vals[:, 1].mean()))
+            line = f"Epoch {ep + 1}/{epochs} - loss: {hist.history['loss'][-1]:.4f} - dice_coeff: {hist.history['dice_coeff'][-1]:.4f}"
+            if validation_data is not None:
+                ev = self.evaluate(validation_data[0], validation_data[1], batch_size=batch_size, verbose=0)
+                hist.history["val_loss"].append(ev["loss"]); hist.history["val_dice_coeff"].append(ev["dice_coeff"])
+                line += f" - val_loss: {ev['loss']:.4f} - val_dice_coeff: {ev['dice_coeff']:.4f}"
+                if checkpoint_dice and ev["dice_coeff"] > best_dice:
+                    if self.verbose:
+                        print(f"\nEpoch {ep + 1:05d}: val_dice_coeff improved from {best_dice:.5f} to {ev['dice_coeff']:.5f}, saving model to {checkpoint_dice}")
+                    best_dice = ev["dice_coeff"]; self.save_weights(checkpoint_dice)
+                if checkpoint_loss and ev["loss"] < best_loss:
+                    if self.verbose:
+                        print(f"\nEpoch {ep + 1:05d}: val_loss improved from {best_loss:.5f} to {ev['loss']:.5f}, saving model to {checkpoint_loss}")
+                    best_loss = ev["loss"]; self.save_weights(checkpoint_loss)
+            if self.verbose:
+                print(line)
+        return hist
+
+    def evaluate(self, x, y, batch_size=32, thresholds=None, verbose=0):
+        """model.evaluate T1:1101: loss = sample-weighted mean over batches; every metric = mean of
+        the per-batch values.  With `thresholds`, ONE forward pass per batch feeds all thresholds
+        (the reference re-compiles and re-runs evaluate per threshold, T1:1205-1211)."""
+        losses, dices, sizes, per_batch = [], [], [], []
+        for i in range(0, len(x), batch_size):
+            xb, yb = x[i:i + batch_size], y[i:i + batch_size]
+            p, ld = self.backend.predict_batch(xb, yb)
+            losses.append(ld); sizes.append(len(xb))
+            if thresholds is not None and len(thresholds):
+                per_batch.append(self.backend.threshold_sums(p, yb, thresholds))
+        vals = np.stack([_host(v) for v in losses])
+        out = {"loss": float(np.average(vals[:, 0], weights=sizes)), "dice_coeff": float(vals[:, 1].mean())}
+        if per_batch:
+            sc = [sm_scores(s[:, 0], s[:, 1], s[:, 2]) for s in (_host(b) for b in per_batch)]
+            for k in ("dice", "iou", "precision", "recall"):
+                out[k] = np.mean([b[k] for b in sc], axis=0)
+        return out
+
+    def predict(self, x, batch_size=32):
+        """model.predict T1:1137."""
+        outs = []
+        for i in range(0, len(x), batch_size):
+            p, _ = self.backend.predict_batch(x[i:i + batch_size])
+            outs.append(p)
+        return np.concatenate([(_o.detach().cpu().numpy() if hasattr(_o, "detach") else np.asarray(_o)) for _o in outs], 0)

@@ -1,0 +1,132 @@
+"""Weight table of the U-Net in Keras order/layouts, initialisers, and (de)serialisation.
+
+Mirrors what the reference gets from Keras for the model built at
+task1_preprocessing_plus_unet_with_comments.py:853-916:  model.get_weights() order,
+``save_weights`` / ``load_weights`` (T1:1073, 1079) and ``to_json`` (T1:1091-1093).
+h5py is not available in this image, so the on-disk container is ``.npz`` keyed by the Keras
+layer/weight names (``conv2d_3/kernel:0`` ...) -- file names ending in .h5/.hdf5 are accepted
+and written as npz so the reference's filenames keep working.
+"""
+from __future__ import annotations
+
+import json
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+ENC = (32, 64, 128, 256)
+DEC = (256, 128, 64, 32)
+
+
+def layer_table(in_ch: int = 1):
+    """[(name, kind, cin, cout)], kind in conv3|convT|bn|conv1 -- Keras creation order."""
+    t, cp = [], in_ch
+    for k, c in enumerate(ENC, 1):
+        t += [(f"c{k}a", "conv3", cp, c), (f"c{k}b", "conv3", c, c), (f"bn{k}", "bn", c, c)]
+        cp = c
+    t += [("c5a", "conv3", 256, 512), ("c5b", "conv3", 512, 512)]
+    cp = 512
+    for k, c in zip((6, 7, 8, 9), DEC):
+        t += [(f"u{k}", "convT", cp, c), (f"bn{k}", "bn", 2 * c, 2 * c), (f"c{k}a", "conv3", 2 * c, c), (f"c{k}b", "conv3", c, c)]
+        cp = c
+    t.append(("out", "conv1", 32, 1))
+    return t
+
+
+def weight_shapes(in_ch: int = 1):
+    d = OrderedDict()
+    for name, kind, cin, cout in layer_table(in_ch):
+        if kind == "conv3":
+            d[f"{name}/kernel"] = (3, 3, cin, cout); d[f"{name}/bias"] = (cout,)
+        elif kind == "conv1":
+            d[f"{name}/kernel"] = (1, 1, cin, cout); d[f"{name}/bias"] = (cout,)
+        elif kind == "convT":
+            d[f"{name}/kernel"] = (2, 2, cout, cin); d[f"{name}/bias"] = (cout,)
+        else:
+            for p in ("gamma", "beta", "mean", "var"):
+                d[f"{name}/{p}"] = (cout,)
+    return d
+
+
+def keras_names(in_ch: int = 1):
+    """our name -> Keras auto-name (conv2d_N/kernel:0 ...), counting per layer type in creation order."""
+    out, nc, nt, nb = OrderedDict(), 0, 0, 0
+    for name, kind, _, _ in layer_table(in_ch):
+        if kind in ("conv3", "conv1"):
+            nc += 1; base = f"conv2d_{nc}"
+            out[f"{name}/kernel"] = f"{base}/kernel:0"; out[f"{name}/bias"] = f"{base}/bias:0"
+        elif kind == "convT":
+            nt += 1; base = f"conv2d_transpose_{nt}"
+            out[f"{name}/kernel"] = f"{base}/kernel:0"; out[f"{name}/bias"] = f"{base}/bias:0"
+        else:
+            nb += 1; base = f"batch_normalization_{nb}"
+            for p, kp in (("gamma", "gamma"), ("beta", "beta"), ("mean", "moving_mean"), ("var", "moving_variance")):
+                out[f"{name}/{p}"] = f"{base}/{kp}:0"
+    return out
+
+
+def count_params(in_ch: int = 1):
+    sh = weight_shapes(in_ch)
+    total = sum(int(np.prod(s)) for s in sh.values())
+    non_train = sum(int(np.prod(s)) for k, s in sh.items() if k.endswith("/mean") or k.endswith("/var"))
+    return total, total - non_train
+
+
+def _truncated_normal(rng, shape):
+    k = rng.standard_normal(shape)
+    bad = np.abs(k) > 2.0
+    while bad.any():
+        k[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(k) > 2.0
+    return k
+
+
+def init_weights(seed: int = 0, in_ch: int = 1):
+    """he_normal for the 3x3 convs (T1:859...), Keras-default glorot_uniform for ConvT / head,
+    zero biases, BN gamma 1 / beta 0 / moving mean 0 / moving var 1."""
+    rng = np.random.default_rng(seed)
+    w = OrderedDict()
+    for name, kind, cin, cout in layer_table(in_ch):
+        if kind == "conv3":
+            std = math.sqrt(2.0 / (9 * cin)) / 0.87962566103423978
+            w[f"{name}/kernel"] = (_truncated_normal(rng, (3, 3, cin, cout)) * std).astype(np.float32)
+            w[f"{name}/bias"] = np.zeros(cout, np.float32)
+        elif kind == "conv1":
+            lim = math.sqrt(6.0 / (cin + cout))
+            w[f"{name}/kernel"] = rng.uniform(-lim, lim, (1, 1, cin, cout)).astype(np.float32)
+            w[f"{name}/bias"] = np.zeros(cout, np.float32)
+        elif kind == "convT":
+            lim = math.sqrt(6.0 / (4 * cout + 4 * cin))
+            w[f"{name}/kernel"] = rng.uniform(-lim, lim, (2, 2, cout, cin)).astype(np.float32)
+            w[f"{name}/bias"] = np.zeros(cout, np.float32)
+        else:
+            w[f"{name}/gamma"] = np.ones(cout, np.float32); w[f"{name}/beta"] = np.zeros(cout, np.float32)
+            w[f"{name}/mean"] = np.zeros(cout, np.float32); w[f"{name}/var"] = np.ones(cout, np.float32)
+    return w
+
+
+def save_weights(path: str, weights, in_ch: int = 1):
+    kn = keras_names(in_ch)
+    with open(path, "wb") as f:          # keep the caller's filename (.hdf5/.h5) -- content is npz
+        np.savez(f, **{kn[k]: np.asarray(v) for k, v in weights.items()})
+
+
+def load_weights(path: str, in_ch: int = 1):
+    kn = keras_names(in_ch)
+    z = np.load(path)
+    sh = weight_shapes(in_ch)
+    out = OrderedDict()
+    for k, shape in sh.items():
+        a = z[kn[k]]
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{path}: {kn[k]} has shape {a.shape}, expected {shape}")
+        out[k] = a.astype(np.float32)
+    return out
+
+
+def to_json(h: int, w: int, in_ch: int = 1) -> str:
+    """Architecture description (the reference dumps model.to_json(), T1:1091-1093)."""
+    layers = [{"name": n, "kind": k, "cin": ci, "cout": co} for n, k, ci, co in layer_table(in_ch)]
+    return json.dumps({"class_name": "Model", "backend": "unet_hip/gfx950", "input_shape": [h, w, in_ch],
+                       "data_format": "channels_last", "layers": layers, "keras_names": keras_names(in_ch)})

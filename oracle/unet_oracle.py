@@ -1,0 +1,350 @@
+"""CPU oracle for the U-Net segmentation hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (torch-CPU / NumPy, fp32 or fp64) of the arithmetic the
+reference executes on its hot path.  It is the *checker* for the HIP engine.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it; the product package never does (it fails loudly without the HIP library).
+
+Reference citations (paths relative to /root/reference/Scripts/):
+  T1 = task1_preprocessing_plus_unet_with_comments.py, T3 = task3_lung_segmentation_unet.py
+
+  graph ............ T1:853-916  (== T3:850-913)
+  dice_coeff ....... T1:784-790      dice_loss T1:792-794     bce_dice_loss T1:797-799
+  BCE arithmetic ... keras.losses.binary_crossentropy (imported T1:60); the identical
+                     logit-form expression is spelled out in the reference's own
+                     weighted_bce_loss T1:819-825
+  compile / fit .... T1:1053, T1:1059-1061 (Adam(lr=5e-4), bs 32, epochs 80)
+  evaluate ......... T1:1101;  threshold sweeps T1:1196-1221, 1250-1281, 1304-1330
+
+PARITY STATUS.  The loss / metric closures (dice_coeff, dice_loss, weighted_bce_loss) are
+PINNED: ``tests/golden/make_loss_goldens.py`` AST-extracts them from the reference source,
+executes them against a NumPy ``K`` shim in the build container and commits input/output
+vectors (tests/golden/loss_goldens.npz) that this oracle must reproduce.
+Everything else -- Conv2D / BatchNormalization / MaxPooling2D / Dropout / Conv2DTranspose /
+Adam / fit / evaluate / segmentation_models metrics -- lives in third-party packages that
+are neither vendored under /root/reference nor installable here (keras ~2.3.x on
+tensorflow 2.2.0, segmentation_models 1.0.x; versions un-pinned by the reference).  For
+those the oracle restates the libraries' documented semantics:
+**parity unpinned** w.r.t. the un-versioned dependencies; cross-checked here against
+``torch.nn.functional`` and analytic known answers only.
+
+Layouts follow Keras ``channels_last``: activations [N,H,W,C]; Conv2D kernel [kh,kw,Cin,Cout];
+Conv2DTranspose kernel [kh,kw,Cout,Cin]; BN weights gamma, beta, moving_mean, moving_variance.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3          # keras BatchNormalization default epsilon
+BN_MOMENTUM = 0.99     # keras BatchNormalization default momentum
+DROPOUT_RATE = 0.25    # T1:863
+ADAM_LR, ADAM_B1, ADAM_B2, ADAM_EPS = 5e-4, 0.9, 0.999, 1e-7   # T1:1053 + keras defaults
+BCE_EPS = 1e-7         # keras.backend.epsilon()
+SM_SMOOTH = 1e-5       # segmentation_models metric smooth default
+
+# ---------------------------------------------------------------------------------------
+# Graph description, T1:853-916.  Names: cKa/cKb 3x3 convs of block K, bnK, uK = ConvT.
+# Order == Keras layer-creation order == model.get_weights() order.
+# ---------------------------------------------------------------------------------------
+ENC = [32, 64, 128, 256]
+
+
+def layer_table(in_ch: int = 1):
+    """[(name, kind, cin, cout)] in Keras creation order (T1:859-913)."""
+    t = []
+    c_prev = in_ch
+    for k, c in enumerate(ENC, start=1):                       # T1:859-881
+        t += [(f"c{k}a", "conv3", c_prev, c), (f"c{k}b", "conv3", c, c), (f"bn{k}", "bn", c, c)]
+        c_prev = c
+    t += [("c5a", "conv3", 256, 512), ("c5b", "conv3", 512, 512)]   # T1:883-884
+    c_prev = 512
+    for k, c in zip([6, 7, 8, 9], [256, 128, 64, 32]):          # T1:886-911
+        t += [(f"u{k}", "convT", c_prev, c), (f"bn{k}", "bn", 2 * c, 2 * c),
+              (f"c{k}a", "conv3", 2 * c, c), (f"c{k}b", "conv3", c, c)]
+        c_prev = c
+    t += [("out", "conv1", 32, 1)]                              # T1:913
+    return t
+
+
+def weight_shapes(in_ch: int = 1):
+    """OrderedDict name -> shape, Keras layouts; 'X/kernel','X/bias','bnK/gamma|beta|mean|var'."""
+    d = OrderedDict()
+    for name, kind, cin, cout in layer_table(in_ch):
+        if kind == "conv3":
+            d[name + "/kernel"] = (3, 3, cin, cout); d[name + "/bias"] = (cout,)
+        elif kind == "conv1":
+            d[name + "/kernel"] = (1, 1, cin, cout); d[name + "/bias"] = (cout,)
+        elif kind == "convT":
+            d[name + "/kernel"] = (2, 2, cout, cin); d[name + "/bias"] = (cout,)
+        else:
+            for p in ("gamma", "beta", "mean", "var"):
+                d[f"{name}/{p}"] = (cout,)
+    return d
+
+
+def trainable_names(in_ch: int = 1):
+    return [k for k in weight_shapes(in_ch) if not (k.endswith("/mean") or k.endswith("/var"))]
+
+
+def count_params(in_ch: int = 1):
+    total = sum(int(np.prod(s)) for s in weight_shapes(in_ch).values())
+    train = sum(int(np.prod(weight_shapes(in_ch)[k])) for k in trainable_names(in_ch))
+    return total, train
+
+
+def init_weights(seed: int = 0, in_ch: int = 1, dtype=np.float32):
+    """Keras initialisers: he_normal (truncated normal, +-2 sigma,
+    sigma = sqrt(2/fan_in)/0.87962566) for the 3x3 convs (T1:859...), glorot_uniform for ConvT
+    and the 1x1 head (Keras default), zero biases, BN gamma=1 beta=0 mean=0 var=1."""
+    rng = np.random.default_rng(seed)
+    w = OrderedDict()
+    for name, kind, cin, cout in layer_table(in_ch):
+        if kind == "conv3":
+            fan_in = 9 * cin
+            std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+            k = rng.standard_normal((3, 3, cin, cout))
+            bad = np.abs(k) > 2.0
+            while bad.any():                                      # resample the tails
+                k[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(k) > 2.0
+            w[name + "/kernel"] = (k * std).astype(dtype)
+            w[name + "/bias"] = np.zeros(cout, dtype)
+        elif kind == "conv1":
+            lim = math.sqrt(6.0 / (cin + cout))
+            w[name + "/kernel"] = rng.uniform(-lim, lim, (1, 1, cin, cout)).astype(dtype)
+            w[name + "/bias"] = np.zeros(cout, dtype)
+        elif kind == "convT":
+            # keras fan computation for a [kh,kw,Cout,Cin] kernel: receptive=4, fan_in=4*Cout, fan_out=4*Cin
+            lim = math.sqrt(6.0 / (4 * cout + 4 * cin))
+            w[name + "/kernel"] = rng.uniform(-lim, lim, (2, 2, cout, cin)).astype(dtype)
+            w[name + "/bias"] = np.zeros(cout, dtype)
+        else:
+            w[name + "/gamma"] = np.ones(cout, dtype); w[name + "/beta"] = np.zeros(cout, dtype)
+            w[name + "/mean"] = np.zeros(cout, dtype); w[name + "/var"] = np.ones(cout, dtype)
+    return w
+
+
+# ---------------------------------------------------------------------------------------
+# Single ops (NHWC numpy/torch in, NHWC torch out).  Internally NCHW for torch functional.
+# ---------------------------------------------------------------------------------------
+def _t(a, dtype):
+    return a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a), dtype=dtype)
+
+
+def conv3x3_bias_relu(x, kernel, bias, relu=True):
+    """Conv2D(C,(3,3),'relu','same') T1:859: cross-correlation, zero pad 1, +bias, ReLU."""
+    y = F.conv2d(x.permute(0, 3, 1, 2), kernel.permute(3, 2, 0, 1), bias, padding=1)
+    y = y.permute(0, 2, 3, 1)
+    return torch.relu(y) if relu else y
+
+
+def conv1x1_sigmoid(x, kernel, bias):
+    """Conv2D(1,(1,1),'sigmoid') T1:913."""
+    z = torch.tensordot(x, kernel[0, 0], dims=([3], [0])) + bias
+    return torch.sigmoid(z)
+
+
+def batchnorm(x, gamma, beta, mean, var, training):
+    """BatchNormalization() T1:861: training -> biased batch statistics over (N,H,W);
+    returns (y, batch_mean, batch_var_biased).  Inference -> moving statistics."""
+    if training:
+        mu = x.mean(dim=(0, 1, 2))
+        va = ((x - mu) ** 2).mean(dim=(0, 1, 2))
+    else:
+        mu, va = mean, var
+    y = (x - mu) / torch.sqrt(va + BN_EPS) * gamma + beta
+    return y, mu, va
+
+
+def bn_moving_update(mean, var, mu, va, n):
+    """keras: moving = moving*momentum + batch*(1-momentum); variance uses n/(n-1) (TF fused BN)."""
+    new_mean = mean * BN_MOMENTUM + mu * (1 - BN_MOMENTUM)
+    new_var = var * BN_MOMENTUM + va * (n / max(n - 1.0, 1.0)) * (1 - BN_MOMENTUM)
+    return new_mean, new_var
+
+
+def maxpool2x2(x):
+    """MaxPooling2D((2,2)) T1:862: stride 2, 'valid'; ties -> first in row-major (di,dj)."""
+    return F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+
+
+def dropout(x, keep_mask, rate=DROPOUT_RATE):
+    """Dropout(0.25) T1:863, inverted: y = x*mask/(1-rate).  keep_mask None -> identity."""
+    if keep_mask is None:
+        return x
+    return x * keep_mask * (1.0 / (1.0 - rate))
+
+
+def convT2x2s2_bias(x, kernel, bias):
+    """Conv2DTranspose(C,(2,2),strides=(2,2),'same') T1:886:
+    u[n,2i+a,2j+b,o] = bias[o] + sum_c x[n,i,j,c]*K[a,b,o,c]."""
+    y = F.conv_transpose2d(x.permute(0, 3, 1, 2), kernel.permute(3, 2, 0, 1), bias, stride=2)
+    return y.permute(0, 2, 3, 1)
+
+
+def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False):
+    """Whole graph T1:853-916.  weights: dict name->array/tensor.  x: [N,H,W,Cin].
+    keep_masks: None (dropout off / inference) or dict 'p1'..'p4' -> {0,1} arrays of the
+    pooled shapes.  Returns (p, acts, bn_batch_stats)."""
+    W = {k: _t(v, dtype) for k, v in weights.items()}
+    a = OrderedDict()
+    stats = OrderedDict()
+    h = _t(x, dtype)
+    skips = {}
+    for k in (1, 2, 3, 4):                                                   # T1:859-881
+        h = conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]); a[f"c{k}a"] = h
+        h = conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]); a[f"c{k}b"] = h
+        h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
+        a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
+        skips[k] = h
+        h = maxpool2x2(h)
+        if training and keep_masks is not None:
+            h = dropout(h, _t(keep_masks[f"p{k}"], dtype))
+        a[f"p{k}"] = h
+    h = conv3x3_bias_relu(h, W["c5a/kernel"], W["c5a/bias"]); a["c5a"] = h    # T1:883-884
+    h = conv3x3_bias_relu(h, W["c5b/kernel"], W["c5b/bias"]); a["c5b"] = h
+    for k, sk in zip((6, 7, 8, 9), (4, 3, 2, 1)):                            # T1:886-911
+        u = convT2x2s2_bias(h, W[f"u{k}/kernel"], W[f"u{k}/bias"]); a[f"u{k}"] = u
+        h = torch.cat([u, skips[sk]], dim=3)                                 # [up, skip]
+        h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
+        a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
+        h = conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]); a[f"c{k}a"] = h
+        h = conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]); a[f"c{k}b"] = h
+    p = conv1x1_sigmoid(h, W["out/kernel"], W["out/bias"])                   # T1:913
+    a["out"] = p
+    return (p, a, stats) if want_acts else (p, None, stats)
+
+
+# ---------------------------------------------------------------------------------------
+# Loss / metrics
+# ---------------------------------------------------------------------------------------
+def dice_coeff(y_true, y_pred):
+    """T1:784-790: (2*sum(t*p)+1)/(sum(t)+sum(p)+1) over ALL elements of the batch."""
+    inter = (y_true * y_pred).sum()
+    return (2.0 * inter + 1.0) / (y_true.sum() + y_pred.sum() + 1.0)
+
+
+def binary_crossentropy_mean(y_true, y_pred):
+    """keras binary_crossentropy on probabilities, then Keras' mean over everything.
+    clip -> logit -> max(z,0) - z*t + log(1+exp(-|z|))  (same algebra as T1:819-825)."""
+    p = torch.clamp(y_pred, BCE_EPS, 1.0 - BCE_EPS)
+    z = torch.log(p / (1.0 - p))
+    l = torch.clamp(z, min=0) - z * y_true + torch.log1p(torch.exp(-torch.abs(z)))
+    return l.mean()
+
+
+def bce_dice_loss(y_true, y_pred):
+    """T1:797-799: 0.5*BCE + 0.5*(1-dice)."""
+    return 0.5 * binary_crossentropy_mean(y_true, y_pred) + 0.5 * (1.0 - dice_coeff(y_true, y_pred))
+
+
+def threshold_sums(y_true, y_pred, thresholds):
+    """segmentation_models building blocks: pr=(p>t); tp=sum(gt*pr); sum(pr); sum(gt) (gt soft)."""
+    gt = np.asarray(y_true, np.float64).ravel()
+    p = np.asarray(y_pred).ravel()
+    out = np.zeros((len(thresholds), 3), np.float64)
+    for i, t in enumerate(thresholds):
+        pr = (p > np.float32(t)).astype(np.float64)
+        out[i] = ((gt * pr).sum(), pr.sum(), gt.sum())
+    return out
+
+
+def sm_scores(tp, spr, sgt, smooth=SM_SMOOTH):
+    """segmentation_models 1.0 FScore(beta=1) / IOUScore / Precision / Recall from the sums."""
+    fp, fn = spr - tp, sgt - tp
+    return {
+        "dice": (2 * tp + smooth) / (2 * tp + fn + fp + smooth),
+        "iou": (tp + smooth) / (sgt + spr - tp + smooth),
+        "precision": (tp + smooth) / (tp + fp + smooth),
+        "recall": (tp + smooth) / (tp + fn + smooth),
+    }
+
+
+# ---------------------------------------------------------------------------------------
+# Training step (fwd -> loss -> autograd bwd -> Keras-form Adam) and evaluation
+# ---------------------------------------------------------------------------------------
+def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False):
+    """One training-mode fwd + bwd.  Returns dict(loss, dice, grads{name}, bn_stats, p[, acts, act_grads])."""
+    names = trainable_names(np.asarray(x).shape[-1])
+    W = {k: _t(v, dtype).clone() for k, v in weights.items()}
+    for k in names:
+        W[k].requires_grad_(True)
+    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=True)
+    t = _t(y, dtype)
+    loss = bce_dice_loss(t, p)
+    dice = dice_coeff(t, p)
+    if want_acts:
+        for v in acts.values():
+            v.retain_grad()
+    loss.backward()
+    out = dict(loss=float(loss.detach()), dice=float(dice.detach()), p=p.detach().numpy(),
+               grads={k: W[k].grad.numpy() for k in names},
+               bn_stats={k: (m.detach().numpy(), v.detach().numpy(), n) for k, (m, v, n) in stats.items()})
+    if want_acts:
+        out["acts"] = {k: v.detach().numpy() for k, v in acts.items()}
+        out["act_grads"] = {k: (v.grad.numpy() if v.grad is not None else None) for k, v in acts.items()}
+    return out
+
+
+def adam_keras(params, grads, m, v, t, lr=ADAM_LR, b1=ADAM_B1, b2=ADAM_B2, eps=ADAM_EPS):
+    """Keras-2.3 Adam (T1:1053): t is the 1-based step AFTER increment.
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps).  In place."""
+    lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    for k in grads:
+        g = grads[k].astype(params[k].dtype)
+        m[k] = b1 * m[k] + (1 - b1) * g
+        v[k] = b2 * v[k] + (1 - b2) * g * g
+        params[k] = (params[k] - lr_t * m[k] / (np.sqrt(v[k]) + eps)).astype(params[k].dtype)
+
+
+class OracleTrainer:
+    """Stateful fwd/bwd/Adam on CPU: the reference's model.compile + train_on_batch."""
+
+    def __init__(self, weights, dtype=torch.float32):
+        self.w = OrderedDict((k, np.array(v)) for k, v in weights.items())
+        self.dtype = dtype
+        self.in_ch = self.w["c1a/kernel"].shape[2]
+        self.m = {k: np.zeros_like(self.w[k]) for k in trainable_names(self.in_ch)}
+        self.v = {k: np.zeros_like(self.w[k]) for k in trainable_names(self.in_ch)}
+        self.t = 0
+
+    def train_step(self, x, y, keep_masks=None):
+        r = loss_and_grads(self.w, x, y, keep_masks, self.dtype)
+        for k, (mu, va, n) in r["bn_stats"].items():
+            nm, nv = bn_moving_update(self.w[k + "/mean"], self.w[k + "/var"], mu, va, n)
+            self.w[k + "/mean"] = nm.astype(self.w[k + "/mean"].dtype)
+            self.w[k + "/var"] = nv.astype(self.w[k + "/var"].dtype)
+        self.t += 1
+        adam_keras(self.w, r["grads"], self.m, self.v, self.t)
+        return r["loss"], r["dice"]
+
+    def predict(self, x, batch_size=32):
+        outs = []
+        with torch.no_grad():
+            for i in range(0, len(x), batch_size):
+                outs.append(forward(self.w, x[i:i + batch_size], training=False, dtype=self.dtype)[0].numpy())
+        return np.concatenate(outs, 0)
+
+    def evaluate(self, x, y, batch_size=32, thresholds=()):
+        """model.evaluate (T1:1101): loss sample-weighted over batches; metrics = mean of the
+        per-batch values (Keras stateful-metric Mean).  Also per-threshold sm metrics."""
+        losses, dices, ns, per_t = [], [], [], []
+        with torch.no_grad():
+            for i in range(0, len(x), batch_size):
+                xb, yb = x[i:i + batch_size], y[i:i + batch_size]
+                p = forward(self.w, xb, training=False, dtype=self.dtype)[0]
+                t = _t(yb, self.dtype)
+                losses.append(float(bce_dice_loss(t, p))); dices.append(float(dice_coeff(t, p))); ns.append(len(xb))
+                if len(thresholds):
+                    s = threshold_sums(yb, p.numpy(), thresholds)
+                    per_t.append({k: v for k, v in sm_scores(s[:, 0], s[:, 1], s[:, 2]).items()})
+        out = dict(loss=float(np.average(losses, weights=ns)), dice_coeff=float(np.mean(dices)))
+        if len(thresholds):
+            for k in ("dice", "iou", "precision", "recall"):
+                out[k] = np.mean([b[k] for b in per_t], axis=0)
+        return out

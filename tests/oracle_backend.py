@@ -1,0 +1,46 @@
+"""Test-only backend: plugs the CPU oracle into keras_like.UNetModel so the HOST logic
+(fit / evaluate / checkpoints / runners) can be exercised without a GPU.  Never shipped."""
+import numpy as np
+
+from oracle import unet_oracle as O
+
+
+class OracleBackend:
+    def __init__(self, h, w, in_ch=1, dtype=None):
+        import torch
+        self.h, self.w, self.in_ch = h, w, in_ch
+        self.dtype = dtype or torch.float32
+        self.lr = O.ADAM_LR
+        self.tr = None
+
+    def set_weights(self, w):
+        if self.tr is None:
+            self.tr = O.OracleTrainer(w, self.dtype)
+        else:
+            for k in self.tr.w:
+                self.tr.w[k] = np.array(w[k], dtype=self.tr.w[k].dtype)
+
+    def get_weights(self):
+        return {k: np.array(v) for k, v in self.tr.w.items()}
+
+    def reset_optimizer(self):
+        for k in self.tr.m:
+            self.tr.m[k][...] = 0; self.tr.v[k][...] = 0
+        self.tr.t = 0
+
+    def train_batch(self, x, y, training_dropout=True):
+        assert abs(self.lr - O.ADAM_LR) < 1e-12
+        return np.array(self.tr.train_step(x, y, None))
+
+    def predict_batch(self, x, y=None):
+        import torch
+        with torch.no_grad():
+            p = O.forward(self.tr.w, x, training=False, dtype=self.dtype)[0]
+            ld = None
+            if y is not None:
+                t = torch.as_tensor(np.asarray(y), dtype=self.dtype)
+                ld = np.array([float(O.bce_dice_loss(t, p)), float(O.dice_coeff(t, p))])
+        return p.numpy(), ld
+
+    def threshold_sums(self, p, y, thresholds):
+        return O.threshold_sums(y, p, thresholds)

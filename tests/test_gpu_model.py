@@ -1,0 +1,173 @@
+"""-m gpu: the whole U-Net (fwd / loss / bwd / Adam / evaluate / predict) on the MI355X against
+(1) the committed golden fixture (tests/golden/model_goldens.npz, fp64 oracle) and (2) the oracle run
+live on the same seeded inputs.  Bar (BASELINE.json): Dice/IoU within 1e-3; we hold fp32-level
+tolerances that are far tighter and written next to each check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def make(h, w=None, **kw):
+    from covidseg_amd.engine import HipUNet
+    return HipUNet(h, w or h, 1, **kw)
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+def test_golden_fixture_fwd_bwd(algo):
+    from covidseg_amd.data import synthetic_ct
+    z = np.load(os.path.join(HERE, "golden", "model_goldens.npz"))
+    w = O.init_weights(seed=123); x, y = synthetic_ct(3, 32, seed=7)
+    assert abs(sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values()) - float(z["w_checksum"])) < 1e-6 * float(z["w_checksum"])
+    assert float(x.astype(np.float64).sum()) == float(z["x_sum"]) and float(y.astype(np.float64).sum()) == float(z["y_sum"])
+    eng = make(32, conv_algo=algo, dropout_rate=0.0)
+    eng.set_weights(w)
+    ld = eng.forward_backward(x, y).cpu().numpy()
+    assert abs(ld[0] - float(z["loss"])) < 1e-5 and abs(ld[1] - float(z["dice"])) < 1e-5          # loss, dice_coeff
+    assert np.abs(eng._p_train.cpu().numpy().reshape(z["p"].shape) - z["p"]).max() < 1e-5         # probabilities
+    g = eng.get_grads()
+    for k in g:
+        assert abs(np.linalg.norm(g[k]) - float(z["gnorm/" + k])) <= 2e-4 * float(z["gnorm/" + k]) + 1e-9, k
+    for k in ("c1a/kernel", "out/kernel", "bn1/gamma", "u9/bias", "c9b/bias"):
+        assert relerr(g[k], z["grad/" + k]) < 2e-4, k
+    # inference forward + thresholded sums
+    eng.set_weights(w)
+    p, _ = eng.predict_batch(x, y)
+    assert np.abs(p.cpu().numpy() - z["p_infer"]).max() < 1e-5
+    s = eng.threshold_sums(p, y, z["thresholds"]).cpu().numpy()
+    sc_g = O.sm_scores(s[:, 0], s[:, 1], s[:, 2]); sc_w = O.sm_scores(z["thr_sums"][:, 0], z["thr_sums"][:, 1], z["thr_sums"][:, 2])
+    for k in ("dice", "iou", "precision", "recall"):
+        assert np.abs(sc_g[k] - sc_w[k]).max() < 1e-3                                               # BASELINE bar
+    # three optimizer steps
+    eng.set_weights(w); eng.reset_optimizer()
+    traj = np.array([eng.train_batch(x, y).cpu().numpy() for _ in range(3)])
+    assert np.abs(traj - z["traj"]).max() < 2e-4
+    wa = eng.get_weights()
+    assert relerr(wa["out/kernel"], z["w_after/out/kernel"]) < 1e-3 and relerr(wa["bn1/mean"], z["w_after/bn1/mean"]) < 1e-4
+
+
+@pytest.mark.parametrize("hw,n", [((64, 48), 2), ((16, 16), 5)])
+def test_live_oracle_all_grads_and_taps(hw, n):
+    h, w_ = hw
+    rng = np.random.default_rng(h)
+    wts = O.init_weights(seed=h)
+    for k in wts:                                                   # non-trivial biases / BN params
+        if k.endswith("/bias") or k.endswith("/beta"):
+            wts[k] = (rng.standard_normal(wts[k].shape) * 0.1).astype(np.float32)
+        if k.endswith("/gamma"):
+            wts[k] = rng.uniform(0.5, 1.5, wts[k].shape).astype(np.float32)
+    x = rng.random((n, h, w_, 1)).astype(np.float32)
+    y = (np.round(rng.random((n, h, w_, 1)) ** 4 * 255) / 255).astype(np.float32)
+    r = O.loss_and_grads(wts, x, y, dtype=torch.float64, want_acts=True)
+    eng = make(h, w_, dropout_rate=0.0)
+    eng.set_weights(wts)
+    ld = eng.forward_backward(x, y).cpu().numpy()
+    assert abs(ld[0] - r["loss"]) < 1e-5 and abs(ld[1] - r["dice"]) < 1e-5
+    for name in ("c1a", "c1b", "bn1", "p1", "c3b", "bn4", "p4", "c5b", "u6", "bn6", "c6a", "u9", "bn9", "c9b"):
+        assert relerr(eng.tap(n, name), r["acts"][name]) < 2e-5, name
+    # gradients wrt activations (ours are already ReLU-masked where the producer is a ReLU conv)
+    for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c5b", True), ("p4", False), ("bn4", False), ("c4b", True), ("c1a", True)):
+        want = r["act_grads"][name] * ((r["acts"][name] > 0) if masked else 1.0)
+        assert relerr(eng.tap(n, name, grad=True), want) < 2e-4, name
+    g = eng.get_grads()
+    for k in g:
+        assert relerr(g[k], r["grads"][k]) < 3e-4, k
+
+
+def test_training_trajectory_and_bn_state_live():
+    rng = np.random.default_rng(3)
+    wts = O.init_weights(seed=5)
+    x = rng.random((4, 32, 32, 1)).astype(np.float32); y = (rng.random((4, 32, 32, 1)) > 0.8).astype(np.float32)
+    tr = O.OracleTrainer({k: v.astype(np.float64) for k, v in wts.items()}, torch.float64)
+    eng = make(32, dropout_rate=0.0)
+    eng.set_weights(wts)
+    for step in range(4):
+        a = eng.train_batch(x, y).cpu().numpy(); b = tr.train_step(x, y)
+        assert abs(a[0] - b[0]) < 3e-4 and abs(a[1] - b[1]) < 3e-4, (step, a, b)
+    wa = eng.get_weights()
+    for k in ("bn1/mean", "bn1/var", "bn6/mean", "bn9/var"):
+        assert relerr(wa[k], tr.w[k]) < 1e-4, k
+
+
+def test_dropout_training_matches_oracle_with_same_masks():
+    rng = np.random.default_rng(11)
+    wts = O.init_weights(seed=9)
+    n = 2
+    x = rng.random((n, 32, 32, 1)).astype(np.float32); y = (rng.random((n, 32, 32, 1)) > 0.7).astype(np.float32)
+    eng = make(32, dropout_rate=0.25, seed=77)
+    eng.set_weights(wts)
+    ld = eng.forward_backward(x, y, training_dropout=True).cpu().numpy()
+    masks = {f"p{k}": (eng.tap(n, f"p{k}") != 0).astype(np.float32) for k in (1, 2, 3, 4)}
+    for k, m in masks.items():
+        assert 0.6 < m.mean() < 0.9, (k, m.mean())
+    r = O.loss_and_grads(wts, x, y, keep_masks=masks, dtype=torch.float64)
+    assert abs(ld[0] - r["loss"]) < 1e-5
+    g = eng.get_grads()
+    for k in ("c1a/kernel", "c3a/kernel", "c5a/kernel", "out/kernel"):
+        assert relerr(g[k], r["grads"][k]) < 3e-4, k
+
+
+def test_evaluate_thresholds_and_predict_224_reference_native_size():
+    """Reference-native input 224x224 (T1:479): inference parity + sm metrics within the 1e-3 bar."""
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.keras_like import UNetModel
+    from oracle_backend import OracleBackend
+    x, y = synthetic_ct(3, 224, seed=2)
+    wts = O.init_weights(seed=2)
+    thr = np.array([0.3, 0.5, 0.547])
+    m = UNetModel(224, dropout_rate=0.0); m.set_weights(wts)
+    ref = UNetModel(224, backend=OracleBackend(224, 224)); ref.set_weights(wts)
+    a = m.evaluate(x, y, batch_size=2, thresholds=thr); b = ref.evaluate(x, y, batch_size=2, thresholds=thr)
+    assert abs(a["loss"] - b["loss"]) < 1e-4 and abs(a["dice_coeff"] - b["dice_coeff"]) < 1e-4
+    for k in ("dice", "iou", "precision", "recall"):
+        assert np.abs(a[k] - b[k]).max() < 1e-3, k
+    assert np.abs(m.predict(x[:1]) - ref.predict(x[:1])).max() < 1e-4
+
+
+def test_runner_end_to_end_small(tmp_path, capsys):
+    """holdout_runner_unet_infection_segmentation() on 8 synthetic slices, 1 epoch (BASELINE config 1 shape,
+    at 64 px so the CPU oracle side finishes in seconds): printed summary + history + checkpoints."""
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.runners import holdout_runner_unet_infection_segmentation
+    from oracle_backend import OracleBackend
+    x, y = synthetic_ct(8, 64, seed=0)
+    out = holdout_runner_unet_infection_segmentation(data=(x, y), epochs=1, dropout=False, workdir=str(tmp_path), verbose=0, dropout_rate=0.0)
+    txt = capsys.readouterr().out
+    for label in ("(5, 64, 64, 1) (3, 64, 64, 1)", "test loss, test dice coefficient:", "DICES:", "IOUS:", "Best Threshold:", "NEW DICES:", "PRECISIONS:", "RRECALLS:"):
+        assert label in txt
+    assert os.path.exists(tmp_path / "unet_covid_weights_dice_coeff.hdf5") and os.path.exists(tmp_path / "unet_covid_weights_val_loss.hdf5")
+    os.makedirs(tmp_path / "r", exist_ok=True)
+    ref = holdout_runner_unet_infection_segmentation(data=(x, y), epochs=1, dropout=False, workdir=str(tmp_path / "r"), verbose=0,
+                                                     backend=OracleBackend(64, 64))
+    assert abs(out["history"]["loss"][0] - ref["history"]["loss"][0]) < 1e-4
+    assert abs(out["history"]["val_dice_coeff"][0] - ref["history"]["val_dice_coeff"][0]) < 1e-3
+    assert abs(out["score"][1] - ref["score"][1]) < 1e-3
+    assert np.abs(np.array(out["dices"]) - np.array(ref["dices"])).max() < 1e-3 and np.abs(np.array(out["ious"]) - np.array(ref["ious"])).max() < 1e-3
+
+
+def test_full_size_512_properties():
+    """BASELINE config 2 size (512x512, batch 2 here to bound memory/time): size-independent properties --
+    probabilities in (0,1), loss finite, dice_coeff identity from sums, gradient of a zero-loss-gradient
+    direction: two identical steps from the same state give identical results (determinism of fwd)."""
+    from covidseg_amd.data import synthetic_ct
+    x, y = synthetic_ct(2, 512, seed=1)
+    eng = make(512, dropout_rate=0.0)
+    wts = O.init_weights(seed=1); eng.set_weights(wts)
+    ld1 = eng.forward_backward(x, y).cpu().numpy(); p1 = eng._p_train.cpu().numpy().copy()
+    ld2 = eng.forward_backward(x, y).cpu().numpy(); p2 = eng._p_train.cpu().numpy()
+    assert np.isfinite(ld1).all() and (p1 > 0).all() and (p1 < 1).all() and (p1 == p2).all() and abs(ld1[0] - ld2[0]) < 1e-6
+    t = y.astype(np.float64).ravel(); p = p1.astype(np.float64)
+    assert abs(ld1[1] - (2 * (t * p).sum() + 1) / (t.sum() + p.sum() + 1)) < 1e-5
+    g = eng.get_grads()
+    assert all(np.isfinite(v).all() for v in g.values()) and np.linalg.norm(g["c1a/kernel"]) > 0

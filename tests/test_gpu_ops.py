@@ -1,0 +1,231 @@
+"""-m gpu: every op-level C-ABI entry point against the CPU oracle / torch-CPU fp64 on seeded inputs.
+fp32 tolerance: relative L2 error <= 2e-5 for single ops (fp32 accumulation-order noise ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gpu_util import Ops
+    return Ops()
+
+
+def T64(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+
+CONV_SHAPES = [(2, 9, 13, 3, 5), (1, 16, 16, 1, 32), (2, 16, 16, 32, 32), (2, 12, 20, 32, 64), (1, 8, 8, 64, 128),
+               (2, 6, 10, 128, 64), (1, 4, 4, 256, 512), (3, 14, 14, 64, 64), (1, 34, 70, 32, 32)]
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_fwd(ops, shape, algo):
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(hash(shape) % 1000)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    for relu in (1, 0):
+        y = ops.z(n, h, w, co)
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, relu, algo, ops.s), "conv fwd")
+        want = O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=bool(relu)).numpy()
+        assert relerr(y.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_bwd(ops, shape, algo):
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(7 + hash(shape) % 1000)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * 0.2).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
+    xt, kt = T64(x).requires_grad_(True), T64(k).requires_grad_(True)
+    bt = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    O.conv3x3_bias_relu(xt, kt, bt, relu=False).backward(T64(dy))
+    # data gradient, with and without the fused ReLU mask of the producer of x
+    for masked in (False, True):
+        dx = ops.z(n, h, w, ci); wt = ops.z(9 * ci * co)
+        xm = ops.d(x)
+        ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), xm.data_ptr() if masked else None, dx.data_ptr(), wt.data_ptr(),
+                                             n, h, w, ci, co, algo, ops.s), "conv bwd data")
+        want = xt.grad.numpy() * ((x > 0) if masked else 1.0)
+        assert relerr(dx.cpu().numpy(), want) < TOL
+    nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    dw = ops.z(3, 3, ci, co); db = ops.z(co)
+    dw.fill_(123.0); db.fill_(-7.0)                                  # must be overwritten, not accumulated
+    ops.ck(ops.lib.unet_conv3x3_bwd_weights(ops.h, ops.d(x).data_ptr(), ops.d(dy).data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, algo, ops.s), "conv bwd w")
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < TOL
+    assert relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 8, 4), (1, 4, 4, 512, 256), (2, 8, 8, 64, 32), (1, 7, 9, 128, 64)])
+def test_convT(ops, shape):
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((2, 2, co, ci)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32); dy = rng.standard_normal((n, 2 * h, 2 * w, co)).astype(np.float32)
+    ld = 2 * co
+    cat = ops.z(n, 2 * h, 2 * w, ld); cat.fill_(9.0)
+    ops.ck(ops.lib.unet_convT2x2_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), cat.data_ptr(), ld, n, h, w, ci, co, 0, ops.s), "convT fwd")
+    xt, kt, bt = T64(x).requires_grad_(True), T64(k).requires_grad_(True), T64(b).requires_grad_(True)
+    yt = O.convT2x2s2_bias(xt, kt, bt)
+    got = cat.cpu().numpy()
+    assert relerr(got[..., :co], yt.detach().numpy()) < TOL and (got[..., co:] == 9.0).all()      # only the slice is written
+    yt.backward(T64(dy))
+    dcat = np.full((n, 2 * h, 2 * w, ld), 5.0, np.float32); dcat[..., :co] = dy
+    for masked in (False, True):
+        dx = ops.z(n, h, w, ci)
+        ops.ck(ops.lib.unet_convT2x2_bwd_data(ops.h, ops.d(dcat).data_ptr(), ld, ops.d(k).data_ptr(), ops.d(x).data_ptr() if masked else None, dx.data_ptr(), n, h, w, ci, co, 0, ops.s), "convT bwd data")
+        assert relerr(dx.cpu().numpy(), xt.grad.numpy() * ((x > 0) if masked else 1.0)) < TOL
+    dw = ops.z(2, 2, co, ci); db = ops.z(co); dw.fill_(3.0)
+    ops.ck(ops.lib.unet_convT2x2_bwd_weights(ops.h, ops.d(x).data_ptr(), ops.d(dcat).data_ptr(), ld, dw.data_ptr(), db.data_ptr(), n, h, w, ci, co, 0, ops.s), "convT bwd w")
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < TOL and relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("c,ld_extra", [(32, 0), (64, 64), (128, 0), (512, 0), (256, 256)])
+def test_batchnorm_train_infer_bwd(ops, c, ld_extra):
+    from gpu_util import relerr
+    n, h, w = 3, 6, 10
+    pixels = n * h * w
+    rng = np.random.default_rng(c)
+    x = np.maximum(rng.standard_normal((n, h, w, c)) * 2 + 0.5, 0).astype(np.float32)        # post-ReLU like
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32); beta = rng.standard_normal(c).astype(np.float32)
+    mm = rng.standard_normal(c).astype(np.float32); mv = rng.uniform(0.5, 2, c).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    ldx = c + ld_extra
+    xw = np.full((n, h, w, ldx), 77.0, np.float32); xw[..., ld_extra:] = x               # x lives in the upper slice
+    xd = ops.d(xw); xp = xd.data_ptr() + 4 * ld_extra
+    sums = ops.z(2 * c, dtype=torch.float64); bnp = ops.z(4 * c)
+    mmd, mvd = ops.d(mm), ops.d(mv)
+    ops.ck(ops.lib.unet_bn_stats(ops.h, xp, ldx, sums.data_ptr(), pixels, c, ops.s), "bn_stats")
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, sums.data_ptr(), float(pixels), ops.d(gamma).data_ptr(), ops.d(beta).data_ptr(), mmd.data_ptr(), mvd.data_ptr(), bnp.data_ptr(), c, ops.s), "bn_fin")
+    y = ops.z(n, h, w, c)
+    ops.ck(ops.lib.unet_bn_apply(ops.h, xp, ldx, bnp.data_ptr(), y.data_ptr(), c, pixels, c, ops.s), "bn_apply")
+    xt, gt, bt = T64(x).requires_grad_(True), T64(gamma).requires_grad_(True), T64(beta).requires_grad_(True)
+    yt, mu, va = O.batchnorm(xt, gt, bt, None, None, True)
+    assert relerr(y.cpu().numpy(), yt.detach().numpy()) < TOL
+    nm, nv = O.bn_moving_update(mm.astype(np.float64), mv.astype(np.float64), mu.detach().numpy(), va.detach().numpy(), pixels)
+    assert relerr(mmd.cpu().numpy(), nm) < 1e-6 and relerr(mvd.cpu().numpy(), nv) < 1e-6
+    # inference form
+    ops.ck(ops.lib.unet_bn_finalize_infer(ops.h, ops.d(gamma).data_ptr(), ops.d(beta).data_ptr(), ops.d(mm).data_ptr(), ops.d(mv).data_ptr(), bnp.data_ptr(), c, ops.s), "bn_fin_inf")
+    yi = ops.z(n, h, w, c)
+    ops.ck(ops.lib.unet_bn_apply(ops.h, xp, ldx, bnp.data_ptr(), yi.data_ptr(), c, pixels, c, ops.s), "bn_apply")
+    want = O.batchnorm(T64(x), T64(gamma), T64(beta), T64(mm), T64(mv), False)[0].numpy()
+    assert relerr(yi.cpu().numpy(), want) < TOL
+    # backward (training statistics)
+    yt.backward(T64(dy))
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, sums.data_ptr(), float(pixels), ops.d(gamma).data_ptr(), ops.d(beta).data_ptr(), mmd.data_ptr(), mvd.data_ptr(), bnp.data_ptr(), c, ops.s), "bn_fin")
+    bs = ops.z(2 * c, dtype=torch.float64); dg = ops.z(c); dbt = ops.z(c)
+    ops.ck(ops.lib.unet_bn_bwd_stats(ops.h, ops.d(dy).data_ptr(), c, xp, ldx, bnp.data_ptr(), bs.data_ptr(), pixels, c, ops.s), "bn_bwd_stats")
+    ops.ck(ops.lib.unet_bn_bwd_param_grads(ops.h, bs.data_ptr(), dg.data_ptr(), dbt.data_ptr(), c, ops.s), "bn_bwd_pg")
+    assert relerr(dg.cpu().numpy(), gt.grad.numpy()) < TOL and relerr(dbt.cpu().numpy(), bt.grad.numpy()) < TOL
+    for mask in (0, 1):
+        dx = ops.z(n, h, w, c)
+        ops.ck(ops.lib.unet_bn_bwd_apply(ops.h, ops.d(dy).data_ptr(), c, xp, ldx, bnp.data_ptr(), bs.data_ptr(), float(pixels), mask, dx.data_ptr(), c, pixels, c, ops.s), "bn_bwd_apply")
+        assert relerr(dx.cpu().numpy(), xt.grad.numpy() * ((x > 0) if mask else 1.0)) < 5e-5
+
+
+def test_maxpool_dropout(ops):
+    from gpu_util import relerr
+    n, h, w, c = 2, 8, 12, 32
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    x[0, :2, :2, :] = 0.0                                             # ties -> first element wins
+    y = ops.z(n, h // 2, w // 2, c)
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_fwd(ops.h, ops.d(x).data_ptr(), c, y.data_ptr(), n, h, w, c, 0.0, 0, ops.s), "pool")
+    xt = T64(x).requires_grad_(True)
+    yt = O.maxpool2x2(xt)
+    assert (y.cpu().numpy() == yt.detach().numpy().astype(np.float32)).all()
+    dy = rng.standard_normal((n, h // 2, w // 2, c)).astype(np.float32)
+    yt.backward(T64(dy))
+    dx = ops.z(n, h, w, c); dx.fill_(1.0)
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd(ops.h, ops.d(x).data_ptr(), c, ops.d(dy).data_ptr(), dx.data_ptr(), c, n, h, w, c, 0.0, 0, 1, ops.s), "pool bwd acc")
+    assert relerr(dx.cpu().numpy(), xt.grad.numpy() + 1.0) < 1e-7
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd(ops.h, ops.d(x).data_ptr(), c, ops.d(dy).data_ptr(), dx.data_ptr(), c, n, h, w, c, 0.0, 0, 0, ops.s), "pool bwd")
+    assert relerr(dx.cpu().numpy(), xt.grad.numpy()) < 1e-7
+    # dropout: deterministic in (seed), keep fraction ~ 0.75, survivors scaled by 1/0.75, bwd uses the same mask
+    ones = np.ones((4, 32, 32, 64), np.float32)
+    a = ops.z(4, 16, 16, 64); b = ops.z(4, 16, 16, 64); c2 = ops.z(4, 16, 16, 64)
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_fwd(ops.h, ops.d(ones).data_ptr(), 64, a.data_ptr(), 4, 32, 32, 64, 0.25, 1234, ops.s), "drop")
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_fwd(ops.h, ops.d(ones).data_ptr(), 64, b.data_ptr(), 4, 32, 32, 64, 0.25, 1234, ops.s), "drop")
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_fwd(ops.h, ops.d(ones).data_ptr(), 64, c2.data_ptr(), 4, 32, 32, 64, 0.25, 99, ops.s), "drop")
+    an = a.cpu().numpy()
+    assert (an == b.cpu().numpy()).all() and (an != c2.cpu().numpy()).any()
+    assert set(np.unique(an).tolist()) == {0.0, np.float32(1 / 0.75)} and abs((an > 0).mean() - 0.75) < 0.01
+    g = ops.z(4, 32, 32, 64)
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd(ops.h, ops.d(ones).data_ptr(), 64, ops.d(np.ones((4, 16, 16, 64), np.float32)).data_ptr(), g.data_ptr(), 64, 4, 32, 32, 64, 0.25, 1234, 0, ops.s), "drop bwd")
+    gn = g.cpu().numpy()
+    assert (gn[:, ::2, ::2, :] == an).all() and gn[:, 1::2, :, :].sum() == 0 and gn[:, :, 1::2, :].sum() == 0
+
+
+def test_head_loss_fwd_bwd(ops):
+    from gpu_util import relerr
+    n, h, w, c = 2, 16, 24, 32
+    pixels = n * h * w
+    rng = np.random.default_rng(9)
+    x = np.maximum(rng.standard_normal((n, h, w, c)), 0).astype(np.float32)
+    k = (rng.standard_normal((1, 1, c, 1)) * 0.5).astype(np.float32); b = np.array([0.1], np.float32)
+    x[0, 0, 0, :] = 60.0 * np.sign(k[0, 0, :, 0]).clip(0)              # saturate one pixel: p == 1 -> clip path, zero grad
+    t = (np.round(rng.random((n, h, w, 1)) ** 2 * 255) / 255).astype(np.float32)
+    p = ops.z(n, h, w, 1); sums = ops.z(4, dtype=torch.float64); out = ops.z(2)
+    ops.ck(ops.lib.unet_head_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p.data_ptr(), ops.d(t).data_ptr(), sums.data_ptr(), pixels, c, ops.s), "head fwd")
+    ops.ck(ops.lib.unet_loss_finalize(ops.h, sums.data_ptr(), float(pixels), out.data_ptr(), ops.s), "loss fin")
+    xt, kt, bt = T64(x).requires_grad_(True), T64(k).requires_grad_(True), T64(b).requires_grad_(True)
+    pt = O.conv1x1_sigmoid(xt, kt, bt)
+    loss = O.bce_dice_loss(T64(t), pt)
+    assert relerr(p.cpu().numpy(), pt.detach().numpy()) < 1e-6
+    lo = out.cpu().numpy()
+    # loss VALUE vs the fp32 oracle: the clip bound 1-1e-7 is 1-1.19e-7 in fp32 (as in TF), which matters
+    # for the one saturated pixel; gradients (below) are compared with fp64.
+    T32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)
+    p32 = O.conv1x1_sigmoid(T32(x), T32(k), T32(b))
+    assert abs(lo[0] - float(O.bce_dice_loss(T32(t), p32))) < 5e-6 and abs(lo[1] - float(O.dice_coeff(T64(t), pt))) < 2e-6
+    loss.backward()
+    dx = ops.z(n, h, w, c); dw = ops.z(c); db = ops.z(1)
+    ops.ck(ops.lib.unet_head_bwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), p.data_ptr(), ops.d(t).data_ptr(), sums.data_ptr(), float(pixels), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), pixels, c, ops.s), "head bwd")
+    assert relerr(dx.cpu().numpy(), xt.grad.numpy() * (x > 0)) < 2e-5
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy().ravel()) < 2e-5 and relerr(db.cpu().numpy(), bt.grad.numpy()) < 2e-5
+    # p-only call (predict): no labels, no sums
+    p2 = ops.z(n, h, w, 1)
+    ops.ck(ops.lib.unet_head_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p2.data_ptr(), None, None, pixels, c, ops.s), "head fwd")
+    assert (p2.cpu().numpy() == p.cpu().numpy()).all()
+
+
+def test_adam_and_metrics(ops):
+    from gpu_util import relerr
+    rng = np.random.default_rng(4)
+    nel = 10007                                                     # not a multiple of 4: tail path
+    p = rng.standard_normal(nel).astype(np.float32); g = rng.standard_normal(nel).astype(np.float32)
+    m = (rng.standard_normal(nel) * 0.1).astype(np.float32); v = (rng.random(nel) * 0.01).astype(np.float32)
+    P = {"a": p.astype(np.float64)}; M = {"a": m.astype(np.float64)}; V = {"a": v.astype(np.float64)}
+    O.adam_keras(P, {"a": g.astype(np.float64)}, M, V, 3)
+    pd, md, vd = ops.d(p), ops.d(m), ops.d(v)
+    lr_t = 5e-4 * np.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3)
+    ops.ck(ops.lib.unet_adam_keras(ops.h, pd.data_ptr(), ops.d(g).data_ptr(), md.data_ptr(), vd.data_ptr(), nel, lr_t, 0.9, 0.999, 1e-7, 1.0, ops.s), "adam")
+    assert relerr(pd.cpu().numpy(), P["a"]) < 1e-6 and relerr(md.cpu().numpy(), M["a"]) < 1e-6 and relerr(vd.cpu().numpy(), V["a"]) < 1e-6
+    cnt = 3 * 37 * 41
+    pr = rng.random(cnt).astype(np.float32); gt = (np.round(rng.random(cnt) ** 3 * 255) / 255).astype(np.float32)
+    for thr in (np.arange(0.1, 0.8, 0.05), np.arange(0.52, 0.60, 0.001), np.array([0.0, 0.5, 1.0])):
+        out = ops.z(len(thr), 3, dtype=torch.float64)
+        ops.ck(ops.lib.unet_seg_metrics_sweep(ops.h, ops.d(pr).data_ptr(), ops.d(gt).data_ptr(), ops.d(thr).data_ptr(), len(thr), out.data_ptr(), cnt, ops.s), "sweep")
+        want = O.threshold_sums(gt, pr, thr.astype(np.float32))
+        got = out.cpu().numpy()
+        assert (got[:, 1] == want[:, 1]).all()                      # counts are exact
+        assert np.allclose(got[:, 0], want[:, 0], rtol=1e-6) and np.allclose(got[:, 2], want[:, 2], rtol=1e-6)
+
+
+def test_bad_arguments_are_reported_not_crashed(ops):
+    rc = ops.lib.unet_bn_apply(ops.h, None, 32, None, None, 32, 10, 32, ops.s)
+    assert rc == -1 and b"bn_apply" in ops.lib.unet_last_error(ops.h)
+    m = __import__("ctypes").c_void_p()
+    assert ops.lib.unet_model_create(ops.h, 1, 2, 30, 32, 1, 0, __import__("ctypes").byref(m)) == -3   # h not a multiple of 16
