@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""bench.py -- CT images/sec of one full U-Net training step (fwd + loss + bwd + Keras-Adam,
+gradient all-reduce when >1 GPU) at 512x512x1, batch 16 per GPU, fp32, synthetic data resident
+in HBM (BASELINE.json configs[1]).  One process per GPU; for N>1 launch with torch.distributed.run.
+
+Prints ONE JSON line (rank 0).  Besides the driver contract it carries
+  roofline     : the dominant kernel (fp32 MFMA 3x3 convolution, forward + data-gradient launches):
+                 algorithmic FLOPs of its launches in a step / their summed hipEvent durations
+  cpu_baseline : the CPU oracle (torch-CPU restatement, kind "port") timed on the host cores on a
+                 bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, no TF32 on gfx950
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(size, seconds_budget=25.0):
+    """Time the oracle's identical training step on the host cores: bounded sample (batch 2)."""
+    import numpy as np
+    import torch
+    from covidseg_amd.data import synthetic_ct
+    from oracle import unet_oracle as O
+    bs = 2
+    x, y = synthetic_ct(bs, size, seed=0)
+    tr = O.OracleTrainer(O.init_weights(seed=0), torch.float32)
+    t0 = time.perf_counter(); tr.train_step(x, y); first = time.perf_counter() - t0     # includes oneDNN warm-up
+    reps = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tr.train_step(x, y)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(bs / dt, 4), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{reps} training step(s) of batch {bs} at {size}x{size}x1 fp32 (torch-CPU oracle, {os.cpu_count()} host cpus visible)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--algo", type=int, default=0, help="0 auto (MFMA), 1 direct kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.engine import HipUNet
+    from covidseg_amd import weights as W
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        pg = dist.group.WORLD
+
+    B, S = args.batch, args.size
+    # synthetic batch: generate a few distinct slices on the host, tile to the batch, keep resident in HBM
+    xs, ys = synthetic_ct(min(B, 4), S, seed=rank)
+    reps = (B + len(xs) - 1) // len(xs)
+    x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
+    eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank)
+    eng.set_weights(W.init_weights(0))       # identical replicas
+
+    for _ in range(args.warmup):
+        eng.train_batch(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = eng.train_batch(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    loss_dice = last.cpu().numpy().tolist()
+
+    # ---- roofline leg: per-op hipEvent timing of two more steps (profiling mode serialises ops)
+    roof = None
+    if rank == 0:
+        eng.set_profiling(True, B)
+        for _ in range(2):
+            eng.train_batch(x, y)
+        torch.cuda.synchronize()
+        eng.set_profiling(False)
+        ops = eng.op_profile(B, 0) + eng.op_profile(B, 1)
+        dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_dgrad:")]
+        dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel
+        fl = sum(o[1] for o in dom); ms = sum(o[3] / max(o[4], 1) for o in dom); launches = len(dom)
+        groups = {}
+        for name, flops, by, tms, calls in ops:
+            k = name.split(":")[0]
+            g = groups.setdefault(k, [0.0, 0.0, 0.0]); g[0] += tms / max(calls, 1); g[1] += flops; g[2] += by
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fwd + data-gradient launches)", "achieved": round(achieved, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
+                "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3),
+                "op_ms_per_step": {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+
+    if rank == 0:
+        total_imgs = B * world * args.steps
+        out = {
+            "metric": "CT images/sec (fwd+bwd) U-Net 512x512x1 bs16", "value": round(total_imgs / dt, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
+                                   f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json configs[1]",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x2" if args.algo == 0 else "direct",
+                       "dropout": 0.25, "last_loss_dice": [round(v, 5) for v in loss_dice]},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

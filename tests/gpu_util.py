@@ -10,13 +10,18 @@ class Ops:
         self.lib = _lib.load()
         self.ctx = _lib.Context.get(torch.cuda.current_device())
         self.h = self.ctx.handle
+        self._keep = []          # keep device inputs alive: the C ABI only sees raw pointers
 
     @property
     def s(self):
         return torch.cuda.current_stream().cuda_stream
 
     def d(self, a, dtype=np.float32):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype)).cuda()
+        self._keep.append(t)
+        if len(self._keep) > 256:
+            torch.cuda.synchronize(); del self._keep[:128]
+        return t
 
     def z(self, *shape, dtype=torch.float32):
         return torch.zeros(shape, dtype=dtype, device="cuda")

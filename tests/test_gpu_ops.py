@@ -212,7 +212,8 @@ def test_adam_and_metrics(ops):
     pd, md, vd = ops.d(p), ops.d(m), ops.d(v)
     lr_t = 5e-4 * np.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3)
     ops.ck(ops.lib.unet_adam_keras(ops.h, pd.data_ptr(), ops.d(g).data_ptr(), md.data_ptr(), vd.data_ptr(), nel, lr_t, 0.9, 0.999, 1e-7, 1.0, ops.s), "adam")
-    assert relerr(pd.cpu().numpy(), P["a"]) < 1e-6 and relerr(md.cpu().numpy(), M["a"]) < 1e-6 and relerr(vd.cpu().numpy(), V["a"]) < 1e-6
+    # (1-b2) evaluated in fp32 is 0.00099998713 (as in TF/Keras, whose hyper-parameters are fp32): 1.3e-5 relative
+    assert relerr(pd.cpu().numpy(), P["a"]) < 1e-6 and relerr(md.cpu().numpy(), M["a"]) < 1e-6 and relerr(vd.cpu().numpy(), V["a"]) < 2e-5
     cnt = 3 * 37 * 41
     pr = rng.random(cnt).astype(np.float32); gt = (np.round(rng.random(cnt) ** 3 * 255) / 255).astype(np.float32)
     for thr in (np.arange(0.1, 0.8, 0.05), np.arange(0.52, 0.60, 0.001), np.array([0.0, 0.5, 1.0])):
