@@ -74,9 +74,12 @@ int32_t unet_convT2x2_fwd(unet_ctx*, const float* x, const float* w, const float
 int32_t unet_convT2x2_bwd_data(unet_ctx*, const float* dy, int32_t lddy, const float* w,
                                const float* relu_src, float* dx, int32_t n, int32_t h, int32_t wd,
                                int32_t cin, int32_t cout, int32_t algo, void* stream);
+/* dw [2,2,Cout,Cin] and db are OVERWRITTEN; ws: split-K scratch (unet_convT2x2_bwd_weights_ws_bytes) */
+size_t unet_convT2x2_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout);
 int32_t unet_convT2x2_bwd_weights(unet_ctx*, const float* x, const float* dy, int32_t lddy,
-                                  float* dw, float* db, int32_t n, int32_t h, int32_t wd,
-                                  int32_t cin, int32_t cout, int32_t algo, void* stream);
+                                  float* dw, float* db, void* ws, size_t ws_bytes, int32_t n,
+                                  int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo,
+                                  void* stream);
 
 /* Replaces: BatchNormalization()  T1:861,867,873,879,888,895,902,909 (eps 1e-3, momentum .99)
  * Training forward = stats -> [optional cross-rank all-reduce of `sums`] -> finalize -> apply.

@@ -39,7 +39,8 @@ _PROTOS = {
     "unet_conv3x3_bwd_weights": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
     "unet_convT2x2_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "unet_convT2x2_bwd_data": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "unet_convT2x2_bwd_weights": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_convT2x2_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "unet_convT2x2_bwd_weights": (i32, [vp, vp, vp, i32, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
     "unet_bn_stats": (i32, [vp, vp, i32, vp, i64, i32, vp]),
     "unet_bn_finalize_train": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, i32, vp]),
     "unet_bn_finalize_infer": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -67,6 +67,9 @@ int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const flo
                             float* y, int n, int h, int wd, int cin, int cout, int relu, hipStream_t s);
 int32_t k_conv3x3_c1_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int n, int h,
                          int wd, int cout, int relu, hipStream_t s);
+size_t c1_wgrad_ws_bytes(int cout);
+int32_t k_conv3x3_c1_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
+                           int wd, int cout, hipStream_t s);
 int32_t k_flip_transpose_w3x3(unet_ctx*, const float* w, float* wt, int cin, int cout, hipStream_t s);
 int32_t k_conv3x3_naive_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, int n, int h,
                               int wd, int cin, int cout, hipStream_t s);
@@ -80,6 +83,15 @@ int32_t k_convT_naive_wgrad(unet_ctx*, const float* x, const float* dy, int lddy
 bool mfma_conv3x3_supported(int cin, int cout);
 int32_t k_conv3x3_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask,
                            float* y, int n, int h, int wd, int cin, int cout, int relu, hipStream_t s);
+bool mfma_wgrad_supported(int ca, int cb);
+bool mfma_convT_supported(int cin, int cout);
+int32_t k_convT_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd,
+                         int cin, int cout, hipStream_t s);
+int32_t k_convT_mfma_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd,
+                           int cin, int cout, hipStream_t s);
+size_t mfma_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
+int32_t k_convT_mfma_wgrad(unet_ctx*, const float* x, const float* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n,
+                           int h, int wd, int cin, int cout, hipStream_t s);
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_mfma_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws,
                              size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);

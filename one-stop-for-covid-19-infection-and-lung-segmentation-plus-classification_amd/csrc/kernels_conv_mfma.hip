@@ -14,7 +14,7 @@
 //   so ONE ds_read_b128 per lane feeds the A operand of 4 consecutive MFMAs.
 //   Epilogue: +bias, ReLU, optional ReLU-mask multiply (backward), coalesced 128-B row stores.
 //
-// Weight-gradient: see conv3x3_wgrad_mfma_kernel below (split-K over pixels, deterministic 2-stage).
+// Weight-gradient: see wgrad_mfma_kernel below (split-K over pixels, deterministic 2-stage).
 #include "common.h"
 
 namespace {
@@ -26,18 +26,26 @@ constexpr int CK = 8;     // input channels per K chunk
 constexpr int CKP = 12;   // padded pixel stride in LDS (floats): 4*odd -> ds_read_b128 conflict-free
 constexpr int PW = 34;    // patch width: 32 + halo
 
-template <int TN, int TH, int WR, int WC>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, const float* __restrict__ mask,
-                                                           float* __restrict__ y, int N, int H, int W, int Cin, int Cout,
-                                                           int relu, int tiles_x, int tiles_y) {
+// MODE 0: conv3x3 'same' (forward, and data-gradient with flipped/transposed weights)
+// MODE 1: convT2x2s2 forward  = 1x1 GEMM [pixels,Cin] x [Cin, 4*Cout] with a scatter epilogue into the
+//         (2i+a, 2j+b) positions of a channel slice (pixel stride ldy) of the concat buffer; the
+//         Keras [2,2,Cout,Cin] kernel is transposed on the fly while staging the weight slab
+// MODE 2: convT2x2s2 data-gradient = 2x2 stride-2 'valid' convolution of dU (pixel stride ldx):
+//         the 2x-upsampled patch is de-interleaved by column parity in LDS so that the A operand of
+//         tap (a,b) is again 32 consecutive pixels (conflict-free ds_read_b128)
+template <int MODE, int TN, int TH, int WR, int WC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ mask,
+                                                        float* __restrict__ y, int ldy, int N, int H, int W, int Cin, int Cout,
+                                                        int relu, int tiles_x, int tiles_y) {
   static_assert(WR * WC == 4, "4 waves");
+  constexpr int TAPS = MODE == 0 ? 9 : (MODE == 1 ? 1 : 4);
   constexpr int RW = TH / WR;          // image rows (M tiles) per wave
   constexpr int NW = TN / 32 / WC;     // N tiles per wave
-  constexpr int PR = TH + 2;
+  constexpr int NPIX = MODE == 0 ? (TH + 2) * PW : (MODE == 1 ? TH * 32 : 2 * TH * 64);
   static_assert(RW >= 1 && NW >= 1, "tile");
-  __shared__ __attribute__((aligned(16))) float s_in[PR * PW * CKP];
-  __shared__ __attribute__((aligned(16))) float s_w[9 * CK * TN];
+  __shared__ __attribute__((aligned(16))) float s_in[NPIX * CKP];
+  __shared__ __attribute__((aligned(16))) float s_w[TAPS * CK * TN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -47,6 +55,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   const int ty = b % tiles_y; const int n = b / tiles_y;
   const int x0 = tx * 32, y0 = ty * TH;
   const int nbase = blockIdx.y * TN;
+  const int HI = MODE == 2 ? 2 * H : H, WI = MODE == 2 ? 2 * W : W;     // input pixel grid
 
   f32x16 acc[RW][NW];
 #pragma unroll
@@ -56,33 +65,49 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const float* xn = x + (long long)n * H * W * Cin;
+  const float* xn = x + (long long)n * HI * WI * ldx;
   for (int c0 = 0; c0 < Cin; c0 += CK) {
-    // ---- stage the halo patch of this channel chunk (zero fill = 'same' padding + ragged edges)
-    for (int idx = tid; idx < PR * PW * 2; idx += 256) {
+    // ---- stage the input patch of this channel chunk (zero fill = 'same' padding + ragged edges)
+    for (int idx = tid; idx < NPIX * 2; idx += 256) {
       const int q = idx & 1, pix = idx >> 1;
-      const int r = pix / PW, c = pix - r * PW;
-      const int gy = y0 + r - 1, gx = x0 + c - 1;
+      int gy, gx, lp;
+      if (MODE == 0) { const int r = pix / PW, c = pix - r * PW; gy = y0 + r - 1; gx = x0 + c - 1; lp = pix; }
+      else if (MODE == 1) { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); lp = pix; }
+      else { const int rr = pix >> 6, cc = pix & 63; gy = 2 * y0 + rr; gx = 2 * x0 + cc; lp = (rr * 2 + (cc & 1)) * 32 + (cc >> 1); }
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = *reinterpret_cast<const float4*>(xn + ((long long)gy * W + gx) * Cin + c0 + q * 4);
-      *reinterpret_cast<float4*>(&s_in[pix * CKP + q * 4]) = v;
+      if (gy >= 0 && gy < HI && gx >= 0 && gx < WI)
+        v = *reinterpret_cast<const float4*>(xn + ((long long)gy * WI + gx) * ldx + c0 + q * 4);
+      *reinterpret_cast<float4*>(&s_in[lp * CKP + q * 4]) = v;
     }
     // ---- stage the weight slab [tap][ci][TN]
-    for (int idx = tid; idx < 9 * CK * (TN / 4); idx += 256) {
-      const int q = idx % (TN / 4), row = idx / (TN / 4);
-      const int tap = row >> 3, ci = row & 7;
-      const float4 v = *reinterpret_cast<const float4*>(w + ((long long)(tap * Cin + c0 + ci)) * Cout + nbase + q * 4);
-      *reinterpret_cast<float4*>(&s_w[row * TN + q * 4]) = v;
+    if (MODE == 1) {
+      // Keras ConvT kernel [ab][o][c]: row nn = ab*Cq + o holds Cin contiguous floats; transpose while staging
+      for (int idx = tid; idx < TN * 2; idx += 256) {
+        const int half = idx & 1, nn = idx >> 1;
+        const float4 v = *reinterpret_cast<const float4*>(w + (long long)(nbase + nn) * Cin + c0 + half * 4);
+        s_w[(half * 4 + 0) * TN + nn] = v.x; s_w[(half * 4 + 1) * TN + nn] = v.y;
+        s_w[(half * 4 + 2) * TN + nn] = v.z; s_w[(half * 4 + 3) * TN + nn] = v.w;
+      }
+    } else {
+      for (int idx = tid; idx < TAPS * CK * (TN / 4); idx += 256) {
+        const int q = idx % (TN / 4), row = idx / (TN / 4);
+        const int tap = row >> 3, ci = row & 7;
+        const float4 v = *reinterpret_cast<const float4*>(w + ((long long)(tap * Cin + c0 + ci)) * Cout + nbase + q * 4);
+        *reinterpret_cast<float4*>(&s_w[row * TN + q * 4]) = v;
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dr = tap / 3, dc = tap % 3;
+    for (int tap = 0; tap < TAPS; ++tap) {
       f32x4 a[RW];
 #pragma unroll
-      for (int i = 0; i < RW; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(&s_in[((wr * RW + i + dr) * PW + l31 + dc) * CKP + hi * 4]);
+      for (int i = 0; i < RW; ++i) {
+        int lp;
+        if (MODE == 0) lp = (wr * RW + i + tap / 3) * PW + l31 + tap % 3;
+        else if (MODE == 1) lp = (wr * RW + i) * 32 + l31;
+        else lp = ((2 * (wr * RW + i) + (tap >> 1)) * 2 + (tap & 1)) * 32 + l31;
+        a[i] = *reinterpret_cast<const f32x4*>(&s_in[lp * CKP + hi * 4]);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float bv[NW];
@@ -98,11 +123,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     __syncthreads();
   }
 
-  // ---- epilogue: D[row = pixel][col = cout]; lane holds col = l31, rows (r&3)+8*(r>>2)+4*hi
+  // ---- epilogue: D[row = pixel][col = n]; lane holds col = l31, rows (r&3)+8*(r>>2)+4*hi
 #pragma unroll
   for (int jn = 0; jn < NW; ++jn) {
     const int co = nbase + (wc * NW + jn) * 32 + l31;
-    const float bb = bias ? bias[co] : 0.0f;
+    const int cq = Cout >> 2;                              // MODE 1: Cout = 4 * (ConvT output channels)
+    const int ab = MODE == 1 ? co / cq : 0, oc = MODE == 1 ? co - ab * cq : co;
+    const float bb = bias ? bias[oc] : 0.0f;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int py = y0 + wr * RW + i;
@@ -111,41 +138,240 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) {
         const int px = x0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (px >= W) continue;
-        const long long o = (((long long)n * H + py) * W + px) * Cout + co;
         float v = acc[i][jn][r] + bb;
-        if (relu) v = fmaxf(v, 0.0f);
-        if (mask) v = mask[o] > 0.0f ? v : 0.0f;
-        y[o] = v;
+        if (MODE == 1) {
+          y[(((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px + (ab & 1)) * ldy + oc] = v;
+        } else {
+          const long long o = (((long long)n * H + py) * W + px) * Cout + co;
+          if (relu) v = fmaxf(v, 0.0f);
+          if (mask) v = mask[o] > 0.0f ? v : 0.0f;
+          y[o] = v;
+        }
       }
     }
   }
 }
 
-template <int TN, int TH, int WR, int WC>
-int32_t launch_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, float* y, int n, int h,
-                   int wd, int cin, int cout, int relu, hipStream_t s) {
+template <int MODE, int TN, int TH, int WR, int WC>
+int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, const float* mask, float* y, int ldy,
+                    int n, int h, int wd, int cin, int cout, int relu, hipStream_t s) {
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH;
   dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)(cout / TN));
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<TN, TH, WR, WC>), grid, dim3(256), 0, s, x, w, bias, mask, y, n, h, wd, cin, cout, relu,
-                     tiles_x, tiles_y);
-  UNET_CHECK_LAUNCH(ctx, "conv3x3_mfma_fwd");
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout,
+                     relu, tiles_x, tiles_y);
+  UNET_CHECK_LAUNCH(ctx, "conv_mfma");
+  return UNET_OK;
+}
+
+// =========================================================================================
+// Weight gradient on the matrix cores.
+//   conv3x3 (MODE 0): dW[tap][ci][co] = sum_p X[p+tap][ci] * dY[p][co]       A = X,  B = dY
+//   convT2x2 (MODE 1): dK[ab][o][c]   = sum_p dU[2i+a,2j+b][o] * X[i,j][c]   A = dU, B = X
+// GEMM view per tap: D[a_ch][b_ch] += A^T B with K = pixels (millions) and a tiny M x N, so the
+// work is split over K: ONE WAVE per workgroup owns one 32x32 (a_ch, b_ch) tile for ALL taps
+// (9 x 16 = 144 accumulator registers -> 3 waves/SIMD) and walks a range of image rows of a
+// 32-pixel-wide column strip.  MFMA k = 2 consecutive pixels of the row (lanes 0-31 / 32-63), lanes
+// run along channels, so every LDS read is 32 consecutive floats (conflict-free) and every global
+// read is a full 128-B line of an NHWC pixel.  conv3x3 keeps a 3-row ring of X rows in LDS: each
+// row is fetched once per strip (no halo re-reads along y).  The B operand (dY) is shared by the
+// 9 taps.  Partials go to a workspace [split][tap][a_ch][b_ch] and a second kernel sums the
+// splits in a fixed order (deterministic, no float atomics).  The bias gradient rides along as
+// per-lane column sums of the dY / dU values the wave already holds.
+// =========================================================================================
+template <int MODE>
+__global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
+                                                        float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
+                                                        int CA, int CB, int tiles_b, int strips, int rows_per_split,
+                                                        long long total_rows) {
+  constexpr int TAPS = MODE == 0 ? 9 : 4;
+  constexpr int ROWF = 34 * 32;                    // floats per ring row (conv3x3)
+  __shared__ __attribute__((aligned(16))) float s_a[MODE == 0 ? 3 * ROWF : 4 * 32 * 32];
+  __shared__ __attribute__((aligned(16))) float s_b[32 * 32];
+  const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+  const int ta = blockIdx.x / tiles_b, tb = blockIdx.x % tiles_b;
+  const int a0 = ta * 32, b0 = tb * 32;
+  const int split = blockIdx.y;
+  const long long u0 = (long long)split * rows_per_split;
+  long long u1 = u0 + rows_per_split; if (u1 > total_rows) u1 = total_rows;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bsum = 0.0f;
+
+  const int HA = MODE == 0 ? H : 2 * H, WA = MODE == 0 ? W : 2 * W;
+  bool fresh = true;
+  for (long long u = u0; u < u1; ++u) {
+    const int yrow = (int)(u % H); const long long t2 = u / H;
+    const int cs = (int)(t2 % strips); const int n = (int)(t2 / strips);
+    const int x0 = cs * 32;
+    const float* An = A + (long long)n * HA * WA * ldA;
+    const float* Bn = B + (long long)n * H * W * ldB;
+    if (MODE == 0) {
+      // ring of X rows: slot(r) = (r + 3) % 3; rows yrow-1, yrow are resident unless the strip just started
+      const int first = (fresh || yrow == 0) ? -1 : 1;
+      for (int rr = first; rr <= 1; ++rr) {
+        const int yy = yrow + rr; const int slot = (yy + 3) % 3;
+        for (int idx = lane; idx < 34 * 8; idx += 64) {
+          const int pix = idx >> 3, q = idx & 7; const int gx = x0 - 1 + pix;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (yy >= 0 && yy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(An + ((long long)yy * W + gx) * ldA + a0 + q * 4);
+          *reinterpret_cast<float4*>(&s_a[slot * ROWF + pix * 32 + q * 4]) = v;
+        }
+      }
+      fresh = false;
+    } else {
+      for (int idx = lane; idx < 2 * 64 * 8; idx += 64) {
+        const int q = idx & 7; const int cc = (idx >> 3) & 63; const int a = idx >> 9;
+        const int gx = 2 * x0 + cc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gx < WA) v = *reinterpret_cast<const float4*>(An + ((long long)(2 * yrow + a) * WA + gx) * ldA + a0 + q * 4);
+        *reinterpret_cast<float4*>(&s_a[(((a * 2 + (cc & 1)) * 32) + (cc >> 1)) * 32 + q * 4]) = v;
+      }
+    }
+    for (int idx = lane; idx < 32 * 8; idx += 64) {
+      const int pix = idx >> 3, q = idx & 7; const int gx = x0 + pix;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gx < W) v = *reinterpret_cast<const float4*>(Bn + ((long long)yrow * W + gx) * ldB + b0 + q * 4);
+      *reinterpret_cast<float4*>(&s_b[pix * 32 + q * 4]) = v;
+    }
+    __syncthreads();
+    int slot_off[3];
+#pragma unroll
+    for (int dr = 0; dr < 3; ++dr) slot_off[dr] = ((yrow + dr + 2) % 3) * ROWF;
+#pragma unroll 4
+    for (int pp = 0; pp < 16; ++pp) {
+      const int c = 2 * pp + hi;
+      const float bv = s_b[c * 32 + l31];
+      if (MODE == 0) bsum += bv;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        float av;
+        if (MODE == 0) av = s_a[slot_off[t / 3] + (c + t % 3) * 32 + l31];
+        else { av = s_a[(t * 32 + c) * 32 + l31]; bsum += av; }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // partial tile: rows = a channel (r&3)+8*(r>>2)+4*hi, cols = b channel l31
+  float* P = part + (long long)split * TAPS * CA * CB;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      P[((long long)t * CA + a0 + i) * CB + b0 + l31] = acc[t][r];
+    }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (MODE == 0) { if (ta == 0 && lane < 32) part_b[(long long)split * CB + b0 + l31] = bsum; }
+  else { if (tb == 0 && lane < 32) part_b[(long long)split * CA + a0 + l31] = bsum; }
+}
+
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, long long n4,
+                                                            long long stride, int nsplit) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 s = *reinterpret_cast<const float4*>(part + i * 4);
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(part + k * stride + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = s;
+  }
+}
+
+struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_split; long long total_rows; size_t part_floats, bias_floats; };
+
+WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
+  WgradPlan p;
+  p.tiles_a = ca / 32; p.tiles_b = cb / 32; p.strips = (w + 31) / 32;
+  p.total_rows = (long long)n * p.strips * h;
+  const long long pairs = (long long)p.tiles_a * p.tiles_b;
+  long long ns = (4096 + pairs - 1) / pairs;                        // ~3072 wave slots on 256 CUs (3 waves/SIMD)
+  const long long per = (long long)taps * ca * cb;
+  const long long cap = std::max<long long>(1, (48LL << 20) / per);   // <= 192 MiB of partials
+  ns = std::min(ns, cap);
+  ns = std::min<long long>(ns, std::max<long long>(1, p.total_rows / 2));
+  ns = std::max<long long>(ns, 1);
+  p.rows_per_split = (int)((p.total_rows + ns - 1) / ns);
+  p.nsplit = (int)((p.total_rows + p.rows_per_split - 1) / p.rows_per_split);
+  p.part_floats = (size_t)p.nsplit * per; p.bias_floats = (size_t)p.nsplit * cbias;
+  return p;
+}
+
+template <int MODE>
+int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ldB, float* dw, float* db, void* ws, size_t ws_bytes, int n,
+                  int h, int w, int ca, int cb, hipStream_t s) {
+  const int taps = MODE == 0 ? 9 : 4; const int cbias = MODE == 0 ? cb : ca;
+  const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias);
+  const size_t need = (p.part_floats + p.bias_floats) * sizeof(float);
+  if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+  float* part = static_cast<float*>(ws); float* part_b = part + p.part_floats;
+  hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, dim3((unsigned)(p.tiles_a * p.tiles_b), (unsigned)p.nsplit), dim3(64), 0, s, A, ldA, B, ldB, part,
+                     part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_split, p.total_rows);
+  UNET_CHECK_LAUNCH(ctx, "wgrad_mfma");
+  const long long per = (long long)taps * ca * cb;
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)std::min<long long>((per / 4 + 255) / 256, 2048)), dim3(256), 0, s, part, dw, per / 4, per, p.nsplit);
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(1), dim3(256), 0, s, part_b, db, (long long)cbias / 4, (long long)cbias, p.nsplit);
+  UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
 }
 
 }  // namespace
 
 bool mfma_conv3x3_supported(int cin, int cout) { return cin >= CK && (cin % CK) == 0 && (cout % 32) == 0; }
+bool mfma_wgrad_supported(int ca, int cb) { return ca >= 32 && (ca % 32) == 0 && cb >= 32 && (cb % 32) == 0; }
 
 int32_t k_conv3x3_mfma_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, float* y, int n,
                            int h, int wd, int cin, int cout, int relu, hipStream_t s) {
   if (!mfma_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 mfma: cin=%d cout=%d unsupported", cin, cout);
-  if (cout % 128 == 0) return launch_fwd<128, 4, 2, 2>(ctx, x, w, bias, mask, y, n, h, wd, cin, cout, relu, s);
-  if (cout % 64 == 0) return launch_fwd<64, 8, 4, 1>(ctx, x, w, bias, mask, y, n, h, wd, cin, cout, relu, s);
-  return launch_fwd<32, 8, 4, 1>(ctx, x, w, bias, mask, y, n, h, wd, cin, cout, relu, s);
+  if (cout % 128 == 0) return launch_conv<0, 128, 4, 2, 2>(ctx, x, cin, w, bias, mask, y, cout, n, h, wd, cin, cout, relu, s);
+  if (cout % 64 == 0) return launch_conv<0, 64, 8, 4, 1>(ctx, x, cin, w, bias, mask, y, cout, n, h, wd, cin, cout, relu, s);
+  return launch_conv<0, 32, 8, 4, 1>(ctx, x, cin, w, bias, mask, y, cout, n, h, wd, cin, cout, relu, s);
 }
 
-size_t mfma_wgrad_ws_bytes(int, int, int, int, int) { return 0; }
-int32_t k_conv3x3_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void*, size_t, int n, int h,
+bool mfma_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0; }
+
+// u[n,2i+a,2j+b,o] = bias[o] + sum_c x[n,i,j,c] * K[a,b,o,c]; GEMM N dimension = 4*cout (ab,o)
+int32_t k_convT_mfma_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd,
+                         int cin, int cout, hipStream_t s) {
+  if (!mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: cin=%d cout=%d unsupported", cin, cout);
+  return launch_conv<1, 128, 4, 2, 2>(ctx, x, cin, w, bias, nullptr, y, ldy, n, h, wd, cin, 4 * cout, 0, s);
+}
+
+// dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]: K is already [tap][o][c] = [tap][Cin'][Cout']
+int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd,
+                           int cin, int cout, hipStream_t s) {
+  if (!mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: cin=%d cout=%d unsupported", cin, cout);
+  if (cin % 128 == 0) return launch_conv<2, 128, 4, 2, 2>(ctx, dy, lddy, w, nullptr, mask, dx, cin, n, h, wd, cout, cin, 0, s);
+  if (cin % 64 == 0) return launch_conv<2, 64, 4, 2, 2>(ctx, dy, lddy, w, nullptr, mask, dx, cin, n, h, wd, cout, cin, 0, s);
+  return launch_conv<2, 32, 4, 4, 1>(ctx, dy, lddy, w, nullptr, mask, dx, cin, n, h, wd, cout, cin, 0, s);
+}
+
+size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {
+  if (!mfma_wgrad_supported(cin, cout)) return 0;
+  const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout);
+  return (p.part_floats + p.bias_floats) * sizeof(float);
+}
+
+int32_t k_conv3x3_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                              int wd, int cin, int cout, hipStream_t s) {
-  return k_conv3x3_naive_wgrad(ctx, x, dy, dw, db, n, h, wd, cin, cout, s);
+  if (!mfma_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad mfma: cin=%d cout=%d unsupported", cin, cout);
+  return run_wgrad<0>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
+}
+
+size_t mfma_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {
+  if (!mfma_wgrad_supported(cout, cin)) return 0;
+  const WgradPlan p = plan_wgrad(4, n, h, wd, cout, cin, cout);
+  return (p.part_floats + p.bias_floats) * sizeof(float);
+}
+
+// convT: A = dU (channels = cout, pixel stride lddy, 2h x 2w), B = x (channels = cin, h x w); dK is [4][cout][cin]
+int32_t k_convT_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n,
+                           int h, int wd, int cin, int cout, hipStream_t s) {
+  if (!mfma_wgrad_supported(cout, cin)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad mfma: cin=%d cout=%d unsupported", cin, cout);
+  return run_wgrad<1>(ctx, dy, lddy, x, cin, dw, db, ws, ws_bytes, n, h, wd, cout, cin, s);
 }

@@ -103,6 +103,63 @@ __global__ __launch_bounds__(TPB) void conv3x3_naive_wgrad_kernel(const float* _
   atomicAdd(dw + (long long)r * Cout + co, acc);
 }
 
+// Weight gradient of the Cin = 1 first layer (c1a): HBM-bound (reads dy once: 128 B/pixel).
+// 8 lanes per pixel (one float4 of dy each), 9 x-neighbours broadcast from L1; per-thread
+// accumulators [9 taps + bias] x float4, xor-shuffle + LDS tree per block, then block partials
+// [grid][10][Cout] that reduce_c1_kernel sums in a fixed order (deterministic).
+constexpr int C1_BLOCKS = 1024;
+__global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ part, int N, int H, int W, int Cout) {
+  const int lpp = Cout >> 2;
+  const int sub = threadIdx.x % lpp;
+  float4 acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long pixels = (long long)N * H * W;
+  const long long g0 = ((long long)blockIdx.x * TPB + threadIdx.x) / lpp, gs = ((long long)gridDim.x * TPB) / lpp;
+  for (long long p = g0; p < pixels; p += gs) {
+    const int j = (int)(p % W); const long long t2 = p / W; const int i = (int)(t2 % H);
+    const float4 g = *reinterpret_cast<const float4*>(dy + p * Cout + sub * 4);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int ii = i + a - 1;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int jj = j + b - 1;
+        const float v = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? x[p + (a - 1) * W + (b - 1)] : 0.0f;
+        float4& r = acc[a * 3 + b];
+        r.x = fmaf(v, g.x, r.x); r.y = fmaf(v, g.y, r.y); r.z = fmaf(v, g.z, r.z); r.w = fmaf(v, g.w, r.w);
+      }
+    }
+    acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+  }
+  __shared__ float4 red[TPB / 64][10][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    float4 r = acc[t];
+    for (int o = lpp; o < 64; o <<= 1) {
+      r.x += __shfl_xor(r.x, o, 64); r.y += __shfl_xor(r.y, o, 64); r.z += __shfl_xor(r.z, o, 64); r.w += __shfl_xor(r.w, o, 64);
+    }
+    if (lane < lpp) red[wv][t][lane] = r;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 10 * lpp; e += TPB) {
+    const int t = e / lpp, q = e % lpp;
+    float4 r = red[0][t][q];
+    for (int k = 1; k < TPB / 64; ++k) { const float4 u = red[k][t][q]; r.x += u.x; r.y += u.y; r.z += u.z; r.w += u.w; }
+    *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * 10 + t) * Cout + q * 4) = r;
+  }
+}
+
+__global__ void reduce_c1_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int Cout) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 10 * Cout) return;
+  float s = 0.0f;
+  for (int k = 0; k < nblocks; ++k) s += part[(long long)k * 10 * Cout + e];
+  if (e < 9 * Cout) dw[e] = s; else db[e - 9 * Cout] = s;
+}
+
 // ---- transposed conv 2x2 stride 2 (kernel [2][2][Cout][Cin]) --------------------------
 __global__ __launch_bounds__(TPB) void convT_naive_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int ldy,
@@ -233,4 +290,17 @@ int32_t k_convT_naive_wgrad(unet_ctx* ctx, const float* x, const float* dy, int 
   int gy = (int)std::min<long long>(std::max<long long>(want, 1), std::max<long long>(pixels / 64, 1));
   hipLaunchKernelGGL(convT_naive_wgrad_kernel, dim3(gx, gy), dim3(TPB), 0, s, x, dy, lddy, dw, db, n, h, wd, cin, cout);
   UNET_CHECK_LAUNCH(ctx, "convT_naive_wgrad"); return UNET_OK;
+}
+
+size_t c1_wgrad_ws_bytes(int cout) { return (size_t)C1_BLOCKS * 10 * cout * sizeof(float); }
+
+int32_t k_conv3x3_c1_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
+                           int wd, int cout, hipStream_t s) {
+  if ((cout & 3) || TPB % (cout / 4) || (cout / 4) > 64) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1_wgrad: cout=%d unsupported", cout);
+  if (!ws || ws_bytes < c1_wgrad_ws_bytes(cout)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_c1_wgrad: workspace too small");
+  long long groups = ((long long)n * h * wd * (cout / 4) + TPB - 1) / TPB;
+  int blocks = (int)std::min<long long>(C1_BLOCKS, std::max<long long>(groups, 1));
+  hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
+  hipLaunchKernelGGL(reduce_c1_kernel, dim3((10 * cout + 127) / 128), dim3(128), 0, s, static_cast<const float*>(ws), dw, db, blocks, cout);
+  UNET_CHECK_LAUNCH(ctx, "conv3x3_c1_wgrad"); return UNET_OK;
 }

@@ -64,9 +64,11 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
 
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
                                       size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
-  if (use_mfma(algo, cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout))
+  if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout))
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   if (algo == UNET_ALGO_MFMA) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 wgrad mfma: unsupported shape or workspace too small");
+  if (cin == 1 && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0 && cout <= 256 && ws && ws_bytes >= c1_wgrad_ws_bytes(cout))
+    return k_conv3x3_c1_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cout, s);
   return k_conv3x3_naive_wgrad(ctx, x, dy, dw, db, n, h, wd, cin, cout, s);
 }
 
@@ -88,7 +90,8 @@ int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, co
 }
 
 size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
-  return mfma_conv3x3_supported(cin, cout) ? mfma_wgrad_ws_bytes(n, h, wd, cin, cout) : 0;
+  if (cin == 1 && (cout % 4) == 0 && 256 % (cout / 4) == 0 && cout <= 256) return c1_wgrad_ws_bytes(cout);
+  return mfma_wgrad_supported(cin, cout) ? mfma_wgrad_ws_bytes(n, h, wd, cin, cout) : 0;
 }
 
 int32_t unet_conv3x3_bwd_weights(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
@@ -100,21 +103,30 @@ int32_t unet_conv3x3_bwd_weights(unet_ctx* ctx, const float* x, const float* dy,
 int32_t unet_convT2x2_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t ldy, int32_t n,
                           int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
   if (!ctx || !x || !w || !y || ldy < cout || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "convT_fwd: bad args");
-  (void)algo;
+  if (algo == UNET_ALGO_MFMA && !mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: unsupported shape");
+  if (algo != UNET_ALGO_NAIVE && mfma_convT_supported(cin, cout)) return k_convT_mfma_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
 }
 
 int32_t unet_convT2x2_bwd_data(unet_ctx* ctx, const float* dy, int32_t lddy, const float* w, const float* relu_src, float* dx,
                                int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
   if (!ctx || !dy || !w || !dx || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_data: bad args");
-  (void)algo;
+  if (algo == UNET_ALGO_MFMA && !mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: unsupported shape");
+  if (algo != UNET_ALGO_NAIVE && mfma_convT_supported(cin, cout)) return k_convT_mfma_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
 }
 
-int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy, int32_t lddy, float* dw, float* db, int32_t n,
-                                  int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+size_t unet_convT2x2_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
+  return mfma_convT_supported(cin, cout) ? mfma_convT_wgrad_ws_bytes(n, h, wd, cin, cout) : 0;
+}
+
+int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy, int32_t lddy, float* dw, float* db, void* ws,
+                                  size_t ws_bytes, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo,
+                                  void* stream) {
   if (!ctx || !x || !dy || !dw || !db || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_weights: bad args");
-  (void)algo;
+  const bool can = mfma_convT_supported(cin, cout) && ws && ws_bytes >= mfma_convT_wgrad_ws_bytes(n, h, wd, cin, cout);
+  if (algo == UNET_ALGO_MFMA && !can) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad mfma: unsupported shape or workspace too small");
+  if (algo != UNET_ALGO_NAIVE && can) return k_convT_mfma_wgrad(ctx, x, dy, lddy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_wgrad(ctx, x, dy, lddy, dw, db, n, h, wd, cin, cout, as_stream(stream));
 }
 
@@ -296,7 +308,13 @@ void plan_workspace(unet_model* m) {
       if (l.name == "c5a" || l.name == "c5b") lvl = 4;
       else { int k = l.name[1] - '0'; lvl = (k <= 4) ? k - 1 : 9 - k; }
       int hs = s >> lvl, ts = t >> lvl;
-      if (mfma_conv3x3_supported(l.cin, l.cout)) wgb = std::max(wgb, mfma_wgrad_ws_bytes(m->N, hs, ts, l.cin, l.cout));
+      wgb = std::max(wgb, unet_conv3x3_bwd_weights_ws_bytes(m->N, hs, ts, l.cin, l.cout));
+    }
+    for (auto& l : m->layers) {
+      if (l.kind != 1) continue;
+      int k = l.name[1] - '0';                 // u6..u9: input at level (10-k), i.e. spatial >> (10-k)
+      int lvl = 10 - k;
+      wgb = std::max(wgb, mfma_convT_wgrad_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout));
     }
   }
   m->wgrad_ws_bytes = wgb;
@@ -466,7 +484,8 @@ void build_programs(unet_model* m) {
       const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
       const std::string un = "u" + ks;
       ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, 4.0 * (nel(ib) + nel(ug)), {
-        return unet_convT2x2_bwd_weights(ctx, m->A(prev), m->D(un), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), ib.n, ib.h, ib.w, cprev, c, algo, s);
+        return unet_convT2x2_bwd_weights(ctx, m->A(prev), m->D(un), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
+                                         ib.n, ib.h, ib.w, cprev, c, algo, s);
       });
       ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, 4.0 * (2 * nel(ib) + nel(ug)), {
         return unet_convT2x2_bwd_data(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->A(prev), m->D(prev), ib.n, ib.h, ib.w, cprev, c, algo, s);

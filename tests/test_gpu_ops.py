@@ -67,7 +67,7 @@ def test_conv3x3_bwd(ops, shape, algo):
     assert relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 5, 8, 4), (1, 4, 4, 512, 256), (2, 8, 8, 64, 32), (1, 7, 9, 128, 64)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 8, 4), (1, 4, 4, 512, 256), (2, 8, 8, 64, 32), (1, 7, 9, 128, 64), (2, 5, 37, 64, 64), (1, 33, 34, 32, 32)])
 def test_convT(ops, shape):
     from gpu_util import relerr
     n, h, w, ci, co = shape
@@ -75,21 +75,26 @@ def test_convT(ops, shape):
     x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((2, 2, co, ci)) * 0.2).astype(np.float32)
     b = rng.standard_normal(co).astype(np.float32); dy = rng.standard_normal((n, 2 * h, 2 * w, co)).astype(np.float32)
     ld = 2 * co
-    cat = ops.z(n, 2 * h, 2 * w, ld); cat.fill_(9.0)
-    ops.ck(ops.lib.unet_convT2x2_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), cat.data_ptr(), ld, n, h, w, ci, co, 0, ops.s), "convT fwd")
     xt, kt, bt = T64(x).requires_grad_(True), T64(k).requires_grad_(True), T64(b).requires_grad_(True)
     yt = O.convT2x2s2_bias(xt, kt, bt)
-    got = cat.cpu().numpy()
-    assert relerr(got[..., :co], yt.detach().numpy()) < TOL and (got[..., co:] == 9.0).all()      # only the slice is written
+    for algo in (0, 1):
+        cat = ops.z(n, 2 * h, 2 * w, ld); cat.fill_(9.0)
+        ops.ck(ops.lib.unet_convT2x2_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), cat.data_ptr(), ld, n, h, w, ci, co, algo, ops.s), "convT fwd")
+        got = cat.cpu().numpy()
+        assert relerr(got[..., :co], yt.detach().numpy()) < TOL and (got[..., co:] == 9.0).all()      # only the slice is written
     yt.backward(T64(dy))
     dcat = np.full((n, 2 * h, 2 * w, ld), 5.0, np.float32); dcat[..., :co] = dy
     for masked in (False, True):
-        dx = ops.z(n, h, w, ci)
-        ops.ck(ops.lib.unet_convT2x2_bwd_data(ops.h, ops.d(dcat).data_ptr(), ld, ops.d(k).data_ptr(), ops.d(x).data_ptr() if masked else None, dx.data_ptr(), n, h, w, ci, co, 0, ops.s), "convT bwd data")
-        assert relerr(dx.cpu().numpy(), xt.grad.numpy() * ((x > 0) if masked else 1.0)) < TOL
-    dw = ops.z(2, 2, co, ci); db = ops.z(co); dw.fill_(3.0)
-    ops.ck(ops.lib.unet_convT2x2_bwd_weights(ops.h, ops.d(x).data_ptr(), ops.d(dcat).data_ptr(), ld, dw.data_ptr(), db.data_ptr(), n, h, w, ci, co, 0, ops.s), "convT bwd w")
-    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < TOL and relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
+        for algo in (0, 1):
+            dx = ops.z(n, h, w, ci)
+            ops.ck(ops.lib.unet_convT2x2_bwd_data(ops.h, ops.d(dcat).data_ptr(), ld, ops.d(k).data_ptr(), ops.d(x).data_ptr() if masked else None, dx.data_ptr(), n, h, w, ci, co, algo, ops.s), "convT bwd data")
+            assert relerr(dx.cpu().numpy(), xt.grad.numpy() * ((x > 0) if masked else 1.0)) < TOL
+    for algo in (0, 1):
+        nb = ops.lib.unet_convT2x2_bwd_weights_ws_bytes(n, h, w, ci, co)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+        dw = ops.z(2, 2, co, ci); db = ops.z(co); dw.fill_(3.0); db.fill_(-2.0)
+        ops.ck(ops.lib.unet_convT2x2_bwd_weights(ops.h, ops.d(x).data_ptr(), ops.d(dcat).data_ptr(), ld, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, algo, ops.s), "convT bwd w")
+        assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < TOL and relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
 
 
 @pytest.mark.parametrize("c,ld_extra", [(32, 0), (64, 64), (128, 0), (512, 0), (256, 256)])
