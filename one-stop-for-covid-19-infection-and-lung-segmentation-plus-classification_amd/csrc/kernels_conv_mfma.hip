@@ -271,19 +271,34 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict_
   else { if (tb == 0 && lane < 32) part_b[(long long)split * CA + a0 + l31] = bsum; }
 }
 
+// Sum the split-K partials in a fixed order.  Two levels so that a tiny output (e.g. 9x32x32) with
+// thousands of splits still spreads over the chip: level 1 reduces groups of splits (grid.y = groups),
+// level 2 reduces the group sums.  4 independent accumulators keep 4 loads in flight per thread.
 __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, long long n4,
-                                                            long long stride, int nsplit) {
+                                                            long long stride, int nsplit, int per_group, long long out_stride) {
+  const int k0 = blockIdx.y * per_group;
+  int k1 = k0 + per_group; if (k1 > nsplit) k1 = nsplit;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    float4 s = *reinterpret_cast<const float4*>(part + i * 4);
-    for (int k = 1; k < nsplit; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(part + k * stride + i * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(part + (long long)k * stride + i * 4);
+      const float4 b = *reinterpret_cast<const float4*>(part + (long long)(k + 1) * stride + i * 4);
+      const float4 c = *reinterpret_cast<const float4*>(part + (long long)(k + 2) * stride + i * 4);
+      const float4 d = *reinterpret_cast<const float4*>(part + (long long)(k + 3) * stride + i * 4);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w; s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
     }
-    *reinterpret_cast<float4*>(out + i * 4) = s;
+    for (; k < k1; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(part + (long long)k * stride + i * 4);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    s0.x += s1.x + (s2.x + s3.x); s0.y += s1.y + (s2.y + s3.y); s0.z += s1.z + (s2.z + s3.z); s0.w += s1.w + (s2.w + s3.w);
+    *reinterpret_cast<float4*>(out + (long long)blockIdx.y * out_stride + i * 4) = s0;
   }
 }
 
-struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_split; long long total_rows; size_t part_floats, bias_floats; };
+struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_split, groups, per_group; long long total_rows; size_t part_floats, bias_floats, part2_floats; };
 
 WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
   WgradPlan p;
@@ -299,6 +314,13 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
   p.rows_per_split = (int)((p.total_rows + ns - 1) / ns);
   p.nsplit = (int)((p.total_rows + p.rows_per_split - 1) / p.rows_per_split);
   p.part_floats = (size_t)p.nsplit * per; p.bias_floats = (size_t)p.nsplit * cbias;
+  // second-level groups: enough blocks to fill the chip when the output tile is tiny
+  const long long out_blocks = std::max<long long>(1, per / 1024);
+  long long g = std::min<long long>(std::min<long long>(64, p.nsplit / 8), 1024 / out_blocks);
+  p.groups = (int)std::max<long long>(1, g);
+  p.per_group = (p.nsplit + p.groups - 1) / p.groups;
+  p.groups = (p.nsplit + p.per_group - 1) / p.per_group;
+  p.part2_floats = p.groups > 1 ? (size_t)p.groups * (per + cbias) : 0;
   return p;
 }
 
@@ -307,15 +329,24 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
                   int h, int w, int ca, int cb, hipStream_t s) {
   const int taps = MODE == 0 ? 9 : 4; const int cbias = MODE == 0 ? cb : ca;
   const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias);
-  const size_t need = (p.part_floats + p.bias_floats) * sizeof(float);
+  const size_t need = (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
   if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   float* part = static_cast<float*>(ws); float* part_b = part + p.part_floats;
   hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, dim3((unsigned)(p.tiles_a * p.tiles_b), (unsigned)p.nsplit), dim3(64), 0, s, A, ldA, B, ldB, part,
                      part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_split, p.total_rows);
   UNET_CHECK_LAUNCH(ctx, "wgrad_mfma");
   const long long per = (long long)taps * ca * cb;
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)std::min<long long>((per / 4 + 255) / 256, 2048)), dim3(256), 0, s, part, dw, per / 4, per, p.nsplit);
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3(1), dim3(256), 0, s, part_b, db, (long long)cbias / 4, (long long)cbias, p.nsplit);
+  const unsigned gx = (unsigned)std::min<long long>((per / 4 + 255) / 256, 2048);
+  if (p.groups > 1) {
+    float* part2 = part_b + p.bias_floats; float* part2_b = part2 + (size_t)p.groups * per;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, p.groups), dim3(256), 0, s, part, part2, per / 4, per, p.nsplit, p.per_group, per);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(1, p.groups), dim3(256), 0, s, part_b, part2_b, (long long)cbias / 4, (long long)cbias, p.nsplit, p.per_group, (long long)cbias);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, 1), dim3(256), 0, s, part2, dw, per / 4, per, p.groups, p.groups, 0LL);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(1, 1), dim3(256), 0, s, part2_b, db, (long long)cbias / 4, (long long)cbias, p.groups, p.groups, 0LL);
+  } else {
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, 1), dim3(256), 0, s, part, dw, per / 4, per, p.nsplit, p.nsplit, 0LL);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(1, 1), dim3(256), 0, s, part_b, db, (long long)cbias / 4, (long long)cbias, p.nsplit, p.nsplit, 0LL);
+  }
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
 }
@@ -354,7 +385,7 @@ int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {
   if (!mfma_wgrad_supported(cin, cout)) return 0;
   const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout);
-  return (p.part_floats + p.bias_floats) * sizeof(float);
+  return (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
 }
 
 int32_t k_conv3x3_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
@@ -366,7 +397,7 @@ int32_t k_conv3x3_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, flo
 size_t mfma_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {
   if (!mfma_wgrad_supported(cout, cin)) return 0;
   const WgradPlan p = plan_wgrad(4, n, h, wd, cout, cin, cout);
-  return (p.part_floats + p.bias_floats) * sizeof(float);
+  return (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
 }
 
 // convT: A = dU (channels = cout, pixel stride lddy, 2h x 2w), B = x (channels = cin, h x w); dK is [4][cout][cin]

@@ -152,12 +152,22 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __re
   }
 }
 
-__global__ void reduce_c1_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int Cout) {
+// two-level fixed-order reduction of the block partials: level 1 sums groups of 32 blocks
+__global__ void reduce_c1_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out_b, int nblocks, int per_group,
+                                 int Cout, int final_level) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 10 * Cout) return;
-  float s = 0.0f;
-  for (int k = 0; k < nblocks; ++k) s += part[(long long)k * 10 * Cout + e];
-  if (e < 9 * Cout) dw[e] = s; else db[e - 9 * Cout] = s;
+  const int k0 = blockIdx.y * per_group; int k1 = k0 + per_group; if (k1 > nblocks) k1 = nblocks;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = k0;
+  for (; k + 3 < k1; k += 4) {
+    s0 += part[(long long)k * 10 * Cout + e]; s1 += part[(long long)(k + 1) * 10 * Cout + e];
+    s2 += part[(long long)(k + 2) * 10 * Cout + e]; s3 += part[(long long)(k + 3) * 10 * Cout + e];
+  }
+  for (; k < k1; ++k) s0 += part[(long long)k * 10 * Cout + e];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (!final_level) out[(long long)blockIdx.y * 10 * Cout + e] = s;
+  else if (e < 9 * Cout) out[e] = s; else out_b[e - 9 * Cout] = s;
 }
 
 // ---- transposed conv 2x2 stride 2 (kernel [2][2][Cout][Cin]) --------------------------
@@ -292,7 +302,7 @@ int32_t k_convT_naive_wgrad(unet_ctx* ctx, const float* x, const float* dy, int 
   UNET_CHECK_LAUNCH(ctx, "convT_naive_wgrad"); return UNET_OK;
 }
 
-size_t c1_wgrad_ws_bytes(int cout) { return (size_t)C1_BLOCKS * 10 * cout * sizeof(float); }
+size_t c1_wgrad_ws_bytes(int cout) { return (size_t)(C1_BLOCKS + 32) * 10 * cout * sizeof(float); }
 
 int32_t k_conv3x3_c1_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                            int wd, int cout, hipStream_t s) {
@@ -301,6 +311,9 @@ int32_t k_conv3x3_c1_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
   long long groups = ((long long)n * h * wd * (cout / 4) + TPB - 1) / TPB;
   int blocks = (int)std::min<long long>(C1_BLOCKS, std::max<long long>(groups, 1));
   hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
-  hipLaunchKernelGGL(reduce_c1_kernel, dim3((10 * cout + 127) / 128), dim3(128), 0, s, static_cast<const float*>(ws), dw, db, blocks, cout);
+  float* part = static_cast<float*>(ws); float* part2 = part + (size_t)C1_BLOCKS * 10 * cout;
+  const int ngroups = (blocks + 31) / 32;
+  hipLaunchKernelGGL(reduce_c1_kernel, dim3((10 * cout + 127) / 128, ngroups), dim3(128), 0, s, part, part2, nullptr, blocks, 32, cout, 0);
+  hipLaunchKernelGGL(reduce_c1_kernel, dim3((10 * cout + 127) / 128, 1), dim3(128), 0, s, part2, dw, db, ngroups, ngroups, cout, 1);
   UNET_CHECK_LAUNCH(ctx, "conv3x3_c1_wgrad"); return UNET_OK;
 }

@@ -78,16 +78,20 @@ def test_live_oracle_all_grads_and_taps(hw, n):
     assert abs(ld[0] - r["loss"]) < 1e-5 and abs(ld[1] - r["dice"]) < 1e-5
     for name in ("c1a", "c1b", "bn1", "p1", "c3b", "bn4", "p4", "c5b", "u6", "bn6", "c6a", "u9", "bn9", "c9b"):
         assert relerr(eng.tap(n, name), r["acts"][name]) < 2e-5, name
+    # A ReLU whose pre-activation rounds to the other side of 0 in fp32 is a discontinuity, not an error: ONE such
+    # element changes every upstream gradient by ~1e-3 relative (the fp32 CPU oracle shows the same, see
+    # tools/debug_parity.py).  So: count mask flips vs the fp64 oracle; tight tolerance when there are none.
+    convs = [f"c{k}{ab}" for k in range(1, 10) for ab in "ab"]
+    flips = sum(int(((eng.tap(n, name) > 0) != (r["acts"][name] > 0)).sum()) for name in convs)
+    tol_a, tol_g = (2e-4, 3e-4) if flips == 0 else (2e-2, 2e-2)
+    assert flips <= 8, flips
     # gradients wrt activations (ours are already ReLU-masked where the producer is a ReLU conv)
     for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c5b", True), ("p4", False), ("bn4", False), ("c4b", True), ("c1a", True)):
-        # mask from the DEVICE activation: an activation that is +-1e-8 around zero may flip its ReLU mask
-        # between fp32 and fp64, which is a discontinuity, not an error
         want = r["act_grads"][name] * ((eng.tap(n, name) > 0) if masked else 1.0)
-        # 2e-3: a handful of such flips upstream (different fp32/fp64 masks) propagate as isolated O(1) differences
-        assert relerr(eng.tap(n, name, grad=True), want) < 2e-3, name
+        assert relerr(eng.tap(n, name, grad=True), want) < tol_a, (name, flips)
     g = eng.get_grads()
     for k in g:
-        assert relerr(g[k], r["grads"][k]) < 3e-4, k
+        assert relerr(g[k], r["grads"][k]) < tol_g, (k, flips)
 
 
 def test_training_trajectory_and_bn_state_live():
@@ -102,7 +106,8 @@ def test_training_trajectory_and_bn_state_live():
         assert abs(a[0] - b[0]) < 3e-4 and abs(a[1] - b[1]) < 3e-4, (step, a, b)
     wa = eng.get_weights()
     for k in ("bn1/mean", "bn1/var", "bn6/mean", "bn9/var"):
-        assert relerr(wa[k], tr.w[k]) < 1e-3, k          # after 4 fp32-vs-fp64 optimizer steps
+        # after 4 fp32-vs-fp64 optimizer steps; moving means are near-zero-mean vectors, so scale by the std too
+        assert np.abs(wa[k] - tr.w[k]).max() < 1e-3 * (np.abs(tr.w[k]).max() + 0.01 * np.sqrt(np.abs(tr.w[k.replace("mean", "var")]).max())), k
 
 
 def test_dropout_training_matches_oracle_with_same_masks():

@@ -21,7 +21,7 @@ def T64(a):
 
 
 CONV_SHAPES = [(2, 9, 13, 3, 5), (1, 16, 16, 1, 32), (2, 16, 16, 32, 32), (2, 12, 20, 32, 64), (1, 8, 8, 64, 128),
-               (2, 6, 10, 128, 64), (1, 4, 4, 256, 512), (3, 14, 14, 64, 64), (1, 34, 70, 32, 32)]
+               (2, 6, 10, 128, 64), (1, 4, 4, 256, 512), (3, 14, 14, 64, 64), (1, 34, 70, 32, 32), (2, 64, 48, 1, 32), (1, 9, 13, 1, 32), (2, 4, 3, 512, 512)]
 
 
 @pytest.mark.parametrize("algo", [0, 1])
