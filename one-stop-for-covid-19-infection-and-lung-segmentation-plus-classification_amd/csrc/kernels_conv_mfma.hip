@@ -15,6 +15,8 @@
 //   Epilogue: +bias, ReLU, optional ReLU-mask multiply (backward), coalesced 128-B row stores.
 //
 // Weight-gradient: see wgrad_mfma_kernel below (split-K over pixels, deterministic 2-stage).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -33,7 +35,7 @@ constexpr int PW = 34;    // patch width: 32 + halo
 // MODE 2: convT2x2s2 data-gradient = 2x2 stride-2 'valid' convolution of dU (pixel stride ldx):
 //         the 2x-upsampled patch is de-interleaved by column parity in LDS so that the A operand of
 //         tap (a,b) is again 32 consecutive pixels (conflict-free ds_read_b128)
-template <int MODE, int TN, int TH, int WR, int WC>
+template <int MODE, int TN, int TH, int WR, int WC, bool PF, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ mask,
                                                         float* __restrict__ y, int ldy, int N, int H, int W, int Cin, int Cout,
@@ -43,6 +45,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
   constexpr int RW = TH / WR;          // image rows (M tiles) per wave
   constexpr int NW = TN / 32 / WC;     // N tiles per wave
   constexpr int NPIX = MODE == 0 ? (TH + 2) * PW : (MODE == 1 ? TH * 32 : 2 * TH * 64);
+  constexpr int PTOT = NPIX * 2;                                        // float4 per patch chunk
+  constexpr int WTOT = MODE == 1 ? TN * 2 : TAPS * CK * (TN / 4);       // float4 per weight slab
+  constexpr int PL = (PTOT + 255) / 256, WL = (WTOT + 255) / 256;       // per-thread staging registers
   static_assert(RW >= 1 && NW >= 1, "tile");
   __shared__ __attribute__((aligned(16))) float s_in[NPIX * CKP];
   __shared__ __attribute__((aligned(16))) float s_w[TAPS * CK * TN];
@@ -65,38 +70,76 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // ---- per-thread staging plan, hoisted out of the K loop: element offsets (-1 = zero fill) and LDS slots
   const float* xn = x + (long long)n * HI * WI * ldx;
-  for (int c0 = 0; c0 < Cin; c0 += CK) {
-    // ---- stage the input patch of this channel chunk (zero fill = 'same' padding + ragged edges)
-    for (int idx = tid; idx < NPIX * 2; idx += 256) {
-      const int q = idx & 1, pix = idx >> 1;
-      int gy, gx, lp;
-      if (MODE == 0) { const int r = pix / PW, c = pix - r * PW; gy = y0 + r - 1; gx = x0 + c - 1; lp = pix; }
-      else if (MODE == 1) { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); lp = pix; }
-      else { const int rr = pix >> 6, cc = pix & 63; gy = 2 * y0 + rr; gx = 2 * x0 + cc; lp = (rr * 2 + (cc & 1)) * 32 + (cc >> 1); }
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < HI && gx >= 0 && gx < WI)
-        v = *reinterpret_cast<const float4*>(xn + ((long long)gy * WI + gx) * ldx + c0 + q * 4);
-      *reinterpret_cast<float4*>(&s_in[lp * CKP + q * 4]) = v;
-    }
-    // ---- stage the weight slab [tap][ci][TN]
+  int poff[PL], plds[PL];
+#pragma unroll
+  for (int k = 0; k < PL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx & 1, pix = idx >> 1;
+    int gy, gx, lp;
+    if (MODE == 0) { const int r = pix / PW, c = pix - r * PW; gy = y0 + r - 1; gx = x0 + c - 1; lp = pix; }
+    else if (MODE == 1) { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); lp = pix; }
+    else { const int rr = pix >> 6, cc = pix & 63; gy = 2 * y0 + rr; gx = 2 * x0 + cc; lp = (rr * 2 + (cc & 1)) * 32 + (cc >> 1); }
+    const bool ok = idx < PTOT && gy >= 0 && gy < HI && gx >= 0 && gx < WI;
+    poff[k] = ok ? (gy * WI + gx) * ldx + q * 4 : -1;
+    plds[k] = idx < PTOT ? lp * CKP + q * 4 : -1;
+  }
+  int woff[WL], wlds[WL];
+#pragma unroll
+  for (int k = 0; k < WL; ++k) {
+    const int idx = tid + k * 256;
     if (MODE == 1) {
-      // Keras ConvT kernel [ab][o][c]: row nn = ab*Cq + o holds Cin contiguous floats; transpose while staging
-      for (int idx = tid; idx < TN * 2; idx += 256) {
-        const int half = idx & 1, nn = idx >> 1;
-        const float4 v = *reinterpret_cast<const float4*>(w + (long long)(nbase + nn) * Cin + c0 + half * 4);
-        s_w[(half * 4 + 0) * TN + nn] = v.x; s_w[(half * 4 + 1) * TN + nn] = v.y;
-        s_w[(half * 4 + 2) * TN + nn] = v.z; s_w[(half * 4 + 3) * TN + nn] = v.w;
-      }
+      const int half = idx & 1, nn = idx >> 1;
+      woff[k] = idx < WTOT ? (nbase + nn) * Cin + half * 4 : -1;     // Keras ConvT kernel [ab][o][c]: row nn holds Cin floats
+      wlds[k] = half * 4 * TN + nn;
     } else {
-      for (int idx = tid; idx < TAPS * CK * (TN / 4); idx += 256) {
-        const int q = idx % (TN / 4), row = idx / (TN / 4);
-        const int tap = row >> 3, ci = row & 7;
-        const float4 v = *reinterpret_cast<const float4*>(w + ((long long)(tap * Cin + c0 + ci)) * Cout + nbase + q * 4);
-        *reinterpret_cast<float4*>(&s_w[row * TN + q * 4]) = v;
+      const int q = idx % (TN / 4), row = idx / (TN / 4);
+      const int tap = row >> 3, ci = row & 7;
+      woff[k] = idx < WTOT ? (tap * Cin + ci) * Cout + nbase + q * 4 : -1;
+      wlds[k] = row * TN + q * 4;
+    }
+  }
+  f32x4 preg[PL], wreg[WL];
+  auto issue_loads = [&](int c0) __attribute__((always_inline)) {                 // all global loads of a chunk in flight before any wait
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+      preg[k] = poff[k] >= 0 ? *reinterpret_cast<const f32x4*>(xn + poff[k] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < WL; ++k)
+      wreg[k] = woff[k] >= 0 ? *reinterpret_cast<const f32x4*>(w + woff[k] + (MODE == 1 ? c0 : c0 * Cout)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+      if (plds[k] >= 0) *reinterpret_cast<f32x4*>(&s_in[plds[k]]) = preg[k];
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      if (woff[k] < 0) continue;
+      if (MODE == 1) {            // transpose while staging: s_w[ci][nn]
+        s_w[wlds[k]] = wreg[k][0]; s_w[wlds[k] + TN] = wreg[k][1]; s_w[wlds[k] + 2 * TN] = wreg[k][2]; s_w[wlds[k] + 3 * TN] = wreg[k][3];
+      } else {
+        *reinterpret_cast<f32x4*>(&s_w[wlds[k]]) = wreg[k];
       }
+    }
+  };
+
+  // ABL (timing ablations only, results are wrong): bit0 = no LDS operand reads, bit1 = stage only the first chunk
+  if (PF) issue_loads(0);
+  f32x4 a_fix[RW]; float b_fix[NW];
+  if (ABL & 1) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) a_fix[i] = (f32x4){1.f + tid, 2.f, 3.f, 4.f};
+#pragma unroll
+    for (int jn = 0; jn < NW; ++jn) b_fix[jn] = 0.5f + lane;
+  }
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    if (!(ABL & 2) || c0 == 0) {
+      if (!PF) issue_loads(c0);
+      store_lds();
     }
     __syncthreads();
+    if (PF && c0 + CK < Cin && !(ABL & 2)) issue_loads(c0 + CK);      // next chunk's loads fly under this chunk's MFMAs
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       f32x4 a[RW];
@@ -106,13 +149,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
         if (MODE == 0) lp = (wr * RW + i + tap / 3) * PW + l31 + tap % 3;
         else if (MODE == 1) lp = (wr * RW + i) * 32 + l31;
         else lp = ((2 * (wr * RW + i) + (tap >> 1)) * 2 + (tap & 1)) * 32 + l31;
-        a[i] = *reinterpret_cast<const f32x4*>(&s_in[lp * CKP + hi * 4]);
+        if (ABL & 1) { a[i] = a_fix[i]; asm volatile("" : "+v"(a[i])); }
+        else a[i] = *reinterpret_cast<const f32x4*>(&s_in[lp * CKP + hi * 4]);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float bv[NW];
 #pragma unroll
-        for (int jn = 0; jn < NW; ++jn) bv[jn] = s_w[(tap * CK + j + 4 * hi) * TN + (wc * NW + jn) * 32 + l31];
+        for (int jn = 0; jn < NW; ++jn) {
+          if (ABL & 1) { bv[jn] = b_fix[jn]; asm volatile("" : "+v"(bv[jn])); }
+          else bv[jn] = s_w[(tap * CK + j + 4 * hi) * TN + (wc * NW + jn) * 32 + l31];
+        }
 #pragma unroll
         for (int i = 0; i < RW; ++i)
 #pragma unroll
@@ -152,13 +199,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
   }
 }
 
+inline int conv_ablation() {
+  static const int v = [] { const char* e = getenv("UNET_CONV_ABL"); return e ? atoi(e) : 0; }();
+  return v;
+}
+inline bool conv_prefetch_enabled() {
+  static const int v = [] { const char* e = getenv("UNET_CONV_PF"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
 template <int MODE, int TN, int TH, int WR, int WC>
 int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, const float* mask, float* y, int ldy,
                     int n, int h, int wd, int cin, int cout, int relu, hipStream_t s) {
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH;
   dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)(cout / TN));
-  hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout,
-                     relu, tiles_x, tiles_y);
+  if (MODE == 0 && conv_ablation()) {          // timing experiments (tools/conv_ablate.py); never set in production
+    const int a = conv_ablation();
+    if (a == 1) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, 1>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, relu, tiles_x, tiles_y);
+    else if (a == 2) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, 2>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, relu, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, 3>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, relu, tiles_x, tiles_y);
+  } else if (conv_prefetch_enabled())
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, true>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin,
+                       cout, relu, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin,
+                       cout, relu, tiles_x, tiles_y);
   UNET_CHECK_LAUNCH(ctx, "conv_mfma");
   return UNET_OK;
 }
@@ -179,20 +244,24 @@ int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, cons
 // per-lane column sums of the dY / dU values the wave already holds.
 // =========================================================================================
 template <int MODE>
-__global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
+__global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
                                                         float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
-                                                        int CA, int CB, int tiles_b, int strips, int rows_per_split,
-                                                        long long total_rows) {
+                                                        int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
+                                                        int chunks_per_strip) {
   constexpr int TAPS = MODE == 0 ? 9 : 4;
   constexpr int ROWF = 34 * 32;                    // floats per ring row (conv3x3)
+  constexpr int AL = MODE == 0 ? 5 : 16, BL = 4;   // float4 staging registers per lane (A rows, B row)
   __shared__ __attribute__((aligned(16))) float s_a[MODE == 0 ? 3 * ROWF : 4 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_b[32 * 32];
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
   const int ta = blockIdx.x / tiles_b, tb = blockIdx.x % tiles_b;
   const int a0 = ta * 32, b0 = tb * 32;
   const int split = blockIdx.y;
-  const long long u0 = (long long)split * rows_per_split;
-  long long u1 = u0 + rows_per_split; if (u1 > total_rows) u1 = total_rows;
+  const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
+  const int cs = t2 % strips, n = t2 / strips;
+  const int x0 = cs * 32;
+  const int ya = chunk * rows_per_chunk;
+  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -202,56 +271,81 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict_
   float bsum = 0.0f;
 
   const int HA = MODE == 0 ? H : 2 * H, WA = MODE == 0 ? W : 2 * W;
-  bool fresh = true;
-  for (long long u = u0; u < u1; ++u) {
-    const int yrow = (int)(u % H); const long long t2 = u / H;
-    const int cs = (int)(t2 % strips); const int n = (int)(t2 / strips);
-    const int x0 = cs * 32;
-    const float* An = A + (long long)n * HA * WA * ldA;
-    const float* Bn = B + (long long)n * H * W * ldB;
+  const float* An = A + (long long)n * HA * WA * ldA;
+  const float* Bn = B + (long long)n * H * W * ldB;
+
+  // per-lane staging plan (column part of the address; -1 = zero fill) hoisted out of the row loop
+  int aoff[AL], alds[AL], boff[BL], blds[BL];
+#pragma unroll
+  for (int k = 0; k < AL; ++k) {
+    const int idx = lane + 64 * k;
     if (MODE == 0) {
-      // ring of X rows: slot(r) = (r + 3) % 3; rows yrow-1, yrow are resident unless the strip just started
-      const int first = (fresh || yrow == 0) ? -1 : 1;
-      for (int rr = first; rr <= 1; ++rr) {
-        const int yy = yrow + rr; const int slot = (yy + 3) % 3;
-        for (int idx = lane; idx < 34 * 8; idx += 64) {
-          const int pix = idx >> 3, q = idx & 7; const int gx = x0 - 1 + pix;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (yy >= 0 && yy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(An + ((long long)yy * W + gx) * ldA + a0 + q * 4);
-          *reinterpret_cast<float4*>(&s_a[slot * ROWF + pix * 32 + q * 4]) = v;
-        }
-      }
-      fresh = false;
+      const int pix = idx >> 3, q = idx & 7; const int gx = x0 - 1 + pix;
+      aoff[k] = (idx < 34 * 8 && gx >= 0 && gx < W) ? gx * ldA + a0 + q * 4 : -1;
+      alds[k] = idx < 34 * 8 ? pix * 32 + q * 4 : -1;
     } else {
-      for (int idx = lane; idx < 2 * 64 * 8; idx += 64) {
-        const int q = idx & 7; const int cc = (idx >> 3) & 63; const int a = idx >> 9;
-        const int gx = 2 * x0 + cc;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gx < WA) v = *reinterpret_cast<const float4*>(An + ((long long)(2 * yrow + a) * WA + gx) * ldA + a0 + q * 4);
-        *reinterpret_cast<float4*>(&s_a[(((a * 2 + (cc & 1)) * 32) + (cc >> 1)) * 32 + q * 4]) = v;
-      }
+      const int q = idx & 7; const int cc = (idx >> 3) & 63; const int a = idx >> 9;   // a = row parity of dU
+      const int gx = 2 * x0 + cc;
+      aoff[k] = gx < WA ? (a * WA + gx) * ldA + a0 + q * 4 : -1;
+      alds[k] = (((a * 2 + (cc & 1)) * 32) + (cc >> 1)) * 32 + q * 4;
     }
-    for (int idx = lane; idx < 32 * 8; idx += 64) {
-      const int pix = idx >> 3, q = idx & 7; const int gx = x0 + pix;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gx < W) v = *reinterpret_cast<const float4*>(Bn + ((long long)yrow * W + gx) * ldB + b0 + q * 4);
-      *reinterpret_cast<float4*>(&s_b[pix * 32 + q * 4]) = v;
+  }
+#pragma unroll
+  for (int k = 0; k < BL; ++k) {
+    const int idx = lane + 64 * k; const int pix = idx >> 3, q = idx & 7; const int gx = x0 + pix;
+    boff[k] = gx < W ? gx * ldB + b0 + q * 4 : -1;
+    blds[k] = pix * 32 + q * 4;
+  }
+  f32x4 areg[AL], breg[BL];            // ext-vector type: stays in registers (a float4 struct select goes through scratch)
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // MODE 0 step t handles ring row yy = ya-1+t (X row yy and dY row yy-1); MODE 1 step t handles row y = ya+t
+  const int nsteps = MODE == 0 ? (yb - ya + 2) : (yb - ya);
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    if (MODE == 0) {
+      const int yy = ya - 1 + t, yd = yy - 1;
+      const bool okx = yy >= 0 && yy < H, okd = yd >= ya && yd < yb;
+      const float* ar = An + (long long)yy * W * ldA; const float* br = Bn + (long long)yd * W * ldB;
+#pragma unroll
+      for (int k = 0; k < AL; ++k) areg[k] = (okx && aoff[k] >= 0) ? *reinterpret_cast<const f32x4*>(ar + aoff[k]) : z4;
+#pragma unroll
+      for (int k = 0; k < BL; ++k) breg[k] = (okd && boff[k] >= 0) ? *reinterpret_cast<const f32x4*>(br + boff[k]) : z4;
+    } else {
+      const int yrow = ya + t;
+      const float* ar = An + (long long)(2 * yrow) * WA * ldA; const float* br = Bn + (long long)yrow * W * ldB;
+#pragma unroll
+      for (int k = 0; k < AL; ++k) areg[k] = aoff[k] >= 0 ? *reinterpret_cast<const f32x4*>(ar + aoff[k]) : z4;
+#pragma unroll
+      for (int k = 0; k < BL; ++k) breg[k] = boff[k] >= 0 ? *reinterpret_cast<const f32x4*>(br + boff[k]) : z4;
     }
+  };
+
+  issue(0);
+  for (int t = 0; t < nsteps; ++t) {
+    const int yy = ya - 1 + t;                                  // MODE 0 only
+    const int slot_w = MODE == 0 ? ((yy + 3) % 3) * ROWF : 0;
+#pragma unroll
+    for (int k = 0; k < AL; ++k)
+      if (alds[k] >= 0) *reinterpret_cast<f32x4*>(&s_a[slot_w + alds[k]]) = areg[k];
+#pragma unroll
+    for (int k = 0; k < BL; ++k) *reinterpret_cast<f32x4*>(&s_b[blds[k]]) = breg[k];
     __syncthreads();
-    int slot_off[3];
+    if (t + 1 < nsteps) issue(t + 1);                            // next row's loads fly under this row's MFMAs
+    if (MODE == 1 || t >= 2) {
+      int slot_off[3];
 #pragma unroll
-    for (int dr = 0; dr < 3; ++dr) slot_off[dr] = ((yrow + dr + 2) % 3) * ROWF;
-#pragma unroll 4
-    for (int pp = 0; pp < 16; ++pp) {
-      const int c = 2 * pp + hi;
-      const float bv = s_b[c * 32 + l31];
-      if (MODE == 0) bsum += bv;
+      for (int dr = 0; dr < 3; ++dr) slot_off[dr] = ((yy - 2 + dr + 3) % 3) * ROWF;   // rows y-1, y, y+1 with y = yy-1
+#pragma unroll 2
+      for (int pp = 0; pp < 16; ++pp) {
+        const int c = 2 * pp + hi;
+        const float bv = s_b[c * 32 + l31];
+        if (MODE == 0) bsum += bv;
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        float av;
-        if (MODE == 0) av = s_a[slot_off[t / 3] + (c + t % 3) * 32 + l31];
-        else { av = s_a[(t * 32 + c) * 32 + l31]; bsum += av; }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        for (int tp = 0; tp < TAPS; ++tp) {
+          float av;
+          if (MODE == 0) av = s_a[slot_off[tp / 3] + (c + tp % 3) * 32 + l31];
+          else { av = s_a[(tp * 32 + c) * 32 + l31]; bsum += av; }
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tp], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -298,21 +392,24 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
   }
 }
 
-struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_split, groups, per_group; long long total_rows; size_t part_floats, bias_floats, part2_floats; };
+struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_chunk, chunks_per_strip, groups, per_group; size_t part_floats, bias_floats, part2_floats; };
 
 WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
   WgradPlan p;
   p.tiles_a = ca / 32; p.tiles_b = cb / 32; p.strips = (w + 31) / 32;
-  p.total_rows = (long long)n * p.strips * h;
   const long long pairs = (long long)p.tiles_a * p.tiles_b;
-  long long ns = (4096 + pairs - 1) / pairs;                        // ~3072 wave slots on 256 CUs (3 waves/SIMD)
   const long long per = (long long)taps * ca * cb;
-  const long long cap = std::max<long long>(1, (48LL << 20) / per);   // <= 192 MiB of partials
-  ns = std::min(ns, cap);
-  ns = std::min<long long>(ns, std::max<long long>(1, p.total_rows / 2));
-  ns = std::max<long long>(ns, 1);
-  p.rows_per_split = (int)((p.total_rows + ns - 1) / ns);
-  p.nsplit = (int)((p.total_rows + p.rows_per_split - 1) / p.rows_per_split);
+  // K-split: every (image, 32-column strip) is cut into row chunks; aim at ~4096 waves (2 waves/SIMD x 256 CUs x 2 rounds),
+  // at least 8 rows per chunk (the 3x3 ring re-reads 2 halo rows per chunk), at most 192 MiB of partials
+  const long long units = (long long)n * p.strips;
+  long long want = (4096 + pairs - 1) / pairs;
+  const long long cap = std::max<long long>(1, (48LL << 20) / per);
+  want = std::min(want, cap);
+  long long cps = std::max<long long>(1, (want + units - 1) / units);
+  cps = std::min<long long>(cps, std::max<long long>(1, h / 8));
+  p.rows_per_chunk = (int)((h + cps - 1) / cps);
+  p.chunks_per_strip = (h + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  p.nsplit = (int)(units * p.chunks_per_strip);
   p.part_floats = (size_t)p.nsplit * per; p.bias_floats = (size_t)p.nsplit * cbias;
   // second-level groups: enough blocks to fill the chip when the output tile is tiny
   const long long out_blocks = std::max<long long>(1, per / 1024);
@@ -333,7 +430,7 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
   if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   float* part = static_cast<float*>(ws); float* part_b = part + p.part_floats;
   hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, dim3((unsigned)(p.tiles_a * p.tiles_b), (unsigned)p.nsplit), dim3(64), 0, s, A, ldA, B, ldB, part,
-                     part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_split, p.total_rows);
+                     part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip);
   UNET_CHECK_LAUNCH(ctx, "wgrad_mfma");
   const long long per = (long long)taps * ca * cb;
   const unsigned gx = (unsigned)std::min<long long>((per / 4 + 255) / 256, 2048);
