@@ -44,8 +44,8 @@ def cpu_baseline(size, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)     # the chip needs ~1 s of load to settle its clocks
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (MFMA), 1 direct kernels")
@@ -65,11 +65,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
+    # test hooks (single-GPU dry run of the multi-process path): UNET_BENCH_BACKEND=gloo UNET_BENCH_ONE_DEVICE=1
+    backend = os.environ.get("UNET_BENCH_BACKEND", "nccl")
+    if os.environ.get("UNET_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     B, S = args.batch, args.size
@@ -95,17 +102,18 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     loss_dice = last.cpu().numpy().tolist()
 
     # ---- roofline leg: per-op hipEvent timing of two more steps (profiling mode serialises ops)
     roof = None
+    eng.set_profiling(True, B)               # every rank runs these steps (they contain collectives); rank 0 reports
+    for _ in range(2):
+        eng.train_batch(x, y)
+    torch.cuda.synchronize()
+    eng.set_profiling(False)
     if rank == 0:
-        eng.set_profiling(True, B)
-        for _ in range(2):
-            eng.train_batch(x, y)
-        torch.cuda.synchronize()
-        eng.set_profiling(False)
         ops = eng.op_profile(B, 0) + eng.op_profile(B, 1)
         dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_dgrad:")]
         dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel

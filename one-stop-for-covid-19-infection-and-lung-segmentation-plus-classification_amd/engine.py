@@ -14,7 +14,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import _lib
+from . import _lib, dp
 from .weights import weight_shapes
 
 ADAM_LR, ADAM_B1, ADAM_B2, ADAM_EPS = 5e-4, 0.9, 0.999, 1e-7     # Adam(lr=0.0005), T1:1053
@@ -131,33 +131,38 @@ class HipUNet:
             return a.to(self.dev, torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)
 
-    def _run(self, plan, prog, overlap_grads=False):
+    def _all_reduce(self, t):
+        """SUM all-reduce.  backend nccl (= RCCL) reduces device tensors in place; the gloo branch (used by the
+        single-GPU multi-process tests) stages through the host."""
+        import torch.distributed as dist
+        if dist.get_backend(self.pg) == "gloo" and t.is_cuda:
+            c = t.cpu(); dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.pg); t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _run(self, plan, prog):
         lib, m = self.lib, plan["m"]
         nops = lib.unet_model_num_ops(m, prog)
+        run_range = lambda b, e: self.ctx.check(lib.unet_model_run(m, prog, b, e, self._stream()), "model_run")
         if self.world == 1:
-            self.ctx.check(lib.unet_model_run(m, prog, 0, nops, self._stream()), "model_run")
+            run_range(0, nops)
             return
-        import torch.distributed as dist
         torch = _torch()
-        begin = 0
-        for after_op, kind, ptr, count in plan["sync"][prog]:
-            if kind in (_lib.SYNC_BN_FWD, _lib.SYNC_BN_BWD) and not self.sync_bn:
-                continue
-            if kind == _lib.SYNC_LOSS and not self.sync_bn:
-                continue
-            self.ctx.check(lib.unet_model_run(m, prog, begin, after_op + 1, self._stream()), "model_run")
-            begin = after_op + 1
-            if kind == _lib.SYNC_GRAD_BUCKET:
-                off = (ptr - self.grads.data_ptr()) // 4
-                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.dev))
-                with torch.cuda.stream(self._comm_stream):
-                    self._comm_stream.wait_event(ev)
-                    dist.all_reduce(self.grads[off:off + count], op=dist.ReduceOp.SUM, group=self.pg)
-            else:
-                dist.all_reduce(self._ws_view_f64(ptr, count), op=dist.ReduceOp.SUM, group=self.pg)
-        self.ctx.check(lib.unet_model_run(m, prog, begin, nops, self._stream()), "model_run")
-        if prog == _lib.PROG_BWD:
-            torch.cuda.current_stream(self.dev).wait_stream(self._comm_stream)
+        cur = torch.cuda.current_stream(self.dev)
+
+        def reduce_small(ptr, count):
+            self._all_reduce(self._ws_view_f64(ptr, count))
+
+        def reduce_bucket(ptr, count):
+            off = (ptr - self.grads.data_ptr()) // 4
+            ev = torch.cuda.Event(); ev.record(cur)
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                self._all_reduce(self.grads[off:off + count])
+
+        kinds = (0, 1, 2, 3) if self.sync_bn else (3,)
+        dp.run_program(run_range, nops, plan["sync"][prog], reduce_small, reduce_bucket,
+                       lambda: cur.wait_stream(self._comm_stream), kinds)
 
     def _loss_tensor(self, plan):
         torch = _torch()
@@ -187,8 +192,8 @@ class HipUNet:
         t = self.step
         lr_t = self.lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         self.ctx.check(self.lib.unet_adam_keras(self.ctx.handle, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
-                                                self.adam_v.data_ptr(), self.n_params, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, 1.0,
-                                                self._stream()), "adam")
+                                                self.adam_v.data_ptr(), self.n_params, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS,
+                                                1.0 if (self.world == 1 or self.sync_bn) else 1.0 / self.world, self._stream()), "adam")
 
     def train_batch(self, x, y, training_dropout=True):
         """One optimizer step (model.fit inner loop, T1:1059).  Returns device tensor [loss, dice]."""
@@ -219,8 +224,7 @@ class HipUNet:
         self.ctx.check(self.lib.unet_seg_metrics_sweep(self.ctx.handle, p.data_ptr(), yd.data_ptr(), th.data_ptr(), len(thresholds),
                                                        out.data_ptr(), p.numel(), self._stream()), "metrics_sweep")
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.pg)
+            self._all_reduce(out)
         return out
 
     def tap(self, n, name, grad=False):

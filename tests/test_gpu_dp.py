@@ -1,0 +1,59 @@
+"""-m gpu: the data-parallel path of the HIP engine with world_size 2 on ONE GPU (two processes, gloo
+process group; the engine stages gloo reductions through the host).  With sync-BN + batch-global Dice +
+SUM-reduced gradients, two ranks holding half the batch each must reproduce the single-process full-batch
+step (the property the 8-GPU RCCL run relies on)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, wfile, x, y, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from covidseg_amd.engine import HipUNet
+    wts = dict(np.load(wfile))
+    eng = HipUNet(x.shape[1], x.shape[2], 1, device=0, process_group=dist.group.WORLD, dropout_rate=0.0)
+    eng.set_weights(wts)
+    n = x.shape[0] // world
+    xs, ys = x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
+    losses = [eng.train_batch(xs, ys).cpu().numpy() for _ in range(2)]
+    p, ld = eng.predict_batch(xs, ys)
+    sums = eng.threshold_sums(p, ys, [0.3, 0.5]).cpu().numpy()
+    if rank == 0:
+        np.savez(out, losses=np.array(losses), ld=ld.cpu().numpy(), sums=sums, **{"w/" + k: v for k, v in eng.get_weights().items()})
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_full_batch(tmp_path):
+    import torch.multiprocessing as mp
+    from covidseg_amd import weights as W
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.engine import HipUNet
+    x, y = synthetic_ct(4, 32, seed=5)
+    wts = W.init_weights(4)
+    wfile = str(tmp_path / "w.npz"); np.savez(wfile, **wts)
+    out = str(tmp_path / "dp.npz")
+    mp.get_context("spawn")
+    mp.spawn(_worker, args=(2, _free_port(), wfile, x, y, out), nprocs=2, join=True)
+    got = np.load(out)
+    eng = HipUNet(32, 32, 1, dropout_rate=0.0); eng.set_weights(wts)
+    ref_losses = np.array([eng.train_batch(x, y).cpu().numpy() for _ in range(2)])
+    p, ld = eng.predict_batch(x, y)
+    sums = eng.threshold_sums(p, y, [0.3, 0.5]).cpu().numpy()
+    assert np.abs(got["losses"] - ref_losses).max() < 2e-5            # batch-global loss / dice on every rank
+    assert np.abs(got["ld"] - ld.cpu().numpy()).max() < 2e-5 and np.allclose(got["sums"], sums, rtol=1e-5)
+    wref = eng.get_weights()
+    for k, v in wref.items():                                         # identical replicas after 2 optimizer steps
+        a = got["w/" + k]
+        assert np.linalg.norm(a - v) <= 2e-4 * np.linalg.norm(v) + 1e-6 * np.sqrt(v.size), k
