@@ -123,8 +123,16 @@ def main():
             k = name.split(":")[0]
             g = groups.setdefault(k, [0.0, 0.0, 0.0]); g[0] += tms / max(calls, 1); g[1] += flops; g[2] += by
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fwd + data-gradient launches)", "achieved": round(achieved, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE; collected offline at
+        # this exact workload, calibration inside the file) -- only quoted for the configuration it was measured on
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0:
+            traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
+        alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
+        roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<0,...> (conv3x3 fwd + data-gradient launches)", "achieved": round(achieved, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)", "algorithmic_bytes_per_launch": round(alg_bytes),
                 "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                 "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3),
                 "op_ms_per_step": {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
