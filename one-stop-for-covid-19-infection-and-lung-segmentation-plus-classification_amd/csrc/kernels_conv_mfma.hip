@@ -170,29 +170,48 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     __syncthreads();
   }
 
-  // ---- epilogue: D[row = pixel][col = n]; lane holds col = l31, rows (r&3)+8*(r>>2)+4*hi
+  // ---- epilogue.  MFMA D layout: lane (l31, hi), register r holds D[pixel (r&3)+8*(r>>2)+4*hi][cout l31].  A 4x4 transpose
+  // inside each lane quad (two xor-shuffle butterfly stages) gives every lane 4 CONSECUTIVE couts of ONE pixel, so the tile
+  // leaves as 16-byte stores (1 KiB per wave instruction): 4x fewer store (and ReLU-mask load) instructions than the natural
+  // one-dword-per-lane form -- the store tail of a tile is instruction-issue bound (cdna guide T21), not bandwidth bound.
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
 #pragma unroll
   for (int jn = 0; jn < NW; ++jn) {
-    const int co = nbase + (wc * NW + jn) * 32 + l31;
-    const int cq = Cout >> 2;                              // MODE 1: Cout = 4 * (ConvT output channels)
+    const int co = nbase + (wc * NW + jn) * 32 + q4;         // first of this lane's 4 output channels
+    const int cq = Cout >> 2;                                // MODE 1: Cout = 4 * (ConvT output channels)
     const int ab = MODE == 1 ? co / cq : 0, oc = MODE == 1 ? co - ab * cq : co;
-    const float bb = bias ? bias[oc] : 0.0f;
+    const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int py = y0 + wr * RW + i;
-      if (py >= H) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int px = x0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (px >= W) continue;
-        float v = acc[i][jn][r] + bb;
+      for (int g = 0; g < 4; ++g) {
+        float v0 = acc[i][jn][4 * g + 0], v1 = acc[i][jn][4 * g + 1], v2 = acc[i][jn][4 * g + 2], v3 = acc[i][jn][4 * g + 3];
+        {   // stage 1: partner lane ^ 1, register pairs (v0,v1) (v2,v3)
+          const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+          const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
+          if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
+        }
+        {   // stage 2: partner lane ^ 2, register pairs (v0,v2) (v1,v3)
+          const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+          const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
+          if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
+        }
+        // now (v0..v3) = D[pixel e + 8g + 4hi][couts q4 .. q4+3]
+        const int px = x0 + e + 8 * g + 4 * hi;
+        if (py >= H || px >= W) continue;
+        float4 v = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
         if (MODE == 1) {
-          y[(((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px + (ab & 1)) * ldy + oc] = v;
+          *reinterpret_cast<float4*>(y + (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px + (ab & 1)) * ldy + oc) = v;
         } else {
           const long long o = (((long long)n * H + py) * W + px) * Cout + co;
-          if (relu) v = fmaxf(v, 0.0f);
-          if (mask) v = mask[o] > 0.0f ? v : 0.0f;
-          y[o] = v;
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (mask) {
+            const float4 m = *reinterpret_cast<const float4*>(mask + o);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          }
+          *reinterpret_cast<float4*>(y + o) = v;
         }
       }
     }
