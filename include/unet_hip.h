@@ -119,6 +119,19 @@ int32_t unet_maxpool2x2_dropout_bwd(unet_ctx*, const float* x, int32_t ldx, cons
                                     int32_t c, float rate, uint64_t seed, int32_t accumulate,
                                     void* stream);
 
+/* Fused encoder tail BatchNormalization -> [skip] -> MaxPooling2D -> Dropout (T1:861-863): y = bn(x) into the concat slice
+ * (ldy) and pooled = dropout(maxpool(y)) in one pass. */
+int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx*, const float* x, int32_t ldx, const float* bnp, float* y,
+                                          int32_t ldy, float* pooled, int32_t n, int32_t h, int32_t wd,
+                                          int32_t c, float rate, uint64_t seed, void* stream);
+/* Fused backward of the same: dx[slice] += routed pool/dropout gradient (dx already holds the skip gradient) and
+ * sums (double[2C], accumulated) += (sum d, sum d*xhat) of the finished gradient d, xhat = (y-beta)/gamma from the BN
+ * output y (gamma != 0).  Replaces unet_maxpool2x2_dropout_bwd(accumulate=1) + unet_bn_bwd_stats. */
+int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx*, const float* y, int32_t ldy, const float* dy, float* dx,
+                                            int32_t lddx, const float* gamma, const float* beta, double* sums,
+                                            int32_t n, int32_t h, int32_t wd, int32_t c, float rate,
+                                            uint64_t seed, void* stream);
+
 /* Replaces: Conv2D(1,(1,1),activation='sigmoid') T1:913 fused with the reductions of
  * bce_dice_loss / dice_coeff T1:784-799.  p = sigmoid(b + x.w).  If y_true != NULL,
  * loss_sums (double[4], accumulated) += (sum bce_elem, sum t*p, sum t, sum p). */

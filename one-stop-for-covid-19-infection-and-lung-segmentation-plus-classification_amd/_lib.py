@@ -50,6 +50,8 @@ _PROTOS = {
     "unet_bn_bwd_apply": (i32, [vp, vp, i32, vp, i32, vp, vp, f64, i32, vp, i32, i64, i32, vp]),
     "unet_maxpool2x2_dropout_fwd": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, u64, i32, vp]),
+    "unet_bn_apply_maxpool_dropout_fwd": (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_maxpool2x2_dropout_bwd_bnstats": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "unet_loss_finalize": (i32, [vp, vp, f64, vp, vp]),
     "unet_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, i64, i32, vp]),

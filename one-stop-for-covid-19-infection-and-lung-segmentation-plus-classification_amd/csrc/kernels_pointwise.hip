@@ -216,6 +216,85 @@ __global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__
   }
 }
 
+// Fused encoder tail (T1:861-863): y = BN(x) written into the skip slice of the concat buffer AND
+// p = dropout(maxpool2x2(y)) in one pass -- saves re-reading y for the pool.
+__global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ bnp,
+                                                          float* __restrict__ y, int ldy, float* __restrict__ pooled, int N, int H,
+                                                          int W, int C, float rate, uint64_t seed) {
+  const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo * lpp;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    int q = (int)(i % lpp); long long p = i / lpp;
+    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    const long long pix = (n * H + 2 * io) * W + 2 * jo;
+    const float* b = x + pix * ldx + q * 4;
+    const float4 sc = ld4(bnp + q * 4), sh = ld4(bnp + C + q * 4);
+    const long long offs[4] = {0, 1, (long long)W, (long long)W + 1};
+    float4 m;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = ld4(b + offs[k] * ldx);
+      const float4 r = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+      st4(y + (pix + offs[k]) * ldy + q * 4, r);
+      if (k == 0) m = r;
+      else { m.x = fmaxf(m.x, r.x); m.y = fmaxf(m.y, r.y); m.z = fmaxf(m.z, r.z); m.w = fmaxf(m.w, r.w); }
+    }
+    if (rate > 0.0f) { float4 kk = keep_scale(i, rate, seed); m.x *= kk.x; m.y *= kk.y; m.z *= kk.z; m.w *= kk.w; }
+    st4(pooled + p * C + q * 4, m);
+  }
+}
+
+// Fused encoder backward head: pool/dropout backward accumulated into the skip-gradient slice, PLUS the BatchNorm
+// backward statistics (sum d, sum d*xhat) of the finished gradient d, with xhat = (y - beta)/gamma recovered from the BN
+// OUTPUT y that the pool backward reads anyway -- saves the separate 2-tensor statistics pass (gamma == 0 is not supported
+// by this fused form: xhat cannot be recovered from a constant output).
+__global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dyp,
+                                                               float* dx, int lddx, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, double* sums, int N, int H, int W,
+                                                               int C, float rate, uint64_t seed) {
+  const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo * lpp;
+  const int tid = threadIdx.x, q = tid % lpp;                        // lpp divides TPB: a thread keeps its channel quad
+  const float4 g4 = ld4(gamma + q * 4), b4 = ld4(beta + q * 4);
+  const float4 ig = make_float4(g4.x != 0.f ? 1.f / g4.x : 0.f, g4.y != 0.f ? 1.f / g4.y : 0.f, g4.z != 0.f ? 1.f / g4.z : 0.f,
+                                g4.w != 0.f ? 1.f / g4.w : 0.f);
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = s1;
+  for (long long i = (long long)blockIdx.x * TPB + tid; i < total; i += (long long)gridDim.x * TPB) {
+    long long p = i / lpp;
+    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    long long pix = (n * H + 2 * io) * W + 2 * jo;
+    const float* b = y + pix * ldy + q * 4;
+    float4 a[4] = {ld4(b), ld4(b + ldy), ld4(b + (long long)W * ldy), ld4(b + (long long)(W + 1) * ldy)};
+    float4 g = ld4(dyp + p * C + q * 4);
+    if (rate > 0.0f) { float4 k = keep_scale(i, rate, seed); g.x *= k.x; g.y *= k.y; g.z *= k.z; g.w *= k.w; }
+    int kx = argmax4(a[0].x, a[1].x, a[2].x, a[3].x), ky = argmax4(a[0].y, a[1].y, a[2].y, a[3].y);
+    int kz = argmax4(a[0].z, a[1].z, a[2].z, a[3].z), kw = argmax4(a[0].w, a[1].w, a[2].w, a[3].w);
+    float* o = dx + pix * lddx + q * 4;
+    const long long offs[4] = {0, lddx, (long long)W * lddx, (long long)(W + 1) * lddx};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 v = ld4(o + offs[k]);
+      v.x += kx == k ? g.x : 0.f; v.y += ky == k ? g.y : 0.f; v.z += kz == k ? g.z : 0.f; v.w += kw == k ? g.w : 0.f;
+      st4(o + offs[k], v);
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x += v.x * (a[k].x - b4.x) * ig.x; s2.y += v.y * (a[k].y - b4.y) * ig.y;
+      s2.z += v.z * (a[k].z - b4.z) * ig.z; s2.w += v.w * (a[k].w - b4.w) * ig.w;
+    }
+  }
+  __shared__ float4 sh1[TPB], sh2[TPB];
+  sh1[tid] = s1; sh2[tid] = s2;
+  __syncthreads();
+  if (tid < lpp) {
+    for (int k = 1; k < TPB / lpp; ++k) {
+      float4 u = sh1[tid + k * lpp], w2 = sh2[tid + k * lpp];
+      s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w; s2.x += w2.x; s2.y += w2.y; s2.z += w2.z; s2.w += w2.w;
+    }
+    double* d1 = sums + q * 4; double* d2 = sums + C + q * 4;
+    atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y); atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
+    atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y); atomicAdd(d2 + 2, (double)s2.z); atomicAdd(d2 + 3, (double)s2.w);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // 1x1 conv + sigmoid head fused with the loss reductions; and its backward.
 // lpp = cin/4 lanes per pixel (power of two <= 64), xor-shuffle dot product.
@@ -465,6 +544,27 @@ int32_t unet_maxpool2x2_dropout_bwd(unet_ctx* ctx, const float* x, int32_t ldx, 
   if (accumulate) hipLaunchKernelGGL(pool_bwd_kernel<true>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
   else hipLaunchKernelGGL(pool_bwd_kernel<false>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd"); return UNET_OK;
+}
+
+int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy,
+                                          float* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
+                                          void* stream) {
+  if (!x || !bnp || !y || !pooled || !bn_c_ok(c) || (h & 1) || (wd & 1) || ldx < c || ldy < c || ((ldx | ldy) & 3) || rate < 0 || rate >= 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "bn_apply_maxpool fwd: bad args (h,w even; c%%4==0)");
+  long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed);
+  UNET_CHECK_LAUNCH(ctx, "bn_apply_maxpool fwd"); return UNET_OK;
+}
+
+int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32_t ldy, const float* dy, float* dx, int32_t lddx,
+                                            const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd,
+                                            int32_t c, float rate, uint64_t seed, void* stream) {
+  if (!y || !dy || !dx || !gamma || !beta || !sums || (c & 3) || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldy | lddx) & 3) || rate < 0 || rate >= 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd + bn stats: bad args (c/4 must divide 256)");
+  long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  int grid = (int)std::min<long long>(cdiv64(total, TPB), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(pool_bwd_bnstats_kernel, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, sums, n, h, wd, c, rate, seed);
+  UNET_CHECK_LAUNCH(ctx, "maxpool bwd + bn stats"); return UNET_OK;
 }
 
 int32_t unet_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* p, const float* y_true,

@@ -355,7 +355,7 @@ void build_programs(unet_model* m) {
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, m->Aw(name), ob.n, ob.h, ob.w, cin, cout, 1, algo, s);
       });
     };
-    auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c) {
+    auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c, bool fuse_pool) {
       const Buf ib = m->act.at(in), ob = m->act.at(out);
       const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
       const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
@@ -371,7 +371,7 @@ void build_programs(unet_model* m) {
           return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
         });
       }
-      ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s); });
+      if (!fuse_pool) ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s); });
     };
     std::string prev = "";
     int cprev = m->in_ch;
@@ -379,13 +379,14 @@ void build_programs(unet_model* m) {
       int c = ENC[k - 1]; std::string ks = std::to_string(k);
       conv("c" + ks + "a", prev, cprev, c);
       conv("c" + ks + "b", "c" + ks + "a", c, c);
-      bn("bn" + ks, "c" + ks + "b", "bn" + ks, c);
-      const Buf ib = m->act.at("bn" + ks);
-      const std::string pin = "bn" + ks, pout = "p" + ks;
+      bn("bn" + ks, "c" + ks + "b", "bn" + ks, c, true);
+      const Buf ib = m->act.at("bn" + ks), xb = m->act.at("c" + ks + "b");
+      const std::string pin = "bn" + ks, pout = "p" + ks, xin = "c" + ks + "b";
       const int tr = training;
-      ADD_OP(F, "pool:" + pout, 0, 4.0 * 1.25 * nel(ib), {
-        return unet_maxpool2x2_dropout_fwd(ctx, m->A(pin), ib.ld, m->Aw(pout), ib.n, ib.h, ib.w, ib.c, tr ? m->drop_rate : 0.0f,
-                                           m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
+      const size_t bo = m->bnp_off.at("bn" + ks);
+      ADD_OP(F, "bn_apply_pool:" + pout, 0, 4.0 * 2.25 * nel(ib), {
+        return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(xin), xb.ld, m->wsf(bo), m->Aw(pin), ib.ld, m->Aw(pout), ib.n, ib.h, ib.w, ib.c,
+                                                 tr ? m->drop_rate : 0.0f, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
       });
       prev = pout; cprev = c;
     }
@@ -400,7 +401,7 @@ void build_programs(unet_model* m) {
       ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * ci * c * nel(ib) / ib.c, 4.0 * (nel(ib) + nel(ub)), {
         return unet_convT2x2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, algo, s);
       });
-      bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c);
+      bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c, false);
       conv("c" + ks + "a", "bn" + ks, 2 * c, c);
       conv("c" + ks + "b", "c" + ks + "a", c, c);
       prev = "c" + ks + "b"; cprev = c;
@@ -454,15 +455,23 @@ void build_programs(unet_model* m) {
       }
     };
     // bn backward: dy tensor `dyname` (grad buffer), x tensor `xname` (act), output grad `dxname`
-    auto bn_bwd = [&](const std::string& name, const std::string& dyname, const std::string& xname, const std::string& dxname, int c, int mask) {
+    // stats_done: the (sum dy, sum dy*xhat) sums were already accumulated by the fused pool backward
+    auto bn_bwd = [&](const std::string& name, const std::string& dyname, const std::string& xname, const std::string& dxname, int c, int mask,
+                      bool stats_done) {
       const Buf gb = m->grad.at(dyname), xb = m->act.at(xname), db = m->grad.at(dxname);
       const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
       const size_t so = m->bn_bsum_off.at(name), bo = m->bnp_off.at(name);
-      ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
-        int32_t r = unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
-        if (r) return r;
-        return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
-      });
+      if (stats_done) {
+        ADD_OP(BW, "bn_bwd_param_grads:" + name, 0, 0, {
+          return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
+        });
+      } else {
+        ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
+          int32_t r = unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
+          if (r) return r;
+          return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
+        });
+      }
       SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
       ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
         return unet_bn_bwd_apply(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, mask, m->D(dxname),
@@ -480,7 +489,7 @@ void build_programs(unet_model* m) {
       int cprev = (k == 6) ? 512 : dec[k - 7];
       conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
       conv_bwd("c" + ks + "a", "bn" + ks, 2 * c, c, true, false);
-      bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0);
+      bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, false);
       const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
       const std::string un = "u" + ks;
       ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, 4.0 * (nel(ib) + nel(ug)), {
@@ -500,11 +509,13 @@ void build_programs(unet_model* m) {
       int c = ENC[k - 1]; std::string ks = std::to_string(k);
       const Buf xb = m->act.at("bn" + ks), gb = m->grad.at("bn" + ks);
       const std::string bnn = "bn" + ks, pn = "p" + ks;
-      ADD_OP(BW, "pool_bwd:" + pn, 0, 4.0 * 3.25 * nel(xb), {
-        return unet_maxpool2x2_dropout_bwd(ctx, m->A(bnn), xb.ld, m->D(pn), m->D(bnn), gb.ld, xb.n, xb.h, xb.w, xb.c, m->drop_rate,
-                                           m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, 1, s);
+      const size_t so = m->bn_bsum_off.at(bnn);
+      ADD_OP(BW, "pool_bwd_bnstats:" + pn, 0, 4.0 * 3.25 * nel(xb), {
+        return unet_maxpool2x2_dropout_bwd_bnstats(ctx, m->A(bnn), xb.ld, m->D(pn), m->D(bnn), gb.ld, m->P(bnn + "/gamma"), m->P(bnn + "/beta"),
+                                                   m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c, m->drop_rate,
+                                                   m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
       });
-      bn_bwd(bnn, bnn, "c" + ks + "b", "c" + ks + "b", c, 1);
+      bn_bwd(bnn, bnn, "c" + ks + "b", "c" + ks + "b", c, 1, true);
       conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
       int cprev = (k == 1) ? m->in_ch : ENC[k - 2];
       conv_bwd("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cprev, c, k > 1, false);

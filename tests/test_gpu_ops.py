@@ -235,3 +235,36 @@ def test_bad_arguments_are_reported_not_crashed(ops):
     assert rc == -1 and b"bn_apply" in ops.lib.unet_last_error(ops.h)
     m = __import__("ctypes").c_void_p()
     assert ops.lib.unet_model_create(ops.h, 1, 2, 30, 32, 1, 0, __import__("ctypes").byref(m)) == -3   # h not a multiple of 16
+
+
+@pytest.mark.parametrize("c", [32, 128, 512])
+def test_fused_bn_pool_fwd_and_pool_bwd_bnstats(ops, c):
+    """The fused encoder tail / head kernels against the unfused C-ABI ops (bit-exact) and the oracle."""
+    from gpu_util import relerr
+    n, h, w = 2, 8, 12
+    pixels = n * h * w
+    rng = np.random.default_rng(c + 1)
+    x = np.maximum(rng.standard_normal((n, h, w, c)) + 0.3, 0).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32); beta = (rng.standard_normal(c) * 0.2).astype(np.float32)
+    ld = 2 * c
+    xd = ops.d(x); sums = ops.z(2 * c, dtype=torch.float64); bnp = ops.z(4 * c); mm, mv = ops.z(c), ops.z(c)
+    ops.ck(ops.lib.unet_bn_stats(ops.h, xd.data_ptr(), c, sums.data_ptr(), pixels, c, ops.s), "stats")
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, sums.data_ptr(), float(pixels), ops.d(gamma).data_ptr(), ops.d(beta).data_ptr(), mm.data_ptr(), mv.data_ptr(), bnp.data_ptr(), c, ops.s), "fin")
+    for rate, seed in ((0.0, 0), (0.25, 77)):
+        cat_a = ops.z(n, h, w, ld); cat_b = ops.z(n, h, w, ld); pa = ops.z(n, h // 2, w // 2, c); pb = ops.z(n, h // 2, w // 2, c)
+        ya = cat_a.data_ptr() + 4 * c; yb = cat_b.data_ptr() + 4 * c
+        ops.ck(ops.lib.unet_bn_apply(ops.h, xd.data_ptr(), c, bnp.data_ptr(), ya, ld, pixels, c, ops.s), "apply")
+        ops.ck(ops.lib.unet_maxpool2x2_dropout_fwd(ops.h, ya, ld, pa.data_ptr(), n, h, w, c, rate, seed, ops.s), "pool")
+        ops.ck(ops.lib.unet_bn_apply_maxpool_dropout_fwd(ops.h, xd.data_ptr(), c, bnp.data_ptr(), yb, ld, pb.data_ptr(), n, h, w, c, rate, seed, ops.s), "fused fwd")
+        assert (cat_a.cpu().numpy() == cat_b.cpu().numpy()).all() and (pa.cpu().numpy() == pb.cpu().numpy()).all()
+        # backward: skip gradient already in the slice, pooled gradient routed + BN backward statistics
+        skip = rng.standard_normal((n, h, w, c)).astype(np.float32); dyp = rng.standard_normal((n, h // 2, w // 2, c)).astype(np.float32)
+        dcat = np.zeros((n, h, w, ld), np.float32); dcat[..., c:] = skip
+        da = ops.d(dcat); db = ops.d(dcat)
+        sa = ops.z(2 * c, dtype=torch.float64); sb = ops.z(2 * c, dtype=torch.float64)
+        ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd(ops.h, ya, ld, ops.d(dyp).data_ptr(), da.data_ptr() + 4 * c, ld, n, h, w, c, rate, seed, 1, ops.s), "pool bwd")
+        ops.ck(ops.lib.unet_bn_bwd_stats(ops.h, da.data_ptr() + 4 * c, ld, xd.data_ptr(), c, bnp.data_ptr(), sa.data_ptr(), pixels, c, ops.s), "bwd stats")
+        ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd_bnstats(ops.h, yb, ld, ops.d(dyp).data_ptr(), db.data_ptr() + 4 * c, ld, ops.d(gamma).data_ptr(), ops.d(beta).data_ptr(),
+                                                          sb.data_ptr(), n, h, w, c, rate, seed, ops.s), "fused bwd")
+        assert (da.cpu().numpy() == db.cpu().numpy()).all()
+        assert relerr(sb.cpu().numpy(), sa.cpu().numpy()) < 1e-5           # xhat recovered from y = gamma*xhat+beta vs from x
