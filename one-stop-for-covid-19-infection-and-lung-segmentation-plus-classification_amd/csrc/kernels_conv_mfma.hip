@@ -372,14 +372,28 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
     __syncthreads();
   }
 
-  // partial tile: rows = a channel (r&3)+8*(r>>2)+4*hi, cols = b channel l31
+  // partial tile: rows = a channel (r&3)+8*(r>>2)+4*hi, cols = b channel l31.  Same quad transpose as the conv epilogue:
+  // each lane ends up with 4 consecutive b channels of one a channel -> 16-byte stores (36 instead of 144 per wave).
   float* P = part + (long long)split * TAPS * CA * CB;
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      P[((long long)t * CA + a0 + i) * CB + b0 + l31] = acc[t][r];
+    for (int g = 0; g < 4; ++g) {
+      float v0 = acc[t][4 * g + 0], v1 = acc[t][4 * g + 1], v2 = acc[t][4 * g + 2], v3 = acc[t][4 * g + 3];
+      {
+        const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+        const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
+        if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
+      }
+      {
+        const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+        const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
+        if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
+      }
+      const int i = e + 8 * g + 4 * hi;
+      *reinterpret_cast<float4*>(&P[((long long)t * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
     }
   bsum += __shfl_xor(bsum, 32, 64);
   if (MODE == 0) { if (ta == 0 && lane < 32) part_b[(long long)split * CB + b0 + l31] = bsum; }
