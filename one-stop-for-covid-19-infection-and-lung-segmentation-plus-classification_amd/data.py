@@ -58,3 +58,21 @@ def train_test_split(x, y, test_size: float = 0.3, random_state: int = 42):
     perm = np.random.RandomState(random_state).permutation(n)
     te, tr = perm[:n_test], perm[n_test:n_test + n_train]
     return x[tr], x[te], y[tr], y[te]
+
+
+def kfold_indices(n: int, n_splits: int, random_state: int = 42):
+    """sklearn.model_selection.KFold(n_splits, random_state=42, shuffle=True).split(range(n)) restated
+    (task1_crossval_4folds_unet.py:1047): indices = arange(n) shuffled by RandomState(seed); fold i takes the next
+    n//k (+1 for the first n%k folds) shuffled indices as TEST; train/test index arrays are returned sorted ascending
+    (sklearn builds them from a boolean mask)."""
+    if n_splits < 2 or n_splits > n:
+        raise ValueError(f"kfold: n_splits={n_splits} invalid for n={n}")
+    idx = np.arange(n)
+    np.random.RandomState(random_state).shuffle(idx)
+    sizes = np.full(n_splits, n // n_splits, dtype=int); sizes[: n % n_splits] += 1
+    out, cur = [], 0
+    for sz in sizes:
+        mask = np.zeros(n, bool); mask[idx[cur:cur + sz]] = True
+        out.append((np.flatnonzero(~mask), np.flatnonzero(mask)))
+        cur += sz
+    return out

@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-from .data import synthetic_ct, train_test_split
+from .data import kfold_indices, synthetic_ct, train_test_split
 from .keras_like import UNetModel
 
 
@@ -106,3 +106,84 @@ def runner_lung_segmentation(**kw):
     kw.setdefault("seed", 1)
     return _segmentation_runner("lung", "unet_covid_weights_dice_coeff.hdf5", "unet_covid_weights_val_loss.hdf5",
                                 np.arange(0.43, 0.53, 0.001), **kw)
+
+
+def _kfold_runner(k, data=None, input_size=None, epochs=None, batch_size=None, n_samples=None, seed=0, backend=None, dropout=True,
+                  init_weights=None, workdir=".", verbose=1, reinit_each_fold=False, overwrite_fold_files=True, **backend_kw):
+    """K-fold driver of task1_crossval_{3,4}folds_unet.py (CV4:1045-1108, 1183-1330; CV3:1005-1052, 1136-1300): same U-Net,
+    same recipe, KFold(n_splits=k, random_state=42, shuffle=True).  Faithful to the reference by default, including its two
+    quirks: ONE model object is trained through all folds without re-initialisation (CV4:1019, 1051-1090 -> fold leakage,
+    `reinit_each_fold=False`), and after training the FINAL weights overwrite every fold's best-checkpoint file
+    (CV4:1105-1108, `overwrite_fold_files=True`).  Set the flags the other way for a sound cross-validation."""
+    import time
+    size = input_size or _env_int("UNET_SIZE", 224)
+    epochs = epochs if epochs is not None else _env_int("UNET_EPOCHS", 80)
+    batch_size = batch_size or _env_int("UNET_BATCH", 32)
+    n_samples = n_samples or _env_int("UNET_SAMPLES", 64)
+    cts, infections = _get_data(data, size, n_samples, seed)
+    size = cts.shape[1]
+    model = UNetModel(size, cts.shape[-1], backend=backend, seed=seed, **backend_kw)
+    model.verbose = verbose
+    w0 = init_weights if init_weights is not None else model.get_weights()
+    model.set_weights(w0)
+    paths = [os.path.join(workdir, f"unet_covid_fold{i + 1}.hdf5") for i in range(k)]                       # CV4:1029-1032
+    folds = kfold_indices(len(cts), k, 42)                                                                   # CV4:1047
+    bar = "%" * 180
+    start = time.perf_counter()
+    histories = []
+    for fold_number, (train_index, test_index) in enumerate(folds, 1):
+        print(bar); print("Current fold number going:", fold_number); print(bar)                             # CV4:1053-1055
+        x_train, x_valid = cts[train_index], cts[test_index]
+        y_train, y_valid = infections[train_index], infections[test_index]
+        print("Shapes:", x_train.shape, x_valid.shape)                                                       # CV4:1059
+        if reinit_each_fold:
+            model.set_weights(w0)
+        model.compile(lr=0.0005)                                                                             # CV4:1062
+        histories.append(model.fit(x_train, y_train, batch_size=batch_size, epochs=epochs, validation_data=(x_valid, y_valid),
+                                   checkpoint_dice=paths[fold_number - 1], dropout=dropout, shuffle_seed=seed + fold_number).history)
+    print(f"Time of {k}-fold cross validation: ", time.perf_counter() - start)                               # CV4:1099
+    if overwrite_fold_files:
+        for p in paths:
+            model.save_weights(p)                                                                            # CV4:1105-1108
+    out = {"histories": histories, "paths": paths, "folds": folds, "model": model, "scores": []}
+    dots = "." * 118
+    for split_number, (train_index, test_index) in enumerate(folds, 1):                                      # CV4:1183-1195
+        print(dots); print("Current fold number going:", split_number); print(dots)
+        model.load_weights(paths[split_number - 1])
+        ev = model.evaluate(cts[test_index], infections[test_index], batch_size=32)
+        score = [ev["loss"], ev["dice_coeff"]]
+        print("test loss, test dice coefficient:", score)
+        out["scores"].append(score)
+    the_range = np.arange(0.30, 0.80, 0.05)                                                                  # CV4:1222
+    print(len(the_range))
+    tables = {m: [] for m in ("dice", "iou", "precision", "recall")}
+    for split_number, (train_index, test_index) in enumerate(folds, 1):                                      # CV4:1231-1266
+        print("." * 145); print("Current split number going:", split_number); print("." * 145)
+        model.load_weights(paths[split_number - 1])
+        for t in the_range:
+            print("%" * 73); print("Calculating for threshold:", t); print("%" * 73)
+        ev = model.evaluate(cts[test_index], infections[test_index], batch_size=32, thresholds=the_range)    # one pass for all t
+        for m in tables:
+            tables[m].append(np.asarray(ev[m]))
+    names = {"dice": ("Dices", "dice", "dices"), "iou": ("Ious", "iou", "ious"), "precision": ("precision", "precision", "precisions"),
+             "recall": ("recall", "recall", "recalls")}
+    for m, (title, one, many) in names.items():                                                              # CV4:1270-1365
+        tab = np.transpose(np.array(tables[m]))                       # rows: thresholds, columns: split number
+        out["table_" + m] = tab
+        print(f"{k}-fold {title} dataframe"); print("Rows indices: Thresholds, Column indices: Split Number")
+        print(f"Maximum validation {one} on any splits:", np.max(tab))
+        print(f"Maximum validation {one} on each of the {k} splits (any threshold chosen):", tab.max(axis=0))
+        print("Best threshold for each split", *[the_range[int(np.argmax(tab[:, j]))] for j in range(k)])
+        print(f"Mean of all obtained {many}:", tab.mean(axis=0).mean())
+    out["range"] = the_range
+    return out
+
+
+def three_fold_runner_unet_infection_segmentation(**kw):
+    """Task 1, 3-fold cross-validation U-Net (app.py 'one'; task1_crossval_3folds_unet.py:6)."""
+    return _kfold_runner(3, **kw)
+
+
+def four_fold_runner_unet_infection_segmentation(**kw):
+    """Task 1, 4-fold cross-validation U-Net (app.py 'two'; task1_crossval_4folds_unet.py:6)."""
+    return _kfold_runner(4, **kw)

@@ -181,3 +181,15 @@ def test_full_size_512_properties():
     assert abs(ld1[1] - (2 * (t * p).sum() + 1) / (t.sum() + p.sum() + 1)) < 1e-5
     g = eng.get_grads()
     assert all(np.isfinite(v).all() for v in g.values()) and np.linalg.norm(g["c1a/kernel"]) > 0
+
+
+def test_kfold_runner_on_gpu(tmp_path, capsys):
+    """three_fold_runner_unet_infection_segmentation (app.py 'one') end to end on the HIP engine, tiny data."""
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.runners import three_fold_runner_unet_infection_segmentation
+    x, y = synthetic_ct(9, 32, seed=3)
+    out = three_fold_runner_unet_infection_segmentation(data=(x, y), epochs=2, batch_size=4, workdir=str(tmp_path), verbose=0, dropout_rate=0.25)
+    txt = capsys.readouterr().out
+    assert "Time of 3-fold cross validation:" in txt and "3-fold Dices dataframe" in txt
+    assert out["table_dice"].shape[1] == 3 and np.isfinite(out["table_dice"]).all() and len(out["scores"]) == 3
+    assert all(os.path.exists(p) for p in out["paths"])

@@ -97,3 +97,36 @@ def test_runner_prints_reference_summary_and_returns_tables(tmp_path, capsys):
     assert os.path.exists(tmp_path / "unet_covid_weights_dice_coeff.hdf5") and os.path.exists(tmp_path / "unet_covid_weights_val_loss.hdf5")
     out3 = runner_lung_segmentation(data=(x, y), epochs=1, batch_size=4, workdir=str(tmp_path), verbose=0, backend=OracleBackend(16, 16))
     assert len(out3["new_dices"]) == len(np.arange(0.43, 0.53, 0.001)) and abs(out3["new_range"][0] - 0.43) < 1e-9                      # T3:1206
+
+
+def test_kfold_indices_match_sklearn():
+    from sklearn.model_selection import KFold
+    from covidseg_amd.data import kfold_indices
+    for n, k in ((10, 3), (12, 4), (37, 4), (64, 3)):
+        want = list(KFold(n_splits=k, random_state=42, shuffle=True).split(np.arange(n)))
+        got = kfold_indices(n, k, 42)
+        assert len(got) == k
+        for (a, b), (c, d) in zip(want, got):
+            assert a.tolist() == c.tolist() and b.tolist() == d.tolist()
+
+
+def test_kfold_runner_reference_flow_and_quirks(tmp_path, capsys):
+    from covidseg_amd.runners import four_fold_runner_unet_infection_segmentation, three_fold_runner_unet_infection_segmentation
+    x, y = synthetic_ct(9, 16, seed=3)
+    out = three_fold_runner_unet_infection_segmentation(data=(x, y), epochs=1, batch_size=4, workdir=str(tmp_path), verbose=0,
+                                                        backend=OracleBackend(16, 16))
+    txt = capsys.readouterr().out
+    for label in ("Current fold number going: 3", "Shapes: (6, 16, 16, 1) (3, 16, 16, 1)", "Time of 3-fold cross validation:",
+                  "test loss, test dice coefficient:", "Calculating for threshold:", "3-fold Dices dataframe",
+                  "Maximum validation iou on each of the 3 splits (any threshold chosen):", "Mean of all obtained recalls:"):
+        assert label in txt, label
+    assert out["table_dice"].shape == (len(np.arange(0.30, 0.80, 0.05)), 3) and len(out["scores"]) == 3
+    # reference quirk CV4:1105-1108: the final weights overwrite every fold file -> all fold files identical
+    w1, w3 = W.load_weights(out["paths"][0]), W.load_weights(out["paths"][2])
+    assert all(np.array_equal(w1[k], w3[k]) for k in w1)
+    # the model is NOT re-initialised between folds (CV4:1051-1090): 3 folds x ceil(6/4) steps accumulated in one trajectory
+    assert out["model"].backend.tr.t == 2                         # optimizer state is reset by every compile(), weights are not
+    os.makedirs(tmp_path / "f4", exist_ok=True)
+    out4 = four_fold_runner_unet_infection_segmentation(data=(x[:8], y[:8]), epochs=1, batch_size=8, workdir=str(tmp_path / "f4"), verbose=0,
+                                                        backend=OracleBackend(16, 16), reinit_each_fold=True, overwrite_fold_files=False)
+    assert out4["table_iou"].shape[1] == 4 and len(out4["paths"]) == 4
