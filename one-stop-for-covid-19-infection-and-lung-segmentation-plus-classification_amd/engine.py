@@ -40,10 +40,15 @@ class HipUNet:
         self.ctx = _lib.Context.get(self.device_index)
         self.h, self.w, self.in_ch, self.algo = h, w, in_ch, conv_algo
         self.pg = process_group
+        self.pg_grad = process_group
         self.world = 1
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
+            if self.world > 1:
+                # gradient buckets get their OWN communicator: collectives of one process group are serialised on one
+                # internal stream, so a bucket all-reduce would otherwise delay the small inline (BN / Dice) reductions
+                self.pg_grad = dist.new_group(ranks=dist.get_process_group_ranks(process_group), backend=dist.get_backend(process_group))
         self.sync_bn = sync_bn
         self.dropout_rate, self.seed, self.lr = float(dropout_rate), int(seed), float(lr)
         self.step = 0
@@ -131,14 +136,15 @@ class HipUNet:
             return a.to(self.dev, torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)
 
-    def _all_reduce(self, t):
+    def _all_reduce(self, t, group=None):
         """SUM all-reduce.  backend nccl (= RCCL) reduces device tensors in place; the gloo branch (used by the
         single-GPU multi-process tests) stages through the host."""
         import torch.distributed as dist
-        if dist.get_backend(self.pg) == "gloo" and t.is_cuda:
-            c = t.cpu(); dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.pg); t.copy_(c)
+        group = group if group is not None else self.pg
+        if dist.get_backend(group) == "gloo" and t.is_cuda:
+            c = t.cpu(); dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group); t.copy_(c)
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     def _run(self, plan, prog):
         lib, m = self.lib, plan["m"]
@@ -158,7 +164,7 @@ class HipUNet:
             ev = torch.cuda.Event(); ev.record(cur)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
-                self._all_reduce(self.grads[off:off + count])
+                self._all_reduce(self.grads[off:off + count], self.pg_grad)
 
         kinds = (0, 1, 2, 3) if self.sync_bn else (3,)
         dp.run_program(run_range, nops, plan["sync"][prog], reduce_small, reduce_bucket,
