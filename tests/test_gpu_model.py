@@ -193,3 +193,40 @@ def test_kfold_runner_on_gpu(tmp_path, capsys):
     assert "Time of 3-fold cross validation:" in txt and "3-fold Dices dataframe" in txt
     assert out["table_dice"].shape[1] == 3 and np.isfinite(out["table_dice"]).all() and len(out["scores"]) == 3
     assert all(os.path.exists(p) for p in out["paths"])
+
+
+def test_baseline_config1_holdout_runner_512_vs_cpu_golden(tmp_path, capsys):
+    """BASELINE.json configs[0] on the MI355X vs the committed CPU-oracle run of the same runner
+    (tests/golden/config1_goldens.npz: 8 synthetic 512x512 slices, 1 epoch): Dice / IoU / precision / recall within 1e-3."""
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.runners import holdout_runner_unet_infection_segmentation
+    z = np.load(os.path.join(HERE, "golden", "config1_goldens.npz"))
+    x, y = synthetic_ct(8, 512, seed=0)
+    assert float(x.astype(np.float64).sum()) == float(z["x_sum"]) and float(y.astype(np.float64).sum()) == float(z["y_sum"])
+    out = holdout_runner_unet_infection_segmentation(data=(x, y), epochs=1, dropout=False, workdir=str(tmp_path), verbose=0, seed=0, dropout_rate=0.0)
+    capsys.readouterr()
+    assert abs(out["history"]["loss"][0] - float(z["hist_loss"][0])) < 1e-3 and abs(out["history"]["dice_coeff"][0] - float(z["hist_dice_coeff"][0])) < 1e-3
+    assert abs(out["history"]["val_loss"][0] - float(z["hist_val_loss"][0])) < 1e-3 and abs(out["history"]["val_dice_coeff"][0] - float(z["hist_val_dice_coeff"][0])) < 1e-3
+    assert np.abs(np.array(out["score"]) - z["score"]).max() < 1e-3
+    for got, want in (("dices", "dices"), ("ious", "ious"), ("new_dices", "new_dices"), ("new_ious", "new_ious"), ("precisions", "precisions"), ("recalls", "recalls")):
+        assert np.abs(np.array(out[got]) - z[want]).max() < 1e-3, got
+
+
+def test_other_shapes_batch1_nonsquare_inch3():
+    """predict at batch 1 (T1:1137), non-square input, 3-channel input (first layer falls back to the direct kernel)."""
+    from covidseg_amd.engine import HipUNet
+    rng = np.random.default_rng(0)
+    for h, w_, cin, n in ((224, 224, 1, 1), (32, 96, 1, 2), (48, 32, 3, 2)):
+        wts = O.init_weights(seed=1, in_ch=cin)
+        x = rng.random((n, h, w_, cin)).astype(np.float32); y = (rng.random((n, h, w_, 1)) > 0.6).astype(np.float32)
+        eng = HipUNet(h, w_, cin, dropout_rate=0.0); eng.set_weights(wts)
+        p, ld = eng.predict_batch(x, y)
+        with torch.no_grad():
+            pw = O.forward(wts, x, training=False, dtype=torch.float64)[0]
+            lw = float(O.bce_dice_loss(torch.as_tensor(y, dtype=torch.float64), pw))
+        assert np.abs(p.cpu().numpy() - pw.numpy()).max() < 2e-5 and abs(float(ld[0]) - lw) < 2e-5
+        r = O.loss_and_grads(wts, x, y, dtype=torch.float64)
+        l2 = eng.forward_backward(x, y).cpu().numpy()
+        assert abs(l2[0] - r["loss"]) < 2e-5
+        g = eng.get_grads()
+        assert relerr(g["c1a/kernel"], r["grads"]["c1a/kernel"]) < 2e-2 and relerr(g["out/kernel"], r["grads"]["out/kernel"]) < 1e-4
