@@ -22,7 +22,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(size, seconds_budget=25.0):
+def cpu_baseline(size, seconds_budget=25.0, arch="unet"):
     """Time the oracle's identical training step on the host cores: bounded sample (batch 2)."""
     import numpy as np
     import torch
@@ -30,7 +30,7 @@ def cpu_baseline(size, seconds_budget=25.0):
     from oracle import unet_oracle as O
     bs = 2
     x, y = synthetic_ct(bs, size, seed=0)
-    tr = O.OracleTrainer(O.init_weights(seed=0), torch.float32)
+    tr = O.OracleTrainer(O.init_weights(seed=0) if arch == "unet" else O.pp_init_weights(seed=0), torch.float32, arch)
     t0 = time.perf_counter(); tr.train_step(x, y); first = time.perf_counter() - t0     # includes oneDNN warm-up
     reps = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
     t0 = time.perf_counter()
@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="0 auto (MFMA), 1 direct kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
+    ap.add_argument("--arch", default="unet", choices=["unet", "unetpp"], help="unetpp = the U-Net++ graph (BASELINE configs[3], at fp32); "
+                    "not the headline metric -- use with --size 256 --batch 32")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,8 +86,9 @@ def main():
     xs, ys = synthetic_ct(min(B, 4), S, seed=rank)
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
-    eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank)
-    eng.set_weights(W.init_weights(0))       # identical replicas
+    eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
+                  arch=args.arch)
+    eng.set_weights(W.init_weights(0, 1, args.arch))       # identical replicas
 
     for _ in range(args.warmup):
         eng.train_batch(x, y)
@@ -140,17 +143,20 @@ def main():
     if rank == 0:
         total_imgs = B * world * args.steps
         out = {
-            "metric": "CT images/sec (fwd+bwd) U-Net 512x512x1 bs16", "value": round(total_imgs / dt, 3), "unit": "images/sec",
+            "metric": "CT images/sec (fwd+bwd) U-Net 512x512x1 bs16" if args.arch == "unet" else f"CT images/sec (fwd+bwd) U-Net++ {S}x{S}x1 bs{B}", "value": round(total_imgs / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
-                                   f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json configs[1]",
+            "config": {"workload": (f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
+                                    if args.arch == "unet" else
+                                    f"U-Net++ infection seg (task1_unet_plus_plus.py:858-950), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam")
+                                   + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
+                                   + ("configs[1]" if args.arch == "unet" else "configs[3] graph at the reference's fp32"),
                        "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x2" if args.algo == 0 else "direct",
-                       "dropout": 0.25, "last_loss_dice": [round(v, 5) for v in loss_dice]},
+                       "dropout": 0.25 if args.arch == "unet" else "0.2/0.4 (fused in the conv epilogue)", "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S)
+            out["cpu_baseline"] = cpu_baseline(S, arch=args.arch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

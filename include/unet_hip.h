@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 1
+#define UNET_ABI_VERSION 2
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -44,17 +44,27 @@ const char* unet_last_error(const unet_ctx* ctx);
 /* 1 = op-level timing with hipEvents (bench.py roofline leg); adds a sync per op */
 int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
 
+/* activations of the conv epilogue and "mask modes" of the backward epilogues (derivative of the activation -- and of the
+ * dropout fused behind it -- that produced a stored tensor m):
+ *   UNET_MASK_RELU 1[m>0]   UNET_MASK_ELU  m>0 ? 1 : m+1   UNET_MASK_ELU_DROP  m = dropout(elu(z)), keep mask recomputed
+ *   from the counter-based RNG stream (rate, seed) of that dropout */
+enum { UNET_ACT_NONE = 0, UNET_ACT_RELU = 1, UNET_ACT_ELU = 2 };
+enum { UNET_MASK_NONE = 0, UNET_MASK_RELU = 1, UNET_MASK_ELU = 2, UNET_MASK_ELU_DROP = 3 };
+
 /* ------------------------------------------------------------------------------------
  * Op level.  Replaces: Conv2D(C,(3,3),activation='relu',padding='same')   T1:859-911
  *   y[n,i,j,o] = act(b[o] + sum_{a,b,c} x[n,i+a-1,j+b-1,c] * w[a,b,c,o]);  w is HWIO.
+ * act: 'relu' (U-Net, T1:859) or 'elu' (U-Net++, task1_unet_plus_plus.py:876); drop_rate > 0 fuses the Keras Dropout
+ * layer that follows the conv (task1_unet_plus_plus.py:862, 877) into the epilogue (inverted dropout, training only).
  * ---------------------------------------------------------------------------------- */
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
                          int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
-                         int32_t relu, int32_t algo, void* stream);
-/* dx = conv3x3(dy, flip/transposed w); if relu_src != NULL, dx *= (relu_src > 0): the ReLU
- * mask of the layer that PRODUCED x is fused here (backward of T1:859-860 pairs).
+                         int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, void* stream);
+/* dx = conv3x3(dy, flip/transposed w) * mask_factor(mask_src): the derivative of the activation (+dropout) of the layer
+ * that PRODUCED x is fused here (backward of the T1:859-860 conv pairs).  mask_rate/mask_seed: UNET_MASK_ELU_DROP only.
  * wt_ws: 9*cin*cout floats of scratch for the transformed weights. */
-int32_t unet_conv3x3_bwd_data(unet_ctx*, const float* dy, const float* w, const float* relu_src,
+int32_t unet_conv3x3_bwd_data(unet_ctx*, const float* dy, const float* w, const float* mask_src,
+                              int32_t mask_mode, float mask_rate, uint64_t mask_seed,
                               float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd,
                               int32_t cin, int32_t cout, int32_t algo, void* stream);
 /* dw[a,b,c,o] = sum x[n,i+a-1,j+b-1,c]*dy[n,i,j,o];  db[o] = sum dy.  dy already ReLU-masked.
@@ -98,14 +108,16 @@ int32_t unet_bn_apply(unet_ctx*, const float* x, int32_t ldx, const float* bnp, 
                       int32_t ldy, int64_t pixels, int32_t c, void* stream);
 /* backward: sums = double[2*C] (sum dy, sum dy*xhat), accumulated.  param_grads writes
  * dgamma/dbeta from the LOCAL sums (call before any cross-rank reduction of sums).
- * apply: dx = scale*(dy - sum_dy/count - xhat*sum_dyxhat/count) [* (x>0) if relu_mask]. */
+ * apply: dx = scale*(dy - sum_dy/count - xhat*sum_dyxhat/count) * mask_factor(x) (UNET_MASK_*: the derivative of what
+ * produced the BN input x; UNET_MASK_ELU_DROP needs a dense x). */
 int32_t unet_bn_bwd_stats(unet_ctx*, const float* dy, int32_t lddy, const float* x, int32_t ldx,
                           const float* bnp, double* sums, int64_t pixels, int32_t c, void* stream);
 int32_t unet_bn_bwd_param_grads(unet_ctx*, const double* sums, float* dgamma, float* dbeta,
                                 int32_t c, void* stream);
 int32_t unet_bn_bwd_apply(unet_ctx*, const float* dy, int32_t lddy, const float* x, int32_t ldx,
-                          const float* bnp, const double* sums, double count, int32_t relu_mask,
-                          float* dx, int32_t lddx, int64_t pixels, int32_t c, void* stream);
+                          const float* bnp, const double* sums, double count, int32_t mask_mode,
+                          float mask_rate, uint64_t mask_seed, float* dx, int32_t lddx, int64_t pixels,
+                          int32_t c, void* stream);
 
 /* Replaces: MaxPooling2D((2,2)) + Dropout(0.25)  T1:862-863 (868-869, 874-875, 880-881).
  * rate 0 => plain pool.  Dropout keep-mask = counter-based RNG keyed by (seed, element index);
@@ -142,11 +154,11 @@ int32_t unet_head_fwd(unet_ctx*, const float* x, const float* w, const float* bi
  * number of label elements. */
 int32_t unet_loss_finalize(unet_ctx*, const double* loss_sums, double count, float* loss_out,
                            void* stream);
-/* backward of loss + sigmoid + 1x1 conv: dx = dz*w*(x>0), dw = sum dz*x, db = sum dz,
+/* backward of loss + sigmoid + 1x1 conv: dx = dz*w [*(x>0) if relu_mask: x is a ReLU conv output, T1:911], dw = sum dz*x, db = sum dz,
  * dz = dL/dp * p(1-p) with dL/dp from the GLOBAL sums.  dw/db (cin+1 floats) are ACCUMULATED. */
 int32_t unet_head_bwd(unet_ctx*, const float* x, const float* w, const float* p, const float* y_true,
                       const double* loss_sums, double count, float* dx, float* dw, float* db,
-                      int64_t pixels, int32_t cin, void* stream);
+                      int64_t pixels, int32_t cin, int32_t relu_mask, void* stream);
 
 /* Replaces: Adam(lr=0.0005) step of model.fit T1:1053,1059 -- Keras-2.3 form:
  *   m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps), lr_t=lr*sqrt(1-b2^t)/(1-b1^t)
@@ -160,6 +172,11 @@ int32_t unet_seg_metrics_sweep(unet_ctx*, const float* p, const float* gt, const
                                int32_t nthr, double* out, int64_t count, void* stream);
 
 int32_t unet_zero(unet_ctx*, void* ptr, size_t bytes, void* stream);
+/* concatenate([...]) of a tensor that feeds SEVERAL concats (U-Net++ nested skips, task1_unet_plus_plus.py:891-923):
+ * copy a dense/sliced tensor into a channel slice of a concat buffer; and the backward: dst (+)= sum of <= 4 gradient slices */
+int32_t unet_copy_slice(unet_ctx*, const float* src, int32_t lds, float* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream);
+int32_t unet_accum_slices(unet_ctx*, const float* const* srcs, const int32_t* lds, int32_t nsrc, float* dst, int32_t ldd,
+                          int64_t pixels, int32_t c, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Model level.  Replaces the Keras Model built at T1:853-916 and driven by
@@ -177,7 +194,9 @@ typedef struct unet_sync_point {
   int64_t count;      /* number of elements */
 } unet_sync_point;
 
-int32_t unet_model_create(unet_ctx*, int32_t in_ch, int32_t n, int32_t h, int32_t w,
+/* arch: UNET_ARCH_UNET (T1:853-916) or UNET_ARCH_UNETPP (task1_unet_plus_plus.py:858-950) */
+enum { UNET_ARCH_UNET = 0, UNET_ARCH_UNETPP = 1 };
+int32_t unet_model_create(unet_ctx*, int32_t arch, int32_t in_ch, int32_t n, int32_t h, int32_t w,
                           int32_t world_size, int32_t conv_algo, unet_model** out);
 void unet_model_destroy(unet_model*);
 int64_t unet_model_param_count(const unet_model*);   /* trainable floats (7,762,401 for in_ch=1) */

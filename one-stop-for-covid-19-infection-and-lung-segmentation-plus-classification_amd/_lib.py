@@ -10,9 +10,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2
+ARCH_UNET, ARCH_UNETPP = 0, 1
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+MASK_NONE, MASK_RELU, MASK_ELU, MASK_ELU_DROP = 0, 1, 2, 3
 PROG_FWD_TRAIN, PROG_BWD, PROG_FWD_INFER = 0, 1, 2
 SYNC_BN_FWD, SYNC_LOSS, SYNC_BN_BWD, SYNC_GRAD_BUCKET = 0, 1, 2, 3
 
@@ -33,8 +36,8 @@ _PROTOS = {
     "unet_ctx_destroy": (None, [vp]),
     "unet_last_error": (C.c_char_p, [vp]),
     "unet_ctx_set_profiling": (i32, [vp, i32]),
-    "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, i32, vp]),
+    "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, i32, f32, u64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "unet_conv3x3_bwd_weights": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
     "unet_convT2x2_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -47,18 +50,20 @@ _PROTOS = {
     "unet_bn_apply": (i32, [vp, vp, i32, vp, vp, i32, i64, i32, vp]),
     "unet_bn_bwd_stats": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, i32, vp]),
     "unet_bn_bwd_param_grads": (i32, [vp, vp, vp, vp, i32, vp]),
-    "unet_bn_bwd_apply": (i32, [vp, vp, i32, vp, i32, vp, vp, f64, i32, vp, i32, i64, i32, vp]),
+    "unet_bn_bwd_apply": (i32, [vp, vp, i32, vp, i32, vp, vp, f64, i32, f32, u64, vp, i32, i64, i32, vp]),
     "unet_maxpool2x2_dropout_fwd": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, u64, i32, vp]),
     "unet_bn_apply_maxpool_dropout_fwd": (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd_bnstats": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "unet_loss_finalize": (i32, [vp, vp, f64, vp, vp]),
-    "unet_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, i64, i32, vp]),
+    "unet_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
     "unet_adam_keras": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     "unet_seg_metrics_sweep": (i32, [vp, vp, vp, vp, i32, vp, i64, vp]),
     "unet_zero": (i32, [vp, vp, sz, vp]),
-    "unet_model_create": (i32, [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
+    "unet_copy_slice": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
+    "unet_accum_slices": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, i64, i32, i32, vp]),
+    "unet_model_create": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     "unet_model_destroy": (None, [vp]),
     "unet_model_param_count": (i64, [vp]),
     "unet_model_state_count": (i64, [vp]),

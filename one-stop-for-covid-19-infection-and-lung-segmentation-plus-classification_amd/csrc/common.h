@@ -61,12 +61,40 @@ __device__ __forceinline__ uint4 philox4x32(uint64_t ctr, uint64_t seed) {
 }
 __device__ __forceinline__ float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
 
+// inverted-dropout factors (0 or 1/(1-rate)) of element quad `quad_idx` (4 consecutive channels of a dense NHWC tensor)
+__device__ __forceinline__ float4 keep_scale(long long quad_idx, float rate, uint64_t seed) {
+  uint4 r = philox4x32((uint64_t)quad_idx, seed);
+  float s = 1.0f / (1.0f - rate);
+  return make_float4(u32_to_unit(r.x) >= rate ? s : 0.f, u32_to_unit(r.y) >= rate ? s : 0.f,
+                     u32_to_unit(r.z) >= rate ? s : 0.f, u32_to_unit(r.w) >= rate ? s : 0.f);
+}
+
+// activations of the conv epilogues (Keras 'relu' T1:859 / 'elu' task1_unet_plus_plus.py:876)
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2 };
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == ACT_ELU) return v > 0.0f ? v : expm1f(v);
+  return v;
+}
+// backward factor of the activation (+ dropout) that PRODUCED a stored tensor value m:
+//   MASK_RELU: 1[m>0]      MASK_ELU: m>0 ? 1 : m+1  (elu' expressed through its output)
+//   MASK_ELU_DROP: m = dropout(elu(z)): keep ? s * elu'(m/s) : 0, keep/s recomputed from the Philox stream
+enum { MASK_NONE = 0, MASK_RELU = 1, MASK_ELU = 2, MASK_ELU_DROP = 3 };
+__device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep_scale component */, float rate) {
+  if (mode == MASK_RELU) return m > 0.0f ? 1.0f : 0.0f;
+  if (mode == MASK_ELU) return m > 0.0f ? 1.0f : m + 1.0f;
+  if (mode == MASK_ELU_DROP) { const float a = m * (1.0f - rate); return ks * (a > 0.0f ? 1.0f : a + 1.0f); }
+  return 1.0f;
+}
+
 // internal launchers shared between the op-level ABI and the model programs -------------
 // (definitions in the .hip files; all return a unet status code)
-int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask,
-                            float* y, int n, int h, int wd, int cin, int cout, int relu, hipStream_t s);
+// act: ACT_*; mask_mode: MASK_* (data-gradient epilogue); rate/seed: the fused output dropout (forward) or the dropout
+// of the mask tensor's producer (MASK_ELU_DROP)
+int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
+                            float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 int32_t k_conv3x3_c1_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int n, int h,
-                         int wd, int cout, int relu, hipStream_t s);
+                         int wd, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 size_t c1_wgrad_ws_bytes(int cout);
 int32_t k_conv3x3_c1_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                            int wd, int cout, hipStream_t s);
@@ -81,8 +109,8 @@ int32_t k_convT_naive_wgrad(unet_ctx*, const float* x, const float* dy, int lddy
                             int h, int wd, int cin, int cout, hipStream_t s);
 // MFMA paths (kernels_conv_mfma.hip); return UNET_E_SHAPE if the shape is unsupported
 bool mfma_conv3x3_supported(int cin, int cout);
-int32_t k_conv3x3_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask,
-                           float* y, int n, int h, int wd, int cin, int cout, int relu, hipStream_t s);
+int32_t k_conv3x3_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
+                           float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 bool mfma_wgrad_supported(int ca, int cb);
 bool mfma_convT_supported(int cin, int cout);
 int32_t k_convT_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd,

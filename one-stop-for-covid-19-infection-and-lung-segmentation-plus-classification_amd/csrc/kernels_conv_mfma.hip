@@ -35,11 +35,14 @@ constexpr int PW = 34;    // patch width: 32 + halo
 // MODE 2: convT2x2s2 data-gradient = 2x2 stride-2 'valid' convolution of dU (pixel stride ldx):
 //         the 2x-upsampled patch is de-interleaved by column parity in LDS so that the A operand of
 //         tap (a,b) is again 32 consecutive pixels (conflict-free ds_read_b128)
-template <int MODE, int TN, int TH, int WR, int WC, bool PF, int ABL = 0>
+// GEN = general epilogue (ELU, fused dropout, ELU-derivative masks: the U-Net++ graph); the plain one (ReLU / ReLU mask) keeps
+// the U-Net instances free of the Philox + expm1 code
+template <int MODE, int TN, int TH, int WR, int WC, bool PF, bool GEN, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ mask,
                                                         float* __restrict__ y, int ldy, int N, int H, int W, int Cin, int Cout,
-                                                        int relu, int tiles_x, int tiles_y) {
+                                                        int act, int mask_mode, float rate, unsigned long long seed, int tiles_x,
+                                                        int tiles_y) {
   static_assert(WR * WC == 4, "4 waves");
   constexpr int TAPS = MODE == 0 ? 9 : (MODE == 1 ? 1 : 4);
   constexpr int RW = TH / WR;          // image rows (M tiles) per wave
@@ -206,10 +209,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
           *reinterpret_cast<float4*>(y + (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px + (ab & 1)) * ldy + oc) = v;
         } else {
           const long long o = (((long long)n * H + py) * W + px) * Cout + co;
-          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (mask) {
+          if (!GEN) {
+            if (act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (mask_mode == MASK_RELU) {
+              const float4 m = *reinterpret_cast<const float4*>(mask + o);
+              v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(y + o) = v;
+            continue;
+          }
+          v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+          if (mask_mode == MASK_NONE) {
+            if (rate > 0.0f) {                        // fused inverted dropout on the output (forward, Keras Dropout after the conv)
+              const float4 ks = keep_scale(o >> 2, rate, seed);
+              v.x *= ks.x; v.y *= ks.y; v.z *= ks.z; v.w *= ks.w;
+            }
+          } else {                                    // backward: derivative of the activation (+dropout) that produced `mask`
             const float4 m = *reinterpret_cast<const float4*>(mask + o);
-            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (mask_mode == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
+            v.x *= mask_factor(m.x, mask_mode, ks.x, rate); v.y *= mask_factor(m.y, mask_mode, ks.y, rate);
+            v.z *= mask_factor(m.z, mask_mode, ks.z, rate); v.w *= mask_factor(m.w, mask_mode, ks.w, rate);
           }
           *reinterpret_cast<float4*>(y + o) = v;
         }
@@ -228,23 +248,28 @@ inline int conv_prefetch_enabled() {        // UNET_CONV_PF: 0 = never, 1 = 128-
 }
 
 template <int MODE, int TN, int TH, int WR, int WC>
-int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, const float* mask, float* y, int ldy,
-                    int n, int h, int wd, int cin, int cout, int relu, hipStream_t s) {
+int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, const float* mask, int mask_mode, float* y,
+                    int ldy, int n, int h, int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
+  if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH;
   dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)(cout / TN));
   if (MODE == 0 && conv_ablation()) {          // timing experiments (tools/conv_ablate.py); never set in production
     const int a = conv_ablation();
-    if (a == 1) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, 1>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, relu, tiles_x, tiles_y);
-    else if (a == 2) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, 2>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, relu, tiles_x, tiles_y);
-    else hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, 3>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, relu, tiles_x, tiles_y);
-  } else if (conv_prefetch_enabled() && (TN >= 128 || conv_prefetch_enabled() > 1))   // default: always.  (In isolation the register
-    // prefetch is +7 % on the 128-wide tile and -5 % on the 32-wide one, where it costs a wave of occupancy; inside the
-    // training step "always" measured +0.7 % over "128-wide only", alternating runs.)
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, true>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin,
-                       cout, relu, tiles_x, tiles_y);
-  else
-    hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin,
-                       cout, relu, tiles_x, tiles_y);
+    if (a == 1) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, false, 1>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+    else if (a == 2) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, false, 2>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, false, 3>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+  } else {
+    // default prefetch: always.  (In isolation the register prefetch is +7 % on the 128-wide tile and -5 % on the 32-wide one,
+    // where it costs a wave of occupancy; inside the training step "always" measured +0.7 % over "128-wide only".)
+    const bool pf = conv_prefetch_enabled() && (TN >= 128 || conv_prefetch_enabled() > 1);
+    const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU);
+#define UNET_LAUNCH_CONV(PF_, GEN_)                                                                                                  \
+  hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, PF_, GEN_>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, \
+                     cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y)
+    if (MODE == 0 && gen) { if (pf) UNET_LAUNCH_CONV(true, (MODE == 0)); else UNET_LAUNCH_CONV(false, (MODE == 0)); }
+    else { if (pf) UNET_LAUNCH_CONV(true, false); else UNET_LAUNCH_CONV(false, false); }
+#undef UNET_LAUNCH_CONV
+  }
   UNET_CHECK_LAUNCH(ctx, "conv_mfma");
   return UNET_OK;
 }
@@ -488,13 +513,13 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
 bool mfma_conv3x3_supported(int cin, int cout) { return cin >= CK && (cin % CK) == 0 && (cout % 32) == 0; }
 bool mfma_wgrad_supported(int ca, int cb) { return ca >= 32 && (ca % 32) == 0 && cb >= 32 && (cb % 32) == 0; }
 
-int32_t k_conv3x3_mfma_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, float* y, int n,
-                           int h, int wd, int cin, int cout, int relu, hipStream_t s) {
+int32_t k_conv3x3_mfma_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode, float* y,
+                           int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   if (!mfma_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 mfma: cin=%d cout=%d unsupported", cin, cout);
-  if (cout % 128 == 0) return launch_conv<0, 128, 4, 2, 2>(ctx, x, cin, w, bias, mask, y, cout, n, h, wd, cin, cout, relu, s);
-  if (cout % 64 == 0) return launch_conv<0, 64, 8, 4, 1>(ctx, x, cin, w, bias, mask, y, cout, n, h, wd, cin, cout, relu, s);
+  if (cout % 128 == 0) return launch_conv<0, 128, 4, 2, 2>(ctx, x, cin, w, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
+  if (cout % 64 == 0) return launch_conv<0, 64, 8, 4, 1>(ctx, x, cin, w, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
   // (a 16-row tile for this config measured 3 % slower end to end: fewer, longer blocks)
-  return launch_conv<0, 32, 8, 4, 1>(ctx, x, cin, w, bias, mask, y, cout, n, h, wd, cin, cout, relu, s);
+  return launch_conv<0, 32, 8, 4, 1>(ctx, x, cin, w, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
 }
 
 bool mfma_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0; }
@@ -503,16 +528,17 @@ bool mfma_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) ==
 int32_t k_convT_mfma_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd,
                          int cin, int cout, hipStream_t s) {
   if (!mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: cin=%d cout=%d unsupported", cin, cout);
-  return launch_conv<1, 128, 4, 2, 2>(ctx, x, cin, w, bias, nullptr, y, ldy, n, h, wd, cin, 4 * cout, 0, s);
+  return launch_conv<1, 128, 4, 2, 2>(ctx, x, cin, w, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
 }
 
-// dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]: K is already [tap][o][c] = [tap][Cin'][Cout']
+// dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]: K is already [tap][o][c] = [tap][Cin'][Cout']; mask: ReLU of the producer of x
 int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd,
                            int cin, int cout, hipStream_t s) {
   if (!mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: cin=%d cout=%d unsupported", cin, cout);
-  if (cin % 128 == 0) return launch_conv<2, 128, 4, 2, 2>(ctx, dy, lddy, w, nullptr, mask, dx, cin, n, h, wd, cout, cin, 0, s);
-  if (cin % 64 == 0) return launch_conv<2, 64, 4, 2, 2>(ctx, dy, lddy, w, nullptr, mask, dx, cin, n, h, wd, cout, cin, 0, s);
-  return launch_conv<2, 32, 4, 4, 1>(ctx, dy, lddy, w, nullptr, mask, dx, cin, n, h, wd, cout, cin, 0, s);
+  const int mm = mask ? MASK_RELU : MASK_NONE;
+  if (cin % 128 == 0) return launch_conv<2, 128, 4, 2, 2>(ctx, dy, lddy, w, nullptr, mask, mm, dx, cin, n, h, wd, cout, cin, ACT_NONE, 0.0f, 0, s);
+  if (cin % 64 == 0) return launch_conv<2, 64, 4, 2, 2>(ctx, dy, lddy, w, nullptr, mask, mm, dx, cin, n, h, wd, cout, cin, ACT_NONE, 0.0f, 0, s);
+  return launch_conv<2, 32, 4, 4, 1>(ctx, dy, lddy, w, nullptr, mask, mm, dx, cin, n, h, wd, cout, cin, ACT_NONE, 0.0f, 0, s);
 }
 
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {

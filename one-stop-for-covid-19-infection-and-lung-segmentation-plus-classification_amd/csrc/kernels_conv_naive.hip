@@ -9,10 +9,10 @@ namespace {
 constexpr int TPB = 256;
 
 // y[pix][co] = act(b[co] + sum_{tap,ci} x[pix+tap][ci] * w[tap][ci][co]); lanes run along co.
-template <bool RELU, bool MASK>
 __global__ __launch_bounds__(TPB) void conv3x3_naive_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, const float* __restrict__ mask,
-                                                            float* __restrict__ y, int N, int H, int W, int Cin, int Cout) {
+                                                            const float* __restrict__ bias, const float* __restrict__ mask, int mask_mode,
+                                                            float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int act,
+                                                            float rate, unsigned long long seed) {
   const long long total = (long long)N * H * W * Cout;
   for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
     int co = (int)(idx % Cout); long long pix = idx / Cout;
@@ -27,18 +27,23 @@ __global__ __launch_bounds__(TPB) void conv3x3_naive_kernel(const float* __restr
         for (int ci = 0; ci < Cin; ++ci) acc = fmaf(xp[ci], wp[(long long)ci * Cout], acc);
       }
     }
-    if (RELU) acc = fmaxf(acc, 0.0f);
-    if (MASK) acc = mask[idx] > 0.0f ? acc : 0.0f;
+    acc = apply_act(acc, act);
+    float ks = 1.0f;
+    if (rate > 0.0f && (mask_mode == MASK_NONE || mask_mode == MASK_ELU_DROP)) {     // same Philox stream as the float4 kernels
+      const float4 k4 = keep_scale(idx >> 2, rate, seed); const int e = (int)(idx & 3);
+      ks = e == 0 ? k4.x : e == 1 ? k4.y : e == 2 ? k4.z : k4.w;
+    }
+    if (mask_mode == MASK_NONE) { if (rate > 0.0f) acc *= ks; }
+    else acc *= mask_factor(mask[idx], mask_mode, ks, rate);
     y[idx] = acc;
   }
 }
 
 // First layer, Cin = 1 (c1a, T1:859): HBM-bound (AI ~2 F/B).  8 lanes per pixel, each lane owns
 // 4 output channels with its 9x4 weights in registers; a wave writes 8 pixels = 1 KiB contiguous.
-template <bool RELU>
 __global__ __launch_bounds__(TPB) void conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                         int N, int H, int W, int Cout) {
+                                                         int N, int H, int W, int Cout, int act, float rate, unsigned long long seed) {
   const int lpp = Cout >> 2;
   const int sub = threadIdx.x % lpp;
   float4 wr[9];
@@ -61,7 +66,8 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1_kernel(const float* __restrict
         acc.x = fmaf(v, k.x, acc.x); acc.y = fmaf(v, k.y, acc.y); acc.z = fmaf(v, k.z, acc.z); acc.w = fmaf(v, k.w, acc.w);
       }
     }
-    if (RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
+    if (rate > 0.0f) { const float4 ks = keep_scale(p * lpp + sub, rate, seed); acc.x *= ks.x; acc.y *= ks.y; acc.z *= ks.z; acc.w *= ks.w; }
     *reinterpret_cast<float4*>(y + p * Cout + sub * 4) = acc;
   }
 }
@@ -236,24 +242,21 @@ inline int grid_for(long long items, int cap = 4096) {
 }
 }  // namespace
 
-int32_t k_conv3x3_naive_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, float* y,
-                            int n, int h, int wd, int cin, int cout, int relu, hipStream_t s) {
+int32_t k_conv3x3_naive_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode, float* y,
+                            int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   long long total = (long long)n * h * wd * cout;
-  dim3 g(grid_for(total, 1 << 20)), b(TPB);
-  if (relu && mask) hipLaunchKernelGGL((conv3x3_naive_kernel<true, true>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
-  else if (relu) hipLaunchKernelGGL((conv3x3_naive_kernel<true, false>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
-  else if (mask) hipLaunchKernelGGL((conv3x3_naive_kernel<false, true>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
-  else hipLaunchKernelGGL((conv3x3_naive_kernel<false, false>), g, b, 0, s, x, w, bias, mask, y, n, h, wd, cin, cout);
+  if (!mask) mask_mode = MASK_NONE;
+  hipLaunchKernelGGL(conv3x3_naive_kernel, dim3(grid_for(total, 1 << 20)), dim3(TPB), 0, s, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act,
+                     rate, (unsigned long long)seed);
   UNET_CHECK_LAUNCH(ctx, "conv3x3_naive_fwd"); return UNET_OK;
 }
 
 int32_t k_conv3x3_c1_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd,
-                         int cout, int relu, hipStream_t s) {
+                         int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   if ((cout & 3) || TPB % (cout / 4)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1: cout=%d unsupported", cout);
   long long threads = (long long)n * h * wd * (cout / 4);
-  dim3 g(grid_for(threads / 2 + 1, 2048)), b(TPB);
-  if (relu) hipLaunchKernelGGL(conv3x3_c1_kernel<true>, g, b, 0, s, x, w, bias, y, n, h, wd, cout);
-  else hipLaunchKernelGGL(conv3x3_c1_kernel<false>, g, b, 0, s, x, w, bias, y, n, h, wd, cout);
+  hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(grid_for(threads / 2 + 1, 2048)), dim3(TPB), 0, s, x, w, bias, y, n, h, wd, cout, act, rate,
+                     (unsigned long long)seed);
   UNET_CHECK_LAUNCH(ctx, "conv3x3_c1_fwd"); return UNET_OK;
 }
 

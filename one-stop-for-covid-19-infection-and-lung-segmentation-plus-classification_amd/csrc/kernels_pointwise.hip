@@ -124,13 +124,16 @@ __global__ void bn_bwd_param_grads_kernel(const double* sums, float* dgamma, flo
   dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c];
 }
 
-template <bool MASK>
+// mask_mode: derivative of what produced the BN input x (MASK_RELU: T1:860; MASK_ELU / MASK_ELU_DROP: U-Net++ conv_block,
+// where x = dropout(elu(conv)) and the keep mask is recomputed from the Philox stream of that dropout)
+template <int MM>       // MASK_* of the producer of x, compile-time so the U-Net (ReLU) instance carries no Philox/ELU code
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy,
                                                            const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ bnp,
                                                            const double* __restrict__ sums, double inv_count,
                                                            float* __restrict__ dx, int lddx,
-                                                           long long pixels, int C) {
+                                                           long long pixels, int C, float rate, unsigned long long seed) {
+  constexpr int mask_mode = MM;
   const int lpp = C >> 2;
   const long long total = pixels * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
@@ -142,13 +145,14 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
     const float gg[4] = {g.x, g.y, g.z, g.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
     const float ss[4] = {sc.x, sc.y, sc.z, sc.w}, mm[4] = {mean.x, mean.y, mean.z, mean.w};
     const float ii[4] = {istd.x, istd.y, istd.z, istd.w};
+    float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask_mode == MASK_ELU_DROP) k4 = keep_scale(i, rate, seed);       // x is dense here: quad index == i
+    const float kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float k1 = (float)(s1[k] * inv_count), k2 = (float)(s2[k] * inv_count);
       float xh = (xx[k] - mm[k]) * ii[k];
-      float v = ss[k] * (gg[k] - k1 - xh * k2);
-      if (MASK) v = xx[k] > 0.0f ? v : 0.0f;
-      r[k] = v;
+      r[k] = ss[k] * (gg[k] - k1 - xh * k2) * mask_factor(xx[k], mask_mode, kk[k], rate);
     }
     st4(dx + p * lddx + q * 4, make_float4(r[0], r[1], r[2], r[3]));
   }
@@ -157,13 +161,6 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------
 // 2x2 max-pool (+ inverted dropout).  One thread = one pooled pixel x 4 channels.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 keep_scale(long long idx, float rate, uint64_t seed) {
-  uint4 r = philox4x32((uint64_t)idx, seed);
-  float s = 1.0f / (1.0f - rate);
-  return make_float4(u32_to_unit(r.x) >= rate ? s : 0.f, u32_to_unit(r.y) >= rate ? s : 0.f,
-                     u32_to_unit(r.z) >= rate ? s : 0.f, u32_to_unit(r.w) >= rate ? s : 0.f);
-}
-
 __global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__ x, int ldx,
                                                        float* __restrict__ y, int N, int H, int W, int C,
                                                        float rate, uint64_t seed) {
@@ -358,7 +355,7 @@ __global__ __launch_bounds__(TPB) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ pin, const float* __restrict__ yt,
                                                        const double* __restrict__ sums, double inv_count,
                                                        float* __restrict__ dx, float* dw, float* db,
-                                                       long long pixels, int cin) {
+                                                       long long pixels, int cin, int relu_mask) {
   const int lpp = cin >> 2;
   const int sub = threadIdx.x & (lpp - 1);
   const float4 wv = ld4(w + sub * 4);
@@ -375,8 +372,8 @@ __global__ __launch_bounds__(TPB) void head_bwd_kernel(const float* __restrict__
     // log terms analytically -- no 1-p cancellation noise near saturation); the Dice part keeps p(1-p)
     float dz = (inr ? hb * (pc - t) : 0.0f) - 0.5f * (2.0f * t - dice) * invS * pr * (1.0f - pr);
     float4 v = ld4(x + p * cin + sub * 4);
-    st4(dx + p * cin + sub * 4, make_float4(v.x > 0 ? dz * wv.x : 0.f, v.y > 0 ? dz * wv.y : 0.f,
-                                            v.z > 0 ? dz * wv.z : 0.f, v.w > 0 ? dz * wv.w : 0.f));
+    st4(dx + p * cin + sub * 4, make_float4((!relu_mask || v.x > 0) ? dz * wv.x : 0.f, (!relu_mask || v.y > 0) ? dz * wv.y : 0.f,
+                                            (!relu_mask || v.z > 0) ? dz * wv.z : 0.f, (!relu_mask || v.w > 0) ? dz * wv.w : 0.f));
     aw.x += dz * v.x; aw.y += dz * v.y; aw.z += dz * v.z; aw.w += dz * v.w;
     if (sub == 0) ab += dz;
   }
@@ -462,6 +459,27 @@ __global__ __launch_bounds__(TPB) void metrics_sweep_kernel(const float* __restr
   }
 }
 
+// dst[slice] = src[slice] (materialise a skip tensor inside a concat buffer) and dst[slice] (+)= sum of up to 4 gradient slices
+__global__ __launch_bounds__(TPB) void copy_slice_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                                         long long pixels, int C) {
+  const int lpp = C >> 2; const long long total = pixels * lpp;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    int q = (int)(i % lpp); long long p = i / lpp;
+    st4(dst + p * ldd + q * 4, ld4(src + p * lds + q * 4));
+  }
+}
+struct SliceList { const float* p[4]; int ld[4]; int n; };
+__global__ __launch_bounds__(TPB) void accum_slices_kernel(SliceList sl, float* __restrict__ dst, int ldd, long long pixels, int C,
+                                                           int accumulate) {
+  const int lpp = C >> 2; const long long total = pixels * lpp;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    int q = (int)(i % lpp); long long p = i / lpp;
+    float4 s = accumulate ? ld4(dst + p * ldd + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < sl.n; ++k) { const float4 v = ld4(sl.p[k] + p * sl.ld[k] + q * 4); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    st4(dst + p * ldd + q * 4, s);
+  }
+}
+
 inline int grid_for(long long work_items) {
   long long b = cdiv64(work_items, TPB);
   return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
@@ -518,12 +536,20 @@ int32_t unet_bn_bwd_param_grads(unet_ctx* ctx, const double* sums, float* dgamma
 }
 
 int32_t unet_bn_bwd_apply(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp,
-                          const double* sums, double count, int32_t relu_mask, float* dx, int32_t lddx, int64_t pixels,
-                          int32_t c, void* stream) {
+                          const double* sums, double count, int32_t mask_mode, float mask_rate, uint64_t mask_seed, float* dx,
+                          int32_t lddx, int64_t pixels, int32_t c, void* stream) {
   if (!dy || !x || !bnp || !sums || !dx || !bn_c_ok(c) || count < 1 || ((ldx | lddy | lddx) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_apply: bad args");
-  int grid = grid_for(pixels * (c / 4));
-  if (relu_mask) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, sums, 1.0 / count, dx, lddx, (long long)pixels, c);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, sums, 1.0 / count, dx, lddx, (long long)pixels, c);
+  if (mask_mode < 0 || mask_mode > 3 || (mask_mode == MASK_ELU_DROP && (ldx != c || mask_rate < 0 || mask_rate >= 1))) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_apply: bad mask mode (MASK_ELU_DROP needs a dense x)");
+#define UNET_LAUNCH_BNBA(MM_)                                                                                                        \
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<MM_>, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, \
+                     sums, 1.0 / count, dx, lddx, (long long)pixels, c, mask_rate, (unsigned long long)mask_seed)
+  switch (mask_mode) {
+    case MASK_NONE: UNET_LAUNCH_BNBA(MASK_NONE); break;
+    case MASK_RELU: UNET_LAUNCH_BNBA(MASK_RELU); break;
+    case MASK_ELU: UNET_LAUNCH_BNBA(MASK_ELU); break;
+    default: UNET_LAUNCH_BNBA(MASK_ELU_DROP); break;
+  }
+#undef UNET_LAUNCH_BNBA
   UNET_CHECK_LAUNCH(ctx, "bn_bwd_apply"); return UNET_OK;
 }
 
@@ -582,9 +608,9 @@ int32_t unet_loss_finalize(unet_ctx* ctx, const double* loss_sums, double count,
 
 int32_t unet_head_bwd(unet_ctx* ctx, const float* x, const float* w, const float* p, const float* y_true,
                       const double* loss_sums, double count, float* dx, float* dw, float* db, int64_t pixels, int32_t cin,
-                      void* stream) {
+                      int32_t relu_mask, void* stream) {
   if (!x || !w || !p || !y_true || !loss_sums || !dx || !dw || !db || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "head_bwd: bad args");
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(grid_for(pixels * (cin / 4) / 4)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(grid_for(pixels * (cin / 4) / 4)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin, relu_mask);
   UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
 }
 
@@ -601,6 +627,21 @@ int32_t unet_seg_metrics_sweep(unet_ctx* ctx, const float* p, const float* gt, c
   int gx = (int)std::min<int64_t>(cdiv64(count, TPB * 8), 1024); if (gx < 1) gx = 1;
   hipLaunchKernelGGL(metrics_sweep_kernel, dim3(gx, (nthr + THR_CHUNK - 1) / THR_CHUNK), dim3(TPB), 0, as_stream(stream), p, gt, thresholds, nthr, out, (long long)count);
   UNET_CHECK_LAUNCH(ctx, "metrics_sweep"); return UNET_OK;
+}
+
+int32_t unet_copy_slice(unet_ctx* ctx, const float* src, int32_t lds, float* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream) {
+  if (!src || !dst || (c & 3) || lds < c || ldd < c || ((lds | ldd) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "copy_slice: bad args");
+  hipLaunchKernelGGL(copy_slice_kernel, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), src, lds, dst, ldd, (long long)pixels, c);
+  UNET_CHECK_LAUNCH(ctx, "copy_slice"); return UNET_OK;
+}
+
+int32_t unet_accum_slices(unet_ctx* ctx, const float* const* srcs, const int32_t* lds, int32_t nsrc, float* dst, int32_t ldd, int64_t pixels,
+                          int32_t c, int32_t accumulate, void* stream) {
+  if (!srcs || !lds || !dst || nsrc < 1 || nsrc > 4 || (c & 3) || ldd < c || (ldd & 3)) UNET_FAIL(ctx, UNET_E_ARG, "accum_slices: bad args (1..4 sources)");
+  SliceList sl; sl.n = nsrc;
+  for (int k = 0; k < 4; ++k) { sl.p[k] = k < nsrc ? srcs[k] : nullptr; sl.ld[k] = k < nsrc ? lds[k] : 0; if (k < nsrc && (!srcs[k] || lds[k] < c || (lds[k] & 3))) UNET_FAIL(ctx, UNET_E_ARG, "accum_slices: bad source %d", k); }
+  hipLaunchKernelGGL(accum_slices_kernel, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), sl, dst, ldd, (long long)pixels, c, accumulate);
+  UNET_CHECK_LAUNCH(ctx, "accum_slices"); return UNET_OK;
 }
 
 int32_t unet_zero(unet_ctx* ctx, void* ptr, size_t bytes, void* stream) {

@@ -53,13 +53,14 @@ static bool use_mfma(int algo, int cin, int cout) {
   return mfma_conv3x3_supported(cin, cout);
 }
 
-static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask,
-                                    float* y, int n, int h, int wd, int cin, int cout, int relu, int algo, hipStream_t s) {
+static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
+                                    float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, int algo,
+                                    hipStream_t s) {
   if (algo == UNET_ALGO_MFMA && !mfma_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 mfma: cin=%d cout=%d unsupported", cin, cout);
-  if (use_mfma(algo, cin, cout)) return k_conv3x3_mfma_fwd(ctx, x, w, bias, mask, y, n, h, wd, cin, cout, relu, s);
+  if (use_mfma(algo, cin, cout)) return k_conv3x3_mfma_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   if (cin == 1 && !mask && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0)
-    return k_conv3x3_c1_fwd(ctx, x, w, bias, y, n, h, wd, cout, relu, s);
-  return k_conv3x3_naive_fwd(ctx, x, w, bias, mask, y, n, h, wd, cin, cout, relu, s);
+    return k_conv3x3_c1_fwd(ctx, x, w, bias, y, n, h, wd, cout, act, rate, seed, s);
+  return k_conv3x3_naive_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
 }
 
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
@@ -75,18 +76,24 @@ static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float
 extern "C" {
 
 int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t h,
-                         int32_t wd, int32_t cin, int32_t cout, int32_t relu, int32_t algo, void* stream) {
-  if (!ctx || !x || !w || !y || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: bad args");
-  return conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, y, n, h, wd, cin, cout, relu, algo, as_stream(stream));
+                         int32_t wd, int32_t cin, int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo,
+                         void* stream) {
+  if (!ctx || !x || !w || !y || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || act < 0 || act > 2 || drop_rate < 0 || drop_rate >= 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: bad args");
+  return conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, algo, as_stream(stream));
 }
 
-int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* relu_src, float* dx, float* wt_ws,
-                              int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
-  if (!ctx || !dy || !w || !dx || !wt_ws || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data: bad args");
+int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* mask_src, int32_t mask_mode, float mask_rate,
+                              uint64_t mask_seed, float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
+                              int32_t algo, void* stream) {
+  if (!ctx || !dy || !w || !dx || !wt_ws || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || mask_mode < 0 || mask_mode > 3 ||
+      (mask_mode != MASK_NONE && !mask_src) || mask_rate < 0 || mask_rate >= 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data: bad args");
   int32_t r = k_flip_transpose_w3x3(ctx, w, wt_ws, cin, cout, as_stream(stream));
   if (r) return r;
   // data gradient = 3x3 convolution of dy (cout channels) with wt -> cin channels
-  return conv3x3_fwd_dispatch(ctx, dy, wt_ws, nullptr, relu_src, dx, n, h, wd, cout, cin, 0, algo, as_stream(stream));
+  return conv3x3_fwd_dispatch(ctx, dy, wt_ws, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
+                              as_stream(stream));
 }
 
 size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
@@ -152,7 +159,7 @@ struct Op {
 
 struct unet_model {
   unet_ctx* ctx = nullptr;
-  int in_ch = 1, N = 0, H = 0, W = 0, world = 1, algo = 0;
+  int arch = 0, in_ch = 1, N = 0, H = 0, W = 0, world = 1, algo = 0;
   std::vector<Layer> layers;
   std::map<std::string, TInfo> tinfo;
   int64_t n_params = 0, n_state = 0;
@@ -186,6 +193,23 @@ namespace {
 
 const int ENC[4] = {32, 64, 128, 256};
 
+void assign_param_offsets(unet_model* m) {
+  int64_t po = 0, so = 0;
+  for (auto& l : m->layers) {
+    if (l.kind == 2) {
+      m->tinfo[l.name + "/gamma"] = {0, po, l.cout}; po += l.cout;
+      m->tinfo[l.name + "/beta"] = {0, po, l.cout}; po += l.cout;
+      m->tinfo[l.name + "/mean"] = {1, so, l.cout}; so += l.cout;
+      m->tinfo[l.name + "/var"] = {1, so, l.cout}; so += l.cout;
+    } else {
+      int64_t kn = (l.kind == 0 ? 9 : l.kind == 1 ? 4 : 1) * (int64_t)l.cin * l.cout;
+      m->tinfo[l.name + "/kernel"] = {0, po, kn}; po += kn;
+      m->tinfo[l.name + "/bias"] = {0, po, l.cout}; po += l.cout;
+    }
+  }
+  m->n_params = po; m->n_state = so;
+}
+
 void build_layers(unet_model* m) {
   auto& L = m->layers;
   int cprev = m->in_ch;
@@ -209,20 +233,7 @@ void build_layers(unet_model* m) {
     cprev = c;
   }
   L.push_back({"out", 3, 32, 1});
-  int64_t po = 0, so = 0;
-  for (auto& l : L) {
-    if (l.kind == 2) {
-      m->tinfo[l.name + "/gamma"] = {0, po, l.cout}; po += l.cout;
-      m->tinfo[l.name + "/beta"] = {0, po, l.cout}; po += l.cout;
-      m->tinfo[l.name + "/mean"] = {1, so, l.cout}; so += l.cout;
-      m->tinfo[l.name + "/var"] = {1, so, l.cout}; so += l.cout;
-    } else {
-      int64_t kn = (l.kind == 0 ? 9 : l.kind == 1 ? 4 : 1) * (int64_t)l.cin * l.cout;
-      m->tinfo[l.name + "/kernel"] = {0, po, kn}; po += kn;
-      m->tinfo[l.name + "/bias"] = {0, po, l.cout}; po += l.cout;
-    }
-  }
-  m->n_params = po; m->n_state = so;
+  assign_param_offsets(m);
 }
 
 struct Carver {
@@ -233,10 +244,7 @@ struct Carver {
 Buf mk(Carver& cv, int n, int h, int w, int c) { Buf b; b.off = cv.take((size_t)n * h * w * c); b.ld = c; b.n = n; b.h = h; b.w = w; b.c = c; return b; }
 Buf slice(const Buf& b, int c0, int c) { Buf s = b; s.chan_off = c0; s.c = c; return s; }
 
-void plan_workspace(unet_model* m) {
-  Carver cv;
-  const int N = m->N;
-  // --- small scratch first ---
+void plan_scratch(unet_model* m, Carver& cv) {          // BN sums / params, loss scalars (the cross-rank sync buffers)
   size_t nd = 0;
   for (auto& l : m->layers) if (l.kind == 2) { m->bn_sum_off[l.name] = nd; nd += 2 * (size_t)l.cout; }
   m->bn_sums_doubles = nd;
@@ -247,6 +255,12 @@ void plan_workspace(unet_model* m) {
   m->off_bn_bsums = cv.take(nb * 2);
   for (auto& l : m->layers) if (l.kind == 2) m->bnp_off[l.name] = cv.take(4 * (size_t)l.cout);
   m->off_loss_out = cv.take(64);
+}
+
+void plan_workspace(unet_model* m) {
+  Carver cv;
+  const int N = m->N;
+  plan_scratch(m, cv);
   // --- activations ---
   int S = m->H, T = m->W;
   for (int k = 1; k <= 4; ++k) {
@@ -352,7 +366,8 @@ void build_programs(unet_model* m) {
       double by = 4.0 * ((double)ob.n * ob.h * ob.w * (cin + cout) + 9.0 * cin * cout);
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
         const float* xin = in.empty() ? m->x : m->A(in);
-        return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, m->Aw(name), ob.n, ob.h, ob.w, cin, cout, 1, algo, s);
+        return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
+                                    ACT_RELU, 0.0f, 0, algo, s);
       });
     };
     auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c, bool fuse_pool) {
@@ -436,7 +451,7 @@ void build_programs(unet_model* m) {
     ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, 4.0 * hp * 66, {
       if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
       return unet_head_bwd(ctx, m->A("c9b"), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, m->D("c9b"),
-                           m->G("out/kernel"), m->G("out/bias"), hp, hb.c, s);
+                           m->G("out/kernel"), m->G("out/bias"), hp, hb.c, 1, s);
     });
     // conv backward: wgrad (x, dy) then dgrad (dy -> dx, optional relu mask = activation that produced x)
     auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, bool mask_in) {
@@ -449,8 +464,8 @@ void build_programs(unet_model* m) {
       });
       if (want_dx) {
         ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cout + cin + (mask_in ? cin : 0)) + 9.0 * cin * cout), {
-          return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), mask_in ? m->A(in) : nullptr, m->D(in), m->wsf(m->off_wt), ob.n, ob.h, ob.w,
-                                       cin, cout, algo, s);
+          return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), mask_in ? m->A(in) : nullptr, mask_in ? MASK_RELU : MASK_NONE, 0.0f, 0, m->D(in),
+                                       m->wsf(m->off_wt), ob.n, ob.h, ob.w, cin, cout, algo, s);
         });
       }
     };
@@ -474,8 +489,8 @@ void build_programs(unet_model* m) {
       }
       SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
       ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
-        return unet_bn_bwd_apply(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, mask, m->D(dxname),
-                                 db.ld, pixels, c, s);
+        return unet_bn_bwd_apply(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, mask ? MASK_RELU : MASK_NONE, 0.0f, 0,
+                                 m->D(dxname), db.ld, pixels, c, s);
       });
     };
     auto bucket = [&](const std::string& first, const std::string& last_tensor) {
@@ -524,6 +539,307 @@ void build_programs(unet_model* m) {
   }
 }
 
+// =========================================================================================
+// U-Net++ (nested skips) -- /root/reference/Scripts/task1_unet_plus_plus.py:858-950.
+//   encoder k : Conv(C,elu) -> Dropout(.2) -> Conv(C,elu) -> BN -> c_k -> MaxPool            (UPP:876-914)
+//   node x    : ConvT(src) ++ skips -> conv_block = [Conv(elu) -> Dropout(.4) -> BN] x 2     (UPP:860-868, 888-924)
+//   head      : Conv 1x1 sigmoid on x1_4                                                      (UPP:946-947)
+// Dropout is fused into the conv epilogue (counter-based RNG, mask recomputed in backward); a tensor that feeds several
+// concats is copied into each concat buffer (copy_slice), its gradient is the sum of the consumers' slices (accum_slices).
+// =========================================================================================
+struct PPNode { const char* name; int c; const char* src; std::vector<const char*> skips; };
+const std::vector<PPNode>& pp_nodes() {
+  static const std::vector<PPNode> v = {{"x1_2", 32, "c2", {"c1"}}, {"x2_2", 64, "c3", {"c2"}}, {"x1_3", 32, "x2_2", {"c1", "x1_2"}},
+                                        {"x3_2", 128, "c4", {"c3"}}, {"x2_3", 64, "x3_2", {"c2", "x2_2"}},
+                                        {"x1_4", 32, "x2_3", {"c1", "x1_2", "x1_3"}}};
+  return v;
+}
+int pp_width(const std::string& t) {
+  if (t[0] == 'c') return ENC[t[1] - '1'];
+  for (auto& n : pp_nodes()) if (t == n.name) return n.c;
+  return 0;
+}
+int pp_level(const std::string& t) { return t[1] - '1'; }        // c1,x1_* -> 0; c2,x2_* -> 1; ...
+constexpr float PP_ENC_DROP = 0.2f, PP_BLOCK_DROP = 0.4f;
+// creation order of the reference: enc1, enc2, x1_2, enc3, x2_2, x1_3, enc4, x3_2, x2_3, x1_4 (UPP:876-924)
+const char* PP_ORDER[10] = {"e1", "e2", "x1_2", "e3", "x2_2", "x1_3", "e4", "x3_2", "x2_3", "x1_4"};
+
+void build_layers_pp(unet_model* m) {
+  auto& L = m->layers;
+  for (const char* item : PP_ORDER) {
+    std::string it = item;
+    if (it[0] == 'e') {
+      int k = it[1] - '0', c = ENC[k - 1], cin = k == 1 ? m->in_ch : ENC[k - 2];
+      std::string ks = std::to_string(k);
+      L.push_back({"c" + ks + "a", 0, cin, c}); L.push_back({"c" + ks + "b", 0, c, c}); L.push_back({"bn" + ks, 2, c, c});
+    } else {
+      const PPNode* nd = nullptr;
+      for (auto& n : pp_nodes()) if (it == n.name) nd = &n;
+      int ctot = nd->c; for (auto sk : nd->skips) ctot += pp_width(sk);
+      L.push_back({"u" + it.substr(1), 1, pp_width(nd->src), nd->c});
+      L.push_back({it + "a", 0, ctot, nd->c}); L.push_back({it + "abn", 2, nd->c, nd->c});
+      L.push_back({it + "b", 0, nd->c, nd->c}); L.push_back({it + "bbn", 2, nd->c, nd->c});
+    }
+  }
+  L.push_back({"out", 3, 32, 1});
+  assign_param_offsets(m);
+}
+
+void plan_workspace_pp(unet_model* m) {
+  Carver cv;
+  const int N = m->N;
+  plan_scratch(m, cv);
+  auto dims = [&](int lvl, int& hh, int& ww) { hh = m->H >> lvl; ww = m->W >> lvl; };
+  int hh, ww;
+  size_t wt0 = 0, wgb = 0, tmp_up = 0;
+  for (int k = 1; k <= 4; ++k) {
+    dims(k - 1, hh, ww); std::string ks = std::to_string(k); int c = ENC[k - 1];
+    m->act["c" + ks + "a"] = mk(cv, N, hh, ww, c); m->act["c" + ks + "b"] = mk(cv, N, hh, ww, c);
+    m->act["c" + ks] = mk(cv, N, hh, ww, c); m->act["bn" + ks] = m->act["c" + ks];
+    if (k <= 3) m->act["p" + ks] = mk(cv, N, hh / 2, ww / 2, c);
+  }
+  for (auto& nd : pp_nodes()) {
+    std::string nm = nd.name; dims(pp_level(nm), hh, ww);
+    int ctot = nd.c; for (auto sk : nd.skips) ctot += pp_width(sk);
+    Buf cat = mk(cv, N, hh, ww, ctot);
+    m->act["cat_" + nm] = cat; m->act["u" + nm.substr(1)] = slice(cat, 0, nd.c);
+    m->act[nm + "a"] = mk(cv, N, hh, ww, nd.c); m->act[nm + "abn"] = mk(cv, N, hh, ww, nd.c);
+    m->act[nm + "b"] = mk(cv, N, hh, ww, nd.c); m->act[nm] = mk(cv, N, hh, ww, nd.c); m->act[nm + "bbn"] = m->act[nm];
+  }
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)9 * l.cin * l.cout);
+  m->off_wt = cv.take(wt0);
+  m->ws_floats_infer = cv.cur;
+  // ---- training: one dense gradient twin per activation buffer (aliases share it)
+  std::map<size_t, std::string> seen;
+  for (auto& kv : m->act) {
+    const Buf& b = kv.second;
+    if (b.chan_off != 0 || b.ld != b.c) continue;                 // slices handled below
+    auto it = seen.find(b.off);
+    if (it != seen.end()) { m->grad[kv.first] = m->grad.at(it->second); continue; }
+    m->grad[kv.first] = mk(cv, b.n, b.h, b.w, b.c); seen[b.off] = kv.first;
+  }
+  for (auto& nd : pp_nodes()) { std::string nm = nd.name; m->grad["u" + nm.substr(1)] = slice(m->grad.at("cat_" + nm), 0, nd.c); }
+  for (auto& nd : pp_nodes()) {                                   // ConvT data-gradient staging buffer (largest source tensor)
+    const Buf& sb = m->act.at(nd.src); tmp_up = std::max(tmp_up, (size_t)sb.n * sb.h * sb.w * sb.c);
+  }
+  { Buf t; t.off = cv.take(tmp_up); m->act["tmp_up"] = t; }
+  for (auto& l : m->layers) {
+    if (l.kind == 0) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, unet_conv3x3_bwd_weights_ws_bytes(N, ob.h, ob.w, l.cin, l.cout)); }
+    if (l.kind == 1) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, mfma_convT_wgrad_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout)); }
+  }
+  m->wgrad_ws_bytes = wgb;
+  m->off_wgrad_ws = cv.take((wgb + 3) / 4);
+  m->ws_floats_train = cv.cur;
+}
+
+void build_programs_pp(unet_model* m) {
+  unet_ctx* ctx = m->ctx;
+  const int algo = m->algo;
+  const double gcount = (double)m->world;
+  auto& BW = m->prog[UNET_PROG_BWD];
+  const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
+  std::map<std::string, int> lidx;
+  for (size_t i = 0; i < m->layers.size(); ++i) lidx[m->layers[i].name] = (int)i;
+  auto seed_of = [=](const std::string& conv) { return (uint64_t)(lidx.at(conv) + 1) * 0x9E3779B97F4A7C15ull; };
+
+  // ------------------------------------------------------------------ forward (train / infer)
+  for (int training = 1; training >= 0; --training) {
+    auto& F = m->prog[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
+    auto& SY = m->syncref[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
+    const int tr = training;
+    ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
+    auto conv = [&](const std::string& name, const std::string& in, int cin, int cout, float rate) {
+      const Buf ob = m->act.at(name);
+      const uint64_t sd = seed_of(name);
+      double px = (double)ob.n * ob.h * ob.w;
+      ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+        const float* xin = in.empty() ? m->x : m->A(in);
+        const float r = (tr && m->drop_rate > 0.0f) ? rate : 0.0f;
+        return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
+                                    ACT_ELU, r, m->drop_seed + sd, algo, s);
+      });
+    };
+    // BN: stats -> [sync] -> finalize -> apply (or apply fused with the 2x2 pool when `pool` names the pooled output)
+    auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c, const std::string& pool) {
+      const Buf ib = m->act.at(in), ob = m->act.at(out);
+      const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
+      const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
+      if (training) {
+        ADD_OP(F, "bn_stats:" + name, 0, 4.0 * pixels * c, { return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s); });
+        SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
+        ADD_OP(F, "bn_finalize:" + name, 0, 0, {
+          return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
+                                        m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
+        });
+      } else {
+        ADD_OP(F, "bn_finalize_infer:" + name, 0, 0, {
+          return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
+        });
+      }
+      if (pool.empty()) {
+        ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s); });
+      } else {
+        ADD_OP(F, "bn_apply_pool:" + pool, 0, 4.0 * 2.25 * pixels * c, {
+          return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, m->Aw(pool), ib.n, ib.h, ib.w, c, 0.0f, 0, s);
+        });
+      }
+    };
+    for (const char* item : PP_ORDER) {
+      std::string it = item;
+      if (it[0] == 'e') {
+        int k = it[1] - '0', c = ENC[k - 1], cin = k == 1 ? m->in_ch : ENC[k - 2];
+        std::string ks = std::to_string(k);
+        conv("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cin, c, PP_ENC_DROP);
+        conv("c" + ks + "b", "c" + ks + "a", c, c, 0.0f);
+        bn("bn" + ks, "c" + ks + "b", "c" + ks, c, k <= 3 ? "p" + ks : "");
+      } else {
+        const PPNode* nd = nullptr;
+        for (auto& n : pp_nodes()) if (it == n.name) nd = &n;
+        const std::string un = "u" + it.substr(1), src = nd->src, cat = "cat_" + it;
+        const Buf sb = m->act.at(src), cb = m->act.at(cat);
+        const int c = nd->c, csrc = pp_width(src);
+        ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, 4.0 * (nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+          return unet_convT2x2_fwd(ctx, m->A(src), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), cb.ld, sb.n, sb.h, sb.w, csrc, c, algo, s);
+        });
+        int off = c;
+        for (auto sk : nd->skips) {
+          const std::string skn = sk; const Buf kb = m->act.at(skn); const int o = off, cw = kb.c;
+          ADD_OP(F, "copy_slice:" + skn + ">" + it, 0, 8.0 * nel(kb), {
+            return unet_copy_slice(ctx, m->A(skn), kb.ld, m->Aw(cat) + o, cb.ld, (int64_t)kb.n * kb.h * kb.w, cw, s);
+          });
+          off += cw;
+        }
+        conv(it + "a", cat, cb.c, c, PP_BLOCK_DROP);
+        bn(it + "abn", it + "a", it + "abn", c, "");
+        conv(it + "b", it + "abn", c, c, PP_BLOCK_DROP);
+        bn(it + "bbn", it + "b", it, c, "");
+      }
+    }
+    const Buf hb = m->act.at("x1_4");
+    const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
+    ADD_OP(F, "head_fwd", 2.0 * 32 * hp, 4.0 * hp * 34, {
+      if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_fwd: p_out not set (unet_model_set_io)");
+      return unet_head_fwd(ctx, m->A("x1_4"), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt, m->yt ? m->wsd(m->off_loss_sums) : nullptr, hp, hb.c, s);
+    });
+    SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
+    ADD_OP(F, "loss_finalize", 0, 0, {
+      if (!m->yt) return UNET_OK;
+      return unet_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsf(m->off_loss_out), s);
+    });
+  }
+
+  // ------------------------------------------------------------------ backward (reverse creation order)
+  auto& SY = m->syncref[UNET_PROG_BWD];
+  size_t bs_bytes = 0;
+  for (auto& l : m->layers) if (l.kind == 2) bs_bytes += 2 * (size_t)l.cout * sizeof(double);
+  std::vector<std::string> multi = {"c1", "c2", "c3", "c4", "x1_2", "x2_2", "x1_3", "x3_2", "x2_3"};   // gradients summed from several consumers
+  ADD_OP(BW, "zero_bwd_sums", 0, 0, {
+    int32_t r = unet_zero(ctx, m->wsf(m->off_bn_bsums), bs_bytes, s); if (r) return r;
+    r = unet_zero(ctx, m->G("out/kernel"), (size_t)(m->tinfo.at("out/kernel").count + 1) * sizeof(float), s); if (r) return r;
+    for (auto& t : multi) { const Buf& b = m->grad.at(t); r = unet_zero(ctx, m->wsf(b.off), (size_t)b.n * b.h * b.w * b.c * sizeof(float), s); if (r) return r; }
+    return UNET_OK;
+  });
+  const Buf hb = m->act.at("x1_4");
+  const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
+  ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, 4.0 * hp * 66, {
+    if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
+    return unet_head_bwd(ctx, m->A("x1_4"), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, m->D("x1_4"),
+                         m->G("out/kernel"), m->G("out/bias"), hp, hb.c, 0, s);
+  });
+  // BN backward: dy = grad[dyname] (dense), x = act[xname] = dropout(elu(conv)) or elu(conv); dx = grad[xname] (pre-activation gradient)
+  auto bn_bwd = [&](const std::string& name, const std::string& dyname, const std::string& xname, int c, int mask_mode, float rate, uint64_t sd) {
+    const Buf gb = m->grad.at(dyname), xb = m->act.at(xname), db = m->grad.at(xname);
+    const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
+    const size_t so = m->bn_bsum_off.at(name), bo = m->bnp_off.at(name);
+    ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
+      int32_t r = unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
+      if (r) return r;
+      return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
+    });
+    SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
+    ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
+      const bool drop = m->drop_rate > 0.0f && rate > 0.0f;
+      return unet_bn_bwd_apply(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount,
+                               (mask_mode == MASK_ELU_DROP && !drop) ? MASK_ELU : mask_mode, drop ? rate : 0.0f, m->drop_seed + sd, m->D(xname), db.ld,
+                               pixels, c, s);
+    });
+  };
+  // conv backward: wgrad (x = act[in] or the network input, dy = grad[name]) + optional dgrad into grad[in] with the mask of act[in]
+  auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, int mask_mode, float rate, uint64_t sd) {
+    const Buf ob = m->act.at(name);
+    const double px = (double)ob.n * ob.h * ob.w;
+    ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+      const float* xin = in.empty() ? m->x : m->A(in);
+      return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
+                                    ob.n, ob.h, ob.w, cin, cout, algo, s);
+    });
+    if (want_dx) {
+      ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cout + cin + (mask_mode ? cin : 0)) + 9.0 * cin * cout), {
+        const bool drop = m->drop_rate > 0.0f && rate > 0.0f;
+        const int mm = (mask_mode == MASK_ELU_DROP && !drop) ? MASK_ELU : mask_mode;
+        return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), mm ? m->A(in) : nullptr, mm, drop ? rate : 0.0f, m->drop_seed + sd, m->D(in),
+                                     m->wsf(m->off_wt), ob.n, ob.h, ob.w, cin, cout, algo, s);
+      });
+    }
+  };
+  auto bucket = [&](const std::string& first, const std::string& last_tensor) {
+    const TInfo a = m->tinfo.at(first), b = m->tinfo.at(last_tensor);
+    SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off});
+  };
+  for (int oi = 9; oi >= 0; --oi) {
+    std::string it = PP_ORDER[oi];
+    if (it[0] == 'e') {
+      int k = it[1] - '0', c = ENC[k - 1], cin = k == 1 ? m->in_ch : ENC[k - 2];
+      std::string ks = std::to_string(k), ca = "c" + ks + "a", cb = "c" + ks + "b";
+      bn_bwd("bn" + ks, "c" + ks, cb, c, MASK_ELU, 0.0f, 0);
+      conv_bwd(cb, ca, c, c, true, MASK_ELU_DROP, PP_ENC_DROP, seed_of(ca));
+      conv_bwd(ca, k == 1 ? "" : "p" + std::to_string(k - 1), cin, c, k > 1, MASK_NONE, 0.0f, 0);
+      if (k > 1) {
+        const std::string pk = "p" + std::to_string(k - 1), ck = "c" + std::to_string(k - 1);
+        const Buf xb = m->act.at(ck);
+        ADD_OP(BW, "pool_bwd:" + pk, 0, 4.0 * 3.25 * nel(xb), {
+          return unet_maxpool2x2_dropout_bwd(ctx, m->A(ck), xb.ld, m->D(pk), m->D(ck), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 1, s);
+        });
+      }
+      if (k == 4) bucket("c4a/kernel", "x2_3bbn/beta");
+      if (k == 3) bucket("c3a/kernel", "x1_3bbn/beta");
+      if (k == 1) bucket("c1a/kernel", "x1_2bbn/beta");
+    } else {
+      const PPNode* nd = nullptr;
+      for (auto& n : pp_nodes()) if (it == n.name) nd = &n;
+      const std::string un = "u" + it.substr(1), src = nd->src, cat = "cat_" + it;
+      const Buf sb = m->act.at(src), cb = m->act.at(cat);
+      const int c = nd->c, csrc = pp_width(src);
+      bn_bwd(it + "bbn", it, it + "b", c, MASK_ELU_DROP, PP_BLOCK_DROP, seed_of(it + "b"));
+      conv_bwd(it + "b", it + "abn", c, c, true, MASK_NONE, 0.0f, 0);
+      bn_bwd(it + "abn", it + "abn", it + "a", c, MASK_ELU_DROP, PP_BLOCK_DROP, seed_of(it + "a"));
+      conv_bwd(it + "a", cat, cb.c, c, true, MASK_NONE, 0.0f, 0);
+      const Buf ug = m->grad.at(un);
+      ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, 4.0 * (nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+        return unet_convT2x2_bwd_weights(ctx, m->A(src), m->D(un), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
+                                         sb.n, sb.h, sb.w, csrc, c, algo, s);
+      });
+      ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, 4.0 * (2 * nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+        float* tmp = m->wsf(m->act.at("tmp_up").off);
+        int32_t r = unet_convT2x2_bwd_data(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), nullptr, tmp, sb.n, sb.h, sb.w, csrc, c, algo, s);
+        if (r) return r;
+        const float* srcs[1] = {tmp}; const int32_t lds[1] = {csrc};
+        return unet_accum_slices(ctx, srcs, lds, 1, m->D(src), m->grad.at(src).ld, (int64_t)sb.n * sb.h * sb.w, csrc, 1, s);
+      });
+      int off = c;
+      for (auto sk : nd->skips) {
+        const std::string skn = sk; const Buf kb = m->act.at(skn); const int o = off, cw = kb.c;
+        ADD_OP(BW, "accum_slice:" + it + ">" + skn, 0, 12.0 * nel(kb), {
+          const float* srcs[1] = {m->D(cat) + o}; const int32_t lds[1] = {cb.ld};
+          return unet_accum_slices(ctx, srcs, lds, 1, m->D(skn), m->grad.at(skn).ld, (int64_t)kb.n * kb.h * kb.w, cw, 1, s);
+        });
+        off += cw;
+      }
+      if (it == "x1_4") bucket("u1_4/kernel", "out/bias");
+    }
+  }
+}
+
 void resolve_sync(unet_model* m) {
   for (int p = 0; p < 3; ++p) {
     m->sync[p].clear();
@@ -540,17 +856,18 @@ void resolve_sync(unet_model* m) {
 
 extern "C" {
 
-int32_t unet_model_create(unet_ctx* ctx, int32_t in_ch, int32_t n, int32_t h, int32_t w, int32_t world_size, int32_t conv_algo,
-                          unet_model** out) {
+int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n, int32_t h, int32_t w, int32_t world_size,
+                          int32_t conv_algo, unet_model** out) {
   if (!ctx || !out) return UNET_E_ARG;
   *out = nullptr;
-  if (in_ch < 1 || n < 1 || h < 16 || w < 16 || (h % 16) || (w % 16) || world_size < 1)
-    UNET_FAIL(ctx, UNET_E_SHAPE, "model_create: need n>=1 and h,w multiples of 16 (4 pool levels, T1:862-880); got n=%d h=%d w=%d", n, h, w);
+  if (arch != UNET_ARCH_UNET && arch != UNET_ARCH_UNETPP) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown arch %d", arch);
+  const int mult = arch == UNET_ARCH_UNET ? 16 : 8;      // 4 pool levels (T1:862-880) / 3 used pool levels (UPP: p4 is dead)
+  if (in_ch < 1 || n < 1 || h < mult || w < mult || (h % mult) || (w % mult) || world_size < 1)
+    UNET_FAIL(ctx, UNET_E_SHAPE, "model_create: need n>=1 and h,w multiples of %d; got n=%d h=%d w=%d", mult, n, h, w);
   unet_model* m = new unet_model();
-  m->ctx = ctx; m->in_ch = in_ch; m->N = n; m->H = h; m->W = w; m->world = world_size; m->algo = conv_algo;
-  build_layers(m);
-  plan_workspace(m);
-  build_programs(m);
+  m->ctx = ctx; m->arch = arch; m->in_ch = in_ch; m->N = n; m->H = h; m->W = w; m->world = world_size; m->algo = conv_algo;
+  if (arch == UNET_ARCH_UNET) { build_layers(m); plan_workspace(m); build_programs(m); }
+  else { build_layers_pp(m); plan_workspace_pp(m); build_programs_pp(m); }
   *out = m;
   return UNET_OK;
 }

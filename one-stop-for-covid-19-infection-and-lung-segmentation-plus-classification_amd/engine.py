@@ -29,7 +29,8 @@ class HipUNet:
     """Backend used by keras_like.UNetModel.  All tensors NHWC fp32 on one MI355X."""
 
     def __init__(self, h: int, w: int, in_ch: int = 1, device: int | None = None, conv_algo: int = _lib.ALGO_AUTO,
-                 process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR):
+                 process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR,
+                 arch: str = "unet"):
         torch = _torch()
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -39,6 +40,8 @@ class HipUNet:
         self.dev = torch.device("cuda", self.device_index)
         self.ctx = _lib.Context.get(self.device_index)
         self.h, self.w, self.in_ch, self.algo = h, w, in_ch, conv_algo
+        self.arch = arch                       # "unet" (T1:853-916) or "unetpp" (task1_unet_plus_plus.py:858-950; its dropout
+        self._arch_id = {"unet": _lib.ARCH_UNET, "unetpp": _lib.ARCH_UNETPP}[arch]   # rates .2/.4 are fixed: dropout_rate>0 = on)
         self.pg = process_group
         self.pg_grad = process_group
         self.world = 1
@@ -64,7 +67,7 @@ class HipUNet:
         self.adam_v = torch.zeros_like(self.params)
         self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.dev)
         self._tinfo = OrderedDict()
-        for name, shape in weight_shapes(in_ch).items():
+        for name, shape in weight_shapes(in_ch, arch).items():
             st, off, cnt = C.c_int32(), C.c_int64(), C.c_int64()
             self.ctx.check(self.lib.unet_model_tensor_info(probe, name.encode(), C.byref(st), C.byref(off), C.byref(cnt)), "tensor_info")
             assert cnt.value == int(np.prod(shape)), (name, cnt.value, shape)
@@ -75,7 +78,7 @@ class HipUNet:
     # ------------------------------------------------------------------ plans / buffers
     def _create_plan(self, n):
         m = _lib.vp()
-        self.ctx.check(self.lib.unet_model_create(self.ctx.handle, self.in_ch, n, self.h, self.w,
+        self.ctx.check(self.lib.unet_model_create(self.ctx.handle, self._arch_id, self.in_ch, n, self.h, self.w,
                                                   self.world if self.sync_bn else 1, self.algo, C.byref(m)), "model_create")
         return m
 

@@ -38,24 +38,25 @@ class History:
 
 
 class UNetModel:
-    def __init__(self, input_size: int = 224, in_ch: int = 1, backend=None, seed: int = 0, **backend_kw):
+    def __init__(self, input_size: int = 224, in_ch: int = 1, backend=None, seed: int = 0, arch: str = "unet", **backend_kw):
         self.h = self.w = int(input_size)
         self.in_ch = in_ch
+        self.arch = arch
         if backend is None:
             from .engine import HipUNet                      # raises loudly without GPU / library
-            backend = HipUNet(self.h, self.w, in_ch, seed=seed, **backend_kw)
+            backend = HipUNet(self.h, self.w, in_ch, seed=seed, arch=arch, **backend_kw)
         self.backend = backend
-        self.backend.set_weights(W.init_weights(seed, in_ch))
+        self.backend.set_weights(W.init_weights(seed, in_ch, arch))
         self.compiled = False
         self.verbose = 1
 
     # --- Keras-shaped surface ---------------------------------------------------------
     def count_params(self):
-        return W.count_params(self.in_ch)[0]
+        return W.count_params(self.in_ch, self.arch)[0]
 
     def summary(self, print_fn=print):
-        total, train = W.count_params(self.in_ch)
-        for n, k, ci, co in W.layer_table(self.in_ch):
+        total, train = W.count_params(self.in_ch, self.arch)
+        for n, k, ci, co in W.layer_table(self.in_ch, self.arch):
             print_fn(f"{n:6s} {k:6s} {ci:4d} -> {co:4d}")
         print_fn(f"Total params: {total:,}\nTrainable params: {train:,}\nNon-trainable params: {total - train:,}")
 
@@ -75,13 +76,13 @@ class UNetModel:
         self.backend.set_weights(w)
 
     def save_weights(self, path):
-        W.save_weights(path, self.backend.get_weights(), self.in_ch)
+        W.save_weights(path, self.backend.get_weights(), self.in_ch, self.arch)
 
     def load_weights(self, path):
-        self.backend.set_weights(W.load_weights(path, self.in_ch))
+        self.backend.set_weights(W.load_weights(path, self.in_ch, self.arch))
 
     def to_json(self):
-        return W.to_json(self.h, self.w, self.in_ch)
+        return W.to_json(self.h, self.w, self.in_ch, self.arch)
 
     def fit(self, x, y, batch_size=32, epochs=1, validation_data=None, checkpoint_dice=None, checkpoint_loss=None,
             shuffle=True, shuffle_seed=0, dropout=True):

@@ -40,7 +40,8 @@ def _get_data(data, size, n_samples, seed):
 
 
 def _segmentation_runner(tag, ckpt_dice, ckpt_loss, fine_range, data=None, input_size=None, epochs=None, batch_size=None,
-                         n_samples=None, seed=0, backend=None, dropout=True, init_weights=None, workdir=".", verbose=1, **backend_kw):
+                         n_samples=None, seed=0, backend=None, dropout=True, init_weights=None, workdir=".", verbose=1, arch="unet",
+                         **backend_kw):
     size = input_size or _env_int("UNET_SIZE", 224)
     epochs = epochs if epochs is not None else _env_int("UNET_EPOCHS", 80)
     batch_size = batch_size or _env_int("UNET_BATCH", 32)
@@ -49,7 +50,7 @@ def _segmentation_runner(tag, ckpt_dice, ckpt_loss, fine_range, data=None, input
     size = cts.shape[1]
     x_train, x_valid, y_train, y_valid = train_test_split(cts, masks, test_size=0.3, random_state=42)      # T1:762
     print(x_train.shape, x_valid.shape)                                                                     # T1:768
-    model = UNetModel(size, cts.shape[-1], backend=backend, seed=seed, **backend_kw)                        # T1:853-915
+    model = UNetModel(size, cts.shape[-1], backend=backend, seed=seed, arch=arch, **backend_kw)             # T1:853-915
     model.verbose = verbose
     if init_weights is not None:
         model.set_weights(init_weights)
@@ -187,3 +188,11 @@ def three_fold_runner_unet_infection_segmentation(**kw):
 def four_fold_runner_unet_infection_segmentation(**kw):
     """Task 1, 4-fold cross-validation U-Net (app.py 'two'; task1_crossval_4folds_unet.py:6)."""
     return _kfold_runner(4, **kw)
+
+
+def holdout_runner_unetplusplus_infection_segmentation(**kw):
+    """Task 1 hold-out U-Net++ (app.py 'four'; task1_unet_plus_plus.py:6): nested-skip graph UPP:858-950, same recipe
+    (Adam 5e-4, bce_dice_loss, batch 32, 80 epochs UPP:1054-1074), fine sweep .40-.50 (UPP:1274)."""
+    kw.setdefault("seed", 2)
+    return _segmentation_runner("infection_unetpp", "unet_covid_weights_dice_coeff.hdf5", "unet_covid_weights_val_loss.hdf5",
+                                np.arange(0.40, 0.50, 0.001), arch="unetpp", **kw)

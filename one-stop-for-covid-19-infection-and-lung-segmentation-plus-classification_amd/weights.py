@@ -19,8 +19,33 @@ ENC = (32, 64, 128, 256)
 DEC = (256, 128, 64, 32)
 
 
-def layer_table(in_ch: int = 1):
+# U-Net++ (task1_unet_plus_plus.py:858-950): (node, width, ConvT source, skip tensors concatenated after the up-sampled one)
+PP_NODES = (("x1_2", 32, "c2", ("c1",)), ("x2_2", 64, "c3", ("c2",)), ("x1_3", 32, "x2_2", ("c1", "x1_2")),
+            ("x3_2", 128, "c4", ("c3",)), ("x2_3", 64, "x3_2", ("c2", "x2_2")), ("x1_4", 32, "x2_3", ("c1", "x1_2", "x1_3")))
+PP_WIDTH = {"c1": 32, "c2": 64, "c3": 128, "c4": 256, "x1_2": 32, "x2_2": 64, "x1_3": 32, "x3_2": 128, "x2_3": 64, "x1_4": 32}
+PP_ORDER = ("e1", "e2", "x1_2", "e3", "x2_2", "x1_3", "e4", "x3_2", "x2_3", "x1_4")          # Keras creation order UPP:876-924
+
+
+def _pp_layer_table(in_ch):
+    nodes = {n[0]: n for n in PP_NODES}
+    t = []
+    for it in PP_ORDER:
+        if it[0] == "e":
+            k = int(it[1]); c = ENC[k - 1]; cin = in_ch if k == 1 else ENC[k - 2]
+            t += [(f"c{k}a", "conv3", cin, c), (f"c{k}b", "conv3", c, c), (f"bn{k}", "bn", c, c)]
+        else:
+            _, c, src, skips = nodes[it]
+            ctot = c + sum(PP_WIDTH[s] for s in skips)
+            t += [(f"u{it[1:]}", "convT", PP_WIDTH[src], c), (f"{it}a", "conv3", ctot, c), (f"{it}abn", "bn", c, c),
+                  (f"{it}b", "conv3", c, c), (f"{it}bbn", "bn", c, c)]
+    t.append(("out", "conv1", 32, 1))
+    return t
+
+
+def layer_table(in_ch: int = 1, arch: str = "unet"):
     """[(name, kind, cin, cout)], kind in conv3|convT|bn|conv1 -- Keras creation order."""
+    if arch == "unetpp":
+        return _pp_layer_table(in_ch)
     t, cp = [], in_ch
     for k, c in enumerate(ENC, 1):
         t += [(f"c{k}a", "conv3", cp, c), (f"c{k}b", "conv3", c, c), (f"bn{k}", "bn", c, c)]
@@ -34,9 +59,9 @@ def layer_table(in_ch: int = 1):
     return t
 
 
-def weight_shapes(in_ch: int = 1):
+def weight_shapes(in_ch: int = 1, arch: str = "unet"):
     d = OrderedDict()
-    for name, kind, cin, cout in layer_table(in_ch):
+    for name, kind, cin, cout in layer_table(in_ch, arch):
         if kind == "conv3":
             d[f"{name}/kernel"] = (3, 3, cin, cout); d[f"{name}/bias"] = (cout,)
         elif kind == "conv1":
@@ -49,10 +74,10 @@ def weight_shapes(in_ch: int = 1):
     return d
 
 
-def keras_names(in_ch: int = 1):
+def keras_names(in_ch: int = 1, arch: str = "unet"):
     """our name -> Keras auto-name (conv2d_N/kernel:0 ...), counting per layer type in creation order."""
     out, nc, nt, nb = OrderedDict(), 0, 0, 0
-    for name, kind, _, _ in layer_table(in_ch):
+    for name, kind, _, _ in layer_table(in_ch, arch):
         if kind in ("conv3", "conv1"):
             nc += 1; base = f"conv2d_{nc}"
             out[f"{name}/kernel"] = f"{base}/kernel:0"; out[f"{name}/bias"] = f"{base}/bias:0"
@@ -66,8 +91,8 @@ def keras_names(in_ch: int = 1):
     return out
 
 
-def count_params(in_ch: int = 1):
-    sh = weight_shapes(in_ch)
+def count_params(in_ch: int = 1, arch: str = "unet"):
+    sh = weight_shapes(in_ch, arch)
     total = sum(int(np.prod(s)) for s in sh.values())
     non_train = sum(int(np.prod(s)) for k, s in sh.items() if k.endswith("/mean") or k.endswith("/var"))
     return total, total - non_train
@@ -82,19 +107,23 @@ def _truncated_normal(rng, shape):
     return k
 
 
-def init_weights(seed: int = 0, in_ch: int = 1):
-    """he_normal for the 3x3 convs (T1:859...), Keras-default glorot_uniform for ConvT / head,
-    zero biases, BN gamma 1 / beta 0 / moving mean 0 / moving var 1."""
+def init_weights(seed: int = 0, in_ch: int = 1, arch: str = "unet"):
+    """he_normal for the 3x3 convs (T1:859...), Keras-default glorot_uniform for ConvT / the U-Net head (he_normal for the
+    U-Net++ head, UPP:946), zero biases, BN gamma 1 / beta 0 / moving mean 0 / moving var 1."""
     rng = np.random.default_rng(seed)
     w = OrderedDict()
-    for name, kind, cin, cout in layer_table(in_ch):
+    for name, kind, cin, cout in layer_table(in_ch, arch):
         if kind == "conv3":
             std = math.sqrt(2.0 / (9 * cin)) / 0.87962566103423978
             w[f"{name}/kernel"] = (_truncated_normal(rng, (3, 3, cin, cout)) * std).astype(np.float32)
             w[f"{name}/bias"] = np.zeros(cout, np.float32)
         elif kind == "conv1":
-            lim = math.sqrt(6.0 / (cin + cout))
-            w[f"{name}/kernel"] = rng.uniform(-lim, lim, (1, 1, cin, cout)).astype(np.float32)
+            if arch == "unetpp":
+                std = math.sqrt(2.0 / cin) / 0.87962566103423978
+                w[f"{name}/kernel"] = (_truncated_normal(rng, (1, 1, cin, cout)) * std).astype(np.float32)
+            else:
+                lim = math.sqrt(6.0 / (cin + cout))
+                w[f"{name}/kernel"] = rng.uniform(-lim, lim, (1, 1, cin, cout)).astype(np.float32)
             w[f"{name}/bias"] = np.zeros(cout, np.float32)
         elif kind == "convT":
             lim = math.sqrt(6.0 / (4 * cout + 4 * cin))
@@ -106,16 +135,16 @@ def init_weights(seed: int = 0, in_ch: int = 1):
     return w
 
 
-def save_weights(path: str, weights, in_ch: int = 1):
-    kn = keras_names(in_ch)
+def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet"):
+    kn = keras_names(in_ch, arch)
     with open(path, "wb") as f:          # keep the caller's filename (.hdf5/.h5) -- content is npz
         np.savez(f, **{kn[k]: np.asarray(v) for k, v in weights.items()})
 
 
-def load_weights(path: str, in_ch: int = 1):
-    kn = keras_names(in_ch)
+def load_weights(path: str, in_ch: int = 1, arch: str = "unet"):
+    kn = keras_names(in_ch, arch)
     z = np.load(path)
-    sh = weight_shapes(in_ch)
+    sh = weight_shapes(in_ch, arch)
     out = OrderedDict()
     for k, shape in sh.items():
         a = z[kn[k]]
@@ -125,8 +154,8 @@ def load_weights(path: str, in_ch: int = 1):
     return out
 
 
-def to_json(h: int, w: int, in_ch: int = 1) -> str:
+def to_json(h: int, w: int, in_ch: int = 1, arch: str = "unet") -> str:
     """Architecture description (the reference dumps model.to_json(), T1:1091-1093)."""
-    layers = [{"name": n, "kind": k, "cin": ci, "cout": co} for n, k, ci, co in layer_table(in_ch)]
-    return json.dumps({"class_name": "Model", "backend": "unet_hip/gfx950", "input_shape": [h, w, in_ch],
-                       "data_format": "channels_last", "layers": layers, "keras_names": keras_names(in_ch)})
+    layers = [{"name": n, "kind": k, "cin": ci, "cout": co} for n, k, ci, co in layer_table(in_ch, arch)]
+    return json.dumps({"class_name": "Model", "arch": arch, "backend": "unet_hip/gfx950", "input_shape": [h, w, in_ch],
+                       "data_format": "channels_last", "layers": layers, "keras_names": keras_names(in_ch, arch)})

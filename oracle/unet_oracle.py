@@ -305,16 +305,19 @@ def adam_keras(params, grads, m, v, t, lr=ADAM_LR, b1=ADAM_B1, b2=ADAM_B2, eps=A
 class OracleTrainer:
     """Stateful fwd/bwd/Adam on CPU: the reference's model.compile + train_on_batch."""
 
-    def __init__(self, weights, dtype=torch.float32):
+    def __init__(self, weights, dtype=torch.float32, arch="unet"):
         self.w = OrderedDict((k, np.array(v)) for k, v in weights.items())
         self.dtype = dtype
+        self.arch = arch
         self.in_ch = self.w["c1a/kernel"].shape[2]
-        self.m = {k: np.zeros_like(self.w[k]) for k in trainable_names(self.in_ch)}
-        self.v = {k: np.zeros_like(self.w[k]) for k in trainable_names(self.in_ch)}
+        names = trainable_names(self.in_ch) if arch == "unet" else pp_trainable_names(self.in_ch)
+        self.m = {k: np.zeros_like(self.w[k]) for k in names}
+        self.v = {k: np.zeros_like(self.w[k]) for k in names}
         self.t = 0
+        self._fwd = forward if arch == "unet" else pp_forward
 
     def train_step(self, x, y, keep_masks=None):
-        r = loss_and_grads(self.w, x, y, keep_masks, self.dtype)
+        r = (loss_and_grads if self.arch == "unet" else pp_loss_and_grads)(self.w, x, y, keep_masks, self.dtype)
         for k, (mu, va, n) in r["bn_stats"].items():
             nm, nv = bn_moving_update(self.w[k + "/mean"], self.w[k + "/var"], mu, va, n)
             self.w[k + "/mean"] = nm.astype(self.w[k + "/mean"].dtype)
@@ -327,7 +330,7 @@ class OracleTrainer:
         outs = []
         with torch.no_grad():
             for i in range(0, len(x), batch_size):
-                outs.append(forward(self.w, x[i:i + batch_size], training=False, dtype=self.dtype)[0].numpy())
+                outs.append(self._fwd(self.w, x[i:i + batch_size], training=False, dtype=self.dtype)[0].numpy())
         return np.concatenate(outs, 0)
 
     def evaluate(self, x, y, batch_size=32, thresholds=()):
@@ -337,7 +340,7 @@ class OracleTrainer:
         with torch.no_grad():
             for i in range(0, len(x), batch_size):
                 xb, yb = x[i:i + batch_size], y[i:i + batch_size]
-                p = forward(self.w, xb, training=False, dtype=self.dtype)[0]
+                p = self._fwd(self.w, xb, training=False, dtype=self.dtype)[0]
                 t = _t(yb, self.dtype)
                 losses.append(float(bce_dice_loss(t, p))); dices.append(float(dice_coeff(t, p))); ns.append(len(xb))
                 if len(thresholds):
@@ -348,3 +351,138 @@ class OracleTrainer:
             for k in ("dice", "iou", "precision", "recall"):
                 out[k] = np.mean([b[k] for b in per_t], axis=0)
         return out
+
+
+# =======================================================================================
+# U-Net++ (nested skips), /root/reference/Scripts/task1_unet_plus_plus.py:858-950  (UPP)
+#   encoder k=1..4 : Conv(C,elu) -> Dropout(.2) -> Conv(C,elu) -> BN -> [c_k] -> MaxPool      UPP:876-914
+#   conv_block(x,C): Conv(C,elu) -> Dropout(.4) -> BN -> Conv(C,elu) -> Dropout(.4) -> BN     UPP:860-868
+#   nested decoder : x1_2=[up(c2),c1] x2_2=[up(c3),c2] x1_3=[up(x2_2),c1,x1_2] x3_2=[up(c4),c3]
+#                    x2_3=[up(x3_2),c2,x2_2] x1_4=[up(x2_3),c1,x1_2,x1_3]                      UPP:888-924
+#   head           : Conv(1,1x1,sigmoid, he_normal) on conv1_4                                UPP:946-947
+#   (the c5 / depth-5 path is commented out in the reference, UPP:926-944; p4 is computed but unused)
+# Same PARITY STATUS as above: third-party Keras semantics restated, "parity unpinned".
+# =======================================================================================
+PP_ENC_DROP, PP_BLOCK_DROP = 0.2, 0.4
+PP_NODES = [  # (node, width, ConvT input, concat sources after the up-sampled tensor)
+    ("x1_2", 32, "c2", ["c1"]), ("x2_2", 64, "c3", ["c2"]), ("x1_3", 32, "x2_2", ["c1", "x1_2"]),
+    ("x3_2", 128, "c4", ["c3"]), ("x2_3", 64, "x3_2", ["c2", "x2_2"]), ("x1_4", 32, "x2_3", ["c1", "x1_2", "x1_3"])]
+PP_WIDTH = {"c1": 32, "c2": 64, "c3": 128, "c4": 256, "x1_2": 32, "x2_2": 64, "x1_3": 32, "x3_2": 128, "x2_3": 64, "x1_4": 32}
+
+
+def pp_layer_table(in_ch: int = 1):
+    """[(name, kind, cin, cout)] in Keras creation order (UPP:876-947)."""
+    t = []
+
+    def enc(k, cin, c):
+        return [(f"c{k}a", "conv3", cin, c), (f"c{k}b", "conv3", c, c), (f"bn{k}", "bn", c, c)]
+
+    def node(name, c, src, skips):
+        cin = c + sum(PP_WIDTH[s] for s in skips)
+        return [(f"u{name[1:]}", "convT", PP_WIDTH[src], c), (f"{name}a", "conv3", cin, c), (f"{name}abn", "bn", c, c),
+                (f"{name}b", "conv3", c, c), (f"{name}bbn", "bn", c, c)]
+
+    t += enc(1, in_ch, 32) + enc(2, 32, 64) + node(*PP_NODES[0]) + enc(3, 64, 128) + node(*PP_NODES[1]) + node(*PP_NODES[2])
+    t += enc(4, 128, 256) + node(*PP_NODES[3]) + node(*PP_NODES[4]) + node(*PP_NODES[5])
+    t += [("out", "conv1", 32, 1)]
+    return t
+
+
+def pp_weight_shapes(in_ch: int = 1):
+    d = OrderedDict()
+    for name, kind, cin, cout in pp_layer_table(in_ch):
+        if kind == "conv3":
+            d[name + "/kernel"] = (3, 3, cin, cout); d[name + "/bias"] = (cout,)
+        elif kind == "conv1":
+            d[name + "/kernel"] = (1, 1, cin, cout); d[name + "/bias"] = (cout,)
+        elif kind == "convT":
+            d[name + "/kernel"] = (2, 2, cout, cin); d[name + "/bias"] = (cout,)
+        else:
+            for p in ("gamma", "beta", "mean", "var"):
+                d[f"{name}/{p}"] = (cout,)
+    return d
+
+
+def pp_trainable_names(in_ch: int = 1):
+    return [k for k in pp_weight_shapes(in_ch) if not (k.endswith("/mean") or k.endswith("/var"))]
+
+
+def pp_init_weights(seed: int = 0, in_ch: int = 1, dtype=np.float32):
+    """he_normal for every Conv2D incl. the head (UPP:861-947), glorot_uniform for ConvT (Keras default)."""
+    rng = np.random.default_rng(seed)
+    w = OrderedDict()
+    for name, kind, cin, cout in pp_layer_table(in_ch):
+        if kind in ("conv3", "conv1"):
+            kk = 3 if kind == "conv3" else 1
+            std = math.sqrt(2.0 / (kk * kk * cin)) / 0.87962566103423978
+            k = rng.standard_normal((kk, kk, cin, cout))
+            bad = np.abs(k) > 2.0
+            while bad.any():
+                k[bad] = rng.standard_normal(int(bad.sum())); bad = np.abs(k) > 2.0
+            w[name + "/kernel"] = (k * std).astype(dtype); w[name + "/bias"] = np.zeros(cout, dtype)
+        elif kind == "convT":
+            lim = math.sqrt(6.0 / (4 * cout + 4 * cin))
+            w[name + "/kernel"] = rng.uniform(-lim, lim, (2, 2, cout, cin)).astype(dtype); w[name + "/bias"] = np.zeros(cout, dtype)
+        else:
+            w[name + "/gamma"] = np.ones(cout, dtype); w[name + "/beta"] = np.zeros(cout, dtype)
+            w[name + "/mean"] = np.zeros(cout, dtype); w[name + "/var"] = np.ones(cout, dtype)
+    return w
+
+
+def pp_forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False):
+    """U-Net++ graph.  keep_masks: None or dict conv-name -> {0,1} array of that conv's output shape (the
+    Dropout that follows it); returns (p, acts, bn_batch_stats)."""
+    W = {k: _t(v, dtype) for k, v in weights.items()}
+    a, stats, T = OrderedDict(), OrderedDict(), {}
+
+    def conv(name, h, rate):
+        z = conv3x3_bias_relu(h, W[name + "/kernel"], W[name + "/bias"], relu=False)
+        y = F.elu(z)
+        if training and keep_masks is not None and rate > 0:
+            y = dropout(y, _t(keep_masks[name], dtype), rate)
+        a[name] = y
+        return y
+
+    def bn(name, h):
+        y, mu, va = batchnorm(h, W[name + "/gamma"], W[name + "/beta"], W[name + "/mean"], W[name + "/var"], training)
+        a[name] = y; stats[name] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
+        return y
+
+    h = _t(x, dtype)
+    todo = {1: [], 2: ["x1_2"], 3: ["x2_2", "x1_3"], 4: ["x3_2", "x2_3", "x1_4"]}
+    nodes = {n[0]: n for n in PP_NODES}
+    for k in (1, 2, 3, 4):
+        h = conv(f"c{k}a", h, PP_ENC_DROP)
+        h = conv(f"c{k}b", h, 0.0)
+        T[f"c{k}"] = bn(f"bn{k}", h)
+        for nm in todo[k]:
+            _, c, src, skips = nodes[nm]
+            u = convT2x2s2_bias(T[src], W[f"u{nm[1:]}/kernel"], W[f"u{nm[1:]}/bias"]); a[f"u{nm[1:]}"] = u
+            hh = torch.cat([u] + [T[s] for s in skips], dim=3)
+            hh = bn(nm + "abn", conv(nm + "a", hh, PP_BLOCK_DROP))
+            T[nm] = bn(nm + "bbn", conv(nm + "b", hh, PP_BLOCK_DROP))
+        h = maxpool2x2(T[f"c{k}"]); a[f"p{k}"] = h
+    p = conv1x1_sigmoid(T["x1_4"], W["out/kernel"], W["out/bias"])
+    a["out"] = p
+    return (p, a, stats) if want_acts else (p, None, stats)
+
+
+def pp_loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False):
+    names = pp_trainable_names(np.asarray(x).shape[-1])
+    W = {k: _t(v, dtype).clone() for k, v in weights.items()}
+    for k in names:
+        W[k].requires_grad_(True)
+    p, acts, stats = pp_forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=True)
+    t = _t(y, dtype)
+    loss = bce_dice_loss(t, p); dice = dice_coeff(t, p)
+    if want_acts:
+        for v in acts.values():
+            v.retain_grad()
+    loss.backward()
+    out = dict(loss=float(loss.detach()), dice=float(dice.detach()), p=p.detach().numpy(),
+               grads={k: W[k].grad.numpy() for k in names},
+               bn_stats={k: (m.detach().numpy(), v.detach().numpy(), n) for k, (m, v, n) in stats.items()})
+    if want_acts:
+        out["acts"] = {k: v.detach().numpy() for k, v in acts.items()}
+        out["act_grads"] = {k: (v.grad.numpy() if v.grad is not None else None) for k, v in acts.items()}
+    return out

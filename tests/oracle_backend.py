@@ -6,16 +6,16 @@ from oracle import unet_oracle as O
 
 
 class OracleBackend:
-    def __init__(self, h, w, in_ch=1, dtype=None):
+    def __init__(self, h, w, in_ch=1, dtype=None, arch="unet"):
         import torch
-        self.h, self.w, self.in_ch = h, w, in_ch
+        self.h, self.w, self.in_ch, self.arch = h, w, in_ch, arch
         self.dtype = dtype or torch.float32
         self.lr = O.ADAM_LR
         self.tr = None
 
     def set_weights(self, w):
         if self.tr is None:
-            self.tr = O.OracleTrainer(w, self.dtype)
+            self.tr = O.OracleTrainer(w, self.dtype, self.arch)
         else:
             for k in self.tr.w:
                 self.tr.w[k] = np.array(w[k], dtype=self.tr.w[k].dtype)
@@ -35,7 +35,7 @@ class OracleBackend:
     def predict_batch(self, x, y=None):
         import torch
         with torch.no_grad():
-            p = O.forward(self.tr.w, x, training=False, dtype=self.dtype)[0]
+            p = self.tr._fwd(self.tr.w, x, training=False, dtype=self.dtype)[0]
             ld = None
             if y is not None:
                 t = torch.as_tensor(np.asarray(y), dtype=self.dtype)

@@ -34,7 +34,7 @@ def test_conv3x3_fwd(ops, shape, algo):
     b = rng.standard_normal(co).astype(np.float32)
     for relu in (1, 0):
         y = ops.z(n, h, w, co)
-        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, relu, algo, ops.s), "conv fwd")
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, relu, 0.0, 0, algo, ops.s), "conv fwd")
         want = O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=bool(relu)).numpy()
         assert relerr(y.cpu().numpy(), want) < TOL
 
@@ -54,7 +54,7 @@ def test_conv3x3_bwd(ops, shape, algo):
     for masked in (False, True):
         dx = ops.z(n, h, w, ci); wt = ops.z(9 * ci * co)
         xm = ops.d(x)
-        ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), xm.data_ptr() if masked else None, dx.data_ptr(), wt.data_ptr(),
+        ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), xm.data_ptr() if masked else None, 1 if masked else 0, 0.0, 0, dx.data_ptr(), wt.data_ptr(),
                                              n, h, w, ci, co, algo, ops.s), "conv bwd data")
         want = xt.grad.numpy() * ((x > 0) if masked else 1.0)
         assert relerr(dx.cpu().numpy(), want) < TOL
@@ -136,7 +136,7 @@ def test_batchnorm_train_infer_bwd(ops, c, ld_extra):
     assert relerr(dg.cpu().numpy(), gt.grad.numpy()) < TOL and relerr(dbt.cpu().numpy(), bt.grad.numpy()) < TOL
     for mask in (0, 1):
         dx = ops.z(n, h, w, c)
-        ops.ck(ops.lib.unet_bn_bwd_apply(ops.h, ops.d(dy).data_ptr(), c, xp, ldx, bnp.data_ptr(), bs.data_ptr(), float(pixels), mask, dx.data_ptr(), c, pixels, c, ops.s), "bn_bwd_apply")
+        ops.ck(ops.lib.unet_bn_bwd_apply(ops.h, ops.d(dy).data_ptr(), c, xp, ldx, bnp.data_ptr(), bs.data_ptr(), float(pixels), mask, 0.0, 0, dx.data_ptr(), c, pixels, c, ops.s), "bn_bwd_apply")
         assert relerr(dx.cpu().numpy(), xt.grad.numpy() * ((x > 0) if mask else 1.0)) < 5e-5
 
 
@@ -197,7 +197,7 @@ def test_head_loss_fwd_bwd(ops):
     assert abs(lo[0] - float(O.bce_dice_loss(T32(t), p32))) < 5e-6 and abs(lo[1] - float(O.dice_coeff(T64(t), pt))) < 2e-6
     loss.backward()
     dx = ops.z(n, h, w, c); dw = ops.z(c); db = ops.z(1)
-    ops.ck(ops.lib.unet_head_bwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), p.data_ptr(), ops.d(t).data_ptr(), sums.data_ptr(), float(pixels), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), pixels, c, ops.s), "head bwd")
+    ops.ck(ops.lib.unet_head_bwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), p.data_ptr(), ops.d(t).data_ptr(), sums.data_ptr(), float(pixels), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), pixels, c, 1, ops.s), "head bwd")
     assert relerr(dx.cpu().numpy(), xt.grad.numpy() * (x > 0)) < 2e-5
     assert relerr(dw.cpu().numpy(), kt.grad.numpy().ravel()) < 2e-5 and relerr(db.cpu().numpy(), bt.grad.numpy()) < 2e-5
     # p-only call (predict): no labels, no sums
@@ -234,7 +234,7 @@ def test_bad_arguments_are_reported_not_crashed(ops):
     rc = ops.lib.unet_bn_apply(ops.h, None, 32, None, None, 32, 10, 32, ops.s)
     assert rc == -1 and b"bn_apply" in ops.lib.unet_last_error(ops.h)
     m = __import__("ctypes").c_void_p()
-    assert ops.lib.unet_model_create(ops.h, 1, 2, 30, 32, 1, 0, __import__("ctypes").byref(m)) == -3   # h not a multiple of 16
+    assert ops.lib.unet_model_create(ops.h, 0, 1, 2, 30, 32, 1, 0, __import__("ctypes").byref(m)) == -3   # h not a multiple of 16
 
 
 @pytest.mark.parametrize("c", [32, 128, 512])
@@ -268,3 +268,77 @@ def test_fused_bn_pool_fwd_and_pool_bwd_bnstats(ops, c):
                                                           sb.data_ptr(), n, h, w, c, rate, seed, ops.s), "fused bwd")
         assert (da.cpu().numpy() == db.cpu().numpy()).all()
         assert relerr(sb.cpu().numpy(), sa.cpu().numpy()) < 1e-5           # xhat recovered from y = gamma*xhat+beta vs from x
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 10, 14, 32, 64), (1, 8, 8, 96, 32), (2, 12, 12, 1, 32), (1, 6, 6, 192, 64)])
+def test_conv3x3_elu_dropout_and_mask_modes(ops, shape, algo):
+    """U-Net++ epilogues (task1_unet_plus_plus.py:860-878): ELU, fused inverted dropout (same mask stream in every kernel
+    variant), and the backward mask modes ELU / ELU+dropout of the data-gradient and of the BatchNorm backward."""
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(31 + ci)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    want = torch.nn.functional.elu(O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=False)).numpy()
+    y0 = ops.z(n, h, w, co)
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y0.data_ptr(), n, h, w, ci, co, 2, 0.0, 0, algo, ops.s), "elu")
+    assert relerr(y0.cpu().numpy(), want) < TOL
+    rate, seed = 0.4, 4242
+    yd = ops.z(n, h, w, co); yn = ops.z(n, h, w, co)
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), yd.data_ptr(), n, h, w, ci, co, 2, rate, seed, algo, ops.s), "elu+drop")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), yn.data_ptr(), n, h, w, ci, co, 2, rate, seed, 1, ops.s), "elu+drop direct")
+    d = yd.cpu().numpy(); keep = d != 0
+    assert abs(keep.mean() - 0.6) < 0.05 and relerr(d, want * keep / 0.6) < TOL
+    assert ((yn.cpu().numpy() != 0) == keep).all()                        # MFMA / direct / Cin=1 kernels share one mask stream
+    if ci < 8:
+        return
+    # data gradient of a conv whose INPUT was produced by elu(+dropout): dx *= elu'(a) * keep/(1-rate)
+    dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
+    a = (rng.standard_normal((n, h, w, ci)) * 1.5).astype(np.float32); a = np.where(a > 0, a, np.expm1(a)).astype(np.float32)   # an ELU output
+    xt, kt = T64(a).requires_grad_(True), T64(k)
+    O.conv3x3_bias_relu(xt, kt, torch.zeros(co, dtype=torch.float64), relu=False).backward(T64(dy))
+    g = xt.grad.numpy(); elup = np.where(a > 0, 1.0, a + 1.0)
+    wt = ops.z(9 * ci * co); dx = ops.z(n, h, w, ci)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), ops.d(a).data_ptr(), 2, 0.0, 0, dx.data_ptr(), wt.data_ptr(), n, h, w, ci, co, algo, ops.s), "mask elu")
+    assert relerr(dx.cpu().numpy(), g * elup) < TOL
+    ones = np.ones((n, h, w, ci), np.float32); km = ops.z(n, h, w, ci)           # keep mask of (rate, seed) on this tensor shape
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(np.zeros((n, h, w, 8), np.float32)).data_ptr(), ops.d(np.zeros((3, 3, 8, ci), np.float32)).data_ptr(),
+                                    ops.d(ones[0, 0, 0]).data_ptr(), km.data_ptr(), n, h, w, 8, ci, 0, rate, seed, 1, ops.s), "mask probe")
+    keep_in = km.cpu().numpy() != 0
+    stored = (a * keep_in / 0.6).astype(np.float32)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), ops.d(stored).data_ptr(), 3, rate, seed, dx.data_ptr(), wt.data_ptr(), n, h, w, ci, co, algo, ops.s), "mask elu+drop")
+    assert relerr(dx.cpu().numpy(), g * elup * keep_in / 0.6) < TOL
+    # BatchNorm backward with the same mask modes on its input
+    pixels, c = n * h * w, ci
+    gam = rng.uniform(0.5, 1.5, c).astype(np.float32); bet = rng.standard_normal(c).astype(np.float32); dyb = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    xs = ops.d(stored); sums = ops.z(2 * c, dtype=torch.float64); bnp = ops.z(4 * c); bs = ops.z(2 * c, dtype=torch.float64)
+    ops.ck(ops.lib.unet_bn_stats(ops.h, xs.data_ptr(), c, sums.data_ptr(), pixels, c, ops.s), "stats")
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, sums.data_ptr(), float(pixels), ops.d(gam).data_ptr(), ops.d(bet).data_ptr(), ops.z(c).data_ptr(), ops.z(c).data_ptr(), bnp.data_ptr(), c, ops.s), "fin")
+    ops.ck(ops.lib.unet_bn_bwd_stats(ops.h, ops.d(dyb).data_ptr(), c, xs.data_ptr(), c, bnp.data_ptr(), bs.data_ptr(), pixels, c, ops.s), "bstats")
+    st = T64(stored).requires_grad_(True)
+    O.batchnorm(st, T64(gam), T64(bet), None, None, True)[0].backward(T64(dyb))
+    for mode, fac in ((2, np.where(stored > 0, 1.0, stored + 1.0)), (3, elup * keep_in / 0.6)):
+        dxb = ops.z(n, h, w, c)
+        ops.ck(ops.lib.unet_bn_bwd_apply(ops.h, ops.d(dyb).data_ptr(), c, xs.data_ptr(), c, bnp.data_ptr(), bs.data_ptr(), float(pixels), mode, rate, seed, dxb.data_ptr(), c, pixels, c, ops.s), "bn bwd mask")
+        assert relerr(dxb.cpu().numpy(), st.grad.numpy() * fac) < 5e-5, mode
+
+
+def test_copy_and_accum_slices(ops):
+    import ctypes
+    rng = np.random.default_rng(8)
+    n, h, w, c = 2, 5, 7, 32
+    pixels = n * h * w
+    a = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    cat = ops.z(n, h, w, 96); cat.fill_(7.0)
+    ops.ck(ops.lib.unet_copy_slice(ops.h, ops.d(a).data_ptr(), c, cat.data_ptr() + 4 * 64, 96, pixels, c, ops.s), "copy")
+    got = cat.cpu().numpy()
+    assert (got[..., 64:] == a).all() and (got[..., :64] == 7.0).all()
+    g1 = rng.standard_normal((n, h, w, 96)).astype(np.float32); g2 = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    d1, d2 = ops.d(g1), ops.d(g2)
+    dst = ops.d(a.copy())
+    srcs = (ctypes.c_void_p * 2)(d1.data_ptr() + 4 * 32, d2.data_ptr()); lds = (ctypes.c_int32 * 2)(96, c)
+    ops.ck(ops.lib.unet_accum_slices(ops.h, srcs, lds, 2, dst.data_ptr(), c, pixels, c, 1, ops.s), "accum")
+    assert np.allclose(dst.cpu().numpy(), a + g1[..., 32:64] + g2, atol=1e-6)
+    ops.ck(ops.lib.unet_accum_slices(ops.h, srcs, lds, 2, dst.data_ptr(), c, pixels, c, 0, ops.s), "accum overwrite")
+    assert np.allclose(dst.cpu().numpy(), g1[..., 32:64] + g2, atol=1e-6)

@@ -41,6 +41,19 @@ def test_param_count_matches_keras_summary():
     assert kn["out/kernel"] == "conv2d_19/kernel:0" and kn["bn6/mean"] == "batch_normalization_5/moving_mean:0"
 
 
+def test_unetpp_table_matches_reference_count():
+    """U-Net++ (task1_unet_plus_plus.py:858-950): 2,209,697 parameters, same tables in product and oracle."""
+    from covidseg_amd import weights as W
+    assert W.count_params(1, "unetpp") == (2_209_697, 2_207_329)
+    assert list(W.weight_shapes(1, "unetpp").items()) == list(O.pp_weight_shapes(1).items())
+    assert W.weight_shapes(1, "unetpp")["x1_4a/kernel"] == (3, 3, 128, 32) and W.weight_shapes(1, "unetpp")["x2_3a/kernel"] == (3, 3, 192, 64)
+    w = O.pp_init_weights(0)
+    rng = np.random.default_rng(0)
+    x = rng.random((2, 16, 16, 1)).astype(np.float32); y = (rng.random((2, 16, 16, 1)) > 0.7).astype(np.float32)
+    r = O.pp_loss_and_grads(w, x, y, dtype=torch.float64)
+    assert r["p"].shape == (2, 16, 16, 1) and all(np.isfinite(g).all() for g in r["grads"].values())
+
+
 def _conv_loop(x, k, b):
     n, h, w, ci = x.shape
     co = k.shape[3]
@@ -153,7 +166,7 @@ def test_dropin_modules_export_reference_names():
         for mod, fn in want.items():
             m = importlib.import_module(mod)
             assert m.__all__ == [fn] and callable(getattr(m, fn))
-        for mod in ("task1_unet_plus_plus", "task2_covid19_classifcation"):           # not on the hot path yet: explicit stubs
+        for mod in ("task2_covid19_classifcation",):                                   # not on the hot path yet: explicit stub
             with pytest.raises(NotImplementedError):
                 getattr(importlib.import_module(mod), want[mod])()
     finally:
@@ -170,7 +183,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in unet_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert _lib.load().unet_abi_version() == 1
+    assert _lib.load().unet_abi_version() == 2
 
 
 def test_product_fails_loudly_without_gpu():
