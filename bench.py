@@ -30,7 +30,13 @@ def cpu_baseline(size, seconds_budget=25.0, arch="unet"):
     from oracle import unet_oracle as O
     bs = 2
     x, y = synthetic_ct(bs, size, seed=0)
-    tr = O.OracleTrainer(O.init_weights(seed=0) if arch == "unet" else O.pp_init_weights(seed=0), torch.float32, arch)
+    if arch == "classifier":
+        from covidseg_amd.data import synthetic_classification
+        bs = 16
+        x, y = synthetic_classification(bs, size, seed=0)
+        tr = O.ClsOracleTrainer(O.cls_init_weights(0, 1, (size, size)), torch.float32)
+    else:
+        tr = O.OracleTrainer(O.init_weights(seed=0) if arch == "unet" else O.pp_init_weights(seed=0), torch.float32, arch)
     t0 = time.perf_counter(); tr.train_step(x, y); first = time.perf_counter() - t0     # includes oneDNN warm-up
     reps = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
     t0 = time.perf_counter()
@@ -51,8 +57,9 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="0 auto (MFMA), 1 direct kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
-    ap.add_argument("--arch", default="unet", choices=["unet", "unetpp"], help="unetpp = the U-Net++ graph (BASELINE configs[3], at fp32); "
-                    "not the headline metric -- use with --size 256 --batch 32")
+    ap.add_argument("--arch", default="unet", choices=["unet", "unetpp", "classifier"], help="unetpp = the U-Net++ graph (BASELINE "
+                    "configs[3], at fp32; --size 256 --batch 32); classifier = the task-2 CNN (configs[4] at the reference's 1-channel fp32; "
+                    "--size 224 --batch 256).  Neither is the headline metric")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,11 +90,18 @@ def main():
 
     B, S = args.batch, args.size
     # synthetic batch: generate a few distinct slices on the host, tile to the batch, keep resident in HBM
-    xs, ys = synthetic_ct(min(B, 4), S, seed=rank)
+    if args.arch == "classifier":
+        from covidseg_amd.data import synthetic_classification
+        xs, ys = synthetic_classification(min(B, 8), S, seed=rank)
+        ys = ys.astype(np.float32)
+    else:
+        xs, ys = synthetic_ct(min(B, 4), S, seed=rank)
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
                   arch=args.arch)
+    if args.arch == "classifier":
+        W.set_classifier_input(S, S)
     eng.set_weights(W.init_weights(0, 1, args.arch))       # identical replicas
 
     for _ in range(args.warmup):
@@ -143,16 +157,20 @@ def main():
     if rank == 0:
         total_imgs = B * world * args.steps
         out = {
-            "metric": "CT images/sec (fwd+bwd) U-Net 512x512x1 bs16" if args.arch == "unet" else f"CT images/sec (fwd+bwd) U-Net++ {S}x{S}x1 bs{B}", "value": round(total_imgs / dt, 3), "unit": "images/sec",
+            "metric": ("CT images/sec (fwd+bwd) U-Net 512x512x1 bs16" if args.arch == "unet" else
+                       f"CT images/sec (fwd+bwd) {'U-Net++' if args.arch == 'unetpp' else 'slice classifier'} {S}x{S}x1 bs{B}"), "value": round(total_imgs / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
                                     if args.arch == "unet" else
-                                    f"U-Net++ infection seg (task1_unet_plus_plus.py:858-950), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam")
+                                    f"U-Net++ infection seg (task1_unet_plus_plus.py:858-950), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
+                                    if args.arch == "unetpp" else
+                                    f"slice classifier (task2_covid19_classifcation.py:747-776), {S}x{S}x1, batch {B}/GPU, fp32, fwd+BCE+bwd+Keras-Adam")
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
-                                   + ("configs[1]" if args.arch == "unet" else "configs[3] graph at the reference's fp32"),
+                                   + {"unet": "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
+                                      "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
                        "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x2" if args.algo == 0 else "direct",
-                       "dropout": 0.25 if args.arch == "unet" else "0.2/0.4 (fused in the conv epilogue)", "last_loss_dice": [round(v, 5) for v in loss_dice]},
+                       "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 2
+#define UNET_ABI_VERSION 3
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -178,6 +178,30 @@ int32_t unet_copy_slice(unet_ctx*, const float* src, int32_t lds, float* dst, in
 int32_t unet_accum_slices(unet_ctx*, const float* const* srcs, const int32_t* lds, int32_t nsrc, float* dst, int32_t ldd,
                           int64_t pixels, int32_t c, int32_t accumulate, void* stream);
 
+/* ---- dense tail of the slice classifier (task2_covid19_classifcation.py:770-776, `T2`) ------------------------------
+ * Replaces: Flatten -> Dense(32, relu) -> Dropout(0.4) T2:772-775.  y[b,:] = dropout(act(x[b,:] W + bias)); x [batch,k] row-major
+ * (the NHWC pooled tensor IS Keras' channels_last flatten order), W [k,n] (Keras Dense kernel), n a power of two in 4..32,
+ * k %% 4 == 0.  Split-K partials in `ws` (unet_dense_ws_bytes), fixed-order reduction -> deterministic. */
+size_t unet_dense_ws_bytes(int32_t batch, int32_t k, int32_t n);
+int32_t unet_dense_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t k, int32_t n,
+                       int32_t act, float drop_rate, uint64_t drop_seed, void* ws, size_t ws_bytes, void* stream);
+/* dx[b,:] = dy[b,:] W^T (dx may be NULL), dw = x^T dy.  dy must already carry the derivative of the activation/dropout
+ * (unet_cls_head_bwd writes it that way). */
+int32_t unet_dense_bwd(unet_ctx*, const float* x, const float* w, const float* dy, float* dx, float* dw, int32_t batch, int32_t k,
+                       int32_t n, void* stream);
+/* Replaces: Dense(1, sigmoid) T2:776 fused with loss='binary_crossentropy' (T2:829, optional class weights T2:801-803, 835) and the
+ * sums of the f1 metric T2:688-703.  p[b] = sigmoid(h[b,:].w + bias).  If y_true != NULL, sums (double[4], accumulated) +=
+ * (sum cw(t)*bce, sum round(t*p), sum round(t), sum round(p)). */
+int32_t unet_cls_head_fwd(unet_ctx*, const float* h, const float* w, const float* bias, float* p, const float* y_true, float class_w0,
+                          float class_w1, double* sums, int32_t batch, int32_t n, void* stream);
+/* out float[2] = (loss = sums[0]/count, f1) from (globally reduced) sums; count = GLOBAL batch size */
+int32_t unet_cls_loss_finalize(unet_ctx*, const double* sums, double count, float* out, void* stream);
+/* backward of loss + sigmoid + Dense(n->1) + the Dropout/ReLU of the hidden layer h = dropout(relu(a)):
+ * dw[n], db[1]; dh[batch,n] = dL/da (ready for unet_dense_bwd); dbias_prev[n] = sum_b dh[b,:] (bias gradient of the hidden Dense). */
+int32_t unet_cls_head_bwd(unet_ctx*, const float* h, const float* w, const float* p, const float* y_true, float class_w0, float class_w1,
+                          double count, float drop_rate, float* dh, float* dw, float* db, float* dbias_prev, int32_t batch, int32_t n,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Model level.  Replaces the Keras Model built at T1:853-916 and driven by
  * compile/fit/evaluate/predict (T1:1053-1061, 1101, 1137).  A model is a fixed-shape plan:
@@ -194,8 +218,9 @@ typedef struct unet_sync_point {
   int64_t count;      /* number of elements */
 } unet_sync_point;
 
-/* arch: UNET_ARCH_UNET (T1:853-916) or UNET_ARCH_UNETPP (task1_unet_plus_plus.py:858-950) */
-enum { UNET_ARCH_UNET = 0, UNET_ARCH_UNETPP = 1 };
+/* arch: UNET_ARCH_UNET (T1:853-916), UNET_ARCH_UNETPP (task1_unet_plus_plus.py:858-950) or UNET_ARCH_CLASSIFIER (the Sequential
+ * CNN of task2_covid19_classifcation.py:747-776: y_true / p_out are [n] floats, loss_ptr = (binary cross-entropy, f1)) */
+enum { UNET_ARCH_UNET = 0, UNET_ARCH_UNETPP = 1, UNET_ARCH_CLASSIFIER = 2 };
 int32_t unet_model_create(unet_ctx*, int32_t arch, int32_t in_ch, int32_t n, int32_t h, int32_t w,
                           int32_t world_size, int32_t conv_algo, unet_model** out);
 void unet_model_destroy(unet_model*);
@@ -210,6 +235,8 @@ int32_t unet_model_bind(unet_model*, float* params, float* grads, float* adam_m,
                         float* bn_state, void* workspace, size_t workspace_bytes);
 int32_t unet_model_set_io(unet_model*, const float* x, const float* y_true, float* p_out);
 int32_t unet_model_set_dropout(unet_model*, float rate, uint64_t seed);
+/* classifier only: weights of class 0 / class 1 in the loss (Keras class_weight, T2:835); default 1, 1 */
+int32_t unet_model_set_class_weights(unet_model*, float w0, float w1);
 int32_t unet_model_num_ops(const unet_model*, int32_t prog);
 int32_t unet_model_sync_points(const unet_model*, int32_t prog, unet_sync_point* out, int32_t cap);
 int32_t unet_model_run(unet_model*, int32_t prog, int32_t begin, int32_t end, void* stream);

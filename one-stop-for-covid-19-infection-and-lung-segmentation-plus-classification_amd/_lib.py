@@ -10,10 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2
-ARCH_UNET, ARCH_UNETPP = 0, 1
+ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 MASK_NONE, MASK_RELU, MASK_ELU, MASK_ELU_DROP = 0, 1, 2, 3
 PROG_FWD_TRAIN, PROG_BWD, PROG_FWD_INFER = 0, 1, 2
@@ -63,6 +63,12 @@ _PROTOS = {
     "unet_zero": (i32, [vp, vp, sz, vp]),
     "unet_copy_slice": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
     "unet_accum_slices": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, i64, i32, i32, vp]),
+    "unet_dense_ws_bytes": (sz, [i32, i32, i32]),
+    "unet_dense_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, sz, vp]),
+    "unet_dense_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "unet_cls_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, f32, f32, vp, i32, i32, vp]),
+    "unet_cls_loss_finalize": (i32, [vp, vp, f64, vp, vp]),
+    "unet_cls_head_bwd": (i32, [vp, vp, vp, vp, vp, f32, f32, f64, f32, vp, vp, vp, vp, i32, i32, vp]),
     "unet_model_create": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     "unet_model_destroy": (None, [vp]),
     "unet_model_param_count": (i64, [vp]),
@@ -72,6 +78,7 @@ _PROTOS = {
     "unet_model_bind": (i32, [vp, vp, vp, vp, vp, vp, vp, sz]),
     "unet_model_set_io": (i32, [vp, vp, vp, vp]),
     "unet_model_set_dropout": (i32, [vp, f32, u64]),
+    "unet_model_set_class_weights": (i32, [vp, f32, f32]),
     "unet_model_num_ops": (i32, [vp, i32]),
     "unet_model_sync_points": (i32, [vp, i32, C.POINTER(SyncPoint), i32]),
     "unet_model_run": (i32, [vp, i32, i32, i32, vp]),

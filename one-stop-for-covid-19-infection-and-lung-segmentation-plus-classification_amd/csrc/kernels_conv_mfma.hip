@@ -94,12 +94,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     const int idx = tid + k * 256;
     if (MODE == 1) {
       const int half = idx & 1, nn = idx >> 1;
-      woff[k] = idx < WTOT ? (nbase + nn) * Cin + half * 4 : -1;     // Keras ConvT kernel [ab][o][c]: row nn holds Cin floats
+      woff[k] = (idx < WTOT && nbase + nn < Cout) ? (nbase + nn) * Cin + half * 4 : -1;     // Keras ConvT kernel [ab][o][c]: row nn holds Cin floats
       wlds[k] = half * 4 * TN + nn;
     } else {
       const int q = idx % (TN / 4), row = idx / (TN / 4);
       const int tap = row >> 3, ci = row & 7;
-      woff[k] = idx < WTOT ? (tap * Cin + ci) * Cout + nbase + q * 4 : -1;
+      woff[k] = (idx < WTOT && nbase + q * 4 < Cout) ? (tap * Cin + ci) * Cout + nbase + q * 4 : -1;   // tile may overhang Cout (zero fill)
       wlds[k] = row * TN + q * 4;
     }
   }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
       if (plds[k] >= 0) *reinterpret_cast<f32x4*>(&s_in[plds[k]]) = preg[k];
 #pragma unroll
     for (int k = 0; k < WL; ++k) {
-      if (woff[k] < 0) continue;
+      if (tid + k * 256 >= WTOT) continue;
       if (MODE == 1) {            // transpose while staging: s_w[ci][nn]
         s_w[wlds[k]] = wreg[k][0]; s_w[wlds[k] + TN] = wreg[k][1]; s_w[wlds[k] + 2 * TN] = wreg[k][2]; s_w[wlds[k] + 3 * TN] = wreg[k][3];
       } else {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     const int co = nbase + (wc * NW + jn) * 32 + q4;         // first of this lane's 4 output channels
     const int cq = Cout >> 2;                                // MODE 1: Cout = 4 * (ConvT output channels)
     const int ab = MODE == 1 ? co / cq : 0, oc = MODE == 1 ? co - ab * cq : co;
-    const float4 bb = bias ? *reinterpret_cast<const float4*>(bias + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int py = y0 + wr * RW + i;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
         }
         // now (v0..v3) = D[pixel e + 8g + 4hi][couts q4 .. q4+3]
         const int px = x0 + e + 8 * g + 4 * hi;
-        if (py >= H || px >= W) continue;
+        if (py >= H || px >= W || co >= Cout) continue;
         float4 v = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
         if (MODE == 1) {
           *reinterpret_cast<float4*>(y + (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px + (ab & 1)) * ldy + oc) = v;
@@ -252,7 +252,7 @@ int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, cons
                     int ldy, int n, int h, int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH;
-  dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)(cout / TN));
+  dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)((cout + TN - 1) / TN));
   if (MODE == 0 && conv_ablation()) {          // timing experiments (tools/conv_ablate.py); never set in production
     const int a = conv_ablation();
     if (a == 1) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, false, 1>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
@@ -327,19 +327,19 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
     const int idx = lane + 64 * k;
     if (MODE == 0) {
       const int pix = idx >> 3, q = idx & 7; const int gx = x0 - 1 + pix;
-      aoff[k] = (idx < 34 * 8 && gx >= 0 && gx < W) ? gx * ldA + a0 + q * 4 : -1;
+      aoff[k] = (idx < 34 * 8 && gx >= 0 && gx < W && a0 + q * 4 < CA) ? gx * ldA + a0 + q * 4 : -1;
       alds[k] = idx < 34 * 8 ? pix * 32 + q * 4 : -1;
     } else {
       const int q = idx & 7; const int cc = (idx >> 3) & 63; const int a = idx >> 9;   // a = row parity of dU
       const int gx = 2 * x0 + cc;
-      aoff[k] = gx < WA ? (a * WA + gx) * ldA + a0 + q * 4 : -1;
+      aoff[k] = (gx < WA && a0 + q * 4 < CA) ? (a * WA + gx) * ldA + a0 + q * 4 : -1;
       alds[k] = (((a * 2 + (cc & 1)) * 32) + (cc >> 1)) * 32 + q * 4;
     }
   }
 #pragma unroll
   for (int k = 0; k < BL; ++k) {
     const int idx = lane + 64 * k; const int pix = idx >> 3, q = idx & 7; const int gx = x0 + pix;
-    boff[k] = gx < W ? gx * ldB + b0 + q * 4 : -1;
+    boff[k] = (gx < W && b0 + q * 4 < CB) ? gx * ldB + b0 + q * 4 : -1;
     blds[k] = pix * 32 + q * 4;
   }
   f32x4 areg[AL], breg[BL];            // ext-vector type: stays in registers (a float4 struct select goes through scratch)
@@ -418,11 +418,11 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
         if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
       }
       const int i = e + 8 * g + 4 * hi;
-      *reinterpret_cast<float4*>(&P[((long long)t * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
+      if (a0 + i < CA && b0 + q4 < CB) *reinterpret_cast<float4*>(&P[((long long)t * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
     }
   bsum += __shfl_xor(bsum, 32, 64);
-  if (MODE == 0) { if (ta == 0 && lane < 32) part_b[(long long)split * CB + b0 + l31] = bsum; }
-  else { if (tb == 0 && lane < 32) part_b[(long long)split * CA + a0 + l31] = bsum; }
+  if (MODE == 0) { if (ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * CB + b0 + l31] = bsum; }
+  else { if (tb == 0 && lane < 32 && a0 + l31 < CA) part_b[(long long)split * CA + a0 + l31] = bsum; }
 }
 
 // Sum the split-K partials in a fixed order.  Two levels so that a tiny output (e.g. 9x32x32) with
@@ -456,7 +456,7 @@ struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_chunk, chunks_
 
 WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
   WgradPlan p;
-  p.tiles_a = ca / 32; p.tiles_b = cb / 32; p.strips = (w + 31) / 32;
+  p.tiles_a = (ca + 31) / 32; p.tiles_b = (cb + 31) / 32; p.strips = (w + 31) / 32;      // a tile may overhang (channels % 32 != 0)
   const long long pairs = (long long)p.tiles_a * p.tiles_b;
   const long long per = (long long)taps * ca * cb;
   // K-split: every (image, 32-column strip) is cut into row chunks; aim at ~4096 waves (2 waves/SIMD x 256 CUs x 2 rounds),
@@ -510,8 +510,8 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
 
 }  // namespace
 
-bool mfma_conv3x3_supported(int cin, int cout) { return cin >= CK && (cin % CK) == 0 && (cout % 32) == 0; }
-bool mfma_wgrad_supported(int ca, int cb) { return ca >= 32 && (ca % 32) == 0 && cb >= 32 && (cb % 32) == 0; }
+bool mfma_conv3x3_supported(int cin, int cout) { return cin >= CK && (cin % CK) == 0 && cout >= 4 && (cout % 4) == 0; }
+bool mfma_wgrad_supported(int ca, int cb) { return ca >= 8 && (ca % 4) == 0 && cb >= 8 && (cb % 4) == 0; }
 
 int32_t k_conv3x3_mfma_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode, float* y,
                            int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s) {

@@ -144,7 +144,7 @@ int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy
 // =========================================================================================
 namespace {
 
-struct Layer { std::string name; int kind; int cin, cout; };   // kind 0 conv3, 1 convT, 2 bn, 3 conv1
+struct Layer { std::string name; int kind; int cin, cout; };   // kind 0 conv3, 1 convT, 2 bn, 3 conv1, 4 dense
 struct TInfo { int is_state; int64_t off, count; };
 struct Buf { size_t off = 0; int ld = 0, n = 0, h = 0, w = 0, c = 0; size_t chan_off = 0; };   // float offsets into workspace
 
@@ -168,6 +168,8 @@ struct unet_model {
   char* ws = nullptr; size_t ws_bytes = 0;
   const float *x = nullptr, *yt = nullptr; float* pout = nullptr;
   float drop_rate = 0.0f; uint64_t drop_seed = 0;
+  float cw0 = 1.0f, cw1 = 1.0f;                       // classifier: class weights of the loss
+  size_t off_dense_ws = 0, dense_ws_bytes = 0;
   // workspace plan (offsets in floats)
   std::map<std::string, Buf> act, grad;
   size_t ws_floats_infer = 0, ws_floats_train = 0;
@@ -202,7 +204,7 @@ void assign_param_offsets(unet_model* m) {
       m->tinfo[l.name + "/mean"] = {1, so, l.cout}; so += l.cout;
       m->tinfo[l.name + "/var"] = {1, so, l.cout}; so += l.cout;
     } else {
-      int64_t kn = (l.kind == 0 ? 9 : l.kind == 1 ? 4 : 1) * (int64_t)l.cin * l.cout;
+      int64_t kn = (l.kind == 0 ? 9 : l.kind == 1 ? 4 : 1) * (int64_t)l.cin * l.cout;      // conv1 / dense: cin*cout
       m->tinfo[l.name + "/kernel"] = {0, po, kn}; po += kn;
       m->tinfo[l.name + "/bias"] = {0, po, l.cout}; po += l.cout;
     }
@@ -840,6 +842,191 @@ void build_programs_pp(unet_model* m) {
   }
 }
 
+// =========================================================================================
+// Slice classifier -- /root/reference/Scripts/task2_covid19_classifcation.py:747-776 (`T2`), Sequential:
+//   block k (C = 16, 32, 64): Conv(C,relu) -> BN -> Conv(C,relu) -> BN -> MaxPool            (T2:748-764)
+//   Flatten -> Dense(32, relu) -> Dropout(.4) -> Dense(1, sigmoid)                            (T2:772-776)
+// loss binary_crossentropy (+ class weights), metric f1 (T2:688-703, 829).  BN follows the ReLU conv directly, so every conv
+// data-gradient lands on a BN output (no activation mask) and every BN backward carries the ReLU mask of its conv.
+// =========================================================================================
+const int CLS_C[3] = {16, 32, 64};
+constexpr int CLS_HIDDEN = 32;
+constexpr float CLS_DROP = 0.4f;
+
+void build_layers_cls(unet_model* m) {
+  auto& L = m->layers;
+  int cprev = m->in_ch;
+  for (int k = 1; k <= 3; ++k) {
+    const int c = CLS_C[k - 1]; const std::string ks = std::to_string(k);
+    L.push_back({"c" + ks + "a", 0, cprev, c}); L.push_back({"bn" + ks + "a", 2, c, c});
+    L.push_back({"c" + ks + "b", 0, c, c}); L.push_back({"bn" + ks + "b", 2, c, c});
+    cprev = c;
+  }
+  L.push_back({"fc1", 4, (m->H / 8) * (m->W / 8) * CLS_C[2], CLS_HIDDEN});
+  L.push_back({"fc2", 4, CLS_HIDDEN, 1});
+  assign_param_offsets(m);
+}
+
+void plan_workspace_cls(unet_model* m) {
+  Carver cv;
+  const int N = m->N;
+  plan_scratch(m, cv);
+  int hh = m->H, ww = m->W;
+  size_t wt0 = 0, wgb = 0;
+  for (int k = 1; k <= 3; ++k) {
+    const int c = CLS_C[k - 1]; const std::string ks = std::to_string(k);
+    for (const char* sfx : {"a", "b"}) { m->act["c" + ks + sfx] = mk(cv, N, hh, ww, c); m->act["bn" + ks + sfx] = mk(cv, N, hh, ww, c); }
+    m->act["p" + ks] = mk(cv, N, hh / 2, ww / 2, c);
+    hh /= 2; ww /= 2;
+  }
+  m->act["h1"] = mk(cv, N, 1, 1, CLS_HIDDEN);
+  const int K = hh * ww * CLS_C[2];
+  m->dense_ws_bytes = unet_dense_ws_bytes(N, K, CLS_HIDDEN);
+  m->off_dense_ws = cv.take((m->dense_ws_bytes + 3) / 4);
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)9 * l.cin * l.cout);
+  m->off_wt = cv.take(wt0);
+  m->ws_floats_infer = cv.cur;
+  for (auto& kv : m->act) { const Buf& b = kv.second; m->grad[kv.first] = mk(cv, b.n, b.h, b.w, b.c); }
+  for (auto& l : m->layers)
+    if (l.kind == 0) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, unet_conv3x3_bwd_weights_ws_bytes(N, ob.h, ob.w, l.cin, l.cout)); }
+  m->wgrad_ws_bytes = wgb;
+  m->off_wgrad_ws = cv.take((wgb + 3) / 4);
+  m->ws_floats_train = cv.cur;
+}
+
+void build_programs_cls(unet_model* m) {
+  unet_ctx* ctx = m->ctx;
+  const int algo = m->algo;
+  const double gcount = (double)m->world;
+  const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
+  const Buf fb = m->act.at("p3");
+  const int N = m->N, K = fb.h * fb.w * fb.c;
+  const uint64_t fc_seed = 0xC2B2AE3D27D4EB4Full;
+
+  for (int training = 1; training >= 0; --training) {
+    auto& F = m->prog[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
+    auto& SY = m->syncref[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
+    const int tr = training;
+    ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
+    auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
+      const Buf ob = m->act.at(name);
+      double px = (double)ob.n * ob.h * ob.w;
+      ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+        const float* xin = in.empty() ? m->x : m->A(in);
+        return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
+                                    ACT_RELU, 0.0f, 0, algo, s);
+      });
+    };
+    auto bn = [&](const std::string& name, const std::string& in, int c, const std::string& pool) {
+      const Buf ib = m->act.at(in), ob = m->act.at(name);
+      const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
+      const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
+      if (training) {
+        ADD_OP(F, "bn_stats:" + name, 0, 4.0 * pixels * c, { return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s); });
+        SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
+        ADD_OP(F, "bn_finalize:" + name, 0, 0, {
+          return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
+                                        m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
+        });
+      } else {
+        ADD_OP(F, "bn_finalize_infer:" + name, 0, 0, {
+          return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
+        });
+      }
+      if (pool.empty()) {
+        ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(name), ob.ld, pixels, c, s); });
+      } else {
+        ADD_OP(F, "bn_apply_pool:" + pool, 0, 4.0 * 2.25 * pixels * c, {
+          return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(name), ob.ld, m->Aw(pool), ib.n, ib.h, ib.w, c, 0.0f, 0, s);
+        });
+      }
+    };
+    int cprev = m->in_ch;
+    for (int k = 1; k <= 3; ++k) {
+      const int c = CLS_C[k - 1]; const std::string ks = std::to_string(k);
+      conv("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cprev, c);
+      bn("bn" + ks + "a", "c" + ks + "a", c, "");
+      conv("c" + ks + "b", "bn" + ks + "a", c, c);
+      bn("bn" + ks + "b", "c" + ks + "b", c, "p" + ks);
+      cprev = c;
+    }
+    ADD_OP(F, "dense_fwd:fc1", 2.0 * N * K * CLS_HIDDEN, 4.0 * ((double)N * K + (double)K * CLS_HIDDEN), {
+      const float r = (tr && m->drop_rate > 0.0f) ? CLS_DROP : 0.0f;
+      return unet_dense_fwd(ctx, m->A("p3"), m->P("fc1/kernel"), m->P("fc1/bias"), m->Aw("h1"), N, K, CLS_HIDDEN, ACT_RELU, r, m->drop_seed + fc_seed,
+                            m->wsf(m->off_dense_ws), m->dense_ws_bytes, s);
+    });
+    ADD_OP(F, "cls_head_fwd", 2.0 * N * CLS_HIDDEN, 4.0 * N * (CLS_HIDDEN + 2), {
+      if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "cls_head_fwd: p_out not set (unet_model_set_io)");
+      return unet_cls_head_fwd(ctx, m->A("h1"), m->P("fc2/kernel"), m->P("fc2/bias"), m->pout, m->yt, m->cw0, m->cw1,
+                               m->yt ? m->wsd(m->off_loss_sums) : nullptr, N, CLS_HIDDEN, s);
+    });
+    SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
+    ADD_OP(F, "loss_finalize", 0, 0, {
+      if (!m->yt) return UNET_OK;
+      return unet_cls_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)N * gcount, m->wsf(m->off_loss_out), s);
+    });
+  }
+
+  // ------------------------------------------------------------------ backward
+  auto& BW = m->prog[UNET_PROG_BWD];
+  auto& SY = m->syncref[UNET_PROG_BWD];
+  size_t bs_bytes = 0;
+  for (auto& l : m->layers) if (l.kind == 2) bs_bytes += 2 * (size_t)l.cout * sizeof(double);
+  ADD_OP(BW, "zero_bwd_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_bsums), bs_bytes, s); });
+  ADD_OP(BW, "cls_head_bwd", 4.0 * N * CLS_HIDDEN, 4.0 * N * (2 * CLS_HIDDEN + 2), {
+    if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "cls_head_bwd: io not set");
+    return unet_cls_head_bwd(ctx, m->A("h1"), m->P("fc2/kernel"), m->pout, m->yt, m->cw0, m->cw1, (double)N * gcount,
+                             m->drop_rate > 0.0f ? CLS_DROP : 0.0f, m->D("h1"), m->G("fc2/kernel"), m->G("fc2/bias"), m->G("fc1/bias"), N, CLS_HIDDEN, s);
+  });
+  ADD_OP(BW, "dense_bwd:fc1", 4.0 * N * K * CLS_HIDDEN, 4.0 * (2.0 * N * K + 2.0 * K * CLS_HIDDEN), {
+    return unet_dense_bwd(ctx, m->A("p3"), m->P("fc1/kernel"), m->D("h1"), m->D("p3"), m->G("fc1/kernel"), N, K, CLS_HIDDEN, s);
+  });
+  { const TInfo a = m->tinfo.at("fc1/kernel"), b = m->tinfo.at("fc2/bias"); SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off}); }
+  auto bn_bwd = [&](const std::string& name, const std::string& xname, int c) {      // dy = grad[name], x = act[xname] (ReLU conv), dx = grad[xname]
+    const Buf gb = m->grad.at(name), xb = m->act.at(xname), db = m->grad.at(xname);
+    const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
+    const size_t so = m->bn_bsum_off.at(name), bo = m->bnp_off.at(name);
+    ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
+      int32_t r = unet_bn_bwd_stats(ctx, m->D(name), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
+      if (r) return r;
+      return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
+    });
+    SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
+    ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
+      return unet_bn_bwd_apply(ctx, m->D(name), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, MASK_RELU, 0.0f, 0,
+                               m->D(xname), db.ld, pixels, c, s);
+    });
+  };
+  auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx) {
+    const Buf ob = m->act.at(name);
+    const double px = (double)ob.n * ob.h * ob.w;
+    ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+      const float* xin = in.empty() ? m->x : m->A(in);
+      return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
+                                    ob.n, ob.h, ob.w, cin, cout, algo, s);
+    });
+    if (want_dx) {
+      ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cout + cin) + 9.0 * cin * cout), {
+        return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), nullptr, MASK_NONE, 0.0f, 0, m->D(in), m->wsf(m->off_wt), ob.n, ob.h, ob.w, cin,
+                                     cout, algo, s);
+      });
+    }
+  };
+  for (int k = 3; k >= 1; --k) {
+    const int c = CLS_C[k - 1], cin = k == 1 ? m->in_ch : CLS_C[k - 2];
+    const std::string ks = std::to_string(k), ca = "c" + ks + "a", cb = "c" + ks + "b", ba = "bn" + ks + "a", bb = "bn" + ks + "b", pk = "p" + ks;
+    const Buf xb = m->act.at(bb);
+    ADD_OP(BW, "pool_bwd:" + pk, 0, 4.0 * 2.25 * nel(xb), {
+      return unet_maxpool2x2_dropout_bwd(ctx, m->A(bb), xb.ld, m->D(pk), m->D(bb), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 0, s);
+    });
+    bn_bwd(bb, cb, c);
+    conv_bwd(cb, ba, c, c, true);
+    bn_bwd(ba, ca, c);
+    conv_bwd(ca, k == 1 ? "" : "p" + std::to_string(k - 1), cin, c, k > 1);
+  }
+  { const TInfo a = m->tinfo.at("c1a/kernel"), b = m->tinfo.at("bn3b/beta"); SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off}); }
+}
+
 void resolve_sync(unet_model* m) {
   for (int p = 0; p < 3; ++p) {
     m->sync[p].clear();
@@ -860,14 +1047,15 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
                           int32_t conv_algo, unet_model** out) {
   if (!ctx || !out) return UNET_E_ARG;
   *out = nullptr;
-  if (arch != UNET_ARCH_UNET && arch != UNET_ARCH_UNETPP) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown arch %d", arch);
+  if (arch != UNET_ARCH_UNET && arch != UNET_ARCH_UNETPP && arch != UNET_ARCH_CLASSIFIER) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown arch %d", arch);
   const int mult = arch == UNET_ARCH_UNET ? 16 : 8;      // 4 pool levels (T1:862-880) / 3 used pool levels (UPP: p4 is dead)
   if (in_ch < 1 || n < 1 || h < mult || w < mult || (h % mult) || (w % mult) || world_size < 1)
     UNET_FAIL(ctx, UNET_E_SHAPE, "model_create: need n>=1 and h,w multiples of %d; got n=%d h=%d w=%d", mult, n, h, w);
   unet_model* m = new unet_model();
   m->ctx = ctx; m->arch = arch; m->in_ch = in_ch; m->N = n; m->H = h; m->W = w; m->world = world_size; m->algo = conv_algo;
   if (arch == UNET_ARCH_UNET) { build_layers(m); plan_workspace(m); build_programs(m); }
-  else { build_layers_pp(m); plan_workspace_pp(m); build_programs_pp(m); }
+  else if (arch == UNET_ARCH_UNETPP) { build_layers_pp(m); plan_workspace_pp(m); build_programs_pp(m); }
+  else { build_layers_cls(m); plan_workspace_cls(m); build_programs_cls(m); }
   *out = m;
   return UNET_OK;
 }
@@ -911,6 +1099,12 @@ int32_t unet_model_set_io(unet_model* m, const float* x, const float* y_true, fl
 int32_t unet_model_set_dropout(unet_model* m, float rate, uint64_t seed) {
   if (!m || rate < 0 || rate >= 1) return UNET_E_ARG;
   m->drop_rate = rate; m->drop_seed = seed;
+  return UNET_OK;
+}
+
+int32_t unet_model_set_class_weights(unet_model* m, float w0, float w1) {
+  if (!m || m->arch != UNET_ARCH_CLASSIFIER || !(w0 >= 0) || !(w1 >= 0)) return UNET_E_ARG;
+  m->cw0 = w0; m->cw1 = w1;
   return UNET_OK;
 }
 

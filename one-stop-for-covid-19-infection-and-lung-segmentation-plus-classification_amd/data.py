@@ -46,6 +46,19 @@ def synthetic_ct(n: int, size: int = 512, seed: int = 0):
     return xs, ys
 
 
+def synthetic_classification(n: int, size: int = 224, seed: int = 0):
+    """x float32 [n,size,size,1], y int [n]: the synthetic CT slices above; label 1 = the slice has an infection mask, and then the
+    lesion is also painted into the image (+0.25 inside the soft mask) so the classes are separable.  Mirrors how the reference
+    derives its labels: y = 1 iff the infection mask of the slice is not uniform (task2_covid19_classifcation.py:413-418)."""
+    xs, ms = synthetic_ct(n, size, seed)
+    rng = np.random.default_rng(seed + 7919)
+    y = (rng.random(n) < 0.6).astype(np.int64)
+    if n >= 4:
+        y[:2] = (0, 1); y[2:4] = (0, 1)                           # both classes present at least twice (stratified split needs it)
+    xs = np.clip(xs + 0.25 * ms * y[:, None, None, None], 0, 1).astype(np.float32)
+    return np.round(xs * 255).astype(np.float32) / 255, y
+
+
 def train_test_split(x, y, test_size: float = 0.3, random_state: int = 42):
     """sklearn.model_selection.train_test_split(x, y, test_size=0.3, random_state=42) as called
     at T1:762 -- restated (ShuffleSplit): n_test = ceil(test_size*n); perm = RandomState(seed)

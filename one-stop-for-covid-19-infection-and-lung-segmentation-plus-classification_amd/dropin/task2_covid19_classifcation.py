@@ -1,13 +1,17 @@
-"""Drop-in stub for the reference module of the same name (Scripts/task2_covid19_classifcation.py:6).  This path is outside the
-accelerated hot path (SURVEY.md section 8f "next" rows); the name is exported so the reference's
-app.py star-imports (app.py:7-12) succeed unchanged."""
+"""Drop-in for the reference module of the same name (Scripts/task2_covid19_classifcation.py:6): exports exactly
+`runner_classification`, so the reference's app.py (`from task2_covid19_classifcation import *`, app.py:7-12) works unchanged with
+this directory on sys.path.  Import has no side effects."""
+import os as _os, sys as _sys
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+if _ROOT not in _sys.path:
+    _sys.path.insert(0, _ROOT)
+
 __all__ = ["runner_classification"]
 
 
 def runner_classification(**kw):
-    raise NotImplementedError(
-        "runner_classification: not part of the MI355X U-Net hot path yet (SURVEY.md 8f); "
-        "use holdout_runner_unet_infection_segmentation / runner_lung_segmentation")
+    from covidseg_amd.runners import runner_classification as _impl
+    return _impl(**kw)
 
 
 if __name__ == "__main__":

@@ -41,7 +41,11 @@ class HipUNet:
         self.ctx = _lib.Context.get(self.device_index)
         self.h, self.w, self.in_ch, self.algo = h, w, in_ch, conv_algo
         self.arch = arch                       # "unet" (T1:853-916) or "unetpp" (task1_unet_plus_plus.py:858-950; its dropout
-        self._arch_id = {"unet": _lib.ARCH_UNET, "unetpp": _lib.ARCH_UNETPP}[arch]   # rates .2/.4 are fixed: dropout_rate>0 = on)
+        self._arch_id = {"unet": _lib.ARCH_UNET, "unetpp": _lib.ARCH_UNETPP, "classifier": _lib.ARCH_CLASSIFIER}[arch]   # rates fixed: >0 = on
+        if arch == "classifier":                 # task2_covid19_classifcation.py:747-776; y / p are [n] vectors, loss tensor = (bce, f1)
+            from . import weights as _W
+            _W.set_classifier_input(h, w)
+        self.class_weights = (1.0, 1.0)
         self.pg = process_group
         self.pg_grad = process_group
         self.world = 1
@@ -88,6 +92,8 @@ class HipUNet:
             m = self._create_plan(n)
             need = self.lib.unet_model_workspace_bytes(m, 1)
             self._plans[n] = {"m": m, "bytes": need, "bound_ws": None}
+            if self.arch == "classifier":
+                self.ctx.check(self.lib.unet_model_set_class_weights(m, *self.class_weights), "set_class_weights")
         p = self._plans[n]
         if self._ws is None or self._ws.numel() < p["bytes"]:
             self._ws = torch.empty(p["bytes"], dtype=torch.uint8, device=self.dev)
@@ -128,6 +134,16 @@ class HipUNet:
         g = self.grads.cpu().numpy()
         return OrderedDict((name, g[off:off + cnt].reshape(shape).copy())
                            for name, (st, off, cnt, shape) in self._tinfo.items() if not st)
+
+    def set_class_weights(self, w0: float, w1: float):
+        """Keras class_weight={0: w0, 1: w1} of model.fit (task2_covid19_classifcation.py:835); classifier only."""
+        assert self.arch == "classifier"
+        self.class_weights = (float(w0), float(w1))
+        for p in self._plans.values():
+            self.ctx.check(self.lib.unet_model_set_class_weights(p["m"], *self.class_weights), "set_class_weights")
+
+    def _out_elems(self, n):
+        return n if self.arch == "classifier" else n * self.h * self.w
 
     def reset_optimizer(self):
         self.adam_m.zero_(); self.adam_v.zero_(); self.step = 0
@@ -186,8 +202,9 @@ class HipUNet:
         xd, yd = self._to_dev(x), self._to_dev(y)
         n = xd.shape[0]
         plan = self._plan(n)
-        if not hasattr(self, "_p_train") or self._p_train.numel() != n * self.h * self.w:
-            self._p_train = torch.empty(n * self.h * self.w, dtype=torch.float32, device=self.dev)
+        if not hasattr(self, "_p_train") or self._p_train.numel() != self._out_elems(n):
+            self._p_train = torch.empty(self._out_elems(n), dtype=torch.float32, device=self.dev)
+        assert yd.numel() == self._out_elems(n), (tuple(yd.shape), self._out_elems(n))
         rate = self.dropout_rate if training_dropout else 0.0
         self.ctx.check(self.lib.unet_model_set_dropout(plan["m"], rate, self.seed * 1000003 + self.step), "set_dropout")
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr(), self._p_train.data_ptr()), "set_io")
@@ -217,7 +234,7 @@ class HipUNet:
         xd = self._to_dev(x)
         n = xd.shape[0]
         plan = self._plan(n)
-        p = torch.empty((n, self.h, self.w, 1), dtype=torch.float32, device=self.dev)
+        p = torch.empty((n, 1) if self.arch == "classifier" else (n, self.h, self.w, 1), dtype=torch.float32, device=self.dev)
         yd = self._to_dev(y) if y is not None else None
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr() if yd is not None else None, p.data_ptr()), "set_io")
         self._keep = (xd, yd)

@@ -2,6 +2,7 @@
 
   holdout_runner_unet_infection_segmentation()   task1_preprocessing_plus_unet_with_comments.py:6
   runner_lung_segmentation()                      task3_lung_segmentation_unet.py:6
+  three_/four_fold_runner_unet_infection_segmentation(), holdout_runner_unetplusplus_infection_segmentation(), runner_classification()
 
 Zero positional arguments (app.py:45, 57 call them bare).  Data acquisition (pip / Kaggle /
 Drive, T1:8-136) and NIfTI pre-processing (T1:163-686) are replaced by injectable arrays:
@@ -17,7 +18,7 @@ import os
 
 import numpy as np
 
-from .data import kfold_indices, synthetic_ct, train_test_split
+from .data import kfold_indices, synthetic_classification, synthetic_ct, train_test_split
 from .keras_like import UNetModel
 
 
@@ -196,3 +197,61 @@ def holdout_runner_unetplusplus_infection_segmentation(**kw):
     kw.setdefault("seed", 2)
     return _segmentation_runner("infection_unetpp", "unet_covid_weights_dice_coeff.hdf5", "unet_covid_weights_val_loss.hdf5",
                                 np.arange(0.40, 0.50, 0.001), arch="unetpp", **kw)
+
+
+def runner_classification(data=None, input_size=None, epochs=None, batch_size=None, n_samples=None, seed=3, backend=None, dropout=True,
+                          init_weights=None, workdir=".", verbose=1, honour_array_class_weight=False, **backend_kw):
+    """Task 2 slice classifier (app.py 'five'; task2_covid19_classifcation.py:6): infected / not-infected CT slice.
+    StratifiedShuffleSplit(1, .3, 42) T2:647; CNN T2:747-776; balanced class weights T2:801 (printed; passed to fit as the ndarray the
+    reference passes, which Keras 2.3 ignores -- `honour_array_class_weight=True` applies them); batch 32 / 25 epochs T2:811-812;
+    RocCallback + ModelCheckpoint(val_loss) T2:814-820; best-AUC weights reloaded T2:851; evaluate T2:884; confusion-matrix
+    reports at thresholds 0.50 and 0.81 T2:916-967.  `data=(cts [N,S,S,1], y_label [N])` or env UNET_DATA_NPZ, else synthetic."""
+    from .classifier import ClassifierModel, compute_class_weight_balanced, confusion_report, stratified_shuffle_split
+    size = input_size or _env_int("UNET_SIZE", 224)
+    epochs = epochs if epochs is not None else _env_int("UNET_EPOCHS", 25)
+    batch_size = batch_size or _env_int("UNET_BATCH", 32)
+    n_samples = n_samples or _env_int("UNET_SAMPLES", 64)
+    if data is not None:
+        cts, y_label = data
+    elif os.environ.get("UNET_DATA_NPZ"):
+        z = np.load(os.environ["UNET_DATA_NPZ"]); cts, y_label = z["x"], z["y"]
+    else:
+        cts, y_label = synthetic_classification(n_samples, size, seed)
+    cts = np.asarray(cts, np.float32); y_label = np.asarray(y_label).reshape(-1).astype(np.int64)
+    if cts.ndim == 3:
+        cts = cts[..., None]
+    size = cts.shape[1]
+    print(cts.shape, y_label.shape)                                                                          # T2:512
+    train_index, test_index = stratified_shuffle_split(y_label, 0.3, 42)                                     # T2:647-650
+    x_train, x_valid = cts[train_index], cts[test_index]
+    y_train, y_valid = y_label[train_index], y_label[test_index]
+    print(x_train.shape, x_valid.shape); print(y_train.shape, y_valid.shape)                                 # T2:675-676
+    model = ClassifierModel(size, cts.shape[-1], backend=backend, seed=seed, **backend_kw)                   # T2:747-776
+    model.verbose = verbose
+    if init_weights is not None:
+        model.set_weights(init_weights)
+    if verbose:
+        model.summary()                                                                                      # T2:778
+    weights = compute_class_weight_balanced(y_train)                                                         # T2:801-803
+    print(weights)                                                                                           # T2:804
+    fl, fa = os.path.join(workdir, "covid_weights_val_loss.hdf5"), os.path.join(workdir, "best_val_auc_weights.h5")   # T2:818, 733
+    model.compile(lr=0.0005)                                                                                 # T2:829
+    results = model.fit(x_train, y_train, batch_size=batch_size, epochs=epochs, validation_data=(x_valid, y_valid), class_weight=weights,
+                        honour_array_class_weight=honour_array_class_weight, best_auc_path=fa, checkpoint_loss=fl, dropout=dropout,
+                        shuffle_seed=seed)                                                                   # T2:833-835
+    if os.path.exists(fa):
+        model.load_weights(fa)                                                                               # T2:851
+    with open(os.path.join(workdir, "best_val_auc_weights.json"), "w") as f:                                 # T2:867-869
+        f.write(model.to_json())
+    print("Best saved AUCROC on validation set :", model.best_val_auc)                                       # T2:878
+    score = model.evaluate(x_valid, y_valid, batch_size=32)                                                  # T2:884
+    print("test loss:", score[0], "\ntest f1 score:", score[1])                                              # T2:885
+    predictions = np.array(model.predict(x_valid).flatten())                                                 # T2:910-911
+    out = {"history": results.history, "model": model, "score": score, "predictions": predictions, "y_valid": y_valid,
+           "class_weights": weights, "best_val_auc": model.best_val_auc, "reports": {}}
+    for thr in (0.50, 0.81):                                                                                 # T2:916, 946
+        r = confusion_report(y_valid, predictions, thr)
+        print('Accuracy:', r["accuracy"]); print('Precision:', r["precision"]); print('Recall:', r["recall"])   # T2:936-939
+        print('F1 score:', r["f1"])
+        out["reports"][thr] = r
+    return out

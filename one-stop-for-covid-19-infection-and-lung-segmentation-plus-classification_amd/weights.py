@@ -42,10 +42,31 @@ def _pp_layer_table(in_ch):
     return t
 
 
+CLS_C = (16, 32, 64)            # slice classifier, task2_covid19_classifcation.py:747-776
+CLS_HIDDEN = 32
+_HW = {"hw": (224, 224)}       # input size of the classifier tables (fc1 fan-in = (H/8)(W/8)64); set by set_classifier_input()
+
+
+def set_classifier_input(h: int, w: int):
+    _HW["hw"] = (int(h), int(w))
+
+
+def _cls_layer_table(in_ch):
+    h, w = _HW["hw"]
+    t, cp = [], in_ch
+    for k, c in enumerate(CLS_C, 1):
+        t += [(f"c{k}a", "conv3", cp, c), (f"bn{k}a", "bn", c, c), (f"c{k}b", "conv3", c, c), (f"bn{k}b", "bn", c, c)]
+        cp = c
+    t += [("fc1", "dense", (h // 8) * (w // 8) * CLS_C[-1], CLS_HIDDEN), ("fc2", "dense", CLS_HIDDEN, 1)]
+    return t
+
+
 def layer_table(in_ch: int = 1, arch: str = "unet"):
-    """[(name, kind, cin, cout)], kind in conv3|convT|bn|conv1 -- Keras creation order."""
+    """[(name, kind, cin, cout)], kind in conv3|convT|bn|conv1|dense -- Keras creation order."""
     if arch == "unetpp":
         return _pp_layer_table(in_ch)
+    if arch == "classifier":
+        return _cls_layer_table(in_ch)
     t, cp = [], in_ch
     for k, c in enumerate(ENC, 1):
         t += [(f"c{k}a", "conv3", cp, c), (f"c{k}b", "conv3", c, c), (f"bn{k}", "bn", c, c)]
@@ -68,6 +89,8 @@ def weight_shapes(in_ch: int = 1, arch: str = "unet"):
             d[f"{name}/kernel"] = (1, 1, cin, cout); d[f"{name}/bias"] = (cout,)
         elif kind == "convT":
             d[f"{name}/kernel"] = (2, 2, cout, cin); d[f"{name}/bias"] = (cout,)
+        elif kind == "dense":
+            d[f"{name}/kernel"] = (cin, cout); d[f"{name}/bias"] = (cout,)
         else:
             for p in ("gamma", "beta", "mean", "var"):
                 d[f"{name}/{p}"] = (cout,)
@@ -76,13 +99,16 @@ def weight_shapes(in_ch: int = 1, arch: str = "unet"):
 
 def keras_names(in_ch: int = 1, arch: str = "unet"):
     """our name -> Keras auto-name (conv2d_N/kernel:0 ...), counting per layer type in creation order."""
-    out, nc, nt, nb = OrderedDict(), 0, 0, 0
+    out, nc, nt, nb, nd = OrderedDict(), 0, 0, 0, 0
     for name, kind, _, _ in layer_table(in_ch, arch):
         if kind in ("conv3", "conv1"):
             nc += 1; base = f"conv2d_{nc}"
             out[f"{name}/kernel"] = f"{base}/kernel:0"; out[f"{name}/bias"] = f"{base}/bias:0"
         elif kind == "convT":
             nt += 1; base = f"conv2d_transpose_{nt}"
+            out[f"{name}/kernel"] = f"{base}/kernel:0"; out[f"{name}/bias"] = f"{base}/bias:0"
+        elif kind == "dense":
+            nd += 1; base = f"dense_{nd}"
             out[f"{name}/kernel"] = f"{base}/kernel:0"; out[f"{name}/bias"] = f"{base}/bias:0"
         else:
             nb += 1; base = f"batch_normalization_{nb}"
@@ -124,6 +150,10 @@ def init_weights(seed: int = 0, in_ch: int = 1, arch: str = "unet"):
             else:
                 lim = math.sqrt(6.0 / (cin + cout))
                 w[f"{name}/kernel"] = rng.uniform(-lim, lim, (1, 1, cin, cout)).astype(np.float32)
+            w[f"{name}/bias"] = np.zeros(cout, np.float32)
+        elif kind == "dense":                        # Keras default glorot_uniform (T2:773, 776)
+            lim = math.sqrt(6.0 / (cin + cout))
+            w[f"{name}/kernel"] = rng.uniform(-lim, lim, (cin, cout)).astype(np.float32)
             w[f"{name}/bias"] = np.zeros(cout, np.float32)
         elif kind == "convT":
             lim = math.sqrt(6.0 / (4 * cout + 4 * cin))

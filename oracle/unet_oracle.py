@@ -486,3 +486,167 @@ def pp_loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_
         out["acts"] = {k: v.detach().numpy() for k, v in acts.items()}
         out["act_grads"] = {k: (v.grad.numpy() if v.grad is not None else None) for k, v in acts.items()}
     return out
+
+
+# =======================================================================================
+# Slice classifier, /root/reference/Scripts/task2_covid19_classifcation.py:747-776  (T2)
+#   block k (C=16,32,64): Conv(C,relu,he_normal) -> BN -> Conv(C,relu,he_normal) -> BN -> MaxPool      T2:748-764
+#   Flatten -> Dense(32,relu) -> Dropout(.4) -> Dense(1,sigmoid)                                        T2:772-776
+#   compile(loss='binary_crossentropy', Adam(5e-4), metrics=[f1])  T2:829; f1/precision/recall closures T2:688-703
+#   fit(..., class_weight=weights) T2:833-835: Keras multiplies the per-sample loss by the weight of the sample's class
+#   and averages over the batch (keras/engine/training_utils.py weighted_masked_objective).  NOTE: the reference passes the
+#   ndarray returned by sklearn's compute_class_weight, which Keras 2.3 only honours when it is a dict -- the oracle exposes
+#   the weights as an explicit argument, (1, 1) = what the reference effectively trains with.
+# Same PARITY STATUS as above: third-party Keras semantics restated, "parity unpinned"; f1/precision/recall are the
+# reference's own closures (restated line by line below).
+# =======================================================================================
+CLS_C = [16, 32, 64]
+CLS_HIDDEN = 32
+CLS_DROP = 0.4
+K_EPS = 1e-7
+
+
+def cls_layer_table(in_ch: int = 1, hw=(224, 224)):
+    t, cp = [], in_ch
+    for k, c in enumerate(CLS_C, 1):
+        t += [(f"c{k}a", "conv3", cp, c), (f"bn{k}a", "bn", c, c), (f"c{k}b", "conv3", c, c), (f"bn{k}b", "bn", c, c)]
+        cp = c
+    t += [("fc1", "dense", (hw[0] // 8) * (hw[1] // 8) * CLS_C[-1], CLS_HIDDEN), ("fc2", "dense", CLS_HIDDEN, 1)]
+    return t
+
+
+def cls_weight_shapes(in_ch: int = 1, hw=(224, 224)):
+    d = OrderedDict()
+    for name, kind, cin, cout in cls_layer_table(in_ch, hw):
+        if kind == "conv3":
+            d[f"{name}/kernel"] = (3, 3, cin, cout); d[f"{name}/bias"] = (cout,)
+        elif kind == "dense":
+            d[f"{name}/kernel"] = (cin, cout); d[f"{name}/bias"] = (cout,)
+        else:
+            for p in ("gamma", "beta", "mean", "var"):
+                d[f"{name}/{p}"] = (cout,)
+    return d
+
+
+def cls_trainable_names(in_ch: int = 1, hw=(224, 224)):
+    return [k for k in cls_weight_shapes(in_ch, hw) if not (k.endswith("/mean") or k.endswith("/var"))]
+
+
+def cls_init_weights(seed: int = 0, in_ch: int = 1, hw=(224, 224), dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    w = OrderedDict()
+    for name, shape in cls_weight_shapes(in_ch, hw).items():
+        if name.endswith("/kernel") and len(shape) == 4:            # he_normal (T2:748...)
+            std = math.sqrt(2.0 / (9 * shape[2])) / 0.87962566103423978
+            k = rng.standard_normal(shape); bad = np.abs(k) > 2
+            while bad.any():
+                k[bad] = rng.standard_normal(int(bad.sum())); bad = np.abs(k) > 2
+            w[name] = (k * std).astype(dtype)
+        elif name.endswith("/kernel"):                              # Dense default glorot_uniform
+            lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+            w[name] = rng.uniform(-lim, lim, shape).astype(dtype)
+        elif name.endswith("/gamma") or name.endswith("/var"):
+            w[name] = np.ones(shape, dtype)
+        else:
+            w[name] = np.zeros(shape, dtype)
+    return w
+
+
+def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32, want_acts=False):
+    """keep_mask: None or {0,1} array [n, 32] of the Dropout(0.4) after Dense(32).  Returns (p [n], acts, bn stats)."""
+    W = {k: _t(v, dtype) for k, v in weights.items()}
+    a, stats = OrderedDict(), OrderedDict()
+    h = _t(x, dtype)
+    for k in (1, 2, 3):
+        for ab in "ab":
+            h = conv3x3_bias_relu(h, W[f"c{k}{ab}/kernel"], W[f"c{k}{ab}/bias"]); a[f"c{k}{ab}"] = h
+            nm = f"bn{k}{ab}"
+            src = h
+            h, mu, va = batchnorm(h, W[nm + "/gamma"], W[nm + "/beta"], W[nm + "/mean"], W[nm + "/var"], training)
+            a[nm] = h; stats[nm] = (mu, va, src.shape[0] * src.shape[1] * src.shape[2])
+        h = maxpool2x2(h); a[f"p{k}"] = h
+    flat = h.reshape(h.shape[0], -1)                                  # channels_last Flatten: (i*W + j)*C + c
+    h1 = torch.relu(flat @ W["fc1/kernel"] + W["fc1/bias"])
+    if training and keep_mask is not None:
+        h1 = dropout(h1, _t(keep_mask, dtype), CLS_DROP)
+    a["h1"] = h1
+    p = torch.sigmoid(h1 @ W["fc2/kernel"] + W["fc2/bias"]).reshape(-1)
+    a["out"] = p
+    return (p, a, stats) if want_acts else (p, None, stats)
+
+
+def cls_f1(y_true, y_pred):
+    """f1 / precision / recall of T2:688-703 (K.round = round-half-even, K.epsilon() = 1e-7)."""
+    tp = torch.sum(torch.round(torch.clamp(y_true * y_pred, 0, 1)))
+    possible = torch.sum(torch.round(torch.clamp(y_true, 0, 1)))
+    predicted = torch.sum(torch.round(torch.clamp(y_pred, 0, 1)))
+    precision = tp / (predicted + K_EPS); recall = tp / (possible + K_EPS)
+    return 2 * ((precision * recall) / (precision + recall + K_EPS))
+
+
+def cls_loss(y_true, y_pred, class_weights=(1.0, 1.0)):
+    p = torch.clamp(y_pred, BCE_EPS, 1.0 - BCE_EPS)
+    z = torch.log(p / (1.0 - p))
+    l = torch.clamp(z, min=0) - z * y_true + torch.log1p(torch.exp(-torch.abs(z)))
+    w = torch.where(y_true >= 0.5, torch.as_tensor(class_weights[1], dtype=l.dtype), torch.as_tensor(class_weights[0], dtype=l.dtype))
+    return (l * w).mean()
+
+
+def cls_loss_and_grads(weights, x, y, keep_mask=None, class_weights=(1.0, 1.0), dtype=torch.float32, want_acts=False):
+    xs = np.asarray(x)
+    names = cls_trainable_names(xs.shape[-1], xs.shape[1:3])
+    W = {k: _t(v, dtype).clone() for k, v in weights.items()}
+    for k in names:
+        W[k].requires_grad_(True)
+    p, acts, stats = cls_forward(W, x, training=True, keep_mask=keep_mask, dtype=dtype, want_acts=True)
+    t = _t(np.asarray(y, np.float64).reshape(-1), dtype)
+    loss = cls_loss(t, p, class_weights); f1 = cls_f1(t, p)
+    if want_acts:
+        for v in acts.values():
+            v.retain_grad()
+    loss.backward()
+    out = dict(loss=float(loss.detach()), f1=float(f1.detach()), p=p.detach().numpy(),
+               grads={k: W[k].grad.numpy() for k in names},
+               bn_stats={k: (m.detach().numpy(), v.detach().numpy(), n) for k, (m, v, n) in stats.items()})
+    if want_acts:
+        out["acts"] = {k: v.detach().numpy() for k, v in acts.items()}
+        out["act_grads"] = {k: (v.grad.numpy() if v.grad is not None else None) for k, v in acts.items()}
+    return out
+
+
+class ClsOracleTrainer:
+    """Stateful fwd/bwd/Adam of the classifier on CPU (model.compile + train_on_batch, T2:829-835)."""
+
+    def __init__(self, weights, dtype=torch.float32, class_weights=(1.0, 1.0)):
+        self.w = OrderedDict((k, np.array(v)) for k, v in weights.items())
+        self.dtype, self.cw = dtype, class_weights
+        names = [k for k in self.w if not (k.endswith("/mean") or k.endswith("/var"))]
+        self.m = {k: np.zeros_like(self.w[k]) for k in names}
+        self.v = {k: np.zeros_like(self.w[k]) for k in names}
+        self.t = 0
+
+    def train_step(self, x, y, keep_mask=None):
+        r = cls_loss_and_grads(self.w, x, y, keep_mask, self.cw, self.dtype)
+        for k, (mu, va, n) in r["bn_stats"].items():
+            nm, nv = bn_moving_update(self.w[k + "/mean"], self.w[k + "/var"], mu, va, n)
+            self.w[k + "/mean"] = nm.astype(self.w[k + "/mean"].dtype); self.w[k + "/var"] = nv.astype(self.w[k + "/var"].dtype)
+        self.t += 1
+        adam_keras(self.w, r["grads"], self.m, self.v, self.t)
+        return r["loss"], r["f1"]
+
+    def predict(self, x, batch_size=32):
+        outs = []
+        with torch.no_grad():
+            for i in range(0, len(x), batch_size):
+                outs.append(cls_forward(self.w, x[i:i + batch_size], training=False, dtype=self.dtype)[0].numpy())
+        return np.concatenate(outs, 0)
+
+    def evaluate(self, x, y, batch_size=32):
+        """model.evaluate (T2:884): loss sample-weighted over batches (no class weights at evaluate), f1 = mean of batch values."""
+        ls, fs, ns = [], [], []
+        with torch.no_grad():
+            for i in range(0, len(x), batch_size):
+                p = cls_forward(self.w, x[i:i + batch_size], training=False, dtype=self.dtype)[0]
+                t = _t(np.asarray(y[i:i + batch_size], np.float64).reshape(-1), self.dtype)
+                ls.append(float(cls_loss(t, p))); fs.append(float(cls_f1(t, p))); ns.append(len(p))
+        return dict(loss=float(np.average(ls, weights=ns)), f1=float(np.mean(fs)))

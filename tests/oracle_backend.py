@@ -44,3 +44,47 @@ class OracleBackend:
 
     def threshold_sums(self, p, y, thresholds):
         return O.threshold_sums(y, p, thresholds)
+
+
+class ClsOracleBackend:
+    """Same, for classifier.ClassifierModel (arch "classifier")."""
+
+    def __init__(self, h, w, in_ch=1, dtype=None):
+        import torch
+        self.h, self.w, self.in_ch, self.arch = h, w, in_ch, "classifier"
+        self.dtype = dtype or torch.float32
+        self.lr = O.ADAM_LR
+        self.tr = None
+        self.cw = (1.0, 1.0)
+
+    def set_weights(self, w):
+        if self.tr is None:
+            self.tr = O.ClsOracleTrainer(w, self.dtype)
+        else:
+            for k in self.tr.w:
+                self.tr.w[k] = np.array(w[k], dtype=self.tr.w[k].dtype)
+
+    def get_weights(self):
+        return {k: np.array(v) for k, v in self.tr.w.items()}
+
+    def reset_optimizer(self):
+        for k in self.tr.m:
+            self.tr.m[k][...] = 0; self.tr.v[k][...] = 0
+        self.tr.t = 0
+
+    def set_class_weights(self, w0, w1):
+        self.cw = (float(w0), float(w1))
+
+    def train_batch(self, x, y, training_dropout=True):
+        self.tr.cw = self.cw
+        return np.array(self.tr.train_step(x, y, None))
+
+    def predict_batch(self, x, y=None):
+        import torch
+        with torch.no_grad():
+            p = O.cls_forward(self.tr.w, x, training=False, dtype=self.dtype)[0]
+            ld = None
+            if y is not None:
+                t = torch.as_tensor(np.asarray(y, np.float64).reshape(-1), dtype=self.dtype)
+                ld = np.array([float(O.cls_loss(t, p, self.cw)), float(O.cls_f1(t, p))])
+        return p.numpy().reshape(-1, 1), ld
