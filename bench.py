@@ -47,6 +47,15 @@ def cpu_baseline(size, seconds_budget=25.0, arch="unet"):
             "sample": f"{reps} training step(s) of batch {bs} at {size}x{size}x1 fp32 (torch-CPU oracle, {os.cpu_count()} host cpus visible)"}
 
 
+def _tap_dims(eng, n, name):
+    import ctypes as C
+    from covidseg_amd import _lib
+    plan = eng._plan(n)
+    ptr, ld, nn, hh, ww, cc = _lib.vp(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    eng.ctx.check(eng.lib.unet_model_tap(plan["m"], name.encode(), 0, C.byref(ptr), C.byref(ld), C.byref(nn), C.byref(hh), C.byref(ww), C.byref(cc)), "tap")
+    return ptr.value, ld.value, nn.value, hh.value, ww.value, cc.value
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +144,17 @@ def main():
         dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_dgrad:")]
         dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel
         fl = sum(o[1] for o in dom); ms = sum(o[3] / max(o[4], 1) for o in dom); launches = len(dom)
+        # executed MFMA work: the Winograd F(2,3)-along-x launches do 12 instead of 18 multiplies per pair of outputs
+        shapes = W.weight_shapes(1, args.arch)
+        fl_exec, n_wino = 0.0, 0
+        for o in dom:
+            kind, lname = o[0].split(":")
+            _, _, ci, co = shapes[lname + "/kernel"]
+            if kind == "conv3x3_dgrad":
+                ci, co = co, ci
+            ptr, ld, nn, hh, ww, cc = _tap_dims(eng, B, lname)
+            wino = eng.lib.unet_conv3x3_pick_algo(args.algo, ww, ci, co) == 3
+            fl_exec += o[1] * (2.0 / 3.0 if wino else 1.0); n_wino += int(wino)
         groups = {}
         for name, flops, by, tms, calls in ops:
             k = name.split(":")[0]
@@ -147,8 +167,13 @@ def main():
         if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0:
             traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
-        roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<0,...> (conv3x3 fwd + data-gradient launches)", "achieved": round(achieved, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino_kernel (Winograd F(2,3) along x, {n_wino} launches) / "
+                                           f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)", "achieved": round(achieved, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "executed_tflops": round(fl_exec / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
+                "executed_frac": round(fl_exec / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ms > 0 else 0.0,
+                "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / time; executed_* counts the multiplies the matrix cores really do",
+                "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)", "algorithmic_bytes_per_launch": round(alg_bytes),
                 "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                 "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3),
@@ -169,7 +194,7 @@ def main():
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
                                    + {"unet": "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
-                       "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x2" if args.algo == 0 else "direct",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": {0: "auto: winograd_f23x / mfma_f32_32x32x2", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd_f23x"}[args.algo],
                        "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }

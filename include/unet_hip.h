@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 3
+#define UNET_ABI_VERSION 4
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -35,7 +35,7 @@ typedef struct unet_model unet_model;
 enum { UNET_OK = 0, UNET_E_ARG = -1, UNET_E_HIP = -2, UNET_E_SHAPE = -3, UNET_E_STATE = -4, UNET_E_NODEV = -5 };
 
 /* conv algorithm selector (all are HIP kernels; NAIVE exists as an on-device cross-check) */
-enum { UNET_ALGO_AUTO = 0, UNET_ALGO_NAIVE = 1, UNET_ALGO_MFMA = 2 };
+enum { UNET_ALGO_AUTO = 0, UNET_ALGO_NAIVE = 1, UNET_ALGO_MFMA = 2, UNET_ALGO_WINOGRAD = 3 };   /* 3: F(2,3)-along-x on the MFMA units where the shape allows, else 2 */
 
 int32_t unet_abi_version(void);
 int32_t unet_ctx_create(int32_t device_id, unet_ctx** out);
@@ -56,13 +56,18 @@ enum { UNET_MASK_NONE = 0, UNET_MASK_RELU = 1, UNET_MASK_ELU = 2, UNET_MASK_ELU_
  *   y[n,i,j,o] = act(b[o] + sum_{a,b,c} x[n,i+a-1,j+b-1,c] * w[a,b,c,o]);  w is HWIO.
  * act: 'relu' (U-Net, T1:859) or 'elu' (U-Net++, task1_unet_plus_plus.py:876); drop_rate > 0 fuses the Keras Dropout
  * layer that follows the conv (task1_unet_plus_plus.py:862, 877) into the epilogue (inverted dropout, training only).
+ * w_ws: device scratch of unet_conv3x3_w_ws_floats(cin, cout) floats for transformed weights (Winograd path); may be NULL, then
+ * only the direct algorithms are used.
  * ---------------------------------------------------------------------------------- */
+size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout);
+/* which algorithm a forward / data-gradient launch of this shape resolves to (UNET_ALGO_WINOGRAD, _MFMA or _NAIVE [direct kernels]) */
+int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout);
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
                          int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
-                         int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, void* stream);
+                         int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, float* w_ws, void* stream);
 /* dx = conv3x3(dy, flip/transposed w) * mask_factor(mask_src): the derivative of the activation (+dropout) of the layer
  * that PRODUCED x is fused here (backward of the T1:859-860 conv pairs).  mask_rate/mask_seed: UNET_MASK_ELU_DROP only.
- * wt_ws: 9*cin*cout floats of scratch for the transformed weights. */
+ * wt_ws: unet_conv3x3_w_ws_floats(cin, cout) floats of scratch for the flipped / Winograd-transformed weights. */
 int32_t unet_conv3x3_bwd_data(unet_ctx*, const float* dy, const float* w, const float* mask_src,
                               int32_t mask_mode, float mask_rate, uint64_t mask_seed,
                               float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd,

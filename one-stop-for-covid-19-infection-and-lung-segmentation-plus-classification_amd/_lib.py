@@ -10,9 +10,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
-ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA, ALGO_WINOGRAD = 0, 1, 2, 3
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 MASK_NONE, MASK_RELU, MASK_ELU, MASK_ELU_DROP = 0, 1, 2, 3
@@ -36,7 +36,9 @@ _PROTOS = {
     "unet_ctx_destroy": (None, [vp]),
     "unet_last_error": (C.c_char_p, [vp]),
     "unet_ctx_set_profiling": (i32, [vp, i32]),
-    "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, i32, vp]),
+    "unet_conv3x3_w_ws_floats": (sz, [i32, i32]),
+    "unet_conv3x3_pick_algo": (i32, [i32, i32, i32, i32]),
+    "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, i32, vp, vp]),
     "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, i32, f32, u64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "unet_conv3x3_bwd_weights": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),

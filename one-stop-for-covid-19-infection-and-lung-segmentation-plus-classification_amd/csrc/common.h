@@ -91,6 +91,12 @@ __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep
 // (definitions in the .hip files; all return a unet status code)
 // act: ACT_*; mask_mode: MASK_* (data-gradient epilogue); rate/seed: the fused output dropout (forward) or the dropout
 // of the mask tensor's producer (MASK_ELU_DROP)
+// Winograd F(2,3)-along-x kernels (kernels_conv_wino.hip): u = transformed weights [12][cin'][cout'] in caller scratch
+bool wino_conv3x3_supported(int cin, int cout);
+size_t wino_u_floats(int cin, int cout);
+int32_t k_wino_weights(unet_ctx*, const float* w, float* u, int cin, int cout, int flip, hipStream_t s);
+int32_t k_conv3x3_wino_fwd(unet_ctx*, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n,
+                           int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                             float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 int32_t k_conv3x3_c1_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int n, int h,

@@ -1,0 +1,278 @@
+// 3x3 convolution with the Winograd F(2,3) transform along the image row, on the fp32 matrix cores.
+//
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector rate (157 TFLOP/s), so the 3x3 convolutions of the U-Net are
+// MFMA-bound: the only way below the direct-convolution floor is fewer multiplies.  F(2,3) along x:
+// two adjacent outputs of a row need 4 multiplies per kernel row instead of 6 -> 12 instead of 18 MFMAs per pair of output
+// pixels, 1.5x less matrix work, with +-1 / 0.5 transform coefficients only (fp32 round-off stays ~1e-7 relative; the 2-D
+// F(2x2,3x3) would save 2.25x but needs 16 live accumulator tiles per output tile and leaves no room for register blocking).
+//
+//   tile t of a row = output columns (2t, 2t+1), input columns d0..d3 = 2t-1 .. 2t+2
+//   V_k[t]  : d0-d2, d1+d2, d2-d1, d1-d3                      (input transform, done while staging the LDS patch)
+//   U_k[ky] : g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2              (weight transform, wino_weight_kernel, once per launch)
+//   M_k[t]  = sum_{ky, ci} V_k[row+ky][t][ci] * U_k[ky][ci][co]   -> 12 "taps" (ky, k), each an MFMA GEMM like the direct kernel
+//   out(2t) = M0+M1+M2, out(2t+1) = M1-M2-M3                  (output transform, in registers, in the epilogue)
+//
+// Same skeleton as conv_mfma_kernel: 256 threads = 4 waves, MFMA M-tile = 32 consecutive TILES of one image row (64 output
+// columns), K loop over 8-channel chunks, transformed patch [(TH+2) rows][4][32 tiles][12] and weight slab [12][8][TN] in LDS,
+// k-pairing (lanes 0-31 channel j, 32-63 channel 4+j), register prefetch of the next chunk, quad-transpose 16-byte epilogue.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Branch-free guarded 16-byte load: hardware range checking of the buffer descriptor returns 0 for byte offsets >= the
+// record count, so halo / overhang lanes simply carry the offset OOB (no exec-mask branch, no select).
+constexpr int OOB = (int)0x80000000u;
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+
+constexpr int CK = 8;     // input channels per K chunk
+constexpr int CKP = 12;   // padded channel stride in LDS (floats): conflict-free ds_read_b128
+constexpr int WT = 32;    // Winograd tiles per MFMA M-tile
+
+// u[ky][k][ci][co] (12 x Cin' x Cout') from the Keras kernel w[ky][kx][cin][cout].
+// flip = 0: forward (Cin' = cin, Cout' = cout).  flip = 1: data gradient, the convolution of dy with the flipped/transposed
+// kernel g[ky][kx][c'][o'] = w[2-ky][2-kx][o'][c']  (Cin' = cout, Cout' = cin).
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int flip) {
+  const int ci2 = flip ? cout : cin, co2 = flip ? cin : cout;
+  const int total = 3 * ci2 * co2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int o = i % co2; const int r = i / co2; const int c = r % ci2; const int ky = r / ci2;
+    float g0, g1, g2;
+    if (!flip) {
+      const float* p = w + ((long long)(ky * 3) * cin + c) * cout + o;
+      g0 = p[0]; g1 = p[(long long)cin * cout]; g2 = p[2LL * cin * cout];
+    } else {
+      const float* p = w + ((long long)((2 - ky) * 3) * cin + o) * cout + c;
+      g0 = p[2LL * cin * cout]; g1 = p[(long long)cin * cout]; g2 = p[0];
+    }
+    float* q = u + ((long long)(ky * 4) * ci2 + c) * co2 + o;
+    const long long st = (long long)ci2 * co2;
+    q[0] = g0; q[st] = 0.5f * (g0 + g1 + g2); q[2 * st] = 0.5f * (g0 - g1 + g2); q[3 * st] = g2;
+  }
+}
+
+template <int TN, int TH, int WR, int WC, bool GEN>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                           const float* __restrict__ bias, const float* __restrict__ mask,
+                                                           float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int act,
+                                                           int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y) {
+  static_assert(WR * WC == 4, "4 waves");
+  constexpr int TAPS = 12;
+  constexpr int RW = TH / WR, NW = TN / 32 / WC;
+  constexpr int ROWF = 4 * WT * CKP;                        // floats per transformed patch row
+  constexpr int ITEMS = (TH + 2) * WT * 2;                  // (row, tile, channel quad) staging items
+  constexpr int WTOT = TAPS * CK * (TN / 4);
+  constexpr int PL = (ITEMS + 255) / 256, WL = (WTOT + 255) / 256;
+  static_assert(RW >= 1 && NW >= 1, "tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_v = smem;                                         // [(TH+2)][4][WT][CKP]
+  float* s_u = smem + (TH + 2) * ROWF;                       // [12][CK][TN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; const int n = b / tiles_y;
+  const int x0 = tx * 2 * WT, y0 = ty * TH;
+  const int nbase = blockIdx.y * TN;
+
+  f32x16 acc[RW][NW][4];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.0f;
+
+  // ---- staging plan: item = (patch row r, tile t, channel quad q): 4 input pixels d0..d3 -> 4 transformed values.
+  // Byte offsets into the image / the weight tensor; out-of-image pixels and overhanging channels are OOB (-> 0).
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)n * H * W * Cin), 0, H * W * Cin * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u), 0, 12 * Cin * Cout * 4, 0x00020000);
+  int poff[PL][4], plds[PL];
+#pragma unroll
+  for (int k = 0; k < PL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx & 1, t = (idx >> 1) & (WT - 1), r = idx >> 6;
+    const int gy = y0 + r - 1, gx = x0 + 2 * t - 1;
+    const bool rok = idx < ITEMS && gy >= 0 && gy < H;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) poff[k][d] = (rok && gx + d >= 0 && gx + d < W) ? ((gy * W + gx + d) * Cin + q * 4) * 4 : OOB;
+    plds[k] = idx < ITEMS ? (r * 4 * WT + t) * CKP + q * 4 : -1;
+  }
+  int woff[WL], wlds[WL];
+#pragma unroll
+  for (int k = 0; k < WL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx % (TN / 4), row = idx / (TN / 4);
+    const int tap = row >> 3, ci = row & 7;
+    woff[k] = (idx < WTOT && nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : OOB;
+    wlds[k] = row * TN + q * 4;
+  }
+  f32x4 preg[PL][4], wreg[WL];
+  auto issue_loads = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) preg[k][d] = buf_ld4(rs_x, poff[k][d] + c0 * 4);
+#pragma unroll
+    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_u, woff[k] + c0 * Cout * 4);
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+      if (plds[k] < 0) continue;
+      float* p = s_v + plds[k];
+      *reinterpret_cast<f32x4*>(p) = preg[k][0] - preg[k][2];
+      *reinterpret_cast<f32x4*>(p + WT * CKP) = preg[k][1] + preg[k][2];
+      *reinterpret_cast<f32x4*>(p + 2 * WT * CKP) = preg[k][2] - preg[k][1];
+      *reinterpret_cast<f32x4*>(p + 3 * WT * CKP) = preg[k][1] - preg[k][3];
+    }
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      if (tid + k * 256 >= WTOT) continue;
+      *reinterpret_cast<f32x4*>(&s_u[wlds[k]]) = wreg[k];
+    }
+  };
+
+  issue_loads(0);
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    store_lds();
+    __syncthreads();
+    if (c0 + CK < Cin) issue_loads(c0 + CK);             // next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 a[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+          a[i] = *reinterpret_cast<const f32x4*>(&s_v[(((wr * RW + i + ky) * 4 + k) * WT + l31) * CKP + hi * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float bv[NW];
+#pragma unroll
+          for (int jn = 0; jn < NW; ++jn) bv[jn] = s_u[((ky * 4 + k) * CK + j + 4 * hi) * TN + (wc * NW + jn) * 32 + l31];
+#pragma unroll
+          for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NW; ++jn)
+              acc[i][jn][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], bv[jn], acc[i][jn][k], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: output transform in registers, then the quad transpose of conv_mfma_kernel (MFMA D layout: lane (l31, hi),
+  // register r holds D[tile (r&3)+8*(r>>2)+4*hi][cout l31]) -> every lane owns 4 consecutive couts of one tile -> 16-byte stores
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
+#pragma unroll
+  for (int jn = 0; jn < NW; ++jn) {
+    const int co = nbase + (wc * NW + jn) * 32 + q4;
+    const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int py = y0 + wr * RW + i;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float m0 = acc[i][jn][0][4 * g + r], m1 = acc[i][jn][1][4 * g + r], m2 = acc[i][jn][2][4 * g + r], m3 = acc[i][jn][3][4 * g + r];
+            v[r] = half == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+          }
+          float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+          {
+            const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+            const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
+            if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
+          }
+          {
+            const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+            const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
+            if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
+          }
+          const int px = x0 + 2 * (e + 8 * g + 4 * hi) + half;
+          if (py >= H || px >= W || co >= Cout) continue;
+          float4 o4 = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
+          const long long o = (((long long)n * H + py) * W + px) * Cout + co;
+          if (!GEN) {
+            if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
+            if (mask_mode == MASK_RELU) {
+              const float4 m = *reinterpret_cast<const float4*>(mask + o);
+              o4.x = m.x > 0.f ? o4.x : 0.f; o4.y = m.y > 0.f ? o4.y : 0.f; o4.z = m.z > 0.f ? o4.z : 0.f; o4.w = m.w > 0.f ? o4.w : 0.f;
+            }
+          } else {
+            o4.x = apply_act(o4.x, act); o4.y = apply_act(o4.y, act); o4.z = apply_act(o4.z, act); o4.w = apply_act(o4.w, act);
+            if (mask_mode == MASK_NONE) {
+              if (rate > 0.0f) { const float4 ks = keep_scale(o >> 2, rate, seed); o4.x *= ks.x; o4.y *= ks.y; o4.z *= ks.z; o4.w *= ks.w; }
+            } else {
+              const float4 m = *reinterpret_cast<const float4*>(mask + o);
+              float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
+              if (mask_mode == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
+              o4.x *= mask_factor(m.x, mask_mode, ks.x, rate); o4.y *= mask_factor(m.y, mask_mode, ks.y, rate);
+              o4.z *= mask_factor(m.z, mask_mode, ks.z, rate); o4.w *= mask_factor(m.w, mask_mode, ks.w, rate);
+            }
+          }
+          *reinterpret_cast<float4*>(y + o) = o4;
+        }
+      }
+    }
+  }
+}
+
+template <int TN, int TH, int WR, int WC>
+int32_t launch_wino(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n, int h,
+                    int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
+  if (!mask) mask_mode = MASK_NONE;
+  const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
+  const dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)((cout + TN - 1) / TN));
+  constexpr size_t lds = (size_t)((TH + 2) * 4 * WT * CKP + 12 * CK * TN) * sizeof(float);
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
+  static bool attr_done = false;                     // > 64 KiB of dynamic LDS needs the opt-in (per kernel instance; set both)
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<TN, TH, WR, WC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<TN, TH, WR, WC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino: cannot reserve %zu bytes of LDS", lds);
+    attr_done = true;
+  }
+  if (gen) hipLaunchKernelGGL((conv_wino_kernel<TN, TH, WR, WC, true>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+  else hipLaunchKernelGGL((conv_wino_kernel<TN, TH, WR, WC, false>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+  UNET_CHECK_LAUNCH(ctx, "conv_wino");
+  return UNET_OK;
+}
+
+}  // namespace
+
+bool wino_conv3x3_supported(int cin, int cout) { return cin >= CK && (cin % CK) == 0 && cout >= 4 && (cout % 4) == 0; }
+size_t wino_u_floats(int cin, int cout) { return (size_t)12 * cin * cout; }
+
+int32_t k_wino_weights(unet_ctx* ctx, const float* w, float* u, int cin, int cout, int flip, hipStream_t s) {
+  const long long total = 3LL * cin * cout;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, w, u, cin, cout, flip);
+  UNET_CHECK_LAUNCH(ctx, "wino_weights");
+  return UNET_OK;
+}
+
+// x [n,h,wd,cin] dense NHWC, u = transformed weights [12][cin][cout] (k_wino_weights), y [n,h,wd,cout]
+int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n,
+                           int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s) {
+  if (!wino_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: cin=%d cout=%d unsupported", cin, cout);
+  if (cout % 64 == 0) return launch_wino<64, 4, 2, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+  return launch_wino<32, 8, 4, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+}

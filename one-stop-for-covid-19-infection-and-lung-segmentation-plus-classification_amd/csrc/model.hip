@@ -53,9 +53,34 @@ static bool use_mfma(int algo, int cin, int cout) {
   return mfma_conv3x3_supported(cin, cout);
 }
 
+// Winograd pays when its 64-column row tiles are reasonably full; `uws` = scratch for the transformed weights (may be null)
+static bool use_wino(int algo, int wd, int cin, int cout, const float* uws) {
+  if (!uws || !wino_conv3x3_supported(cin, cout)) return false;
+  if (algo == UNET_ALGO_WINOGRAD) return true;
+  if (algo != UNET_ALGO_AUTO) return false;
+  static const int enabled = [] { const char* e = getenv("UNET_WINO"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
+  if (!enabled) return false;
+  // 1.5x fewer MFMAs, but its row tiles are 64 columns wide (the direct kernel's 32): compare how full the last tile is
+  const double uw = (double)wd / (64.0 * ((wd + 63) / 64)), ud = (double)wd / (32.0 * ((wd + 31) / 32));
+  return 1.5 * uw >= 1.15 * ud;
+}
+
+// `w` are Keras-layout weights [3][3][cin][cout] when flip == 0; for the data gradient (flip == 1) the caller passes the FORWARD
+// weights [3][3][cout][cin] of the layer and the roles of cin/cout below are already swapped (cin = channels of dy).
 static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                                     float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, int algo,
-                                    hipStream_t s) {
+                                    hipStream_t s, float* uws = nullptr, int flip = 0) {
+  if (use_wino(algo, wd, cin, cout, uws)) {
+    int32_t r = flip ? k_wino_weights(ctx, w, uws, cout, cin, 1, s) : k_wino_weights(ctx, w, uws, cin, cout, 0, s);
+    if (r) return r;
+    return k_conv3x3_wino_fwd(ctx, x, uws, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+  }
+  if (flip) {                                   // direct algorithms want the flipped/transposed copy
+    int32_t r = k_flip_transpose_w3x3(ctx, w, uws, cout, cin, s);
+    if (r) return r;
+    w = uws;
+  }
+  if (algo == UNET_ALGO_WINOGRAD) algo = UNET_ALGO_AUTO;
   if (algo == UNET_ALGO_MFMA && !mfma_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 mfma: cin=%d cout=%d unsupported", cin, cout);
   if (use_mfma(algo, cin, cout)) return k_conv3x3_mfma_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   if (cin == 1 && !mask && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0)
@@ -77,11 +102,21 @@ extern "C" {
 
 int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t h,
                          int32_t wd, int32_t cin, int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo,
-                         void* stream) {
+                         float* w_ws, void* stream) {
   if (!ctx || !x || !w || !y || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || act < 0 || act > 2 || drop_rate < 0 || drop_rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: bad args");
-  return conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, algo, as_stream(stream));
+  if (algo == UNET_ALGO_WINOGRAD && !w_ws) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: the Winograd path needs w_ws (unet_conv3x3_w_ws_floats)");
+  return conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, algo, as_stream(stream), w_ws, 0);
 }
+
+int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout) {
+  static float dummy;
+  if (use_wino(algo, wd, cin, cout, &dummy)) return UNET_ALGO_WINOGRAD;
+  if (algo != UNET_ALGO_NAIVE && mfma_conv3x3_supported(cin, cout)) return UNET_ALGO_MFMA;
+  return UNET_ALGO_NAIVE;
+}
+
+size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return (size_t)12 * (cin > 0 ? cin : 0) * (cout > 0 ? cout : 0); }
 
 int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* mask_src, int32_t mask_mode, float mask_rate,
                               uint64_t mask_seed, float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
@@ -89,11 +124,9 @@ int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, co
   if (!ctx || !dy || !w || !dx || !wt_ws || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || mask_mode < 0 || mask_mode > 3 ||
       (mask_mode != MASK_NONE && !mask_src) || mask_rate < 0 || mask_rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data: bad args");
-  int32_t r = k_flip_transpose_w3x3(ctx, w, wt_ws, cin, cout, as_stream(stream));
-  if (r) return r;
-  // data gradient = 3x3 convolution of dy (cout channels) with wt -> cin channels
-  return conv3x3_fwd_dispatch(ctx, dy, wt_ws, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
-                              as_stream(stream));
+  // data gradient = 3x3 convolution of dy (cout channels) with the flipped/transposed kernel -> cin channels
+  return conv3x3_fwd_dispatch(ctx, dy, w, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
+                              as_stream(stream), wt_ws, 1);
 }
 
 size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
@@ -287,8 +320,9 @@ void plan_workspace(unet_model* m) {
     m->act["c" + ks + "a"] = mk(cv, N, S, T, c);
     m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
   }
+  { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)12 * l.cin * l.cout); m->off_wt = cv.take(wt); }   // transformed-weight scratch
   m->ws_floats_infer = cv.cur;
-  // --- training extras: gradient twins + weight scratch ---
+  // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
     const std::string& nm = kv.first; const Buf& b = kv.second;
     if (nm.rfind("cat", 0) == 0) {
@@ -308,11 +342,9 @@ void plan_workspace(unet_model* m) {
       m->grad[nm] = mk(cv, b.n, b.h, b.w, b.c);
     }
   }
-  size_t wt = 0, wgb = 0;
+  size_t wgb = 0;
   int S2 = m->H, T2 = m->W;
   (void)S2; (void)T2;
-  for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)9 * l.cin * l.cout);
-  m->off_wt = cv.take(wt);
   // wgrad split-K workspace: max over conv layers at their spatial sizes
   {
     int s = m->H, t = m->W, idx = 0;
@@ -369,7 +401,7 @@ void build_programs(unet_model* m) {
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
         const float* xin = in.empty() ? m->x : m->A(in);
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
-                                    ACT_RELU, 0.0f, 0, algo, s);
+                                    ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0);
       });
     };
     auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c, bool fuse_pool) {
@@ -608,7 +640,7 @@ void plan_workspace_pp(unet_model* m) {
     m->act[nm + "a"] = mk(cv, N, hh, ww, nd.c); m->act[nm + "abn"] = mk(cv, N, hh, ww, nd.c);
     m->act[nm + "b"] = mk(cv, N, hh, ww, nd.c); m->act[nm] = mk(cv, N, hh, ww, nd.c); m->act[nm + "bbn"] = m->act[nm];
   }
-  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)9 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)12 * l.cin * l.cout);
   m->off_wt = cv.take(wt0);
   m->ws_floats_infer = cv.cur;
   // ---- training: one dense gradient twin per activation buffer (aliases share it)
@@ -658,7 +690,7 @@ void build_programs_pp(unet_model* m) {
         const float* xin = in.empty() ? m->x : m->A(in);
         const float r = (tr && m->drop_rate > 0.0f) ? rate : 0.0f;
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
-                                    ACT_ELU, r, m->drop_seed + sd, algo, s);
+                                    ACT_ELU, r, m->drop_seed + sd, algo, s, m->wsf(m->off_wt), 0);
       });
     };
     // BN: stats -> [sync] -> finalize -> apply (or apply fused with the 2x2 pool when `pool` names the pooled output)
@@ -883,7 +915,7 @@ void plan_workspace_cls(unet_model* m) {
   const int K = hh * ww * CLS_C[2];
   m->dense_ws_bytes = unet_dense_ws_bytes(N, K, CLS_HIDDEN);
   m->off_dense_ws = cv.take((m->dense_ws_bytes + 3) / 4);
-  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)9 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)12 * l.cin * l.cout);
   m->off_wt = cv.take(wt0);
   m->ws_floats_infer = cv.cur;
   for (auto& kv : m->act) { const Buf& b = kv.second; m->grad[kv.first] = mk(cv, b.n, b.h, b.w, b.c); }
@@ -914,7 +946,7 @@ void build_programs_cls(unet_model* m) {
       ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
         const float* xin = in.empty() ? m->x : m->A(in);
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
-                                    ACT_RELU, 0.0f, 0, algo, s);
+                                    ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0);
       });
     };
     auto bn = [&](const std::string& name, const std::string& in, int c, const std::string& pool) {

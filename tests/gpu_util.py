@@ -23,6 +23,12 @@ class Ops:
             torch.cuda.synchronize(); del self._keep[:128]
         return t
 
+    def wws(self, cin, cout):
+        """device scratch for transformed conv weights (unet_conv3x3_w_ws_floats)"""
+        t = torch.empty(max(int(self.lib.unet_conv3x3_w_ws_floats(cin, cout)), 4), dtype=torch.float32, device="cuda")
+        self._keep.append(t)
+        return t.data_ptr()
+
     def z(self, *shape, dtype=torch.float32):
         return torch.zeros(shape, dtype=dtype, device="cuda")
 

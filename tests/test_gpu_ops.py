@@ -23,10 +23,12 @@ def T64(a):
 CONV_SHAPES = [(2, 9, 13, 3, 5), (1, 16, 16, 1, 32), (2, 16, 16, 32, 32), (2, 12, 20, 32, 64), (1, 8, 8, 64, 128),
                (2, 6, 10, 128, 64), (1, 4, 4, 256, 512), (3, 14, 14, 64, 64), (1, 34, 70, 32, 32), (2, 64, 48, 1, 32), (1, 9, 13, 1, 32), (2, 4, 3, 512, 512),
                # channel counts that are not multiples of 32 (the classifier's 16-wide layers, T2:748-750): tiles overhang
-               (2, 16, 16, 16, 16), (1, 12, 20, 16, 32), (2, 8, 8, 32, 16), (1, 10, 10, 24, 80), (1, 8, 8, 8, 48), (2, 16, 16, 1, 16)]
+               (2, 16, 16, 16, 16), (1, 12, 20, 16, 32), (2, 8, 8, 32, 16), (1, 10, 10, 24, 80), (1, 8, 8, 8, 48), (2, 16, 16, 1, 16),
+               # wide rows: several 64-column Winograd tiles, ragged right edge, odd width
+               (1, 6, 128, 32, 64), (2, 5, 150, 16, 32), (1, 9, 67, 64, 128), (1, 3, 64, 8, 8)]
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 3])
 @pytest.mark.parametrize("shape", CONV_SHAPES)
 def test_conv3x3_fwd(ops, shape, algo):
     from gpu_util import relerr
@@ -36,12 +38,12 @@ def test_conv3x3_fwd(ops, shape, algo):
     b = rng.standard_normal(co).astype(np.float32)
     for relu in (1, 0):
         y = ops.z(n, h, w, co)
-        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, relu, 0.0, 0, algo, ops.s), "conv fwd")
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, relu, 0.0, 0, algo, ops.wws(ci, co), ops.s), "conv fwd")
         want = O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=bool(relu)).numpy()
         assert relerr(y.cpu().numpy(), want) < TOL
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 3])
 @pytest.mark.parametrize("shape", CONV_SHAPES)
 def test_conv3x3_bwd(ops, shape, algo):
     from gpu_util import relerr
@@ -54,7 +56,7 @@ def test_conv3x3_bwd(ops, shape, algo):
     O.conv3x3_bias_relu(xt, kt, bt, relu=False).backward(T64(dy))
     # data gradient, with and without the fused ReLU mask of the producer of x
     for masked in (False, True):
-        dx = ops.z(n, h, w, ci); wt = ops.z(9 * ci * co)
+        dx = ops.z(n, h, w, ci); wt = ops.z(12 * ci * co)
         xm = ops.d(x)
         ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), xm.data_ptr() if masked else None, 1 if masked else 0, 0.0, 0, dx.data_ptr(), wt.data_ptr(),
                                              n, h, w, ci, co, algo, ops.s), "conv bwd data")
@@ -284,12 +286,12 @@ def test_conv3x3_elu_dropout_and_mask_modes(ops, shape, algo):
     b = rng.standard_normal(co).astype(np.float32)
     want = torch.nn.functional.elu(O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=False)).numpy()
     y0 = ops.z(n, h, w, co)
-    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y0.data_ptr(), n, h, w, ci, co, 2, 0.0, 0, algo, ops.s), "elu")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y0.data_ptr(), n, h, w, ci, co, 2, 0.0, 0, algo, ops.wws(ci, co), ops.s), "elu")
     assert relerr(y0.cpu().numpy(), want) < TOL
     rate, seed = 0.4, 4242
     yd = ops.z(n, h, w, co); yn = ops.z(n, h, w, co)
-    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), yd.data_ptr(), n, h, w, ci, co, 2, rate, seed, algo, ops.s), "elu+drop")
-    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), yn.data_ptr(), n, h, w, ci, co, 2, rate, seed, 1, ops.s), "elu+drop direct")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), yd.data_ptr(), n, h, w, ci, co, 2, rate, seed, algo, ops.wws(ci, co), ops.s), "elu+drop")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), yn.data_ptr(), n, h, w, ci, co, 2, rate, seed, 1, None, ops.s), "elu+drop direct")
     d = yd.cpu().numpy(); keep = d != 0
     assert abs(keep.mean() - 0.6) < 0.05 and relerr(d, want * keep / 0.6) < TOL
     assert ((yn.cpu().numpy() != 0) == keep).all()                        # MFMA / direct / Cin=1 kernels share one mask stream
@@ -301,12 +303,12 @@ def test_conv3x3_elu_dropout_and_mask_modes(ops, shape, algo):
     xt, kt = T64(a).requires_grad_(True), T64(k)
     O.conv3x3_bias_relu(xt, kt, torch.zeros(co, dtype=torch.float64), relu=False).backward(T64(dy))
     g = xt.grad.numpy(); elup = np.where(a > 0, 1.0, a + 1.0)
-    wt = ops.z(9 * ci * co); dx = ops.z(n, h, w, ci)
+    wt = ops.z(12 * ci * co); dx = ops.z(n, h, w, ci)
     ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), ops.d(a).data_ptr(), 2, 0.0, 0, dx.data_ptr(), wt.data_ptr(), n, h, w, ci, co, algo, ops.s), "mask elu")
     assert relerr(dx.cpu().numpy(), g * elup) < TOL
     ones = np.ones((n, h, w, ci), np.float32); km = ops.z(n, h, w, ci)           # keep mask of (rate, seed) on this tensor shape
     ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(np.zeros((n, h, w, 8), np.float32)).data_ptr(), ops.d(np.zeros((3, 3, 8, ci), np.float32)).data_ptr(),
-                                    ops.d(ones[0, 0, 0]).data_ptr(), km.data_ptr(), n, h, w, 8, ci, 0, rate, seed, 1, ops.s), "mask probe")
+                                    ops.d(ones[0, 0, 0]).data_ptr(), km.data_ptr(), n, h, w, 8, ci, 0, rate, seed, 1, None, ops.s), "mask probe")
     keep_in = km.cpu().numpy() != 0
     stored = (a * keep_in / 0.6).astype(np.float32)
     ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), ops.d(stored).data_ptr(), 3, rate, seed, dx.data_ptr(), wt.data_ptr(), n, h, w, ci, co, algo, ops.s), "mask elu+drop")

@@ -11,11 +11,11 @@ out = []
 for name, n, h, w, ci, co in shapes:
     x = torch.randn(n, h, w, ci, device="cuda"); k = torch.randn(3, 3, ci, co, device="cuda") * 0.05; b = torch.zeros(co, device="cuda"); y = torch.empty(n, h, w, co, device="cuda")
     for _ in range(2):
-        ctx.check(lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, s))
+        ctx.check(lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, None, s))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, s)
+        lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, None, s)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     out.append(f"{name}:{2*9*ci*co*n*h*w/ms/1e9:6.1f}TF")

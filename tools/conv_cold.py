@@ -19,7 +19,7 @@ for relu_like in (0, 1):
             for _ in range(4):
                 if flush: junk.add_(1.0)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, s); e1.record()
+                e0.record(); lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, None, s); e1.record()
                 torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
             ms = sorted(ts)[1]
             res.append(f"{2*9*ci*co*n*h*w/ms/1e9:6.1f}")

@@ -22,7 +22,7 @@ def timeit(xp, kp, bp, yp, n, h, w, ci, co):
     ts = []
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); lib.unet_conv3x3_fwd(ctx.handle, xp, kp, bp, yp, n, h, w, ci, co, 1, 0.0, 0, 0, s); e1.record(); torch.cuda.synchronize()
+        e0.record(); lib.unet_conv3x3_fwd(ctx.handle, xp, kp, bp, yp, n, h, w, ci, co, 1, 0.0, 0, 0, None, s); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     return sorted(ts)[2]
 for lname, inp in (("c5b", "c5a"), ("c6a", "bn6"), ("c4b", "c4a"), ("c3b", "c3a")):
