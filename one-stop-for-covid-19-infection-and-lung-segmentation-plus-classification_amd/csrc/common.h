@@ -45,6 +45,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Branch-free guarded 16-byte load: the hardware range check of a buffer descriptor returns 0 for byte offsets >= the record
+// count, so halo / overhang lanes simply carry an out-of-range offset (no exec-mask branch, no select).  Tensors addressed this
+// way must be smaller than 1 GiB (COL_OOB + a valid row offset must still be out of range).
+typedef float unet_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned unet_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int UNET_OOB = (int)0x80000000u;        // invalid element (or row)
+constexpr int UNET_COL_OOB = 0x40000000;          // invalid column part, may be added to a valid or invalid row part
+__device__ __forceinline__ unet_f32x4 buf_ld4(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(unet_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+
 // Philox-4x32-10 counter RNG (dropout keep-mask): counter = element-quad index, key = seed.
 __device__ __forceinline__ uint4 philox4x32(uint64_t ctr, uint64_t seed) {
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
@@ -93,6 +107,8 @@ __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep
 // of the mask tensor's producer (MASK_ELU_DROP)
 // Winograd F(2,3)-along-x kernels (kernels_conv_wino.hip): u = transformed weights [12][cin'][cout'] in caller scratch
 bool wino_conv3x3_supported(int cin, int cout);
+int32_t k_conv3x3_wino_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
+                             int cin, int cout, hipStream_t s);      // kernels_conv_mfma.hip (shares the split-K machinery)
 size_t wino_u_floats(int cin, int cout);
 int32_t k_wino_weights(unet_ctx*, const float* w, float* u, int cin, int cout, int flip, hipStream_t s);
 int32_t k_conv3x3_wino_fwd(unet_ctx*, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n,

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     else if (MODE == 1) { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); lp = pix; }
     else { const int rr = pix >> 6, cc = pix & 63; gy = 2 * y0 + rr; gx = 2 * x0 + cc; lp = (rr * 2 + (cc & 1)) * 32 + (cc >> 1); }
     const bool ok = idx < PTOT && gy >= 0 && gy < HI && gx >= 0 && gx < WI;
-    poff[k] = ok ? (gy * WI + gx) * ldx + q * 4 : -1;
+    poff[k] = ok ? ((gy * WI + gx) * ldx + q * 4) * 4 : UNET_OOB;           // byte offset into image n; halo -> out of range -> 0
     plds[k] = idx < PTOT ? lp * CKP + q * 4 : -1;
   }
   int woff[WL], wlds[WL];
@@ -94,23 +94,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     const int idx = tid + k * 256;
     if (MODE == 1) {
       const int half = idx & 1, nn = idx >> 1;
-      woff[k] = (idx < WTOT && nbase + nn < Cout) ? (nbase + nn) * Cin + half * 4 : -1;     // Keras ConvT kernel [ab][o][c]: row nn holds Cin floats
+      woff[k] = (idx < WTOT && nbase + nn < Cout) ? ((nbase + nn) * Cin + half * 4) * 4 : UNET_OOB;     // Keras ConvT kernel [ab][o][c]: row nn holds Cin floats
       wlds[k] = half * 4 * TN + nn;
     } else {
       const int q = idx % (TN / 4), row = idx / (TN / 4);
       const int tap = row >> 3, ci = row & 7;
-      woff[k] = (idx < WTOT && nbase + q * 4 < Cout) ? (tap * Cin + ci) * Cout + nbase + q * 4 : -1;   // tile may overhang Cout (zero fill)
+      woff[k] = (idx < WTOT && nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : UNET_OOB;   // tile may overhang Cout (zero fill)
       wlds[k] = row * TN + q * 4;
     }
   }
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xn, (long long)HI * WI * ldx * 4);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(w, (long long)TAPS * Cin * Cout * 4);      // MODE 1: Cout = 4 x ConvT channels, TAPS = 1
   f32x4 preg[PL], wreg[WL];
-  auto issue_loads = [&](int c0) __attribute__((always_inline)) {                 // all global loads of a chunk in flight before any wait
+  auto issue_loads = [&](int c0) __attribute__((always_inline)) {                 // all global loads of a chunk in flight before any wait;
+#pragma unroll                                                                    // branch-free: invalid lanes read out of range -> 0
+    for (int k = 0; k < PL; ++k) preg[k] = buf_ld4(rs_x, poff[k] + c0 * 4);
 #pragma unroll
-    for (int k = 0; k < PL; ++k)
-      preg[k] = poff[k] >= 0 ? *reinterpret_cast<const f32x4*>(xn + poff[k] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < WL; ++k)
-      wreg[k] = woff[k] >= 0 ? *reinterpret_cast<const f32x4*>(w + woff[k] + (MODE == 1 ? c0 : c0 * Cout)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_w, woff[k] + (MODE == 1 ? c0 : c0 * Cout) * 4);
   };
   auto store_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -294,10 +294,14 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
                                                         float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
                                                         int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
                                                         int chunks_per_strip) {
-  constexpr int TAPS = MODE == 0 ? 9 : 4;
+  // MODE 2 = conv3x3 with the Winograd F(2,3)-along-x transform (see kernels_conv_wino.hip): same data movement as MODE 0, but per
+  // pair of output columns 4 products per kernel row instead of 6 -> 12 accumulator tiles dU[ky][k] instead of 9 dW[ky][kx];
+  // dU_k[ky][ci][co] = sum V_k[y+ky][t][ci] * dM_k[y][t][co] with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the X row and
+  // dM = (dy0, dy0+dy1, dy0-dy1, -dy1) of the dY row, both formed in registers from the raw LDS rows.
+  constexpr int TAPS = MODE == 0 ? 9 : (MODE == 1 ? 4 : 12);
   constexpr int ROWF = 34 * 32;                    // floats per ring row (conv3x3)
-  constexpr int AL = MODE == 0 ? 5 : 16, BL = 4;   // float4 staging registers per lane (A rows, B row)
-  __shared__ __attribute__((aligned(16))) float s_a[MODE == 0 ? 3 * ROWF : 4 * 32 * 32];
+  constexpr int AL = MODE != 1 ? 5 : 16, BL = 4;   // float4 staging registers per lane (A rows, B row)
+  __shared__ __attribute__((aligned(16))) float s_a[MODE != 1 ? 3 * ROWF : 4 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_b[32 * 32];
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
   const int ta = blockIdx.x / tiles_b, tb = blockIdx.x % tiles_b;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   float bsum = 0.0f;
 
-  const int HA = MODE == 0 ? H : 2 * H, WA = MODE == 0 ? W : 2 * W;
+  const int HA = MODE != 1 ? H : 2 * H, WA = MODE != 1 ? W : 2 * W;
   const float* An = A + (long long)n * HA * WA * ldA;
   const float* Bn = B + (long long)n * H * W * ldB;
 
@@ -325,61 +329,83 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < AL; ++k) {
     const int idx = lane + 64 * k;
-    if (MODE == 0) {
+    if (MODE != 1) {
       const int pix = idx >> 3, q = idx & 7; const int gx = x0 - 1 + pix;
-      aoff[k] = (idx < 34 * 8 && gx >= 0 && gx < W && a0 + q * 4 < CA) ? gx * ldA + a0 + q * 4 : -1;
+      aoff[k] = (idx < 34 * 8 && gx >= 0 && gx < W && a0 + q * 4 < CA) ? (gx * ldA + a0 + q * 4) * 4 : UNET_COL_OOB;
       alds[k] = idx < 34 * 8 ? pix * 32 + q * 4 : -1;
     } else {
       const int q = idx & 7; const int cc = (idx >> 3) & 63; const int a = idx >> 9;   // a = row parity of dU
       const int gx = 2 * x0 + cc;
-      aoff[k] = (gx < WA && a0 + q * 4 < CA) ? (a * WA + gx) * ldA + a0 + q * 4 : -1;
+      aoff[k] = (gx < WA && a0 + q * 4 < CA) ? ((a * WA + gx) * ldA + a0 + q * 4) * 4 : UNET_COL_OOB;
       alds[k] = (((a * 2 + (cc & 1)) * 32) + (cc >> 1)) * 32 + q * 4;
     }
   }
 #pragma unroll
   for (int k = 0; k < BL; ++k) {
     const int idx = lane + 64 * k; const int pix = idx >> 3, q = idx & 7; const int gx = x0 + pix;
-    boff[k] = (gx < W && b0 + q * 4 < CB) ? gx * ldB + b0 + q * 4 : -1;
+    boff[k] = (gx < W && b0 + q * 4 < CB) ? (gx * ldB + b0 + q * 4) * 4 : UNET_COL_OOB;
     blds[k] = pix * 32 + q * 4;
   }
   f32x4 areg[AL], breg[BL];            // ext-vector type: stays in registers (a float4 struct select goes through scratch)
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  // MODE 0 step t handles ring row yy = ya-1+t (X row yy and dY row yy-1); MODE 1 step t handles row y = ya+t
-  const int nsteps = MODE == 0 ? (yb - ya + 2) : (yb - ya);
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(An, (long long)HA * WA * ldA * 4), rs_b = make_rsrc(Bn, (long long)H * W * ldB * 4);
+  // MODE 0 step t handles ring row yy = ya-1+t (X row yy and dY row yy-1); MODE 1 step t handles row y = ya+t.
+  // Branch-free: rows outside the image / the chunk and columns outside the strip carry out-of-range byte offsets -> 0.
+  const int nsteps = MODE != 1 ? (yb - ya + 2) : (yb - ya);
   auto issue = [&](int t) __attribute__((always_inline)) {
-    if (MODE == 0) {
+    if (MODE != 1) {
       const int yy = ya - 1 + t, yd = yy - 1;
-      const bool okx = yy >= 0 && yy < H, okd = yd >= ya && yd < yb;
-      const float* ar = An + (long long)yy * W * ldA; const float* br = Bn + (long long)yd * W * ldB;
+      const int ra = (yy >= 0 && yy < H) ? yy * W * ldA * 4 : UNET_OOB, rb = (yd >= ya && yd < yb) ? yd * W * ldB * 4 : UNET_OOB;
 #pragma unroll
-      for (int k = 0; k < AL; ++k) areg[k] = (okx && aoff[k] >= 0) ? *reinterpret_cast<const f32x4*>(ar + aoff[k]) : z4;
+      for (int k = 0; k < AL; ++k) areg[k] = buf_ld4(rs_a, aoff[k] + ra);
 #pragma unroll
-      for (int k = 0; k < BL; ++k) breg[k] = (okd && boff[k] >= 0) ? *reinterpret_cast<const f32x4*>(br + boff[k]) : z4;
+      for (int k = 0; k < BL; ++k) breg[k] = buf_ld4(rs_b, boff[k] + rb);
     } else {
       const int yrow = ya + t;
-      const float* ar = An + (long long)(2 * yrow) * WA * ldA; const float* br = Bn + (long long)yrow * W * ldB;
+      const int ra = 2 * yrow * WA * ldA * 4, rb = yrow * W * ldB * 4;
 #pragma unroll
-      for (int k = 0; k < AL; ++k) areg[k] = aoff[k] >= 0 ? *reinterpret_cast<const f32x4*>(ar + aoff[k]) : z4;
+      for (int k = 0; k < AL; ++k) areg[k] = buf_ld4(rs_a, aoff[k] + ra);
 #pragma unroll
-      for (int k = 0; k < BL; ++k) breg[k] = boff[k] >= 0 ? *reinterpret_cast<const f32x4*>(br + boff[k]) : z4;
+      for (int k = 0; k < BL; ++k) breg[k] = buf_ld4(rs_b, boff[k] + rb);
     }
   };
 
-  issue(0);
+  // MODE 2 carries 192 accumulator registers: the next-row register prefetch would spill, so it loads at the top of the step and
+  // leaves the latency to the second wave of the SIMD (UNET_WGRAD2_PF=1 compiles the prefetching variant back in for experiments)
+  constexpr bool PFW = MODE != 2;
+  if (PFW) issue(0);
   for (int t = 0; t < nsteps; ++t) {
-    const int yy = ya - 1 + t;                                  // MODE 0 only
-    const int slot_w = MODE == 0 ? ((yy + 3) % 3) * ROWF : 0;
+    if (!PFW) issue(t);
+    const int yy = ya - 1 + t;                                  // conv3x3 only
+    const int slot_w = MODE != 1 ? ((yy + 3) % 3) * ROWF : 0;
 #pragma unroll
     for (int k = 0; k < AL; ++k)
       if (alds[k] >= 0) *reinterpret_cast<f32x4*>(&s_a[slot_w + alds[k]]) = areg[k];
 #pragma unroll
     for (int k = 0; k < BL; ++k) *reinterpret_cast<f32x4*>(&s_b[blds[k]]) = breg[k];
     __syncthreads();
-    if (t + 1 < nsteps) issue(t + 1);                            // next row's loads fly under this row's MFMAs
+    if (PFW && t + 1 < nsteps) issue(t + 1);                     // next row's loads fly under this row's MFMAs
     if (MODE == 1 || t >= 2) {
       int slot_off[3];
 #pragma unroll
       for (int dr = 0; dr < 3; ++dr) slot_off[dr] = ((yy - 2 + dr + 3) % 3) * ROWF;   // rows y-1, y, y+1 with y = yy-1
+      if (MODE == 2) {
+#pragma unroll 2
+        for (int pp = 0; pp < 8; ++pp) {
+          const int tt = 2 * pp + hi;                             // MFMA k-pair = 2 consecutive Winograd tiles of the strip
+          const float dy0 = s_b[(2 * tt) * 32 + l31], dy1 = s_b[(2 * tt + 1) * 32 + l31];
+          bsum += dy0 + dy1;
+          const float bm0 = dy0, bm1 = dy0 + dy1, bm2 = dy0 - dy1, bm3 = -dy1;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const float* r = &s_a[slot_off[ky] + (2 * tt) * 32 + l31];    // ring px index 0 <-> column x0-1: d_j = px 2tt+j
+            const float d0 = r[0], d1 = r[32], d2 = r[64], d3 = r[96];
+            acc[(ky * 4 + 0) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0 - d2, bm0, acc[(ky * 4 + 0) % TAPS], 0, 0, 0);
+            acc[(ky * 4 + 1) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 + d2, bm1, acc[(ky * 4 + 1) % TAPS], 0, 0, 0);
+            acc[(ky * 4 + 2) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2 - d1, bm2, acc[(ky * 4 + 2) % TAPS], 0, 0, 0);
+            acc[(ky * 4 + 3) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 - d3, bm3, acc[(ky * 4 + 3) % TAPS], 0, 0, 0);
+          }
+        }
+      } else
 #pragma unroll 2
       for (int pp = 0; pp < 16; ++pp) {
         const int c = 2 * pp + hi;
@@ -421,7 +447,7 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
       if (a0 + i < CA && b0 + q4 < CB) *reinterpret_cast<float4*>(&P[((long long)t * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
     }
   bsum += __shfl_xor(bsum, 32, 64);
-  if (MODE == 0) { if (ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * CB + b0 + l31] = bsum; }
+  if (MODE != 1) { if (ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * CB + b0 + l31] = bsum; }
   else { if (tb == 0 && lane < 32 && a0 + l31 < CA) part_b[(long long)split * CA + a0 + l31] = bsum; }
 }
 
@@ -449,6 +475,23 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
     }
     s0.x += s1.x + (s2.x + s3.x); s0.y += s1.y + (s2.y + s3.y); s0.z += s1.z + (s2.z + s3.z); s0.w += s1.w + (s2.w + s3.w);
     *reinterpret_cast<float4*>(out + (long long)blockIdx.y * out_stride + i * 4) = s0;
+  }
+}
+
+// dW[ky][kx] from the reduced Winograd-domain gradient dU[ky][k] (transpose of the weight transform G):
+//   dg0 = dU0 + (dU1+dU2)/2,  dg1 = (dU1-dU2)/2,  dg2 = (dU1+dU2)/2 + dU3
+__global__ __launch_bounds__(256) void wino_wgrad_finalize_kernel(const float* __restrict__ du, float* __restrict__ dw, int n4 /* ca*cb/4 */) {
+  const long long st = (long long)n4 * 4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * n4; i += gridDim.x * 256) {
+    const int ky = i / n4, j = i - ky * n4;
+    const float* p = du + (long long)ky * 4 * st + (long long)j * 4;
+    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + st);
+    const float4 u2 = *reinterpret_cast<const float4*>(p + 2 * st), u3 = *reinterpret_cast<const float4*>(p + 3 * st);
+    float* q = dw + (long long)ky * 3 * st + (long long)j * 4;
+    const float4 hs = make_float4(0.5f * (u1.x + u2.x), 0.5f * (u1.y + u2.y), 0.5f * (u1.z + u2.z), 0.5f * (u1.w + u2.w));
+    *reinterpret_cast<float4*>(q) = make_float4(u0.x + hs.x, u0.y + hs.y, u0.z + hs.z, u0.w + hs.w);
+    *reinterpret_cast<float4*>(q + st) = make_float4(0.5f * (u1.x - u2.x), 0.5f * (u1.y - u2.y), 0.5f * (u1.z - u2.z), 0.5f * (u1.w - u2.w));
+    *reinterpret_cast<float4*>(q + 2 * st) = make_float4(hs.x + u3.x, hs.y + u3.y, hs.z + u3.z, hs.w + u3.w);
   }
 }
 
@@ -484,11 +527,14 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
 template <int MODE>
 int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ldB, float* dw, float* db, void* ws, size_t ws_bytes, int n,
                   int h, int w, int ca, int cb, hipStream_t s) {
-  const int taps = MODE == 0 ? 9 : 4; const int cbias = MODE == 0 ? cb : ca;
+  const int taps = MODE == 0 ? 9 : (MODE == 1 ? 4 : 12); const int cbias = MODE != 1 ? cb : ca;
   const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias);
-  const size_t need = (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
+  const size_t du_floats = MODE == 2 ? (size_t)12 * ca * cb : 0;            // reduced Winograd-domain gradient, before the 12 -> 9 transform
+  const size_t need = (p.part_floats + p.bias_floats + p.part2_floats + du_floats) * sizeof(float);
   if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   float* part = static_cast<float*>(ws); float* part_b = part + p.part_floats;
+  float* dw_final = dw;
+  if (MODE == 2) dw = part_b + p.bias_floats + p.part2_floats;
   hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, dim3((unsigned)(p.tiles_a * p.tiles_b), (unsigned)p.nsplit), dim3(64), 0, s, A, ldA, B, ldB, part,
                      part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip);
   UNET_CHECK_LAUNCH(ctx, "wgrad_mfma");
@@ -503,6 +549,10 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
   } else {
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, 1), dim3(256), 0, s, part, dw, per / 4, per, p.nsplit, p.nsplit, 0LL);
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(1, 1), dim3(256), 0, s, part_b, db, (long long)cbias / 4, (long long)cbias, p.nsplit, p.nsplit, 0LL);
+  }
+  if (MODE == 2) {
+    const int n4 = ca * cb / 4;
+    hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3((unsigned)std::min(2048, (3 * n4 + 255) / 256)), dim3(256), 0, s, dw, dw_final, n4);
   }
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
@@ -541,10 +591,16 @@ int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float
   return launch_conv<2, 32, 4, 4, 1>(ctx, dy, lddy, w, nullptr, mask, mm, dx, cin, n, h, wd, cout, cin, ACT_NONE, 0.0f, 0, s);
 }
 
-size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {
+size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // large enough for the direct AND the Winograd form
   if (!mfma_wgrad_supported(cin, cout)) return 0;
-  const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout);
-  return (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
+  const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout), q = plan_wgrad(12, n, h, wd, cin, cout, cout);
+  return std::max((p.part_floats + p.bias_floats + p.part2_floats), (q.part_floats + q.bias_floats + q.part2_floats + (size_t)12 * cin * cout)) * sizeof(float);
+}
+
+int32_t k_conv3x3_wino_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
+                             int wd, int cin, int cout, hipStream_t s) {
+  if (!mfma_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad winograd: cin=%d cout=%d unsupported", cin, cout);
+  return run_wgrad<2>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
 }
 
 int32_t k_conv3x3_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,

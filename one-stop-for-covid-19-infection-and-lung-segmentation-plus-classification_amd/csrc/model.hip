@@ -90,8 +90,11 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
 
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
                                       size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
-  if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout))
+  if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout)) {
+    static const int wino = [] { const char* e = getenv("UNET_WINO_WGRAD"); return e ? atoi(e) : 1; }();      // A/B switch for measurements
+    if (algo == UNET_ALGO_WINOGRAD || (algo == UNET_ALGO_AUTO && wino)) return k_conv3x3_wino_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
+  }
   if (algo == UNET_ALGO_MFMA) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 wgrad mfma: unsupported shape or workspace too small");
   if (cin == 1 && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0 && cout <= 256 && ws && ws_bytes >= c1_wgrad_ws_bytes(cout))
     return k_conv3x3_c1_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cout, s);
