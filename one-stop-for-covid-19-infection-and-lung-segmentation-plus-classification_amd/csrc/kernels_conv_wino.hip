@@ -33,22 +33,40 @@ constexpr int WT = 32;    // Winograd tiles per MFMA M-tile
 // u[ky][k][ci][co] (12 x Cin' x Cout') from the Keras kernel w[ky][kx][cin][cout].
 // flip = 0: forward (Cin' = cin, Cout' = cout).  flip = 1: data gradient, the convolution of dy with the flipped/transposed
 // kernel g[ky][kx][c'][o'] = w[2-ky][2-kx][o'][c']  (Cin' = cout, Cout' = cin).
-__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int flip) {
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int flip, int two_d) {
   const int ci2 = flip ? cout : cin, co2 = flip ? cin : cout;
-  const int total = 3 * ci2 * co2;
+  const int total = ci2 * co2;
+  const long long st = (long long)ci2 * co2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int o = i % co2; const int r = i / co2; const int c = r % ci2; const int ky = r / ci2;
-    float g0, g1, g2;
-    if (!flip) {
-      const float* p = w + ((long long)(ky * 3) * cin + c) * cout + o;
-      g0 = p[0]; g1 = p[(long long)cin * cout]; g2 = p[2LL * cin * cout];
-    } else {
-      const float* p = w + ((long long)((2 - ky) * 3) * cin + o) * cout + c;
-      g0 = p[2LL * cin * cout]; g1 = p[(long long)cin * cout]; g2 = p[0];
+    const int o = i % co2; const int c = i / co2;
+    float u1[3][4];                                    // x-transformed rows ky = 0..2
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      float g0, g1, g2;
+      if (!flip) {
+        const float* p = w + ((long long)(ky * 3) * cin + c) * cout + o;
+        g0 = p[0]; g1 = p[(long long)cin * cout]; g2 = p[2LL * cin * cout];
+      } else {
+        const float* p = w + ((long long)((2 - ky) * 3) * cin + o) * cout + c;
+        g0 = p[2LL * cin * cout]; g1 = p[(long long)cin * cout]; g2 = p[0];
+      }
+      u1[ky][0] = g0; u1[ky][1] = 0.5f * (g0 + g1 + g2); u1[ky][2] = 0.5f * (g0 - g1 + g2); u1[ky][3] = g2;
     }
-    float* q = u + ((long long)(ky * 4) * ci2 + c) * co2 + o;
-    const long long st = (long long)ci2 * co2;
-    q[0] = g0; q[st] = 0.5f * (g0 + g1 + g2); q[2 * st] = 0.5f * (g0 - g1 + g2); q[3 * st] = g2;
+    float* q = u + (long long)c * co2 + o;
+    if (!two_d) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[(ky * 4 + k) * st] = u1[ky][k];
+    } else {                                           // the same transform once more along ky: 4 x 4 taps
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        q[(0 * 4 + k) * st] = u1[0][k];
+        q[(1 * 4 + k) * st] = 0.5f * (u1[0][k] + u1[1][k] + u1[2][k]);
+        q[(2 * 4 + k) * st] = 0.5f * (u1[0][k] - u1[1][k] + u1[2][k]);
+        q[(3 * 4 + k) * st] = u1[2][k];
+      }
+    }
   }
 }
 
@@ -228,6 +246,218 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// F(2x2,3x3): the same transform along y as well -> 16 instead of 24 MFMAs per 2x2 output tile (direct: 36).  The 16
+// accumulator tiles M[ky'][k] of a (row pair x 32 tiles x 32 couts) tile are split between TWO waves by ky' (kh = 0: ky' 0,1;
+// kh = 1: ky' 2,3 -> 128 accumulator registers each); the y-transform of the input is done at operand-read time from the
+// x-transformed LDS rows (R0 = V0-V2, R1 = V1+V2, R2 = V2-V1, R3 = V1-V3: one extra ds_read_b128 + 4 subtractions per operand);
+// the output transform needs both halves: out(row 0) = M0+M1+M2, out(row 1) = M1-M2-M3, so the two waves swap one partial
+// each through LDS in the epilogue (kh = 0 finishes row 0, kh = 1 row 1).  Waves = 2 (kh) x WM (row pairs) x WC (cout tiles).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WM, int WC, bool GEN>
+__global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                             const float* __restrict__ bias, const float* __restrict__ mask,
+                                                             float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int act,
+                                                             int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y) {
+  static_assert(WM * WC == 2, "4 waves = 2 x WM x WC");
+  constexpr int TAPS = 16, TH = 2 * WM, TN = 32 * WC;
+  constexpr int ROWF = 4 * WT * CKP;
+  constexpr int ITEMS = (TH + 2) * WT * 2;
+  constexpr int WTOT = TAPS * CK * (TN / 4);
+  constexpr int PL = (ITEMS + 255) / 256, WL = (WTOT + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_v = smem;                                         // [(TH+2)][4][WT][CKP]  x-transformed patch rows
+  float* s_u = smem + (TH + 2) * ROWF;                       // [16][CK][TN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int kh = wave & 1, wm = (wave >> 1) / WC, wc = (wave >> 1) % WC;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; const int n = b / tiles_y;
+  const int x0 = tx * 2 * WT, y0 = ty * TH;
+  const int nbase = blockIdx.y * TN;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x + (long long)n * H * W * Cin, (long long)H * W * Cin * 4);
+  const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(u, 16LL * Cin * Cout * 4);
+  int poff[PL][4], plds[PL];
+#pragma unroll
+  for (int k = 0; k < PL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx & 1, t = (idx >> 1) & (WT - 1), r = idx >> 6;
+    const int gy = y0 + r - 1, gx = x0 + 2 * t - 1;
+    const bool rok = idx < ITEMS && gy >= 0 && gy < H;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) poff[k][d] = (rok && gx + d >= 0 && gx + d < W) ? ((gy * W + gx + d) * Cin + q * 4) * 4 : OOB;
+    plds[k] = idx < ITEMS ? (r * 4 * WT + t) * CKP + q * 4 : -1;
+  }
+  int woff[WL], wlds[WL];
+#pragma unroll
+  for (int k = 0; k < WL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx % (TN / 4), row = idx / (TN / 4);
+    const int tap = row >> 3, ci = row & 7;
+    woff[k] = (idx < WTOT && nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : OOB;
+    wlds[k] = row * TN + q * 4;
+  }
+  f32x4 preg[PL][4], wreg[WL];
+  auto issue_loads = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) preg[k][d] = buf_ld4(rs_x, poff[k][d] + c0 * 4);
+#pragma unroll
+    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_u, woff[k] + c0 * Cout * 4);
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+      if (plds[k] < 0) continue;
+      float* p = s_v + plds[k];
+      *reinterpret_cast<f32x4*>(p) = preg[k][0] - preg[k][2];
+      *reinterpret_cast<f32x4*>(p + WT * CKP) = preg[k][1] + preg[k][2];
+      *reinterpret_cast<f32x4*>(p + 2 * WT * CKP) = preg[k][2] - preg[k][1];
+      *reinterpret_cast<f32x4*>(p + 3 * WT * CKP) = preg[k][1] - preg[k][3];
+    }
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      if (tid + k * 256 >= WTOT) continue;
+      *reinterpret_cast<f32x4*>(&s_u[wlds[k]]) = wreg[k];
+    }
+  };
+
+  issue_loads(0);
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    store_lds();
+    __syncthreads();
+    if (c0 + CK < Cin) issue_loads(c0 + CK);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // patch rows of this wave's row pair: kh = 0 needs rows 0,1,2 (R0 = r0-r2, R1 = r1+r2); kh = 1 rows 1,2,3 (R2 = r2-r1, R3 = r1-r3)
+      const float* vb = &s_v[((2 * wm * 4 + k) * WT + l31) * CKP + hi * 4];
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(vb + 1 * ROWF), r2 = *reinterpret_cast<const f32x4*>(vb + 2 * ROWF);
+      const f32x4 re = *reinterpret_cast<const f32x4*>(vb + (kh ? 3 : 0) * ROWF);
+      f32x4 a[2];
+      if (kh == 0) { a[0] = re - r2; a[1] = r1 + r2; } else { a[0] = r2 - r1; a[1] = r1 - re; }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float bv = s_u[(((2 * kh + kk) * 4 + k) * CK + j + 4 * hi) * TN + wc * 32 + l31];
+          acc[kk][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][j], bv, acc[kk][k], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  x-direction output transform per accumulator pair, then the y-direction combination across the two waves.
+  //   T[kk][half] = half 0: m0+m1+m2, half 1: m1-m2-m3 (over k).   kh=0 holds M0,M1: row0 partial T0+T1, row1 partial T1.
+  //   kh=1 holds M2,M3: row0 partial T0 (= M2), row1 partial -(T0+T1).   Each wave keeps the partial of ITS output row (row kh)
+  //   and sends the other one to its partner (wave ^ 1) through LDS (the operand buffers are dead after the last barrier).
+  float* xb = smem + wave * (32 * 64);                       // this wave's outbox: [32 values][64 lanes]
+  const float* pb = smem + (wave ^ 1) * (32 * 64);
+  f32x16 mine[2];                                            // [half]
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float t[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const float m0 = acc[kk][0][r], m1 = acc[kk][1][r], m2 = acc[kk][2][r], m3 = acc[kk][3][r];
+        t[kk] = half == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+      }
+      float keep, send;
+      if (kh == 0) { keep = t[0] + t[1]; send = t[1]; } else { keep = -(t[0] + t[1]); send = t[0]; }
+      mine[half][r] = keep;
+      xb[(half * 16 + r) * 64 + lane] = send;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[half][r] += pb[(half * 16 + r) * 64 + lane];
+
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
+  const int co = nbase + wc * 32 + q4;
+  const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int py = y0 + 2 * wm + kh;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float v0 = mine[half][4 * g + 0], v1 = mine[half][4 * g + 1], v2 = mine[half][4 * g + 2], v3 = mine[half][4 * g + 3];
+      {
+        const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+        const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
+        if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
+      }
+      {
+        const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+        const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
+        if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
+      }
+      const int px = x0 + 2 * (e + 8 * g + 4 * hi) + half;
+      if (py >= H || px >= W || co >= Cout) continue;
+      float4 o4 = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
+      const long long o = (((long long)n * H + py) * W + px) * Cout + co;
+      if (!GEN) {
+        if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
+        if (mask_mode == MASK_RELU) {
+          const float4 m = *reinterpret_cast<const float4*>(mask + o);
+          o4.x = m.x > 0.f ? o4.x : 0.f; o4.y = m.y > 0.f ? o4.y : 0.f; o4.z = m.z > 0.f ? o4.z : 0.f; o4.w = m.w > 0.f ? o4.w : 0.f;
+        }
+      } else {
+        o4.x = apply_act(o4.x, act); o4.y = apply_act(o4.y, act); o4.z = apply_act(o4.z, act); o4.w = apply_act(o4.w, act);
+        if (mask_mode == MASK_NONE) {
+          if (rate > 0.0f) { const float4 ks = keep_scale(o >> 2, rate, seed); o4.x *= ks.x; o4.y *= ks.y; o4.z *= ks.z; o4.w *= ks.w; }
+        } else {
+          const float4 m = *reinterpret_cast<const float4*>(mask + o);
+          float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (mask_mode == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
+          o4.x *= mask_factor(m.x, mask_mode, ks.x, rate); o4.y *= mask_factor(m.y, mask_mode, ks.y, rate);
+          o4.z *= mask_factor(m.z, mask_mode, ks.z, rate); o4.w *= mask_factor(m.w, mask_mode, ks.w, rate);
+        }
+      }
+      *reinterpret_cast<float4*>(y + o) = o4;
+    }
+  }
+}
+
+template <int WM, int WC>
+int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n, int h,
+                      int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
+  if (!mask) mask_mode = MASK_NONE;
+  constexpr int TH = 2 * WM, TN = 32 * WC;
+  const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
+  const dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)((cout + TN - 1) / TN));
+  constexpr size_t lds = (size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float);
+  static_assert(lds >= 4 * 32 * 64 * sizeof(float), "the epilogue exchange reuses the operand buffers");
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %zu bytes of LDS", lds);
+    attr_done = true;
+  }
+  if (gen) hipLaunchKernelGGL((conv_wino2d_kernel<WM, WC, true>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+  else hipLaunchKernelGGL((conv_wino2d_kernel<WM, WC, false>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+  UNET_CHECK_LAUNCH(ctx, "conv_wino2d");
+  return UNET_OK;
+}
+
 template <int TN, int TH, int WR, int WC>
 int32_t launch_wino(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n, int h,
                     int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
@@ -252,19 +482,31 @@ int32_t launch_wino(unet_ctx* ctx, const float* x, const float* u, const float* 
 }  // namespace
 
 bool wino_conv3x3_supported(int cin, int cout) { return cin >= CK && (cin % CK) == 0 && cout >= 4 && (cout % 4) == 0; }
-size_t wino_u_floats(int cin, int cout) { return (size_t)12 * cin * cout; }
+size_t wino_u_floats(int cin, int cout) { return (size_t)16 * cin * cout; }
 
-int32_t k_wino_weights(unet_ctx* ctx, const float* w, float* u, int cin, int cout, int flip, hipStream_t s) {
-  const long long total = 3LL * cin * cout;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, w, u, cin, cout, flip);
+inline int wino_2d_mode() {          // UNET_WINO2D: 0 = F(2,3) along x only, 1 (default) = F(2x2,3x3) where the shape allows
+  static const int v = [] { const char* e = getenv("UNET_WINO2D"); return e ? atoi(e) : 1; }();
+  return v;
+}
+static bool use_2d(int h, int cout) { return wino_2d_mode() && h >= 2 && cout % 32 == 0; }
+
+// transformed weights for k_conv3x3_wino_fwd on an image of `h` rows (the 2-D form is picked per shape, both sides must agree)
+int32_t k_wino_weights(unet_ctx* ctx, const float* w, float* u, int cin, int cout, int flip, int h, hipStream_t s) {
+  const long long total = (long long)cin * cout;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, w, u, cin, cout, flip,
+                     use_2d(h, flip ? cin : cout) ? 1 : 0);
   UNET_CHECK_LAUNCH(ctx, "wino_weights");
   return UNET_OK;
 }
 
-// x [n,h,wd,cin] dense NHWC, u = transformed weights [12][cin][cout] (k_wino_weights), y [n,h,wd,cout]
+// x [n,h,wd,cin] dense NHWC, u = transformed weights [12 or 16][cin][cout] (k_wino_weights with the same h), y [n,h,wd,cout]
 int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n,
                            int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   if (!wino_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: cin=%d cout=%d unsupported", cin, cout);
+  if (use_2d(h, cout)) {
+    if (cout % 64 == 0) return launch_wino2d<1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+    return launch_wino2d<2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+  }
   // One image row per wave (64 accumulator registers) -> 3 workgroups per CU: occupancy pays more than sharing the weight operand
   // between two rows did (the <64,4,2,2> / <32,8,4,1> tiles measured 1-8 % slower on every U-Net layer).
   if (cout % 64 == 0) return launch_wino<64, 2, 2, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);

@@ -71,7 +71,7 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
                                     float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, int algo,
                                     hipStream_t s, float* uws = nullptr, int flip = 0) {
   if (use_wino(algo, wd, cin, cout, uws)) {
-    int32_t r = flip ? k_wino_weights(ctx, w, uws, cout, cin, 1, s) : k_wino_weights(ctx, w, uws, cin, cout, 0, s);
+    int32_t r = flip ? k_wino_weights(ctx, w, uws, cout, cin, 1, h, s) : k_wino_weights(ctx, w, uws, cin, cout, 0, h, s);
     if (r) return r;
     return k_conv3x3_wino_fwd(ctx, x, uws, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   }
@@ -119,7 +119,7 @@ int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t co
   return UNET_ALGO_NAIVE;
 }
 
-size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return (size_t)12 * (cin > 0 ? cin : 0) * (cout > 0 ? cout : 0); }
+size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return (size_t)16 * (cin > 0 ? cin : 0) * (cout > 0 ? cout : 0); }
 
 int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* mask_src, int32_t mask_mode, float mask_rate,
                               uint64_t mask_seed, float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
@@ -323,7 +323,7 @@ void plan_workspace(unet_model* m) {
     m->act["c" + ks + "a"] = mk(cv, N, S, T, c);
     m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
   }
-  { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)12 * l.cin * l.cout); m->off_wt = cv.take(wt); }   // transformed-weight scratch
+  { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)16 * l.cin * l.cout); m->off_wt = cv.take(wt); }   // transformed-weight scratch
   m->ws_floats_infer = cv.cur;
   // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
@@ -643,7 +643,7 @@ void plan_workspace_pp(unet_model* m) {
     m->act[nm + "a"] = mk(cv, N, hh, ww, nd.c); m->act[nm + "abn"] = mk(cv, N, hh, ww, nd.c);
     m->act[nm + "b"] = mk(cv, N, hh, ww, nd.c); m->act[nm] = mk(cv, N, hh, ww, nd.c); m->act[nm + "bbn"] = m->act[nm];
   }
-  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)12 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)16 * l.cin * l.cout);
   m->off_wt = cv.take(wt0);
   m->ws_floats_infer = cv.cur;
   // ---- training: one dense gradient twin per activation buffer (aliases share it)
@@ -918,7 +918,7 @@ void plan_workspace_cls(unet_model* m) {
   const int K = hh * ww * CLS_C[2];
   m->dense_ws_bytes = unet_dense_ws_bytes(N, K, CLS_HIDDEN);
   m->off_dense_ws = cv.take((m->dense_ws_bytes + 3) / 4);
-  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)12 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)16 * l.cin * l.cout);
   m->off_wt = cv.take(wt0);
   m->ws_floats_infer = cv.cur;
   for (auto& kv : m->act) { const Buf& b = kv.second; m->grad[kv.first] = mk(cv, b.n, b.h, b.w, b.c); }

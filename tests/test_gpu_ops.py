@@ -56,7 +56,7 @@ def test_conv3x3_bwd(ops, shape, algo):
     O.conv3x3_bias_relu(xt, kt, bt, relu=False).backward(T64(dy))
     # data gradient, with and without the fused ReLU mask of the producer of x
     for masked in (False, True):
-        dx = ops.z(n, h, w, ci); wt = ops.z(12 * ci * co)
+        dx = ops.z(n, h, w, ci); wt = ops.z(16 * ci * co)
         xm = ops.d(x)
         ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), xm.data_ptr() if masked else None, 1 if masked else 0, 0.0, 0, dx.data_ptr(), wt.data_ptr(),
                                              n, h, w, ci, co, algo, ops.s), "conv bwd data")
@@ -303,7 +303,7 @@ def test_conv3x3_elu_dropout_and_mask_modes(ops, shape, algo):
     xt, kt = T64(a).requires_grad_(True), T64(k)
     O.conv3x3_bias_relu(xt, kt, torch.zeros(co, dtype=torch.float64), relu=False).backward(T64(dy))
     g = xt.grad.numpy(); elup = np.where(a > 0, 1.0, a + 1.0)
-    wt = ops.z(12 * ci * co); dx = ops.z(n, h, w, ci)
+    wt = ops.z(16 * ci * co); dx = ops.z(n, h, w, ci)
     ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), ops.d(a).data_ptr(), 2, 0.0, 0, dx.data_ptr(), wt.data_ptr(), n, h, w, ci, co, algo, ops.s), "mask elu")
     assert relerr(dx.cpu().numpy(), g * elup) < TOL
     ones = np.ones((n, h, w, ci), np.float32); km = ops.z(n, h, w, ci)           # keep mask of (rate, seed) on this tensor shape
