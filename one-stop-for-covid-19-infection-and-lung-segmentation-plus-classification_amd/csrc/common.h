@@ -52,8 +52,10 @@ typedef float unet_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned unet_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int UNET_OOB = (int)0x80000000u;        // invalid element (or row)
 constexpr int UNET_COL_OOB = 0x40000000;          // invalid column part, may be added to a valid or invalid row part
-__device__ __forceinline__ unet_f32x4 buf_ld4(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-  return __builtin_bit_cast(unet_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+// `soff` = wave-uniform byte offset (an SGPR operand of the instruction: no per-lane add; it does not bring an out-of-range lane
+// back in range, the per-lane offset alone is already >= the record count)
+__device__ __forceinline__ unet_f32x4 buf_ld4(__amdgpu_buffer_rsrc_t rs, int byte_off, int soff = 0) {
+  return __builtin_bit_cast(unet_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, soff, 0));
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);

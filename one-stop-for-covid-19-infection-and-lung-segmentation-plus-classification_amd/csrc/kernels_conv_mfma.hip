@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float s_in[NPIX * CKP];
   __shared__ __attribute__((aligned(16))) float s_w[TAPS * CK * TN];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, and the compiler is told so (scalar address math)
   const int l31 = lane & 31, hi = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
   int b = blockIdx.x;
@@ -108,9 +109,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
   f32x4 preg[PL], wreg[WL];
   auto issue_loads = [&](int c0) __attribute__((always_inline)) {                 // all global loads of a chunk in flight before any wait;
 #pragma unroll                                                                    // branch-free: invalid lanes read out of range -> 0
-    for (int k = 0; k < PL; ++k) preg[k] = buf_ld4(rs_x, poff[k] + c0 * 4);
+    for (int k = 0; k < PL; ++k) preg[k] = buf_ld4(rs_x, poff[k], c0 * 4);
 #pragma unroll
-    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_w, woff[k] + (MODE == 1 ? c0 : c0 * Cout) * 4);
+    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_w, woff[k], (MODE == 1 ? c0 : c0 * Cout) * 4);
   };
   auto store_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
   float* s_v = smem;                                         // [(TH+2)][4][WT][CKP]
   float* s_u = smem + (TH + 2) * ROWF;                       // [12][CK][TN]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, and the compiler is told so (scalar address math)
   const int l31 = lane & 31, hi = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
   int b = blockIdx.x;
@@ -113,21 +114,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
   int poff[PL][4], plds[PL];
 #pragma unroll
   for (int k = 0; k < PL; ++k) {
-    const int idx = tid + k * 256;
+    const int idx = min(tid + k * 256, ITEMS - 1);      // surplus threads redo the last item (same data, same slot): no branch in the loop
     const int q = idx & 1, t = (idx >> 1) & (WT - 1), r = idx >> 6;
     const int gy = y0 + r - 1, gx = x0 + 2 * t - 1;
-    const bool rok = idx < ITEMS && gy >= 0 && gy < H;
+    const bool rok = gy >= 0 && gy < H;
 #pragma unroll
     for (int d = 0; d < 4; ++d) poff[k][d] = (rok && gx + d >= 0 && gx + d < W) ? ((gy * W + gx + d) * Cin + q * 4) * 4 : OOB;
-    plds[k] = idx < ITEMS ? (r * 4 * WT + t) * CKP + q * 4 : -1;
+    plds[k] = (r * 4 * WT + t) * CKP + q * 4;
   }
   int woff[WL], wlds[WL];
 #pragma unroll
   for (int k = 0; k < WL; ++k) {
-    const int idx = tid + k * 256;
+    const int idx = min(tid + k * 256, WTOT - 1);
     const int q = idx % (TN / 4), row = idx / (TN / 4);
     const int tap = row >> 3, ci = row & 7;
-    woff[k] = (idx < WTOT && nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : OOB;
+    woff[k] = (nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : OOB;
     wlds[k] = row * TN + q * 4;
   }
   f32x4 preg[PL][4], wreg[WL];
@@ -135,23 +136,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < PL; ++k)
 #pragma unroll
-      for (int d = 0; d < 4; ++d) preg[k][d] = buf_ld4(rs_x, poff[k][d] + c0 * 4);
+      for (int d = 0; d < 4; ++d) preg[k][d] = buf_ld4(rs_x, poff[k][d], c0 * 4);
 #pragma unroll
-    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_u, woff[k] + c0 * Cout * 4);
+    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_u, woff[k], c0 * Cout * 4);
   };
   auto store_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < PL; ++k) {
-      if (plds[k] < 0) continue;
       float* p = s_v + plds[k];
-      *reinterpret_cast<f32x4*>(p) = preg[k][0] - preg[k][2];
-      *reinterpret_cast<f32x4*>(p + WT * CKP) = preg[k][1] + preg[k][2];
-      *reinterpret_cast<f32x4*>(p + 2 * WT * CKP) = preg[k][2] - preg[k][1];
-      *reinterpret_cast<f32x4*>(p + 3 * WT * CKP) = preg[k][1] - preg[k][3];
+      // (the empty asm pins each transformed quad in a register tuple: without it the backend scalarises the four stores and
+      //  re-pairs them ACROSS the k planes into 8 ds_write2st64_b32 instead of 4 ds_write_b128)
+      f32x4 t0 = preg[k][0] - preg[k][2], t1 = preg[k][1] + preg[k][2], t2 = preg[k][2] - preg[k][1], t3 = preg[k][1] - preg[k][3];
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+      *reinterpret_cast<f32x4*>(p) = t0;
+      *reinterpret_cast<f32x4*>(p + WT * CKP) = t1;
+      *reinterpret_cast<f32x4*>(p + 2 * WT * CKP) = t2;
+      *reinterpret_cast<f32x4*>(p + 3 * WT * CKP) = t3;
     }
 #pragma unroll
     for (int k = 0; k < WL; ++k) {
-      if (tid + k * 256 >= WTOT) continue;
       *reinterpret_cast<f32x4*>(&s_u[wlds[k]]) = wreg[k];
     }
   };
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   float* s_v = smem;                                         // [(TH+2)][4][WT][CKP]  x-transformed patch rows
   float* s_u = smem + (TH + 2) * ROWF;                       // [16][CK][TN]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the kh branches below are scalar branches
   const int l31 = lane & 31, hi = lane >> 5;
   const int kh = wave & 1, wm = (wave >> 1) / WC, wc = (wave >> 1) % WC;
   int b = blockIdx.x;
@@ -291,21 +295,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   int poff[PL][4], plds[PL];
 #pragma unroll
   for (int k = 0; k < PL; ++k) {
-    const int idx = tid + k * 256;
+    const int idx = min(tid + k * 256, ITEMS - 1);      // surplus threads redo the last item (same data, same slot): no branch in the loop
     const int q = idx & 1, t = (idx >> 1) & (WT - 1), r = idx >> 6;
     const int gy = y0 + r - 1, gx = x0 + 2 * t - 1;
-    const bool rok = idx < ITEMS && gy >= 0 && gy < H;
+    const bool rok = gy >= 0 && gy < H;
 #pragma unroll
     for (int d = 0; d < 4; ++d) poff[k][d] = (rok && gx + d >= 0 && gx + d < W) ? ((gy * W + gx + d) * Cin + q * 4) * 4 : OOB;
-    plds[k] = idx < ITEMS ? (r * 4 * WT + t) * CKP + q * 4 : -1;
+    plds[k] = (r * 4 * WT + t) * CKP + q * 4;
   }
   int woff[WL], wlds[WL];
 #pragma unroll
   for (int k = 0; k < WL; ++k) {
-    const int idx = tid + k * 256;
+    const int idx = min(tid + k * 256, WTOT - 1);
     const int q = idx % (TN / 4), row = idx / (TN / 4);
     const int tap = row >> 3, ci = row & 7;
-    woff[k] = (idx < WTOT && nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : OOB;
+    woff[k] = (nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : OOB;
     wlds[k] = row * TN + q * 4;
   }
   f32x4 preg[PL][4], wreg[WL];
@@ -313,23 +317,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < PL; ++k)
 #pragma unroll
-      for (int d = 0; d < 4; ++d) preg[k][d] = buf_ld4(rs_x, poff[k][d] + c0 * 4);
+      for (int d = 0; d < 4; ++d) preg[k][d] = buf_ld4(rs_x, poff[k][d], c0 * 4);
 #pragma unroll
-    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_u, woff[k] + c0 * Cout * 4);
+    for (int k = 0; k < WL; ++k) wreg[k] = buf_ld4(rs_u, woff[k], c0 * Cout * 4);
   };
   auto store_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < PL; ++k) {
-      if (plds[k] < 0) continue;
       float* p = s_v + plds[k];
-      *reinterpret_cast<f32x4*>(p) = preg[k][0] - preg[k][2];
-      *reinterpret_cast<f32x4*>(p + WT * CKP) = preg[k][1] + preg[k][2];
-      *reinterpret_cast<f32x4*>(p + 2 * WT * CKP) = preg[k][2] - preg[k][1];
-      *reinterpret_cast<f32x4*>(p + 3 * WT * CKP) = preg[k][1] - preg[k][3];
+      // (the empty asm pins each transformed quad in a register tuple: without it the backend scalarises the four stores and
+      //  re-pairs them ACROSS the k planes into 8 ds_write2st64_b32 instead of 4 ds_write_b128)
+      f32x4 t0 = preg[k][0] - preg[k][2], t1 = preg[k][1] + preg[k][2], t2 = preg[k][2] - preg[k][1], t3 = preg[k][1] - preg[k][3];
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+      *reinterpret_cast<f32x4*>(p) = t0;
+      *reinterpret_cast<f32x4*>(p + WT * CKP) = t1;
+      *reinterpret_cast<f32x4*>(p + 2 * WT * CKP) = t2;
+      *reinterpret_cast<f32x4*>(p + 3 * WT * CKP) = t3;
     }
 #pragma unroll
     for (int k = 0; k < WL; ++k) {
-      if (tid + k * 256 >= WTOT) continue;
       *reinterpret_cast<f32x4*>(&s_u[wlds[k]]) = wreg[k];
     }
   };
@@ -339,20 +345,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
     store_lds();
     __syncthreads();
     if (c0 + CK < Cin) issue_loads(c0 + CK);
+    // Rows A, B, C = patch rows kh, kh+1, kh+2 of this wave's row pair.  kh = 0 (ky' 0,1): R0 = A-C, R1 = B+C.  kh = 1 (ky' 2,3):
+    // R3 = A-C, R2 = B-A.  So both halves compute d = A-C and e = B + sgn*Z (Z = kh ? A : C) -- no branch, the loop body stays one
+    // basic block -- and kh = 1 simply walks its two taps in the order (3, 2): tap of slot kk = kh ? 3-kk : kk.
+    // k in pairs: 4 accumulators (kk, k) in rotation -> no back-to-back MFMAs on one accumulator (16-pass dependency stall).
+    const float sgn = kh ? -1.0f : 1.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // patch rows of this wave's row pair: kh = 0 needs rows 0,1,2 (R0 = r0-r2, R1 = r1+r2); kh = 1 rows 1,2,3 (R2 = r2-r1, R3 = r1-r3)
-      const float* vb = &s_v[((2 * wm * 4 + k) * WT + l31) * CKP + hi * 4];
-      const f32x4 r1 = *reinterpret_cast<const f32x4*>(vb + 1 * ROWF), r2 = *reinterpret_cast<const f32x4*>(vb + 2 * ROWF);
-      const f32x4 re = *reinterpret_cast<const f32x4*>(vb + (kh ? 3 : 0) * ROWF);
-      f32x4 a[2];
-      if (kh == 0) { a[0] = re - r2; a[1] = r1 + r2; } else { a[0] = r2 - r1; a[1] = r1 - re; }
+    for (int kp = 0; kp < 2; ++kp) {
+      f32x4 a[2][2];                                            // [kk][k - 2kp]
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kq = 0; kq < 2; ++kq) {
+        const float* vb = &s_v[(((2 * wm + kh) * 4 + 2 * kp + kq) * WT + l31) * CKP + hi * 4];
+        const f32x4 A = *reinterpret_cast<const f32x4*>(vb), B = *reinterpret_cast<const f32x4*>(vb + ROWF), C = *reinterpret_cast<const f32x4*>(vb + 2 * ROWF);
+        const f32x4 Z = kh ? A : C;
+        a[0][kq] = A - C;
+        a[1][kq] = B + sgn * Z;
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float bv = s_u[(((2 * kh + kk) * 4 + k) * CK + j + 4 * hi) * TN + wc * 32 + l31];
-          acc[kk][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][j], bv, acc[kk][k], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int kq = 0; kq < 2; ++kq) {
+            const int k = 2 * kp + kq;
+            const float bv = s_u[(((kh ? 3 - kk : kk) * 4 + k) * CK + j + 4 * hi) * TN + wc * 32 + l31];
+            acc[kk][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][kq][j], bv, acc[kk][k], 0, 0, 0);
+          }
         }
       }
     }
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
 
   // ---- epilogue.  x-direction output transform per accumulator pair, then the y-direction combination across the two waves.
   //   T[kk][half] = half 0: m0+m1+m2, half 1: m1-m2-m3 (over k).   kh=0 holds M0,M1: row0 partial T0+T1, row1 partial T1.
-  //   kh=1 holds M2,M3: row0 partial T0 (= M2), row1 partial -(T0+T1).   Each wave keeps the partial of ITS output row (row kh)
+  //   kh=1 holds M3,M2 (slots 0,1): row0 partial T1 (= M2), row1 partial -(T0+T1).   Each wave keeps the partial of ITS output row (row kh)
   //   and sends the other one to its partner (wave ^ 1) through LDS (the operand buffers are dead after the last barrier).
   float* xb = smem + wave * (32 * 64);                       // this wave's outbox: [32 values][64 lanes]
   const float* pb = smem + (wave ^ 1) * (32 * 64);
@@ -377,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
         t[kk] = half == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
       }
       float keep, send;
-      if (kh == 0) { keep = t[0] + t[1]; send = t[1]; } else { keep = -(t[0] + t[1]); send = t[0]; }
+      if (kh == 0) { keep = t[0] + t[1]; send = t[1]; } else { keep = -(t[0] + t[1]); send = t[1]; }      // kh = 1: t[0] = M3, t[1] = M2
       mine[half][r] = keep;
       xb[(half * 16 + r) * 64 + lane] = send;
     }

@@ -14,6 +14,12 @@ LAYERS = [("c1b", 512, 32, 32), ("c2a", 256, 32, 64), ("c2b", 256, 64, 64), ("c3
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser(); ap.add_argument("--layers", default=""); ap.add_argument("--reps", type=int, default=30)
+    a = ap.parse_args()
+    global LAYERS
+    if a.layers:
+        LAYERS = [l for l in LAYERS if l[0] in a.layers.split(",")]
     lib = _lib.load(); ctx = _lib.Context.get(0)
     n = 16
     s = torch.cuda.current_stream().cuda_stream
@@ -25,15 +31,15 @@ def main():
         res = []
         for algo in (2, 3):
             y = torch.empty(n, S, S, co, device="cuda")
-            for _ in range(20):
+            for _ in range(min(20, a.reps)):
                 ctx.check(lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, S, S, ci, co, 1, 0.0, 0, algo, ws.data_ptr(), s))
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(30):
+            for _ in range(a.reps):
                 lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, S, S, ci, co, 1, 0.0, 0, algo, ws.data_ptr(), s)
             e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 30
+            ms = e0.elapsed_time(e1) / a.reps
             res.append(ms); ys.append(y)
         fl = 2.0 * 9 * ci * co * n * S * S
         print(f"{name:6s} {S:4d} {ci:4d} {co:4d} {res[0]:10.3f} {fl / res[0] / 1e9:7.1f} {res[1]:9.3f} {fl / res[1] / 1e9:7.1f} {res[0] / res[1]:8.2f} {float((ys[0] - ys[1]).abs().max()):9.2e}")
