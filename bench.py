@@ -153,8 +153,8 @@ def main():
             if kind == "conv3x3_dgrad":
                 ci, co = co, ci
             ptr, ld, nn, hh, ww, cc = _tap_dims(eng, B, lname)
-            wino = eng.lib.unet_conv3x3_pick_algo(args.algo, ww, ci, co) == 3
-            fl_exec += o[1] * (2.0 / 3.0 if wino else 1.0); n_wino += int(wino)
+            ratio = eng.lib.unet_conv3x3_exec_ratio(args.algo, hh, ww, ci, co)
+            fl_exec += o[1] * ratio; n_wino += int(ratio < 1.0)
         groups = {}
         for name, flops, by, tms, calls in ops:
             k = name.split(":")[0]
@@ -167,7 +167,7 @@ def main():
         if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0:
             traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
-        roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino_kernel (Winograd F(2,3) along x, {n_wino} launches) / "
+        roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
                                            f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)", "achieved": round(achieved, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "executed_tflops": round(fl_exec / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,

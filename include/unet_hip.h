@@ -62,6 +62,8 @@ enum { UNET_MASK_NONE = 0, UNET_MASK_RELU = 1, UNET_MASK_ELU = 2, UNET_MASK_ELU_
 size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout);
 /* which algorithm a forward / data-gradient launch of this shape resolves to (UNET_ALGO_WINOGRAD, _MFMA or _NAIVE [direct kernels]) */
 int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout);
+/* executed / algorithmic multiplies of that launch: 1 (direct), 2/3 (Winograd F(2,3) along x), 4/9 (F(2x2,3x3)) */
+double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
                          int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
                          int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, float* w_ws, void* stream);

@@ -294,7 +294,7 @@ template <int MODE>
 __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
                                                         float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
                                                         int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
-                                                        int chunks_per_strip) {
+                                                        int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
   // MODE 2 = conv3x3 with the Winograd F(2,3)-along-x transform (see kernels_conv_wino.hip): same data movement as MODE 0, but per
   // pair of output columns 4 products per kernel row instead of 6 -> 12 accumulator tiles dU[ky][k] instead of 9 dW[ky][kx];
   // dU_k[ky][ci][co] = sum V_k[y+ky][t][ci] * dM_k[y][t][co] with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the X row and
@@ -305,9 +305,13 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
   __shared__ __attribute__((aligned(16))) float s_a[MODE != 1 ? 3 * ROWF : 4 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_b[32 * 32];
   const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
-  const int ta = blockIdx.x / tiles_b, tb = blockIdx.x % tiles_b;
+  // XCD-aware block map (workgroup L runs on XCD L % 8): all (a, b) channel-tile pairs of one pixel split go to the SAME XCD back to
+  // back, so the X / dY rows of that split are fetched into one L2 once instead of once per pair on eight different L2s.
+  const int npairs = tiles_a_x_b, sq = blockIdx.x >> 3;
+  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);
+  if (split >= nsplit) return;                                  // grid padded to 8 * ceil(nsplit / 8) * npairs workgroups
+  const int ta = pair / tiles_b, tb = pair % tiles_b;
   const int a0 = ta * 32, b0 = tb * 32;
-  const int split = blockIdx.y;
   const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
   const int cs = t2 % strips, n = t2 / strips;
   const int x0 = cs * 32;
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
 
   // partial tile: rows = a channel (r&3)+8*(r>>2)+4*hi, cols = b channel l31.  Same quad transpose as the conv epilogue:
   // each lane ends up with 4 consecutive b channels of one a channel -> 16-byte stores (36 instead of 144 per wave).
-  float* P = part + (long long)split * TAPS * CA * CB;
+  float* P = part + (long long)split * pstride;                 // partials of one split: [TAPS][CA][CB] weights, then the bias sums
   const int e = l31 & 3, q4 = l31 & ~3;
   const bool odd1 = e & 1, odd2 = e & 2;
 #pragma unroll
@@ -448,8 +452,137 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
       if (a0 + i < CA && b0 + q4 < CB) *reinterpret_cast<float4*>(&P[((long long)t * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
     }
   bsum += __shfl_xor(bsum, 32, 64);
-  if (MODE != 1) { if (ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * CB + b0 + l31] = bsum; }
-  else { if (tb == 0 && lane < 32 && a0 + l31 < CA) part_b[(long long)split * CA + a0 + l31] = bsum; }
+  if (MODE != 1) { if (ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * pstride + b0 + l31] = bsum; }
+  else { if (tb == 0 && lane < 32 && a0 + l31 < CA) part_b[(long long)split * pstride + a0 + l31] = bsum; }
+}
+
+// Winograd-domain conv3x3 weight gradient, two waves per workgroup (see MODE 2 above for the math).  The 12 accumulator tiles
+// dU[ky][k] are split by k between the waves (wave 0: k = 0,1; wave 1: k = 3,2 -> 96 accumulator registers each, so the next-row
+// register prefetch fits again and 3 waves share a SIMD); both read the same raw LDS rows.  With e0,e1,e2 = columns (w, w+1, w+2)
+// of the tile's 4-pixel input window both waves form slot 0 = e0-e2 (V0 resp. V3) and slot 1 = e1 + sgn*(w ? e0 : e2) (V1 resp.
+// V2); the dY factors are slot 0 = (w ? -dy1 : dy0), slot 1 = dy0 + sgn*dy1: no divergent code, one basic block per row step.
+__global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
+                                                            float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
+                                                            int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
+                                                            int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
+  constexpr int ROWF = 34 * 32;
+  constexpr int AL = 3, BL = 2;                       // float4 staging registers per lane (272 / 256 items over 128 lanes)
+  __shared__ __attribute__((aligned(16))) float s_a[3 * ROWF];
+  __shared__ __attribute__((aligned(16))) float s_b[32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware block map (workgroup L runs on XCD L % 8): all (a, b) channel-tile pairs of one pixel split go to the SAME XCD back to
+  // back, so the X / dY rows of that split are fetched into one L2 once instead of once per pair on eight different L2s.
+  const int npairs = tiles_a_x_b, sq = blockIdx.x >> 3;
+  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);
+  if (split >= nsplit) return;                                  // grid padded to 8 * ceil(nsplit / 8) * npairs workgroups
+  const int ta = pair / tiles_b, tb = pair % tiles_b;
+  const int a0 = ta * 32, b0 = tb * 32;
+  const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
+  const int cs = t2 % strips, n = t2 / strips;
+  const int x0 = cs * 32;
+  const int ya = chunk * rows_per_chunk;
+  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float bsum = 0.0f;
+  const float* An = A + (long long)n * H * W * ldA;
+  const float* Bn = B + (long long)n * H * W * ldB;
+
+  int aoff[AL], alds[AL], boff[BL], blds[BL];
+#pragma unroll
+  for (int k = 0; k < AL; ++k) {
+    const int idx = min(tid + 128 * k, 34 * 8 - 1);               // surplus lanes redo the last item: no branch in the loop
+    const int pix = idx >> 3, q = idx & 7; const int gx = x0 - 1 + pix;
+    aoff[k] = (gx >= 0 && gx < W && a0 + q * 4 < CA) ? (gx * ldA + a0 + q * 4) * 4 : UNET_COL_OOB;
+    alds[k] = pix * 32 + q * 4;
+  }
+#pragma unroll
+  for (int k = 0; k < BL; ++k) {
+    const int idx = tid + 128 * k; const int pix = idx >> 3, q = idx & 7; const int gx = x0 + pix;
+    boff[k] = (gx < W && b0 + q * 4 < CB) ? (gx * ldB + b0 + q * 4) * 4 : UNET_COL_OOB;
+    blds[k] = pix * 32 + q * 4;
+  }
+  f32x4 areg[AL], breg[BL];
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(An, (long long)H * W * ldA * 4), rs_b = make_rsrc(Bn, (long long)H * W * ldB * 4);
+  const int nsteps = yb - ya + 2;                        // step t: ring row yy = ya-1+t (X row yy, dY row yy-1)
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    const int yy = ya - 1 + t, yd = yy - 1;
+    const int ra = (yy >= 0 && yy < H) ? yy * W * ldA * 4 : UNET_OOB, rb = (yd >= ya && yd < yb) ? yd * W * ldB * 4 : UNET_OOB;
+#pragma unroll
+    for (int k = 0; k < AL; ++k) areg[k] = buf_ld4(rs_a, aoff[k] + ra);
+#pragma unroll
+    for (int k = 0; k < BL; ++k) breg[k] = buf_ld4(rs_b, boff[k] + rb);
+  };
+  const float sgn = w ? -1.0f : 1.0f;
+
+  issue(0);
+  for (int t = 0; t < nsteps; ++t) {
+    const int yy = ya - 1 + t;
+    const int slot_w = ((yy + 3) % 3) * ROWF;
+#pragma unroll
+    for (int k = 0; k < AL; ++k) *reinterpret_cast<f32x4*>(&s_a[slot_w + alds[k]]) = areg[k];
+#pragma unroll
+    for (int k = 0; k < BL; ++k) *reinterpret_cast<f32x4*>(&s_b[blds[k]]) = breg[k];
+    __syncthreads();
+    if (t + 1 < nsteps) issue(t + 1);                      // next row's loads fly under this row's MFMAs
+    if (t >= 2) {
+      int slot_off[3];
+#pragma unroll
+      for (int dr = 0; dr < 3; ++dr) slot_off[dr] = ((yy - 2 + dr + 3) % 3) * ROWF;   // rows y-1, y, y+1 with y = yy-1
+#pragma unroll 2
+      for (int pp = 0; pp < 8; ++pp) {
+        const int tt = 2 * pp + hi;                        // MFMA k-pair = 2 consecutive Winograd tiles of the strip
+        const float dy0 = s_b[(2 * tt) * 32 + l31], dy1 = s_b[(2 * tt + 1) * 32 + l31];
+        if (w == 0) bsum += dy0 + dy1;
+        const float bm0 = w ? -dy1 : dy0, bm1 = dy0 + sgn * dy1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* r = &s_a[slot_off[ky] + (2 * tt + w) * 32 + l31];    // ring px 0 <-> column x0-1: window px 2tt .. 2tt+3
+          const float e0 = r[0], e1 = r[32], e2 = r[64];
+          const float z = w ? e0 : e2;
+          acc[ky][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e2, bm0, acc[ky][0], 0, 0, 0);
+          acc[ky][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 + sgn * z, bm1, acc[ky][1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // partial tiles: slot j of wave w is Winograd index k = w ? 3 - j : j; quad transpose -> 16-byte stores (see wgrad_mfma_kernel)
+  float* P = part + (long long)split * pstride;
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tap = ky * 4 + (w ? 3 - j : j);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v0 = acc[ky][j][4 * g + 0], v1 = acc[ky][j][4 * g + 1], v2 = acc[ky][j][4 * g + 2], v3 = acc[ky][j][4 * g + 3];
+        {
+          const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+          const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
+          if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
+        }
+        {
+          const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+          const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
+          if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
+        }
+        const int i = e + 8 * g + 4 * hi;
+        if (a0 + i < CA && b0 + q4 < CB) *reinterpret_cast<float4*>(&P[((long long)tap * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
+      }
+    }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (w == 0 && ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * pstride + b0 + l31] = bsum;
 }
 
 // Sum the split-K partials in a fixed order.  Two levels so that a tiny output (e.g. 9x32x32) with
@@ -479,15 +612,30 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
   }
 }
 
-// dW[ky][kx] from the reduced Winograd-domain gradient dU[ky][k] (transpose of the weight transform G):
-//   dg0 = dU0 + (dU1+dU2)/2,  dg1 = (dU1-dU2)/2,  dg2 = (dU1+dU2)/2 + dU3
-__global__ __launch_bounds__(256) void wino_wgrad_finalize_kernel(const float* __restrict__ du, float* __restrict__ dw, int n4 /* ca*cb/4 */) {
+// Last reduction level, weights and bias in ONE launch.  src = `count` slabs of `stride` floats, each [taps][ca*cb] weight partials
+// followed by the bias partials.  WINO: the slab is in the Winograd domain dU[ky][k] (12 taps); the 12 -> 9 transform (transpose of
+// the weight transform G: dg0 = dU0 + (dU1+dU2)/2, dg1 = (dU1-dU2)/2, dg2 = (dU1+dU2)/2 + dU3) is applied on the fly.
+template <bool WINO>
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ src, long long stride, int count, int n4 /* ca*cb/4 */, int taps,
+                                                           int nb4 /* bias floats / 4 */, float* __restrict__ dw, float* __restrict__ db) {
   const long long st = (long long)n4 * 4;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * n4; i += gridDim.x * 256) {
+  const int nw = (WINO ? 3 : taps) * n4;
+  auto sum = [&](long long off) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    int c = 0;
+    for (; c + 1 < count; c += 2) {
+      const float4 u = *reinterpret_cast<const float4*>(src + (long long)c * stride + off), v = *reinterpret_cast<const float4*>(src + (long long)(c + 1) * stride + off);
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (c < count) { const float4 u = *reinterpret_cast<const float4*>(src + (long long)c * stride + off); a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  };
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nw + nb4; i += gridDim.x * 256) {
+    if (i >= nw) { *reinterpret_cast<float4*>(db + (long long)(i - nw) * 4) = sum((long long)taps * st + (long long)(i - nw) * 4); continue; }
+    if (!WINO) { *reinterpret_cast<float4*>(dw + (long long)i * 4) = sum((long long)i * 4); continue; }
     const int ky = i / n4, j = i - ky * n4;
-    const float* p = du + (long long)ky * 4 * st + (long long)j * 4;
-    const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + st);
-    const float4 u2 = *reinterpret_cast<const float4*>(p + 2 * st), u3 = *reinterpret_cast<const float4*>(p + 3 * st);
+    const long long o = (long long)ky * 4 * st + (long long)j * 4;
+    const float4 u0 = sum(o), u1 = sum(o + st), u2 = sum(o + 2 * st), u3 = sum(o + 3 * st);
     float* q = dw + (long long)ky * 3 * st + (long long)j * 4;
     const float4 hs = make_float4(0.5f * (u1.x + u2.x), 0.5f * (u1.y + u2.y), 0.5f * (u1.z + u2.z), 0.5f * (u1.w + u2.w));
     *reinterpret_cast<float4*>(q) = make_float4(u0.x + hs.x, u0.y + hs.y, u0.z + hs.z, u0.w + hs.w);
@@ -530,31 +678,34 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
                   int h, int w, int ca, int cb, hipStream_t s) {
   const int taps = MODE == 0 ? 9 : (MODE == 1 ? 4 : 12); const int cbias = MODE != 1 ? cb : ca;
   const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias);
-  const size_t du_floats = MODE == 2 ? (size_t)12 * ca * cb : 0;            // reduced Winograd-domain gradient, before the 12 -> 9 transform
-  const size_t need = (p.part_floats + p.bias_floats + p.part2_floats + du_floats) * sizeof(float);
+  const long long per = (long long)taps * ca * cb, S = per + cbias;      // one split's partial slab: weights, then bias sums
+  const size_t need = (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
   if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
-  float* part = static_cast<float*>(ws); float* part_b = part + p.part_floats;
-  float* dw_final = dw;
-  if (MODE == 2) dw = part_b + p.bias_floats + p.part2_floats;
-  hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, dim3((unsigned)(p.tiles_a * p.tiles_b), (unsigned)p.nsplit), dim3(64), 0, s, A, ldA, B, ldB, part,
-                     part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip);
+  float* part = static_cast<float*>(ws); float* part_b = part + per;
+  static const int one_wave = [] { const char* e = getenv("UNET_WGRAD_WINO_1WAVE"); return e ? atoi(e) : 0; }();     // A/B switch (MODE 2 only)
+  const int npairs = p.tiles_a * p.tiles_b;
+  const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));            // see the block map in the kernels
+  if (MODE == 2 && !one_wave)
+    hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(128), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk,
+                       p.chunks_per_strip, p.nsplit, npairs, S);
+  else
+    hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, grid, dim3(64), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips,
+                       p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S);
   UNET_CHECK_LAUNCH(ctx, "wgrad_mfma");
-  const long long per = (long long)taps * ca * cb;
-  const unsigned gx = (unsigned)std::min<long long>((per / 4 + 255) / 256, 2048);
+  // deterministic two-level reduction of the split slabs: level 1 sums groups of splits (skipped when there are few), the final
+  // level also writes the bias gradient and (MODE 2) applies the 12 -> 9 Winograd transform: 2 launches instead of 5
+  const float* src = part; int count = p.nsplit;
   if (p.groups > 1) {
-    float* part2 = part_b + p.bias_floats; float* part2_b = part2 + (size_t)p.groups * per;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, p.groups), dim3(256), 0, s, part, part2, per / 4, per, p.nsplit, p.per_group, per);
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(1, p.groups), dim3(256), 0, s, part_b, part2_b, (long long)cbias / 4, (long long)cbias, p.nsplit, p.per_group, (long long)cbias);
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, 1), dim3(256), 0, s, part2, dw, per / 4, per, p.groups, p.groups, 0LL);
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(1, 1), dim3(256), 0, s, part2_b, db, (long long)cbias / 4, (long long)cbias, p.groups, p.groups, 0LL);
-  } else {
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, 1), dim3(256), 0, s, part, dw, per / 4, per, p.nsplit, p.nsplit, 0LL);
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(1, 1), dim3(256), 0, s, part_b, db, (long long)cbias / 4, (long long)cbias, p.nsplit, p.nsplit, 0LL);
+    float* part2 = part + (size_t)p.nsplit * S;
+    const unsigned gx = (unsigned)std::min<long long>((S / 4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, p.groups), dim3(256), 0, s, part, part2, S / 4, S, p.nsplit, p.per_group, S);
+    src = part2; count = p.groups;
   }
-  if (MODE == 2) {
-    const int n4 = ca * cb / 4;
-    hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3((unsigned)std::min(2048, (3 * n4 + 255) / 256)), dim3(256), 0, s, dw, dw_final, n4);
-  }
+  const int n4 = ca * cb / 4, nb4 = cbias / 4;
+  const int items = (MODE == 2 ? 3 : taps) * n4 + nb4;
+  const dim3 gf((unsigned)std::min(2048, (items + 255) / 256));
+  if (MODE == 2) hipLaunchKernelGGL(reduce_final_kernel<true>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  else hipLaunchKernelGGL(reduce_final_kernel<false>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
 }
@@ -595,7 +746,7 @@ int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // large enough for the direct AND the Winograd form
   if (!mfma_wgrad_supported(cin, cout)) return 0;
   const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout), q = plan_wgrad(12, n, h, wd, cin, cout, cout);
-  return std::max((p.part_floats + p.bias_floats + p.part2_floats), (q.part_floats + q.bias_floats + q.part2_floats + (size_t)12 * cin * cout)) * sizeof(float);
+  return std::max((p.part_floats + p.bias_floats + p.part2_floats), (q.part_floats + q.bias_floats + q.part2_floats)) * sizeof(float);
 }
 
 int32_t k_conv3x3_wino_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,

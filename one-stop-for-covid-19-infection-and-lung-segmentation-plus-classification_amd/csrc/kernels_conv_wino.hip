@@ -91,11 +91,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform, and the compiler is told so (scalar address math)
   const int l31 = lane & 31, hi = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
-  int b = blockIdx.x;
-  const int tx = b % tiles_x; b /= tiles_x;
-  const int ty = b % tiles_y; const int n = b / tiles_y;
+  // XCD-aware block -> tile map (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): an XCD walks a contiguous run of
+  // pixel tiles ordered with ty fastest (vertical neighbours share 2 of their 4 patch rows) and does ALL cout groups of a tile
+  // back to back, so the re-reads of an input patch (once per cout group, plus the halo rows) hit that XCD's L2.
+  int n, tx, ty, nbase;
+  {
+    const int G = (Cout + TN - 1) / TN, P = tiles_x * tiles_y * N, per = (P + 7) >> 3;
+    const int L = blockIdx.x, xcd = L & 7, sq = L >> 3;
+    const int lt = sq / G, g = sq - lt * G;
+    const int pt = xcd * per + lt;
+    if (pt >= P) return;                               // grid is padded to 8 * per * G workgroups
+    ty = pt % tiles_y; const int r = pt / tiles_y;
+    tx = r % tiles_x; n = r / tiles_x;
+    nbase = g * TN;
+  }
   const int x0 = tx * 2 * WT, y0 = ty * TH;
-  const int nbase = blockIdx.y * TN;
 
   f32x16 acc[RW][NW][4];
 #pragma unroll
@@ -276,11 +286,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the kh branches below are scalar branches
   const int l31 = lane & 31, hi = lane >> 5;
   const int kh = wave & 1, wm = (wave >> 1) / WC, wc = (wave >> 1) % WC;
-  int b = blockIdx.x;
-  const int tx = b % tiles_x; b /= tiles_x;
-  const int ty = b % tiles_y; const int n = b / tiles_y;
+  // XCD-aware block -> tile map (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): an XCD walks a contiguous run of
+  // pixel tiles ordered with ty fastest (vertical neighbours share 2 of their 4 patch rows) and does ALL cout groups of a tile
+  // back to back, so the re-reads of an input patch (once per cout group, plus the halo rows) hit that XCD's L2.
+  int n, tx, ty, nbase;
+  {
+    const int G = (Cout + TN - 1) / TN, P = tiles_x * tiles_y * N, per = (P + 7) >> 3;
+    const int L = blockIdx.x, xcd = L & 7, sq = L >> 3;
+    const int lt = sq / G, g = sq - lt * G;
+    const int pt = xcd * per + lt;
+    if (pt >= P) return;                               // grid is padded to 8 * per * G workgroups
+    ty = pt % tiles_y; const int r = pt / tiles_y;
+    tx = r % tiles_x; n = r / tiles_x;
+    nbase = g * TN;
+  }
   const int x0 = tx * 2 * WT, y0 = ty * TH;
-  const int nbase = blockIdx.y * TN;
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -459,7 +479,7 @@ int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float
   if (!mask) mask_mode = MASK_NONE;
   constexpr int TH = 2 * WM, TN = 32 * WC;
   const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
-  const dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)((cout + TN - 1) / TN));
+  const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));       // see the block -> tile map in the kernel
   constexpr size_t lds = (size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float);
   static_assert(lds >= 4 * 32 * 64 * sizeof(float), "the epilogue exchange reuses the operand buffers");
   const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
@@ -481,7 +501,7 @@ int32_t launch_wino(unet_ctx* ctx, const float* x, const float* u, const float* 
                     int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
-  const dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)((cout + TN - 1) / TN));
+  const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));       // see the block -> tile map in the kernel
   constexpr size_t lds = (size_t)((TH + 2) * 4 * WT * CKP + 12 * CK * TN) * sizeof(float);
   const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
   static bool attr_done = false;                     // > 64 KiB of dynamic LDS needs the opt-in (per kernel instance; set both)
@@ -507,6 +527,7 @@ inline int wino_2d_mode() {          // UNET_WINO2D: 0 = F(2,3) along x only, 1 
   return v;
 }
 static bool use_2d(int h, int cout) { return wino_2d_mode() && h >= 2 && cout % 32 == 0; }
+bool wino_uses_2d(int h, int cout) { return use_2d(h, cout); }
 
 // transformed weights for k_conv3x3_wino_fwd on an image of `h` rows (the 2-D form is picked per shape, both sides must agree)
 int32_t k_wino_weights(unet_ctx* ctx, const float* w, float* u, int cin, int cout, int flip, int h, hipStream_t s) {

@@ -119,6 +119,13 @@ int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t co
   return UNET_ALGO_NAIVE;
 }
 
+/* executed / algorithmic multiply count of a forward or data-gradient launch of this shape: 1 (direct), 2/3 (F(2,3) along x), 4/9 (F(2x2,3x3)) */
+double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
+  static float dummy;
+  if (!use_wino(algo, wd, cin, cout, &dummy)) return 1.0;
+  return wino_uses_2d(h, cout) ? 4.0 / 9.0 : 2.0 / 3.0;
+}
+
 size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return (size_t)16 * (cin > 0 ? cin : 0) * (cout > 0 ? cout : 0); }
 
 int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* mask_src, int32_t mask_mode, float mask_rate,

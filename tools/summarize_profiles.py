@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Post-process tools/collect_profiles.sh output: kernel_stats.csv (per-kernel time table of the bench run) and pmc_traffic.json
+(HBM bytes per launch of the dominant kernel family = conv3x3 forward / data-gradient launches, calibrated on kernels whose byte
+counts are known exactly: bn_apply and adam).  MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> x2."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out = sys.argv[1]
+# ---- 1. kernel stats ------------------------------------------------------------------
+stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out, "kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
+        for r in rows:
+            name = r.get("Name", r.get("KernelName", ""))
+            w.writerow([name[:140], r.get("Calls"), round(float(r.get("TotalDurationNs", 0)) / 1e6, 3), round(float(r.get("AverageNs", 0)) / 1e3, 2),
+                        r.get("Percentage")])
+    print("kernel_stats.csv:", len(rows), "kernels")
+
+
+# ---- 2. PMC traffic -------------------------------------------------------------------
+def collect(counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(out, "pmc_" + counter, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            a = agg[r["Kernel_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return agg
+
+
+def family(name):
+    if "conv_wino2d_kernel" in name or "conv_wino_kernel" in name:
+        return "dom"
+    if "conv_mfma_kernel<0" in name:
+        return "dom"
+    if "bn_apply_kernel" in name:
+        return "bn_apply"
+    if "adam_kernel" in name:
+        return "adam"
+    return None
+
+
+fetch, write = collect("FETCH_SIZE"), collect("WRITE_SIZE")
+fam = collections.defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "launches": 0, "names": set()})
+for name, (v, n) in fetch.items():
+    k = family(name)
+    if k:
+        fam[k]["fetch_kb"] += v; fam[k]["launches"] += n; fam[k]["names"].add(name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60])
+for name, (v, n) in write.items():
+    k = family(name)
+    if k:
+        fam[k]["write_kb"] += v
+if "dom" in fam and fam["dom"]["launches"]:
+    d = fam["dom"]
+    steps = 4
+    res = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/profile_ops.py --reps 1 --warm 3 (4 training steps, 512x512x1, batch 16); tools/collect_profiles.sh",
+        "correction": "FETCH_SIZE (KB) x 1024 x 2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE (KB) x 1024; calibrated on bn_apply / adam whose byte counts are known",
+        "calibration": {k: {"fetch_x2_GB": fam[k]["fetch_kb"] * 2048 / 1e9, "write_GB": fam[k]["write_kb"] * 1024 / 1e9} for k in ("bn_apply", "adam") if k in fam},
+        "dominant_kernel": "conv3x3 fwd + data-gradient launches: " + ", ".join(sorted(d["names"])),
+        "launches": d["launches"], "launches_per_step": d["launches"] / steps,
+        "read_bytes_per_launch": d["fetch_kb"] * 2048 / d["launches"], "write_bytes_per_launch": d["write_kb"] * 1024 / d["launches"],
+    }
+    res["hbm_bytes_per_launch"] = res["read_bytes_per_launch"] + res["write_bytes_per_launch"]
+    res["hbm_bytes_per_step"] = res["hbm_bytes_per_launch"] * res["launches_per_step"]
+    json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1)[:1500])
+else:
+    print("no PMC data for the dominant kernel family found")
