@@ -57,6 +57,9 @@ constexpr int UNET_COL_OOB = 0x40000000;          // invalid column part, may be
 __device__ __forceinline__ unet_f32x4 buf_ld4(__amdgpu_buffer_rsrc_t rs, int byte_off, int soff = 0) {
   return __builtin_bit_cast(unet_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, soff, 0));
 }
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t rs, int byte_off, int soff = 0) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, soff, 0));
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }

@@ -267,7 +267,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
 // the output transform needs both halves: out(row 0) = M0+M1+M2, out(row 1) = M1-M2-M3, so the two waves swap one partial
 // each through LDS in the epilogue (kh = 0 finishes row 0, kh = 1 row 1).  Waves = 2 (kh) x WM (row pairs) x WC (cout tiles).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int WM, int WC, bool GEN>
+// BREG: every weight element of the slab is used by exactly ONE wave (its 8 taps x its 32 couts), so the B operands go straight
+// from L2 into registers in MFMA operand layout (lane = cout, 128-B coalesced rows) and never touch LDS: no weight slab, no LDS
+// writes/reads for it, and the next chunk's value is loaded into the same register right behind the MFMA that consumed it.
+template <int WM, int WC, bool GEN, bool BREG>
 __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                              const float* __restrict__ bias, const float* __restrict__ mask,
                                                              float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int act,
@@ -277,10 +280,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   constexpr int ROWF = 4 * WT * CKP;
   constexpr int ITEMS = (TH + 2) * WT * 2;
   constexpr int WTOT = TAPS * CK * (TN / 4);
-  constexpr int PL = (ITEMS + 255) / 256, WL = (WTOT + 255) / 256;
+  constexpr int PL = (ITEMS + 255) / 256, WL = BREG ? 0 : (WTOT + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_v = smem;                                         // [(TH+2)][4][WT][CKP]  x-transformed patch rows
-  float* s_u = smem + (TH + 2) * ROWF;                       // [16][CK][TN]
+  float* s_u = smem + (TH + 2) * ROWF;                       // [16][CK][TN]   (!BREG only)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the kh branches below are scalar branches
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
     for (int d = 0; d < 4; ++d) poff[k][d] = (rok && gx + d >= 0 && gx + d < W) ? ((gy * W + gx + d) * Cin + q * 4) * 4 : OOB;
     plds[k] = (r * 4 * WT + t) * CKP + q * 4;
   }
-  int woff[WL], wlds[WL];
+  int woff[WL + 1], wlds[WL + 1];
 #pragma unroll
   for (int k = 0; k < WL; ++k) {
     const int idx = min(tid + k * 256, WTOT - 1);
@@ -332,7 +335,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
     woff[k] = (nbase + q * 4 < Cout) ? ((tap * Cin + ci) * Cout + nbase + q * 4) * 4 : OOB;
     wlds[k] = row * TN + q * 4;
   }
-  f32x4 preg[PL][4], wreg[WL];
+  // BREG: per-lane byte offset of U[tap(kk,k)][ci = 4*hi][cout of this lane]; + (c0 + j) * Cout * 4 (uniform, SGPR operand)
+  int boff[2][4];
+  float breg[2][4][4];                                     // [kk][k][j]: B operand of the MFMA (kk, k, j) of the current chunk
+  if (BREG) {
+    const int co = nbase + wc * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) boff[kk][k] = co < Cout ? (((((kh ? 3 - kk : kk) * 4 + k) * Cin + 4 * hi) * Cout) + co) * 4 : OOB;
+  }
+  f32x4 preg[PL][4], wreg[WL + 1];
   auto issue_loads = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < PL; ++k)
@@ -361,10 +374,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   };
 
   issue_loads(0);
+  if (BREG) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) breg[kk][k][j] = buf_ld1(rs_u, boff[kk][k], j * Cout * 4);
+  }
   for (int c0 = 0; c0 < Cin; c0 += CK) {
     store_lds();
     __syncthreads();
     if (c0 + CK < Cin) issue_loads(c0 + CK);
+    const int cn = c0 + CK < Cin ? c0 + CK : c0;            // BREG: chunk whose weights are fetched behind the MFMAs (the last chunk re-reads itself)
     // Rows A, B, C = patch rows kh, kh+1, kh+2 of this wave's row pair.  kh = 0 (ky' 0,1): R0 = A-C, R1 = B+C.  kh = 1 (ky' 2,3):
     // R3 = A-C, R2 = B-A.  So both halves compute d = A-C and e = B + sgn*Z (Z = kh ? A : C) -- no branch, the loop body stays one
     // basic block -- and kh = 1 simply walks its two taps in the order (3, 2): tap of slot kk = kh ? 3-kk : kk.
@@ -388,8 +410,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
 #pragma unroll
           for (int kq = 0; kq < 2; ++kq) {
             const int k = 2 * kp + kq;
-            const float bv = s_u[(((kh ? 3 - kk : kk) * 4 + k) * CK + j + 4 * hi) * TN + wc * 32 + l31];
-            acc[kk][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][kq][j], bv, acc[kk][k], 0, 0, 0);
+            if (BREG) {
+              acc[kk][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][kq][j], breg[kk][k][j], acc[kk][k], 0, 0, 0);
+              breg[kk][k][j] = buf_ld1(rs_u, boff[kk][k], (cn + j) * Cout * 4);
+            } else {
+              const float bv = s_u[(((kh ? 3 - kk : kk) * 4 + k) * CK + j + 4 * hi) * TN + wc * 32 + l31];
+              acc[kk][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][kq][j], bv, acc[kk][k], 0, 0, 0);
+            }
           }
         }
       }
@@ -480,18 +507,26 @@ int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float
   constexpr int TH = 2 * WM, TN = 32 * WC;
   const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
   const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));       // see the block -> tile map in the kernel
-  constexpr size_t lds = (size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float);
-  static_assert(lds >= 4 * 32 * 64 * sizeof(float), "the epilogue exchange reuses the operand buffers");
+  // weights via registers (BREG) or through LDS: registers win 3-8 % on the 64-wide tile (two cout tiles share the patch), the
+  // 32-wide tile (two row pairs, 1.5x the patch traffic per wave) measured 2-5 % slower with it.  UNET_WINO_BREG=0/1 forces one.
+  static const int breg_env = [] { const char* e = getenv("UNET_WINO_BREG"); return e ? atoi(e) : -1; }();
+  const int breg = breg_env >= 0 ? breg_env : (WC == 2 ? 1 : 0);
+  const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * CKP + (breg ? 0 : 16 * CK * TN)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));   // >= the epilogue exchange
   const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %zu bytes of LDS", lds);
+    const int big = (int)((size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float));
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
+      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %d bytes of LDS", big);
     attr_done = true;
   }
-  if (gen) hipLaunchKernelGGL((conv_wino2d_kernel<WM, WC, true>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
-  else hipLaunchKernelGGL((conv_wino2d_kernel<WM, WC, false>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+#define UNET_LAUNCH_W2D(G_, B_) hipLaunchKernelGGL((conv_wino2d_kernel<WM, WC, G_, B_>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y)
+  if (gen) { if (breg) UNET_LAUNCH_W2D(true, true); else UNET_LAUNCH_W2D(true, false); }
+  else { if (breg) UNET_LAUNCH_W2D(false, true); else UNET_LAUNCH_W2D(false, false); }
+#undef UNET_LAUNCH_W2D
   UNET_CHECK_LAUNCH(ctx, "conv_wino2d");
   return UNET_OK;
 }
