@@ -252,6 +252,8 @@ template <int MODE, int TN, int TH, int WR, int WC>
 int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, const float* mask, int mask_mode, float* y,
                     int ldy, int n, int h, int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
   if (!mask) mask_mode = MASK_NONE;
+  if ((long long)(MODE == 2 ? 4 : 1) * h * wd * ldx * 4 >= (1LL << 30) || (long long)(MODE == 1 ? 1 : 9) * cin * cout * 4 >= (1LL << 30))
+    UNET_FAIL(ctx, UNET_E_SHAPE, "conv mfma: one image / the weight tensor must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH;
   dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)((cout + TN - 1) / TN));
   if (MODE == 0 && conv_ablation()) {          // timing experiments (tools/conv_ablate.py); never set in production
@@ -677,6 +679,8 @@ template <int MODE>
 int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ldB, float* dw, float* db, void* ws, size_t ws_bytes, int n,
                   int h, int w, int ca, int cb, hipStream_t s) {
   const int taps = MODE == 0 ? 9 : (MODE == 1 ? 4 : 12); const int cbias = MODE != 1 ? cb : ca;
+  if ((long long)(MODE == 1 ? 4 : 1) * h * w * ldA * 4 >= (1LL << 30) || (long long)h * w * ldB * 4 >= (1LL << 30))
+    UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad mfma: one image must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
   const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias);
   const long long per = (long long)taps * ca * cb, S = per + cbias;      // one split's partial slab: weights, then bias sums
   const size_t need = (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);

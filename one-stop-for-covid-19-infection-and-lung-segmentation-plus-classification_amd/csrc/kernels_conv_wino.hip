@@ -577,6 +577,7 @@ int32_t k_wino_weights(unet_ctx* ctx, const float* w, float* u, int cin, int cou
 int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n,
                            int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   if (!wino_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: cin=%d cout=%d unsupported", cin, cout);
+  if ((long long)h * wd * std::max(cin, cout) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: one image must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
   if (use_2d(h, cout)) {
     if (cout % 64 == 0) return launch_wino2d<1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
     return launch_wino2d<2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
