@@ -112,7 +112,8 @@ __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep
 // of the mask tensor's producer (MASK_ELU_DROP)
 // Winograd F(2,3)-along-x kernels (kernels_conv_wino.hip): u = transformed weights [12][cin'][cout'] in caller scratch
 bool wino_conv3x3_supported(int cin, int cout);
-bool wino_uses_2d(int h, int cout);                                 // F(2x2,3x3) instead of F(2,3)-along-x for this output shape
+bool wino_uses_2d(int h, int cout);
+int wino_tile_cols(int wd);                                          // 64 or 32 columns per row tile of the 2-D kernel                                 // F(2x2,3x3) instead of F(2,3)-along-x for this output shape
 int32_t k_conv3x3_wino_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
                              int cin, int cout, hipStream_t s);      // kernels_conv_mfma.hip (shares the split-K machinery)
 size_t wino_u_floats(int cin, int cout);

@@ -270,13 +270,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
 // BREG: every weight element of the slab is used by exactly ONE wave (its 8 taps x its 32 couts), so the B operands go straight
 // from L2 into registers in MFMA operand layout (lane = cout, 128-B coalesced rows) and never touch LDS: no weight slab, no LDS
 // writes/reads for it, and the next chunk's value is loaded into the same register right behind the MFMA that consumed it.
-template <int WM, int WC, bool GEN, bool BREG>
+// WTT = Winograd tiles per row of the MFMA M-tile: 32 (one row pair x 64 columns) or 16 (two row pairs x 32 columns, for images
+// narrower than 64 columns: lane l31 -> row pair l31 / 16, tile l31 % 16).
+template <int WTT, int WM, int WC, bool GEN, bool BREG>
 __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                              const float* __restrict__ bias, const float* __restrict__ mask,
                                                              float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int act,
                                                              int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y) {
   static_assert(WM * WC == 2, "4 waves = 2 x WM x WC");
-  constexpr int TAPS = 16, TH = 2 * WM, TN = 32 * WC;
+  constexpr int WT = WTT, RPW = 32 / WTT;                    // (shadows the file-level WT) row pairs per wave tile
+  constexpr int TAPS = 16, TH = 2 * RPW * WM, TN = 32 * WC;
   constexpr int ROWF = 4 * WT * CKP;
   constexpr int ITEMS = (TH + 2) * WT * 2;
   constexpr int WTOT = TAPS * CK * (TN / 4);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < PL; ++k) {
     const int idx = min(tid + k * 256, ITEMS - 1);      // surplus threads redo the last item (same data, same slot): no branch in the loop
-    const int q = idx & 1, t = (idx >> 1) & (WT - 1), r = idx >> 6;
+    const int q = idx & 1, t = (idx >> 1) & (WT - 1), r = idx / (2 * WT);
     const int gy = y0 + r - 1, gx = x0 + 2 * t - 1;
     const bool rok = gy >= 0 && gy < H;
 #pragma unroll
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
       f32x4 a[2][2];                                            // [kk][k - 2kp]
 #pragma unroll
       for (int kq = 0; kq < 2; ++kq) {
-        const float* vb = &s_v[(((2 * wm + kh) * 4 + 2 * kp + kq) * WT + l31) * CKP + hi * 4];
+        const float* vb = &s_v[(((2 * (wm * RPW + l31 / WT) + kh) * 4 + 2 * kp + kq) * WT + l31 % WT) * CKP + hi * 4];
         const f32x4 A = *reinterpret_cast<const f32x4*>(vb), B = *reinterpret_cast<const f32x4*>(vb + ROWF), C = *reinterpret_cast<const f32x4*>(vb + 2 * ROWF);
         const f32x4 Z = kh ? A : C;
         a[0][kq] = A - C;
@@ -457,7 +460,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   const bool odd1 = e & 1, odd2 = e & 2;
   const int co = nbase + wc * 32 + q4;
   const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int py = y0 + 2 * wm + kh;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -473,7 +475,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
         const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
         if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
       }
-      const int px = x0 + 2 * (e + 8 * g + 4 * hi) + half;
+      const int mt = e + 8 * g + 4 * hi;                      // M index of this value: row pair mt / WT, tile mt % WT
+      const int px = x0 + 2 * (mt % WT) + half, py = y0 + 2 * (wm * RPW + mt / WT) + kh;
       if (py >= H || px >= W || co >= Cout) continue;
       float4 o4 = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
       const long long o = (((long long)n * H + py) * W + px) * Cout + co;
@@ -500,11 +503,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   }
 }
 
-template <int WM, int WC>
+template <int WTT, int WM, int WC>
 int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n, int h,
                       int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
   if (!mask) mask_mode = MASK_NONE;
-  constexpr int TH = 2 * WM, TN = 32 * WC;
+  constexpr int WT = WTT, TH = 2 * (32 / WTT) * WM, TN = 32 * WC;
   const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
   const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));       // see the block -> tile map in the kernel
   // weights via registers (BREG) or through LDS: registers win 3-8 % on the 64-wide tile (two cout tiles share the patch), the
@@ -516,14 +519,14 @@ int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float
   static bool attr_done = false;
   if (!attr_done) {
     const int big = (int)((size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float));
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WM, WC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
       UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %d bytes of LDS", big);
     attr_done = true;
   }
-#define UNET_LAUNCH_W2D(G_, B_) hipLaunchKernelGGL((conv_wino2d_kernel<WM, WC, G_, B_>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y)
+#define UNET_LAUNCH_W2D(G_, B_) hipLaunchKernelGGL((conv_wino2d_kernel<WTT, WM, WC, G_, B_>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y)
   if (gen) { if (breg) UNET_LAUNCH_W2D(true, true); else UNET_LAUNCH_W2D(true, false); }
   else { if (breg) UNET_LAUNCH_W2D(false, true); else UNET_LAUNCH_W2D(false, false); }
 #undef UNET_LAUNCH_W2D
@@ -562,6 +565,11 @@ inline int wino_2d_mode() {          // UNET_WINO2D: 0 = F(2,3) along x only, 1 
   return v;
 }
 static bool use_2d(int h, int cout) { return wino_2d_mode() && h >= 2 && cout % 32 == 0; }
+// columns per row tile the 2-D kernel uses for an image of width wd: 64, or 32 when that fills the last tile much better
+int wino_tile_cols(int wd) {
+  const double u64 = (double)wd / (64.0 * ((wd + 63) / 64)), u32 = (double)wd / (32.0 * ((wd + 31) / 32));
+  return u32 > 1.1 * u64 ? 32 : 64;
+}
 bool wino_uses_2d(int h, int cout) { return use_2d(h, cout); }
 
 // transformed weights for k_conv3x3_wino_fwd on an image of `h` rows (the 2-D form is picked per shape, both sides must agree)
@@ -579,8 +587,12 @@ int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const 
   if (!wino_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: cin=%d cout=%d unsupported", cin, cout);
   if ((long long)h * wd * std::max(cin, cout) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: one image must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
   if (use_2d(h, cout)) {
-    if (cout % 64 == 0) return launch_wino2d<1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
-    return launch_wino2d<2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+    if (wino_tile_cols(wd) == 32) {                        // narrow images: two row pairs x 16 tiles per MFMA M-tile
+      if (cout % 64 == 0) return launch_wino2d<16, 1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+      return launch_wino2d<16, 2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+    }
+    if (cout % 64 == 0) return launch_wino2d<32, 1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+    return launch_wino2d<32, 2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   }
   // One image row per wave (64 accumulator registers) -> 3 workgroups per CU: occupancy pays more than sharing the weight operand
   // between two rows did (the <64,4,2,2> / <32,8,4,1> tiles measured 1-8 % slower on every U-Net layer).

@@ -61,7 +61,12 @@ static bool use_wino(int algo, int wd, int cin, int cout, const float* uws) {
   static const int enabled = [] { const char* e = getenv("UNET_WINO"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
   if (!enabled) return false;
   // 1.5x fewer MFMAs, but its row tiles are 64 columns wide (the direct kernel's 32): compare how full the last tile is
-  const double uw = (double)wd / (64.0 * ((wd + 63) / 64)), ud = (double)wd / (32.0 * ((wd + 31) / 32));
+  const double ud = (double)wd / (32.0 * ((wd + 31) / 32));
+  if (wino_uses_2d(2, cout)) {                            // F(2x2,3x3): 64- or 32-column tiles, 2.25x fewer MFMAs
+    const int tc = wino_tile_cols(wd);
+    return 2.25 * ((double)wd / (tc * ((wd + tc - 1) / tc))) >= 1.3 * ud;
+  }
+  const double uw = (double)wd / (64.0 * ((wd + 63) / 64));
   return 1.5 * uw >= 1.15 * ud;
 }
 

@@ -25,7 +25,9 @@ CONV_SHAPES = [(2, 9, 13, 3, 5), (1, 16, 16, 1, 32), (2, 16, 16, 32, 32), (2, 12
                # channel counts that are not multiples of 32 (the classifier's 16-wide layers, T2:748-750): tiles overhang
                (2, 16, 16, 16, 16), (1, 12, 20, 16, 32), (2, 8, 8, 32, 16), (1, 10, 10, 24, 80), (1, 8, 8, 8, 48), (2, 16, 16, 1, 16),
                # wide rows: several 64-column Winograd tiles, ragged right edge, odd width
-               (1, 6, 128, 32, 64), (2, 5, 150, 16, 32), (1, 9, 67, 64, 128), (1, 3, 64, 8, 8)]
+               (1, 6, 128, 32, 64), (2, 5, 150, 16, 32), (1, 9, 67, 64, 128), (1, 3, 64, 8, 8),
+               # narrow images: the 2-D Winograd kernel packs two row pairs x 16 tiles into an MFMA M-tile
+               (2, 32, 32, 64, 64), (1, 28, 28, 32, 32), (1, 7, 30, 16, 64), (2, 9, 20, 8, 96)]
 
 
 @pytest.mark.parametrize("algo", [0, 1, 3])
