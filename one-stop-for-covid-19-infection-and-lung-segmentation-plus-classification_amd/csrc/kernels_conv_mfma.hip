@@ -656,7 +656,8 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
   // K-split: every (image, 32-column strip) is cut into row chunks; aim at ~4096 waves (2 waves/SIMD x 256 CUs x 2 rounds),
   // at least 8 rows per chunk (the 3x3 ring re-reads 2 halo rows per chunk), at most 192 MiB of partials
   const long long units = (long long)n * p.strips;
-  long long want = (4096 + pairs - 1) / pairs;
+  static const long long target = [] { const char* e = getenv("UNET_WGRAD_BLOCKS"); return e ? atoll(e) : 1536LL; }();      // = one resident round of the two-wave kernel (256 CUs x 6): measured best of 1536..6144
+  long long want = (target + pairs - 1) / pairs;
   const long long cap = std::max<long long>(1, (48LL << 20) / per);
   want = std::min(want, cap);
   long long cps = std::max<long long>(1, (want + units - 1) / units);

@@ -223,7 +223,7 @@ class HipUNet:
 
     def train_batch(self, x, y, training_dropout=True):
         """One optimizer step (model.fit inner loop, T1:1059).  Returns device tensor [loss, dice]."""
-        out = self.forward_backward(x, y, training_dropout).clone()
+        out = self.forward_backward(x, y, training_dropout) + 0.0      # a copy made by a kernel (clone() takes the D2D-copy path: ~20 us bubble)
         self.adam_step()
         return out
 
@@ -239,7 +239,7 @@ class HipUNet:
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr() if yd is not None else None, p.data_ptr()), "set_io")
         self._keep = (xd, yd)
         self._run(plan, _lib.PROG_FWD_INFER)
-        return p, (self._loss_tensor(plan).clone() if yd is not None else None)
+        return p, (self._loss_tensor(plan) + 0.0 if yd is not None else None)
 
     def threshold_sums(self, p, y, thresholds):
         """[T,3] float64 (sum gt*pr, sum pr, sum gt) with pr = p > t  (sm.metrics, T1:1206-1207)."""
