@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const float* __restri
 // writes/reads for it, and the next chunk's value is loaded into the same register right behind the MFMA that consumed it.
 // WTT = Winograd tiles per row of the MFMA M-tile: 32 (one row pair x 64 columns) or 16 (two row pairs x 32 columns, for images
 // narrower than 64 columns: lane l31 -> row pair l31 / 16, tile l31 % 16).
-template <int WTT, int WM, int WC, bool GEN, bool BREG>
+// CKV = input channels per staged chunk: 8, or 16 (BREG only, Cin % 16 == 0): half as many barriers per MFMA.
+template <int WTT, int WM, int WC, bool GEN, bool BREG, int CKV>
 __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                              const float* __restrict__ bias, const float* __restrict__ mask,
                                                              float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int act,
@@ -280,8 +281,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   static_assert(WM * WC == 2, "4 waves = 2 x WM x WC");
   constexpr int WT = WTT, RPW = 32 / WTT;                    // (shadows the file-level WT) row pairs per wave tile
   constexpr int TAPS = 16, TH = 2 * RPW * WM, TN = 32 * WC;
+  static_assert(CKV == 8 || (CKV == 16 && BREG), "16-channel chunks only with register-resident weights");
+  constexpr int CKP = CKV + 4, QPI = CKV / 4;                // (shadows the file-level CKP) padded channel stride, channel quads per pixel
   constexpr int ROWF = 4 * WT * CKP;
-  constexpr int ITEMS = (TH + 2) * WT * 2;
+  constexpr int ITEMS = (TH + 2) * WT * QPI;
   constexpr int WTOT = TAPS * CK * (TN / 4);
   constexpr int PL = (ITEMS + 255) / 256, WL = BREG ? 0 : (WTOT + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < PL; ++k) {
     const int idx = min(tid + k * 256, ITEMS - 1);      // surplus threads redo the last item (same data, same slot): no branch in the loop
-    const int q = idx & 1, t = (idx >> 1) & (WT - 1), r = idx / (2 * WT);
+    const int q = idx % QPI, t = (idx / QPI) % WT, r = idx / (QPI * WT);
     const int gy = y0 + r - 1, gx = x0 + 2 * t - 1;
     const bool rok = gy >= 0 && gy < H;
 #pragma unroll
@@ -385,11 +388,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) breg[kk][k][j] = buf_ld1(rs_u, boff[kk][k], j * Cout * 4);
   }
-  for (int c0 = 0; c0 < Cin; c0 += CK) {
+  for (int c0 = 0; c0 < Cin; c0 += CKV) {
     store_lds();
     __syncthreads();
-    if (c0 + CK < Cin) issue_loads(c0 + CK);
-    const int cn = c0 + CK < Cin ? c0 + CK : c0;            // BREG: chunk whose weights are fetched behind the MFMAs (the last chunk re-reads itself)
+    if (c0 + CKV < Cin) issue_loads(c0 + CKV);
+#pragma unroll
+    for (int sub = 0; sub < CKV / 8; ++sub) {
+    const int cb = c0 + sub * 8;
+    const int cn = cb + 8 < Cin ? cb + 8 : cb;              // BREG: 8-channel group whose weights are fetched behind the MFMAs (the last one re-reads itself)
     // Rows A, B, C = patch rows kh, kh+1, kh+2 of this wave's row pair.  kh = 0 (ky' 0,1): R0 = A-C, R1 = B+C.  kh = 1 (ky' 2,3):
     // R3 = A-C, R2 = B-A.  So both halves compute d = A-C and e = B + sgn*Z (Z = kh ? A : C) -- no branch, the loop body stays one
     // basic block -- and kh = 1 simply walks its two taps in the order (3, 2): tap of slot kk = kh ? 3-kk : kk.
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
       f32x4 a[2][2];                                            // [kk][k - 2kp]
 #pragma unroll
       for (int kq = 0; kq < 2; ++kq) {
-        const float* vb = &s_v[(((2 * (wm * RPW + l31 / WT) + kh) * 4 + 2 * kp + kq) * WT + l31 % WT) * CKP + hi * 4];
+        const float* vb = &s_v[(((2 * (wm * RPW + l31 / WT) + kh) * 4 + 2 * kp + kq) * WT + l31 % WT) * CKP + sub * 8 + hi * 4];
         const f32x4 A = *reinterpret_cast<const f32x4*>(vb), B = *reinterpret_cast<const f32x4*>(vb + ROWF), C = *reinterpret_cast<const f32x4*>(vb + 2 * ROWF);
         const f32x4 Z = kh ? A : C;
         a[0][kq] = A - C;
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
           }
         }
       }
+    }
     }
     __syncthreads();
   }
@@ -519,14 +526,30 @@ int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float
   static bool attr_done = false;
   if (!attr_done) {
     const int big = (int)((size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float));
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
       UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %d bytes of LDS", big);
     attr_done = true;
   }
-#define UNET_LAUNCH_W2D(G_, B_) hipLaunchKernelGGL((conv_wino2d_kernel<WTT, WM, WC, G_, B_>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y)
+  static const int ck16_env = [] { const char* e = getenv("UNET_WINO_CK16"); return e ? atoi(e) : 1; }();
+  const bool ck16 = ck16_env && breg && (cin % 16) == 0;
+  if (ck16) {
+    const size_t lds16 = std::max((size_t)((TH + 2) * 4 * WT * 20) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));
+    static bool attr16 = false;
+    if (!attr16) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess)
+        UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %zu bytes of LDS", lds16);
+      attr16 = true;
+    }
+    if (gen) hipLaunchKernelGGL((conv_wino2d_kernel<WTT, WM, WC, true, true, 16>), grid, dim3(256), lds16, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_wino2d_kernel<WTT, WM, WC, false, true, 16>), grid, dim3(256), lds16, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+    UNET_CHECK_LAUNCH(ctx, "conv_wino2d");
+    return UNET_OK;
+  }
+#define UNET_LAUNCH_W2D(G_, B_) hipLaunchKernelGGL((conv_wino2d_kernel<WTT, WM, WC, G_, B_, 8>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y)
   if (gen) { if (breg) UNET_LAUNCH_W2D(true, true); else UNET_LAUNCH_W2D(true, false); }
   else { if (breg) UNET_LAUNCH_W2D(false, true); else UNET_LAUNCH_W2D(false, false); }
 #undef UNET_LAUNCH_W2D
