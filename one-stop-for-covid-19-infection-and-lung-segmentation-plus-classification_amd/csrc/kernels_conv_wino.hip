@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
     store_lds();
     __syncthreads();
     if (c0 + CKV < Cin) issue_loads(c0 + CKV);
+    __builtin_amdgcn_s_setprio(2);                         // MFMA phase outranks the other wave's staging phase at the issue arbiter
 #pragma unroll
     for (int sub = 0; sub < CKV / 8; ++sub) {
     const int cb = c0 + sub * 8;
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
       }
     }
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 
