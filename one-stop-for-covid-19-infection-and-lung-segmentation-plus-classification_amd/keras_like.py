@@ -141,6 +141,19 @@ class UNetModel:
                 out[k] = np.mean([b[k] for b in sc], axis=0)
         return out
 
+    def intermediate_output(self, layer_name, x, batch_size=32):
+        """Model(inputs=model.input, outputs=model.get_layer(layer_name).output).predict(x)  (T1:1385-1387, layer 'conv2d_9' = the
+        first bottleneck conv): the activation of a named layer in inference mode.  `layer_name` is a Keras auto-name
+        ('conv2d_9', 'batch_normalization_3', 'conv2d_transpose_1') or an engine name ('c5a', 'bn3', 'u6', 'p2')."""
+        rev = {v.split("/")[0]: k.split("/")[0] for k, v in W.keras_names(self.in_ch, self.arch).items()}
+        name = rev.get(layer_name, layer_name)
+        outs = []
+        for i in range(0, len(x), batch_size):
+            xb = x[i:i + batch_size]
+            self.backend.predict_batch(xb)
+            outs.append(self.backend.tap(len(xb), name))
+        return np.concatenate(outs, 0)
+
     def predict(self, x, batch_size=32):
         """model.predict T1:1137."""
         outs = []

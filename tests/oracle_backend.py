@@ -35,7 +35,8 @@ class OracleBackend:
     def predict_batch(self, x, y=None):
         import torch
         with torch.no_grad():
-            p = self.tr._fwd(self.tr.w, x, training=False, dtype=self.dtype)[0]
+            p, acts, _ = self.tr._fwd(self.tr.w, x, training=False, dtype=self.dtype, want_acts=True)
+            self._last_acts = {k: v.numpy() for k, v in acts.items()}
             ld = None
             if y is not None:
                 t = torch.as_tensor(np.asarray(y), dtype=self.dtype)
@@ -44,6 +45,10 @@ class OracleBackend:
 
     def threshold_sums(self, p, y, thresholds):
         return O.threshold_sums(y, p, thresholds)
+
+    def tap(self, n, name):
+        """activation `name` of the last predict_batch (inference mode)"""
+        return self._last_acts[name]
 
 
 class ClsOracleBackend:

@@ -241,3 +241,15 @@ def test_other_shapes_batch1_nonsquare_inch3():
         assert abs(l2[0] - r["loss"]) < 2e-5
         g = eng.get_grads()
         assert relerr(g["c1a/kernel"], r["grads"]["c1a/kernel"]) < 2e-2 and relerr(g["out/kernel"], r["grads"]["out/kernel"]) < 1e-4
+
+
+def test_intermediate_output_conv2d_9_matches_oracle():
+    """The feature tap the reference clusters on (T1:1385-1387): layer 'conv2d_9' (= c5a) in inference mode."""
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.keras_like import UNetModel
+    x, _ = synthetic_ct(3, 64, seed=6)
+    m = UNetModel(64, seed=3, dropout_rate=0.0)
+    f = m.intermediate_output("conv2d_9", x, batch_size=2)
+    with torch.no_grad():
+        acts = O.forward(m.get_weights(), x, training=False, dtype=torch.float64, want_acts=True)[1]
+    assert f.shape == (3, 4, 4, 512) and relerr(f, acts["c5a"].numpy()) < 2e-5

@@ -130,3 +130,20 @@ def test_kfold_runner_reference_flow_and_quirks(tmp_path, capsys):
     out4 = four_fold_runner_unet_infection_segmentation(data=(x[:8], y[:8]), epochs=1, batch_size=8, workdir=str(tmp_path / "f4"), verbose=0,
                                                         backend=OracleBackend(16, 16), reinit_each_fold=True, overwrite_fold_files=False)
     assert out4["table_iou"].shape[1] == 4 and len(out4["paths"]) == 4
+
+
+def test_intermediate_output_by_keras_layer_name():
+    """T1:1385-1387: Model(inputs, outputs=model.get_layer('conv2d_9').output) -- conv2d_9 is the first bottleneck conv (c5a)."""
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.keras_like import UNetModel
+    from oracle import unet_oracle as O
+    from oracle_backend import OracleBackend
+    x, _ = synthetic_ct(3, 32, seed=4)
+    m = UNetModel(32, backend=OracleBackend(32, 32), seed=2)
+    f = m.intermediate_output("conv2d_9", x, batch_size=2)
+    assert f.shape == (3, 2, 2, 512)
+    import torch
+    with torch.no_grad():
+        acts = O.forward(m.get_weights(), x, training=False, want_acts=True)[1]
+    assert np.allclose(f, acts["c5a"].numpy(), atol=1e-6) and np.allclose(m.intermediate_output("c5a", x), f, atol=1e-6)
+    assert m.intermediate_output("batch_normalization_3", x).shape == (3, 8, 8, 128)
