@@ -497,8 +497,9 @@ def pp_loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_
 #   and averages over the batch (keras/engine/training_utils.py weighted_masked_objective).  NOTE: the reference passes the
 #   ndarray returned by sklearn's compute_class_weight, which Keras 2.3 only honours when it is a dict -- the oracle exposes
 #   the weights as an explicit argument, (1, 1) = what the reference effectively trains with.
-# Same PARITY STATUS as above: third-party Keras semantics restated, "parity unpinned"; f1/precision/recall are the
-# reference's own closures (restated line by line below).
+# Same PARITY STATUS as above for the Keras layers: third-party semantics restated, "parity unpinned".  f1/precision/recall are the
+# reference's own closures and ARE pinned: tests/golden/f1_goldens.npz holds the outputs of the reference's functions executed on
+# seeded vectors (tests/golden/make_f1_goldens.py), tests/test_classifier_host.py checks cls_f1 against them.
 # =======================================================================================
 CLS_C = [16, 32, 64]
 CLS_HIDDEN = 32

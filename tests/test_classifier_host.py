@@ -48,6 +48,18 @@ def test_confusion_report_and_f1_closure():
     assert abs(float(O.cls_f1(t, q)) - 2 * (2 / 3) ** 2 / (4 / 3)) < 1e-6
 
 
+def test_f1_closure_pinned_by_reference_goldens():
+    """tests/golden/f1_goldens.npz was produced by executing the reference's own recall / precision / f1 closures (T2:688-703,
+    tests/golden/make_f1_goldens.py): the oracle's restatement must reproduce them."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f1_goldens.npz"))
+    for i in range(int(z["n_cases"])):
+        t, p = torch.as_tensor(z[f"t{i}"]), torch.as_tensor(z[f"p{i}"])
+        assert abs(float(O.cls_f1(t, p)) - float(z[f"f1{i}"])) < 1e-12, i
+        tp = float(torch.sum(torch.round(torch.clamp(t * p, 0, 1))))
+        assert abs(tp / (float(torch.sum(torch.round(torch.clamp(p, 0, 1)))) + 1e-7) - float(z[f"precision{i}"])) < 1e-12
+        assert abs(tp / (float(torch.sum(torch.round(torch.clamp(t, 0, 1)))) + 1e-7) - float(z[f"recall{i}"])) < 1e-12
+
+
 def test_tables_and_param_count():
     W.set_classifier_input(224, 224)
     assert W.count_params(1, "classifier") == (1_678_385, 1_677_937)                   # model.summary() of T2:747-776
