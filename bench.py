@@ -194,7 +194,7 @@ def main():
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
                                    + {"unet": "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
-                       "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": {0: "auto: winograd_f23x / mfma_f32_32x32x2", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd_f23x"}[args.algo],
+                       "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": {0: "auto: winograd F(2x2,3x3) / F(2,3) on mfma_f32_32x32x2, direct mfma otherwise", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd"}[args.algo],
                        "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
