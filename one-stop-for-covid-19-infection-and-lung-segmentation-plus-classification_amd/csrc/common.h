@@ -8,10 +8,16 @@
 
 #include "../../include/unet_hip.h"
 
+// BN_SLOTS copies of a per-channel reduction target (<= 2 * 1024 doubles each): the workgroups of a statistics kernel spread their
+// final fp64 atomics over the copies (512 workgroups hammering the same 16 cache lines cost ~40 us per launch), a tiny kernel then
+// folds the copies into the caller's sums and clears them.  Owned by the context => statistics ops of ONE context must be issued on
+// one stream at a time (use a context per stream otherwise).
+constexpr int UNET_BN_SLOTS = 64, UNET_BN_SLOT_DOUBLES = 2048;
 struct unet_ctx {
   int device = 0;
   int num_cu = 256;
   int profiling = 0;
+  double* bn_slots = nullptr;       // device, UNET_BN_SLOTS x UNET_BN_SLOT_DOUBLES, all zero between launches
   std::string err;
 };
 

@@ -12,7 +12,12 @@ constexpr int TPB = 256;
 constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident blocks; grid-stride beyond that
 // BN statistics end in 2C fp64 atomics per block on a handful of cache lines: measured 0.2 ms of pure
 // atomic serialisation at 2048 blocks, so the reduction kernels run 2 blocks per CU instead
-constexpr int BN_STATS_BLOCKS = 512;
+// Workgroups of the reduction kernels.  Every workgroup ends in 2C fp64 atomics (spread over UNET_BN_SLOTS copies of the target), so
+// more workgroups buy memory-level parallelism and pay atomic traffic; measured optima per kernel (UNET_BN_BLOCKS overrides all three):
+static const int BN_BLOCKS_ENV = [] { const char* e = getenv("UNET_BN_BLOCKS"); return e ? atoi(e) : 0; }();
+static const int BN_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 512;          // one tensor in        (0.86 -> 0.68 ms per step with the slots)
+static const int BN_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 1024;     // two tensors in       (1.06 -> 0.79)
+static const int POOL_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 768;    // read-modify-write    (0.73 -> 0.63)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__
       s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w;
       s2.x += w.x; s2.y += w.y; s2.z += w.z; s2.w += w.w;
     }
-    double* d1 = sums + q * 4; double* d2 = sums + C + q * 4;
+    double* d1 = sums + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies
     atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y);
     atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
     atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y);
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const float* __re
       float4 u = sh1[tid + k * lpp], w2 = sh2[tid + k * lpp];
       s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w; s2.x += w2.x; s2.y += w2.y; s2.z += w2.z; s2.w += w2.w;
     }
-    double* d1 = sums + q * 4; double* d2 = sums + C + q * 4;
+    double* d1 = sums + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies
     atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y); atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
     atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y); atomicAdd(d2 + 2, (double)s2.z); atomicAdd(d2 + 3, (double)s2.w);
   }
@@ -488,6 +493,16 @@ __global__ __launch_bounds__(TPB) void zero_kernel(float4* __restrict__ p, long 
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// sums[i] += sum over the slot copies; the copies are cleared for the next launch
+__global__ void bn_slot_fold_kernel(double* __restrict__ slots, double* __restrict__ sums, int n2c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2c) return;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < UNET_BN_SLOTS; ++k) { double* p = slots + (size_t)k * UNET_BN_SLOT_DOUBLES + i; s += *p; *p = 0.0; }
+  sums[i] += s;
+}
+
 inline bool bn_c_ok(int c) { return c >= 4 && (c % 4) == 0 && (c / 4) <= TPB; }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -496,10 +511,11 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" {
 
 int32_t unet_bn_stats(unet_ctx* ctx, const float* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) {
-  if (!x || !sums || !bn_c_ok(c) || ldx < c || (ldx & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: bad args c=%d ldx=%d", c, ldx);
+  if (!ctx || !x || !sums || !bn_c_ok(c) || ldx < c || (ldx & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: bad args c=%d ldx=%d", c, ldx);
   int ppb = TPB / (c / 4);
   int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(bn_stats_kernel<0>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, nullptr, 0, nullptr, sums, (long long)pixels, c);
+  hipLaunchKernelGGL(bn_stats_kernel<0>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c);
+  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "bn_stats"); return UNET_OK;
 }
 
@@ -526,10 +542,11 @@ int32_t unet_bn_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* b
 
 int32_t unet_bn_bwd_stats(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp,
                           double* sums, int64_t pixels, int32_t c, void* stream) {
-  if (!dy || !x || !bnp || !sums || !bn_c_ok(c) || ((ldx | lddy) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_stats: bad args");
+  if (!ctx || !dy || !x || !bnp || !sums || !bn_c_ok(c) || ((ldx | lddy) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_stats: bad args");
   int ppb = TPB / (c / 4);
-  int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, sums, (long long)pixels, c);
+  int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_BWD_STATS_BLOCKS); if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, ctx->bn_slots, (long long)pixels, c);
+  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "bn_bwd_stats"); return UNET_OK;
 }
 
@@ -589,11 +606,12 @@ int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx* ctx, const float* x, int32_t
 int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32_t ldy, const float* dy, float* dx, int32_t lddx,
                                             const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd,
                                             int32_t c, float rate, uint64_t seed, void* stream) {
-  if (!y || !dy || !dx || !gamma || !beta || !sums || (c & 3) || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldy | lddx) & 3) || rate < 0 || rate >= 1)
+  if (!ctx || !y || !dy || !dx || !gamma || !beta || !sums || (c & 3) || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldy | lddx) & 3) || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd + bn stats: bad args (c/4 must divide 256)");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
-  int grid = (int)std::min<long long>(cdiv64(total, TPB), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(pool_bwd_bnstats_kernel, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, sums, n, h, wd, c, rate, seed);
+  int grid = (int)std::min<long long>(cdiv64(total, TPB), POOL_BWD_STATS_BLOCKS); if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(pool_bwd_bnstats_kernel, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, ctx->bn_slots, n, h, wd, c, rate, seed);
+  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd + bn stats"); return UNET_OK;
 }
 

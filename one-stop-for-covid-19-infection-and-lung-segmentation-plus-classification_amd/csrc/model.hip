@@ -35,11 +35,20 @@ int32_t unet_ctx_create(int32_t device_id, unet_ctx** out) {
   unet_ctx* c = new unet_ctx();
   c->device = device_id;
   c->num_cu = prop.multiProcessorCount;
+  const size_t sb = sizeof(double) * UNET_BN_SLOTS * UNET_BN_SLOT_DOUBLES;
+  int prev = 0;
+  hipGetDevice(&prev);
+  if (hipSetDevice(device_id) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&c->bn_slots), sb) != hipSuccess ||
+      hipMemset(c->bn_slots, 0, sb) != hipSuccess) { hipSetDevice(prev); delete c; return UNET_E_HIP; }
+  hipSetDevice(prev);
   *out = c;
   return UNET_OK;
 }
 
-void unet_ctx_destroy(unet_ctx* ctx) { delete ctx; }
+void unet_ctx_destroy(unet_ctx* ctx) {
+  if (ctx && ctx->bn_slots) hipFree(ctx->bn_slots);
+  delete ctx;
+}
 const char* unet_last_error(const unet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on) { if (!ctx) return UNET_E_ARG; ctx->profiling = on; return UNET_OK; }
 
