@@ -104,7 +104,7 @@ int32_t unet_convT2x2_bwd_weights(unet_ctx*, const float* x, const float* dy, in
  *   bnp : float[4*C]  = scale, shift, mean, invstd.
  *   count = elements per channel over the GLOBAL batch (n*h*w*world).
  * The statistics kernels (unet_bn_stats, unet_bn_bwd_stats, unet_maxpool2x2_dropout_bwd_bnstats) stage their atomics in a scratch the
- * CONTEXT owns: issue them on one stream at a time per unet_ctx (one context per stream otherwise). */
+ * CONTEXT owns: issue them on one stream at a time per context; use one context per stream otherwise. */
 int32_t unet_bn_stats(unet_ctx*, const float* x, int32_t ldx, double* sums, int64_t pixels,
                       int32_t c, void* stream);
 int32_t unet_bn_finalize_train(unet_ctx*, const double* sums, double count, const float* gamma,
