@@ -53,7 +53,8 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1_kernel(const float* __restrict
   const long long pixels = (long long)N * H * W;
   const long long g0 = ((long long)blockIdx.x * TPB + threadIdx.x) / lpp, gs = ((long long)gridDim.x * TPB) / lpp;
   for (long long p = g0; p < pixels; p += gs) {
-    int j = (int)(p % W); long long t = p / W; int i = (int)(t % H);
+    const unsigned pu = (unsigned)p, tq = pu / (unsigned)W;             // 32-bit index math (the launcher guarantees pixels < 2^31):
+    const int j = (int)(pu - tq * (unsigned)W), i = (int)(tq % (unsigned)H);   // the 64-bit div/mod pair cost more than the 9 FMAs
     float4 acc = b4;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __re
   const long long pixels = (long long)N * H * W;
   const long long g0 = ((long long)blockIdx.x * TPB + threadIdx.x) / lpp, gs = ((long long)gridDim.x * TPB) / lpp;
   for (long long p = g0; p < pixels; p += gs) {
-    const int j = (int)(p % W); const long long t2 = p / W; const int i = (int)(t2 % H);
+    const unsigned pu = (unsigned)p, tq = pu / (unsigned)W;             // 32-bit index math (pixels < 2^31, checked by the launcher)
+    const int j = (int)(pu - tq * (unsigned)W), i = (int)(tq % (unsigned)H);
     const float4 g = *reinterpret_cast<const float4*>(dy + p * Cout + sub * 4);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -253,7 +255,7 @@ int32_t k_conv3x3_naive_fwd(unet_ctx* ctx, const float* x, const float* w, const
 
 int32_t k_conv3x3_c1_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd,
                          int cout, int act, float rate, uint64_t seed, hipStream_t s) {
-  if ((cout & 3) || TPB % (cout / 4)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1: cout=%d unsupported", cout);
+  if ((cout & 3) || TPB % (cout / 4) || (long long)n * h * wd >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1: cout=%d / %d x %d x %d pixels unsupported", cout, n, h, wd);
   long long threads = (long long)n * h * wd * (cout / 4);
   hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(grid_for(threads / 2 + 1, 2048)), dim3(TPB), 0, s, x, w, bias, y, n, h, wd, cout, act, rate,
                      (unsigned long long)seed);
@@ -309,7 +311,7 @@ size_t c1_wgrad_ws_bytes(int cout) { return (size_t)(C1_BLOCKS + 32) * 10 * cout
 
 int32_t k_conv3x3_c1_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                            int wd, int cout, hipStream_t s) {
-  if ((cout & 3) || TPB % (cout / 4) || (cout / 4) > 64) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1_wgrad: cout=%d unsupported", cout);
+  if ((cout & 3) || TPB % (cout / 4) || (cout / 4) > 64 || (long long)n * h * wd >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1_wgrad: cout=%d unsupported", cout);
   if (!ws || ws_bytes < c1_wgrad_ws_bytes(cout)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_c1_wgrad: workspace too small");
   long long groups = ((long long)n * h * wd * (cout / 4) + TPB - 1) / TPB;
   int blocks = (int)std::min<long long>(C1_BLOCKS, std::max<long long>(groups, 1));
