@@ -348,3 +348,27 @@ def test_copy_and_accum_slices(ops):
     assert np.allclose(dst.cpu().numpy(), a + g1[..., 32:64] + g2, atol=1e-6)
     ops.ck(ops.lib.unet_accum_slices(ops.h, srcs, lds, 2, dst.data_ptr(), c, pixels, c, 0, ops.s), "accum overwrite")
     assert np.allclose(dst.cpu().numpy(), g1[..., 32:64] + g2, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 512, 32, 32), (2, 256, 256, 64, 64), (4, 32, 32, 256, 512), (1, 224, 224, 16, 32)])
+def test_winograd_matches_direct_mfma_at_full_size(ops, shape):
+    """BASELINE-size layers (too big for the CPU oracle in a unit test): the Winograd kernels (forward, data gradient, weight gradient)
+    against the direct MFMA kernels on the same device buffers -- two independent algorithms, relative L2 difference <= 1e-5."""
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    g = torch.Generator(device="cuda").manual_seed(n + ci)
+    x = torch.randn(n, h, w, ci, device="cuda", generator=g); k = torch.randn(3, 3, ci, co, device="cuda", generator=g) * 0.1
+    b = torch.randn(co, device="cuda", generator=g); dy = torch.randn(n, h, w, co, device="cuda", generator=g)
+    ws = torch.empty(int(ops.lib.unet_conv3x3_w_ws_floats(ci, co)), device="cuda")
+    nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co)
+    wgs = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    res = {}
+    for algo in (2, 3):
+        y = torch.empty(n, h, w, co, device="cuda"); dx = torch.empty(n, h, w, ci, device="cuda")
+        dw = torch.empty(3, 3, ci, co, device="cuda"); db = torch.empty(co, device="cuda")
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, algo, ws.data_ptr(), ops.s), "fwd")
+        ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, dy.data_ptr(), k.data_ptr(), x.data_ptr(), 1, 0.0, 0, dx.data_ptr(), ws.data_ptr(), n, h, w, ci, co, algo, ops.s), "dgrad")
+        ops.ck(ops.lib.unet_conv3x3_bwd_weights(ops.h, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), wgs.data_ptr(), nb, n, h, w, ci, co, algo, ops.s), "wgrad")
+        res[algo] = [t.cpu().numpy() for t in (y, dx, dw, db)]
+    for a, c, nm in zip(res[2], res[3], ("y", "dx", "dw", "db")):
+        assert relerr(c, a) < 1e-5, nm
