@@ -297,11 +297,8 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
                                                         float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
                                                         int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
                                                         int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
-  // MODE 2 = conv3x3 with the Winograd F(2,3)-along-x transform (see kernels_conv_wino.hip): same data movement as MODE 0, but per
-  // pair of output columns 4 products per kernel row instead of 6 -> 12 accumulator tiles dU[ky][k] instead of 9 dW[ky][kx];
-  // dU_k[ky][ci][co] = sum V_k[y+ky][t][ci] * dM_k[y][t][co] with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the X row and
-  // dM = (dy0, dy0+dy1, dy0-dy1, -dy1) of the dY row, both formed in registers from the raw LDS rows.
-  constexpr int TAPS = MODE == 0 ? 9 : (MODE == 1 ? 4 : 12);
+  static_assert(MODE == 0 || MODE == 1, "the Winograd-domain gradient (run_wgrad<2>) has its own kernel: wgrad_wino_kernel");
+  constexpr int TAPS = MODE == 0 ? 9 : 4;
   constexpr int ROWF = 34 * 32;                    // floats per ring row (conv3x3)
   constexpr int AL = MODE != 1 ? 5 : 16, BL = 4;   // float4 staging registers per lane (A rows, B row)
   __shared__ __attribute__((aligned(16))) float s_a[MODE != 1 ? 3 * ROWF : 4 * 32 * 32];
@@ -376,12 +373,8 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
     }
   };
 
-  // MODE 2 carries 192 accumulator registers: the next-row register prefetch would spill, so it loads at the top of the step and
-  // leaves the latency to the second wave of the SIMD (UNET_WGRAD2_PF=1 compiles the prefetching variant back in for experiments)
-  constexpr bool PFW = MODE != 2;
-  if (PFW) issue(0);
+  issue(0);
   for (int t = 0; t < nsteps; ++t) {
-    if (!PFW) issue(t);
     const int yy = ya - 1 + t;                                  // conv3x3 only
     const int slot_w = MODE != 1 ? ((yy + 3) % 3) * ROWF : 0;
 #pragma unroll
@@ -390,29 +383,11 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < BL; ++k) *reinterpret_cast<f32x4*>(&s_b[blds[k]]) = breg[k];
     __syncthreads();
-    if (PFW && t + 1 < nsteps) issue(t + 1);                     // next row's loads fly under this row's MFMAs
+    if (t + 1 < nsteps) issue(t + 1);                            // next row's loads fly under this row's MFMAs
     if (MODE == 1 || t >= 2) {
       int slot_off[3];
 #pragma unroll
       for (int dr = 0; dr < 3; ++dr) slot_off[dr] = ((yy - 2 + dr + 3) % 3) * ROWF;   // rows y-1, y, y+1 with y = yy-1
-      if (MODE == 2) {
-#pragma unroll 2
-        for (int pp = 0; pp < 8; ++pp) {
-          const int tt = 2 * pp + hi;                             // MFMA k-pair = 2 consecutive Winograd tiles of the strip
-          const float dy0 = s_b[(2 * tt) * 32 + l31], dy1 = s_b[(2 * tt + 1) * 32 + l31];
-          bsum += dy0 + dy1;
-          const float bm0 = dy0, bm1 = dy0 + dy1, bm2 = dy0 - dy1, bm3 = -dy1;
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky) {
-            const float* r = &s_a[slot_off[ky] + (2 * tt) * 32 + l31];    // ring px index 0 <-> column x0-1: d_j = px 2tt+j
-            const float d0 = r[0], d1 = r[32], d2 = r[64], d3 = r[96];
-            acc[(ky * 4 + 0) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0 - d2, bm0, acc[(ky * 4 + 0) % TAPS], 0, 0, 0);
-            acc[(ky * 4 + 1) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 + d2, bm1, acc[(ky * 4 + 1) % TAPS], 0, 0, 0);
-            acc[(ky * 4 + 2) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2 - d1, bm2, acc[(ky * 4 + 2) % TAPS], 0, 0, 0);
-            acc[(ky * 4 + 3) % TAPS] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 - d3, bm3, acc[(ky * 4 + 3) % TAPS], 0, 0, 0);
-          }
-        }
-      } else
 #pragma unroll 2
       for (int pp = 0; pp < 16; ++pp) {
         const int c = 2 * pp + hi;
@@ -687,10 +662,9 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
   const size_t need = (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
   if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   float* part = static_cast<float*>(ws); float* part_b = part + per;
-  static const int one_wave = [] { const char* e = getenv("UNET_WGRAD_WINO_1WAVE"); return e ? atoi(e) : 0; }();     // A/B switch (MODE 2 only)
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));            // see the block map in the kernels
-  if (MODE == 2 && !one_wave)
+  if constexpr (MODE == 2)
     hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(128), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk,
                        p.chunks_per_strip, p.nsplit, npairs, S);
   else
