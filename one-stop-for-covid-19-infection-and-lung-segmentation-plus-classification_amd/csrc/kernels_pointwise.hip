@@ -14,6 +14,7 @@ constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident blocks; grid-stride be
 // atomic serialisation at 2048 blocks, so the reduction kernels run 2 blocks per CU instead
 // Workgroups of the reduction kernels.  Every workgroup ends in 2C fp64 atomics (spread over UNET_BN_SLOTS copies of the target), so
 // more workgroups buy memory-level parallelism and pay atomic traffic; measured optima per kernel (UNET_BN_BLOCKS overrides all three):
+static const int HEAD_BLOCKS = [] { const char* e = getenv("UNET_HEAD_BLOCKS"); return e ? atoi(e) : 8192; }();   // head_fwd: one load in flight per thread, wants many workgroups (0.20 -> 0.18 ms); head_bwd ends in 33 atomics on two cache lines: 1024 (0.25 -> 0.215)
 static const int BN_BLOCKS_ENV = [] { const char* e = getenv("UNET_BN_BLOCKS"); return e ? atoi(e) : 0; }();
 static const int BN_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 512;          // one tensor in        (0.86 -> 0.68 ms per step with the slots)
 static const int BN_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 1024;     // two tensors in       (1.06 -> 0.79)
@@ -618,7 +619,7 @@ int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32
 int32_t unet_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* p, const float* y_true,
                       double* loss_sums, int64_t pixels, int32_t cin, void* stream) {
   if (!x || !w || !bias || !p || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || (y_true && !loss_sums)) UNET_FAIL(ctx, UNET_E_ARG, "head_fwd: bad args (cin/4 must be a power of two <= 64)");
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for(pixels * (cin / 4) / 4)), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels, cin);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels * (cin / 4) / 4, TPB), HEAD_BLOCKS))), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels, cin);
   UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
 }
 
@@ -632,7 +633,7 @@ int32_t unet_head_bwd(unet_ctx* ctx, const float* x, const float* w, const float
                       const double* loss_sums, double count, float* dx, float* dw, float* db, int64_t pixels, int32_t cin,
                       int32_t relu_mask, void* stream) {
   if (!x || !w || !p || !y_true || !loss_sums || !dx || !dw || !db || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "head_bwd: bad args");
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(grid_for(pixels * (cin / 4) / 4)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin, relu_mask);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(std::min(grid_for(pixels * (cin / 4) / 4), 1024)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin, relu_mask);
   UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
 }
 
