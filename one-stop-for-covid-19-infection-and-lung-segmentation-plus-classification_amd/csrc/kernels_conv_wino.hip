@@ -512,6 +512,209 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Same F(2x2,3x3) math, accumulators split FOUR ways: wave ky' (0..3) of a workgroup owns the 4 taps (ky', k = 0..3) of one
+// (row pair x 32 tiles x 32 couts) tile -> 64 accumulator registers, ~150 VGPRs -> three workgroups per CU instead of two.
+// Every weight of the slab belongs to exactly one wave (register-resident B operands, as BREG above).  A operand of wave ky':
+// R = row[ra] + sg * row[rb] with (ra, rb, sg) = (0,2,-) (1,2,+) (2,1,-) (1,3,-): two ds_read_b128 + one fma per operand quad.
+// Epilogue: each wave x-transforms its M_ky' and posts both halves in LDS; wave w then finishes (output row w & 1, column parity
+// w >> 1) = sum over ky' of c[row][ky'] * T_ky' with c[0] = (1,1,1,0), c[1] = (0,1,-1,-1).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WTT, bool GEN, int CKV>
+__global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                              const float* __restrict__ bias, const float* __restrict__ mask,
+                                                              float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int act,
+                                                              int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y) {
+  constexpr int WT = WTT, RPW = 32 / WTT, TH = 2 * RPW, TN = 32;
+  constexpr int CKP = CKV + 4, QPI = CKV / 4;
+  constexpr int ROWF = 4 * WT * CKP;
+  constexpr int ITEMS = (TH + 2) * WT * QPI;
+  constexpr int PL = (ITEMS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_v = smem;                                         // [(TH+2)][4][WT][CKP]  x-transformed patch rows
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kq = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's ky'
+  const int l31 = lane & 31, hi = lane >> 5;
+  int n, tx, ty, nbase;
+  {
+    const int G = (Cout + TN - 1) / TN, P = tiles_x * tiles_y * N, per = (P + 7) >> 3;
+    const int L = blockIdx.x, xcd = L & 7, sq = L >> 3;
+    const int lt = sq / G, g = sq - lt * G;
+    const int pt = xcd * per + lt;
+    if (pt >= P) return;
+    ty = pt % tiles_y; const int r = pt / tiles_y;
+    tx = r % tiles_x; n = r / tiles_x;
+    nbase = g * TN;
+  }
+  const int x0 = tx * 2 * WT, y0 = ty * TH;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x + (long long)n * H * W * Cin, (long long)H * W * Cin * 4);
+  const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(u, 16LL * Cin * Cout * 4);
+  int poff[PL][4], plds[PL];
+#pragma unroll
+  for (int k = 0; k < PL; ++k) {
+    const int idx = min(tid + k * 256, ITEMS - 1);
+    const int q = idx % QPI, t = (idx / QPI) % WT, r = idx / (QPI * WT);
+    const int gy = y0 + r - 1, gx = x0 + 2 * t - 1;
+    const bool rok = gy >= 0 && gy < H;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) poff[k][d] = (rok && gx + d >= 0 && gx + d < W) ? ((gy * W + gx + d) * Cin + q * 4) * 4 : OOB;
+    plds[k] = (r * 4 * WT + t) * CKP + q * 4;
+  }
+  int boff[4];
+  float breg[4][4];                                          // [k][j]
+  {
+    const int co = nbase + l31;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) boff[k] = co < Cout ? ((((kq * 4 + k) * Cin + 4 * hi) * Cout) + co) * 4 : OOB;
+  }
+  f32x4 preg[PL][4];
+  auto issue_loads = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) preg[k][d] = buf_ld4(rs_x, poff[k][d], c0 * 4);
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+      float* p = s_v + plds[k];
+      f32x4 t0 = preg[k][0] - preg[k][2], t1 = preg[k][1] + preg[k][2], t2 = preg[k][2] - preg[k][1], t3 = preg[k][1] - preg[k][3];
+      asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+      *reinterpret_cast<f32x4*>(p) = t0;
+      *reinterpret_cast<f32x4*>(p + WT * CKP) = t1;
+      *reinterpret_cast<f32x4*>(p + 2 * WT * CKP) = t2;
+      *reinterpret_cast<f32x4*>(p + 3 * WT * CKP) = t3;
+    }
+  };
+  // patch rows this wave combines: R_ky' = row[ra] + sg * row[rb]
+  const int ra = kq == 0 ? 0 : (kq == 2 ? 2 : 1), rb = kq == 3 ? 3 : (kq == 2 ? 1 : 2);
+  const float sg = kq == 1 ? 1.0f : -1.0f;
+
+  issue_loads(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) breg[k][j] = buf_ld1(rs_u, boff[k], j * Cout * 4);
+  for (int c0 = 0; c0 < Cin; c0 += CKV) {
+    store_lds();
+    __syncthreads();
+    if (c0 + CKV < Cin) issue_loads(c0 + CKV);
+    __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+    for (int sub = 0; sub < CKV / 8; ++sub) {
+      const int cb = c0 + sub * 8;
+      const int cn = cb + 8 < Cin ? cb + 8 : cb;
+      f32x4 a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* vb = &s_v[((2 * (l31 / WT) * 4 + k) * WT + l31 % WT) * CKP + sub * 8 + hi * 4];
+        const f32x4 A = *reinterpret_cast<const f32x4*>(vb + ra * ROWF), B = *reinterpret_cast<const f32x4*>(vb + rb * ROWF);
+        a[k] = A + sg * B;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][j], breg[k][j], acc[k], 0, 0, 0);
+          breg[k][j] = buf_ld1(rs_u, boff[k], (cn + j) * Cout * 4);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: post T[half] = x-output-transform of this wave's M_ky', then wave w finishes (row w & 1, half w >> 1)
+  float* xb = smem + kq * (32 * 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+    xb[r * 64 + lane] = (m0 + m1) + m2;
+    xb[(16 + r) * 64 + lane] = (m1 - m2) - m3;
+  }
+  __syncthreads();
+  const int orow = kq & 1, half = kq >> 1;
+  f32x16 mine;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float* q = smem + (half * 16 + r) * 64 + lane;
+    const float t0 = q[0], t1 = q[32 * 64], t2 = q[2 * 32 * 64], t3 = q[3 * 32 * 64];
+    mine[r] = orow == 0 ? (t0 + t1) + t2 : (t1 - t2) - t3;
+  }
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
+  const int co = nbase + q4;
+  const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v0 = mine[4 * g + 0], v1 = mine[4 * g + 1], v2 = mine[4 * g + 2], v3 = mine[4 * g + 3];
+    {
+      const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+      const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
+      if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
+    }
+    {
+      const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+      const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
+      if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
+    }
+    const int mt = e + 8 * g + 4 * hi;
+    const int px = x0 + 2 * (mt % WT) + half, py = y0 + 2 * (mt / WT) + orow;
+    if (py >= H || px >= W || co >= Cout) continue;
+    float4 o4 = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
+    const long long o = (((long long)n * H + py) * W + px) * Cout + co;
+    if (!GEN) {
+      if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
+      if (mask_mode == MASK_RELU) {
+        const float4 m = *reinterpret_cast<const float4*>(mask + o);
+        o4.x = m.x > 0.f ? o4.x : 0.f; o4.y = m.y > 0.f ? o4.y : 0.f; o4.z = m.z > 0.f ? o4.z : 0.f; o4.w = m.w > 0.f ? o4.w : 0.f;
+      }
+    } else {
+      o4.x = apply_act(o4.x, act); o4.y = apply_act(o4.y, act); o4.z = apply_act(o4.z, act); o4.w = apply_act(o4.w, act);
+      if (mask_mode == MASK_NONE) {
+        if (rate > 0.0f) { const float4 ks = keep_scale(o >> 2, rate, seed); o4.x *= ks.x; o4.y *= ks.y; o4.z *= ks.z; o4.w *= ks.w; }
+      } else {
+        const float4 m = *reinterpret_cast<const float4*>(mask + o);
+        float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (mask_mode == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
+        o4.x *= mask_factor(m.x, mask_mode, ks.x, rate); o4.y *= mask_factor(m.y, mask_mode, ks.y, rate);
+        o4.z *= mask_factor(m.z, mask_mode, ks.z, rate); o4.w *= mask_factor(m.w, mask_mode, ks.w, rate);
+      }
+    }
+    *reinterpret_cast<float4*>(y + o) = o4;
+  }
+}
+
+template <int WTT, int CKV>
+int32_t launch_wino2d4(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n, int h,
+                       int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
+  if (!mask) mask_mode = MASK_NONE;
+  constexpr int WT = WTT, TH = 2 * (32 / WTT), TN = 32;
+  const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
+  const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));
+  const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * (CKV + 4)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d4_kernel<WTT, false, CKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d4_kernel<WTT, true, CKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d4: cannot reserve %zu bytes of LDS", lds);
+    attr_done = true;
+  }
+  if (gen) hipLaunchKernelGGL((conv_wino2d4_kernel<WTT, true, CKV>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+  else hipLaunchKernelGGL((conv_wino2d4_kernel<WTT, false, CKV>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
+  UNET_CHECK_LAUNCH(ctx, "conv_wino2d4");
+  return UNET_OK;
+}
+
 template <int WTT, int WM, int WC>
 int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n, int h,
                       int wd, int cin, int cout, int act, float rate, unsigned long long seed, hipStream_t s) {
@@ -612,6 +815,16 @@ int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const 
   if (!wino_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: cin=%d cout=%d unsupported", cin, cout);
   if ((long long)h * wd * std::max(cin, cout) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: one image must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
   if (use_2d(h, cout)) {
+    // UNET_WINO_4WAY: 0 never, 1 (default) the four-way accumulator split for 32-wide cout groups (c1b 0.54 -> 0.52 ms, c9a 0.89 -> 0.86;
+    // on the 64-wide layers it stages the patch twice as often and measured 3-10 % slower), 2 everywhere
+    static const int fourway = [] { const char* e = getenv("UNET_WINO_4WAY"); return e ? atoi(e) : 1; }();
+    if (fourway == 2 || (fourway == 1 && cout % 64 != 0)) {
+      const bool c16 = (cin % 16) == 0;
+      if (wino_tile_cols(wd) == 32) return c16 ? launch_wino2d4<16, 16>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s)
+                                               : launch_wino2d4<16, 8>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+      return c16 ? launch_wino2d4<32, 16>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s)
+                 : launch_wino2d4<32, 8>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+    }
     if (wino_tile_cols(wd) == 32) {                        // narrow images: two row pairs x 16 tiles per MFMA M-tile
       if (cout % 64 == 0) return launch_wino2d<16, 1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
       return launch_wino2d<16, 2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
