@@ -109,9 +109,7 @@ def main():
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
                   arch=args.arch)
-    if args.arch == "classifier":
-        W.set_classifier_input(S, S)
-    eng.set_weights(W.init_weights(0, 1, args.arch))       # identical replicas
+    eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     for _ in range(args.warmup):
         eng.train_batch(x, y)
@@ -145,7 +143,7 @@ def main():
         dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel
         fl = sum(o[1] for o in dom); ms = sum(o[3] / max(o[4], 1) for o in dom); launches = len(dom)
         # executed MFMA work: the Winograd F(2,3)-along-x launches do 12 instead of 18 multiplies per pair of outputs
-        shapes = W.weight_shapes(1, args.arch)
+        shapes = W.weight_shapes(1, args.arch, (S, S))
         fl_exec, n_wino = 0.0, 0
         for o in dom:
             kind, lname = o[0].split(":")

@@ -114,26 +114,25 @@ class ClassifierModel:
     def __init__(self, input_size: int = 224, in_ch: int = 1, backend=None, seed: int = 0, **backend_kw):
         self.h = self.w = int(input_size)
         self.in_ch = in_ch
-        W.set_classifier_input(self.h, self.w)
         if backend is None:
             from .engine import HipUNet                      # raises loudly without GPU / library
             backend = HipUNet(self.h, self.w, in_ch, seed=seed, arch="classifier", dropout_rate=0.4, **backend_kw)
         self.backend = backend
-        self.backend.set_weights(W.init_weights(seed, in_ch, "classifier"))
+        self.backend.set_weights(W.init_weights(seed, in_ch, "classifier", (self.h, self.w)))
         self.compiled = False
         self.verbose = 1
         self.best_val_auc = -1.0                              # the reference's global best_val_auc (T2:813)
 
-    def _tables(self):
-        W.set_classifier_input(self.h, self.w)
+    @property
+    def _hw(self):
+        return (self.h, self.w)
 
     def count_params(self):
-        self._tables(); return W.count_params(self.in_ch, "classifier")[0]
+        return W.count_params(self.in_ch, "classifier", self._hw)[0]
 
     def summary(self, print_fn=print):
-        self._tables()
-        total, train = W.count_params(self.in_ch, "classifier")
-        for n, k, ci, co in W.layer_table(self.in_ch, "classifier"):
+        total, train = W.count_params(self.in_ch, "classifier", self._hw)
+        for n, k, ci, co in W.layer_table(self.in_ch, "classifier", self._hw):
             print_fn(f"{n:6s} {k:6s} {ci:6d} -> {co:4d}")
         print_fn(f"Total params: {total:,}\nTrainable params: {train:,}\nNon-trainable params: {total - train:,}")
 
@@ -152,13 +151,13 @@ class ClassifierModel:
         self.backend.set_weights(w)
 
     def save_weights(self, path):
-        self._tables(); W.save_weights(path, self.backend.get_weights(), self.in_ch, "classifier")
+        W.save_weights(path, self.backend.get_weights(), self.in_ch, "classifier", self._hw)
 
     def load_weights(self, path):
-        self._tables(); self.backend.set_weights(W.load_weights(path, self.in_ch, "classifier"))
+        self.backend.set_weights(W.load_weights(path, self.in_ch, "classifier", self._hw))
 
     def to_json(self):
-        self._tables(); return W.to_json(self.h, self.w, self.in_ch, "classifier")
+        return W.to_json(self.h, self.w, self.in_ch, "classifier")
 
     @staticmethod
     def _class_weight_pair(class_weight, honour_array):

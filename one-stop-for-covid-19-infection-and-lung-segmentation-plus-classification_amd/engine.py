@@ -42,9 +42,7 @@ class HipUNet:
         self.h, self.w, self.in_ch, self.algo = h, w, in_ch, conv_algo
         self.arch = arch                       # "unet" (T1:853-916) or "unetpp" (task1_unet_plus_plus.py:858-950; its dropout
         self._arch_id = {"unet": _lib.ARCH_UNET, "unetpp": _lib.ARCH_UNETPP, "classifier": _lib.ARCH_CLASSIFIER}[arch]   # rates fixed: >0 = on
-        if arch == "classifier":                 # task2_covid19_classifcation.py:747-776; y / p are [n] vectors, loss tensor = (bce, f1)
-            from . import weights as _W
-            _W.set_classifier_input(h, w)
+        # (classifier: task2_covid19_classifcation.py:747-776; y / p are [n] vectors, the loss tensor is (bce, f1))
         self.class_weights = (1.0, 1.0)
         self.pg = process_group
         self.pg_grad = process_group
@@ -71,7 +69,7 @@ class HipUNet:
         self.adam_v = torch.zeros_like(self.params)
         self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.dev)
         self._tinfo = OrderedDict()
-        for name, shape in weight_shapes(in_ch, arch).items():
+        for name, shape in weight_shapes(in_ch, arch, (h, w)).items():
             st, off, cnt = C.c_int32(), C.c_int64(), C.c_int64()
             self.ctx.check(self.lib.unet_model_tensor_info(probe, name.encode(), C.byref(st), C.byref(off), C.byref(cnt)), "tensor_info")
             assert cnt.value == int(np.prod(shape)), (name, cnt.value, shape)

@@ -44,15 +44,11 @@ def _pp_layer_table(in_ch):
 
 CLS_C = (16, 32, 64)            # slice classifier, task2_covid19_classifcation.py:747-776
 CLS_HIDDEN = 32
-_HW = {"hw": (224, 224)}       # input size of the classifier tables (fc1 fan-in = (H/8)(W/8)64); set by set_classifier_input()
+CLS_HW = (224, 224)             # the reference's input size (new_dim = 224, T2:489); `hw` overrides it (fc1 fan-in = (H/8)(W/8)64)
 
 
-def set_classifier_input(h: int, w: int):
-    _HW["hw"] = (int(h), int(w))
-
-
-def _cls_layer_table(in_ch):
-    h, w = _HW["hw"]
+def _cls_layer_table(in_ch, hw=None):
+    h, w = hw or CLS_HW
     t, cp = [], in_ch
     for k, c in enumerate(CLS_C, 1):
         t += [(f"c{k}a", "conv3", cp, c), (f"bn{k}a", "bn", c, c), (f"c{k}b", "conv3", c, c), (f"bn{k}b", "bn", c, c)]
@@ -61,12 +57,12 @@ def _cls_layer_table(in_ch):
     return t
 
 
-def layer_table(in_ch: int = 1, arch: str = "unet"):
+def layer_table(in_ch: int = 1, arch: str = "unet", hw=None):
     """[(name, kind, cin, cout)], kind in conv3|convT|bn|conv1|dense -- Keras creation order."""
     if arch == "unetpp":
         return _pp_layer_table(in_ch)
     if arch == "classifier":
-        return _cls_layer_table(in_ch)
+        return _cls_layer_table(in_ch, hw)
     t, cp = [], in_ch
     for k, c in enumerate(ENC, 1):
         t += [(f"c{k}a", "conv3", cp, c), (f"c{k}b", "conv3", c, c), (f"bn{k}", "bn", c, c)]
@@ -80,9 +76,9 @@ def layer_table(in_ch: int = 1, arch: str = "unet"):
     return t
 
 
-def weight_shapes(in_ch: int = 1, arch: str = "unet"):
+def weight_shapes(in_ch: int = 1, arch: str = "unet", hw=None):
     d = OrderedDict()
-    for name, kind, cin, cout in layer_table(in_ch, arch):
+    for name, kind, cin, cout in layer_table(in_ch, arch, hw):
         if kind == "conv3":
             d[f"{name}/kernel"] = (3, 3, cin, cout); d[f"{name}/bias"] = (cout,)
         elif kind == "conv1":
@@ -97,10 +93,10 @@ def weight_shapes(in_ch: int = 1, arch: str = "unet"):
     return d
 
 
-def keras_names(in_ch: int = 1, arch: str = "unet"):
+def keras_names(in_ch: int = 1, arch: str = "unet", hw=None):
     """our name -> Keras auto-name (conv2d_N/kernel:0 ...), counting per layer type in creation order."""
     out, nc, nt, nb, nd = OrderedDict(), 0, 0, 0, 0
-    for name, kind, _, _ in layer_table(in_ch, arch):
+    for name, kind, _, _ in layer_table(in_ch, arch, hw):
         if kind in ("conv3", "conv1"):
             nc += 1; base = f"conv2d_{nc}"
             out[f"{name}/kernel"] = f"{base}/kernel:0"; out[f"{name}/bias"] = f"{base}/bias:0"
@@ -117,8 +113,8 @@ def keras_names(in_ch: int = 1, arch: str = "unet"):
     return out
 
 
-def count_params(in_ch: int = 1, arch: str = "unet"):
-    sh = weight_shapes(in_ch, arch)
+def count_params(in_ch: int = 1, arch: str = "unet", hw=None):
+    sh = weight_shapes(in_ch, arch, hw)
     total = sum(int(np.prod(s)) for s in sh.values())
     non_train = sum(int(np.prod(s)) for k, s in sh.items() if k.endswith("/mean") or k.endswith("/var"))
     return total, total - non_train
@@ -133,12 +129,12 @@ def _truncated_normal(rng, shape):
     return k
 
 
-def init_weights(seed: int = 0, in_ch: int = 1, arch: str = "unet"):
+def init_weights(seed: int = 0, in_ch: int = 1, arch: str = "unet", hw=None):
     """he_normal for the 3x3 convs (T1:859...), Keras-default glorot_uniform for ConvT / the U-Net head (he_normal for the
     U-Net++ head, UPP:946), zero biases, BN gamma 1 / beta 0 / moving mean 0 / moving var 1."""
     rng = np.random.default_rng(seed)
     w = OrderedDict()
-    for name, kind, cin, cout in layer_table(in_ch, arch):
+    for name, kind, cin, cout in layer_table(in_ch, arch, hw):
         if kind == "conv3":
             std = math.sqrt(2.0 / (9 * cin)) / 0.87962566103423978
             w[f"{name}/kernel"] = (_truncated_normal(rng, (3, 3, cin, cout)) * std).astype(np.float32)
@@ -165,16 +161,16 @@ def init_weights(seed: int = 0, in_ch: int = 1, arch: str = "unet"):
     return w
 
 
-def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet"):
-    kn = keras_names(in_ch, arch)
+def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet", hw=None):
+    kn = keras_names(in_ch, arch, hw)
     with open(path, "wb") as f:          # keep the caller's filename (.hdf5/.h5) -- content is npz
         np.savez(f, **{kn[k]: np.asarray(v) for k, v in weights.items()})
 
 
-def load_weights(path: str, in_ch: int = 1, arch: str = "unet"):
-    kn = keras_names(in_ch, arch)
+def load_weights(path: str, in_ch: int = 1, arch: str = "unet", hw=None):
+    kn = keras_names(in_ch, arch, hw)
     z = np.load(path)
-    sh = weight_shapes(in_ch, arch)
+    sh = weight_shapes(in_ch, arch, hw)
     out = OrderedDict()
     for k, shape in sh.items():
         a = z[kn[k]]
@@ -185,7 +181,8 @@ def load_weights(path: str, in_ch: int = 1, arch: str = "unet"):
 
 
 def to_json(h: int, w: int, in_ch: int = 1, arch: str = "unet") -> str:
+    hw = (h, w)
     """Architecture description (the reference dumps model.to_json(), T1:1091-1093)."""
-    layers = [{"name": n, "kind": k, "cin": ci, "cout": co} for n, k, ci, co in layer_table(in_ch, arch)]
+    layers = [{"name": n, "kind": k, "cin": ci, "cout": co} for n, k, ci, co in layer_table(in_ch, arch, hw)]
     return json.dumps({"class_name": "Model", "arch": arch, "backend": "unet_hip/gfx950", "input_shape": [h, w, in_ch],
-                       "data_format": "channels_last", "layers": layers, "keras_names": keras_names(in_ch, arch)})
+                       "data_format": "channels_last", "layers": layers, "keras_names": keras_names(in_ch, arch, hw)})

@@ -61,14 +61,11 @@ def test_f1_closure_pinned_by_reference_goldens():
 
 
 def test_tables_and_param_count():
-    W.set_classifier_input(224, 224)
     assert W.count_params(1, "classifier") == (1_678_385, 1_677_937)                   # model.summary() of T2:747-776
     assert list(W.weight_shapes(1, "classifier").items()) == list(O.cls_weight_shapes(1, (224, 224)).items())
     kn = W.keras_names(1, "classifier")
     assert kn["fc1/kernel"] == "dense_1/kernel:0" and kn["bn3b/var"] == "batch_normalization_6/moving_variance:0" and kn["c3b/bias"] == "conv2d_6/bias:0"
-    W.set_classifier_input(32, 48)
-    assert W.weight_shapes(1, "classifier")["fc1/kernel"] == (4 * 6 * 64, 32)
-    W.set_classifier_input(224, 224)
+    assert W.weight_shapes(1, "classifier", (32, 48))["fc1/kernel"] == (4 * 6 * 64, 32)
 
 
 def test_oracle_classifier_grads_finite_difference():

@@ -46,10 +46,9 @@ def test_two_ranks_equal_single_process_full_batch(tmp_path, arch):
     from covidseg_amd.engine import HipUNet
     if arch == "classifier":
         x, y = synthetic_classification(8, 32, seed=5); y = y.astype(np.float32)
-        W.set_classifier_input(32, 32)
     else:
         x, y = synthetic_ct(4, 32, seed=5)
-    wts = W.init_weights(4, 1, arch)
+    wts = W.init_weights(4, 1, arch, (32, 32))
     wfile = str(tmp_path / "w.npz"); np.savez(wfile, **wts)
     out = str(tmp_path / "dp.npz")
     mp.get_context("spawn")
