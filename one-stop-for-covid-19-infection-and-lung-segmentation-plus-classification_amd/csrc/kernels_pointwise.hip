@@ -115,6 +115,22 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
                                                        float* __restrict__ y, int ldy,
                                                        long long pixels, int C) {
   const int lpp = C >> 2;
+  if (TPB % lpp == 0) {          // a thread keeps its channel quad: parameters live in registers, no per-element 64-bit div/mod
+    const int q = threadIdx.x % lpp, ppb = TPB / lpp;
+    const float4 sc = ld4(bnp + q * 4), sh = ld4(bnp + C + q * 4);
+    const long long step = (long long)gridDim.x * ppb;
+    long long p = (long long)blockIdx.x * ppb + threadIdx.x / lpp;
+    for (; p + step < pixels; p += 2 * step) {                   // two independent 16-B loads in flight per lane
+      const float4 v0 = ld4(x + p * ldx + q * 4), v1 = ld4(x + (p + step) * ldx + q * 4);
+      st4(y + p * ldy + q * 4, make_float4(fmaf(v0.x, sc.x, sh.x), fmaf(v0.y, sc.y, sh.y), fmaf(v0.z, sc.z, sh.z), fmaf(v0.w, sc.w, sh.w)));
+      st4(y + (p + step) * ldy + q * 4, make_float4(fmaf(v1.x, sc.x, sh.x), fmaf(v1.y, sc.y, sh.y), fmaf(v1.z, sc.z, sh.z), fmaf(v1.w, sc.w, sh.w)));
+    }
+    if (p < pixels) {
+      const float4 v = ld4(x + p * ldx + q * 4);
+      st4(y + p * ldy + q * 4, make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)));
+    }
+    return;
+  }
   const long long total = pixels * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     int q = (int)(i % lpp); long long p = i / lpp;
@@ -123,6 +139,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
                                           fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)));
   }
 }
+
 
 __global__ void bn_bwd_param_grads_kernel(const double* sums, float* dgamma, float* dbeta, int C) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,26 +158,37 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            long long pixels, int C, float rate, unsigned long long seed) {
   constexpr int mask_mode = MM;
   const int lpp = C >> 2;
+  // dx = scale * (dy - k1 - xhat * k2) * mask'(x);  k1 = sum(dy)/count, k2 = sum(dy*xhat)/count
+  auto one = [&](long long p, int q, const float4& sc, const float4& mean, const float4& istd, const float4& k1, const float4& k2) {
+    const float4 g = ld4(dy + p * lddy + q * 4), xv = ld4(x + p * ldx + q * 4);
+    float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask_mode == MASK_ELU_DROP) k4 = keep_scale(p * lpp + q, rate, seed);       // x is dense here: quad index == p*lpp + q
+    float4 r;
+    r.x = sc.x * (g.x - k1.x - (xv.x - mean.x) * istd.x * k2.x) * mask_factor(xv.x, mask_mode, k4.x, rate);
+    r.y = sc.y * (g.y - k1.y - (xv.y - mean.y) * istd.y * k2.y) * mask_factor(xv.y, mask_mode, k4.y, rate);
+    r.z = sc.z * (g.z - k1.z - (xv.z - mean.z) * istd.z * k2.z) * mask_factor(xv.z, mask_mode, k4.z, rate);
+    r.w = sc.w * (g.w - k1.w - (xv.w - mean.w) * istd.w * k2.w) * mask_factor(xv.w, mask_mode, k4.w, rate);
+    st4(dx + p * lddx + q * 4, r);
+  };
+  auto params = [&](int q, float4& sc, float4& mean, float4& istd, float4& k1, float4& k2) {
+    sc = ld4(bnp + q * 4); mean = ld4(bnp + 2 * C + q * 4); istd = ld4(bnp + 3 * C + q * 4);
+    const double* s1 = sums + q * 4; const double* s2 = sums + C + q * 4;
+    k1 = make_float4((float)(s1[0] * inv_count), (float)(s1[1] * inv_count), (float)(s1[2] * inv_count), (float)(s1[3] * inv_count));
+    k2 = make_float4((float)(s2[0] * inv_count), (float)(s2[1] * inv_count), (float)(s2[2] * inv_count), (float)(s2[3] * inv_count));
+  };
+  float4 sc, mean, istd, k1, k2;
+  if (TPB % lpp == 0) {          // a thread keeps its channel quad: the 5 parameter quads (8 of them doubles) are loaded once
+    const int q = threadIdx.x % lpp, ppb = TPB / lpp;
+    params(q, sc, mean, istd, k1, k2);
+    const long long step = (long long)gridDim.x * ppb;
+    for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / lpp; p < pixels; p += step) one(p, q, sc, mean, istd, k1, k2);
+    return;
+  }
   const long long total = pixels * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    int q = (int)(i % lpp); long long p = i / lpp;
-    float4 g = ld4(dy + p * lddy + q * 4), xv = ld4(x + p * ldx + q * 4);
-    float4 sc = ld4(bnp + q * 4), mean = ld4(bnp + 2 * C + q * 4), istd = ld4(bnp + 3 * C + q * 4);
-    const double* s1 = sums + q * 4; const double* s2 = sums + C + q * 4;
-    float r[4];
-    const float gg[4] = {g.x, g.y, g.z, g.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float ss[4] = {sc.x, sc.y, sc.z, sc.w}, mm[4] = {mean.x, mean.y, mean.z, mean.w};
-    const float ii[4] = {istd.x, istd.y, istd.z, istd.w};
-    float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (mask_mode == MASK_ELU_DROP) k4 = keep_scale(i, rate, seed);       // x is dense here: quad index == i
-    const float kk[4] = {k4.x, k4.y, k4.z, k4.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float k1 = (float)(s1[k] * inv_count), k2 = (float)(s2[k] * inv_count);
-      float xh = (xx[k] - mm[k]) * ii[k];
-      r[k] = ss[k] * (gg[k] - k1 - xh * k2) * mask_factor(xx[k], mask_mode, kk[k], rate);
-    }
-    st4(dx + p * lddx + q * 4, make_float4(r[0], r[1], r[2], r[3]));
+    const int q = (int)(i % lpp); const long long p = i / lpp;
+    params(q, sc, mean, istd, k1, k2);
+    one(p, q, sc, mean, istd, k1, k2);
   }
 }
 
