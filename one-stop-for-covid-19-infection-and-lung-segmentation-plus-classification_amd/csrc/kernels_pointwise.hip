@@ -201,8 +201,9 @@ __global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    int q = (int)(i % lpp); long long p = i / lpp;
-    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    const unsigned iu = (unsigned)i, pu = iu / (unsigned)lpp, tu = pu / (unsigned)Wo;    // 32-bit index math (launchers check total < 2^31)
+    const int q = (int)(iu - pu * (unsigned)lpp), jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
+    const long long p = pu, n = tu / (unsigned)Ho;
     const float* b = x + ((n * H + 2 * io) * W + 2 * jo) * (long long)ldx + q * 4;
     float4 a0 = ld4(b), a1 = ld4(b + ldx), a2 = ld4(b + (long long)W * ldx), a3 = ld4(b + (long long)(W + 1) * ldx);
     float4 m = make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)), fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
@@ -227,8 +228,9 @@ __global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    int q = (int)(i % lpp); long long p = i / lpp;
-    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    const unsigned iu = (unsigned)i, pu = iu / (unsigned)lpp, tu = pu / (unsigned)Wo;    // 32-bit index math (launchers check total < 2^31)
+    const int q = (int)(iu - pu * (unsigned)lpp), jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
+    const long long p = pu, n = tu / (unsigned)Ho;
     long long pix = (n * H + 2 * io) * W + 2 * jo;
     const float* b = x + pix * ldx + q * 4;
     float4 a0 = ld4(b), a1 = ld4(b + ldx), a2 = ld4(b + (long long)W * ldx), a3 = ld4(b + (long long)(W + 1) * ldx);
@@ -255,8 +257,9 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const float* __restric
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    int q = (int)(i % lpp); long long p = i / lpp;
-    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    const unsigned iu = (unsigned)i, pu = iu / (unsigned)lpp, tu = pu / (unsigned)Wo;    // 32-bit index math (launchers check total < 2^31)
+    const int q = (int)(iu - pu * (unsigned)lpp), jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
+    const long long p = pu, n = tu / (unsigned)Ho;
     const long long pix = (n * H + 2 * io) * W + 2 * jo;
     const float* b = x + pix * ldx + q * 4;
     const float4 sc = ld4(bnp + q * 4), sh = ld4(bnp + C + q * 4);
@@ -291,8 +294,9 @@ __global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const float* __re
                                 g4.w != 0.f ? 1.f / g4.w : 0.f);
   float4 s1 = make_float4(0, 0, 0, 0), s2 = s1;
   for (long long i = (long long)blockIdx.x * TPB + tid; i < total; i += (long long)gridDim.x * TPB) {
-    long long p = i / lpp;
-    int jo = (int)(p % Wo); long long t = p / Wo; int io = (int)(t % Ho); long long n = t / Ho;
+    const unsigned pu = (unsigned)i / (unsigned)lpp, tu = pu / (unsigned)Wo;             // 32-bit index math (launcher checks total < 2^31)
+    const int jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
+    const long long p = pu, n = tu / (unsigned)Ho;
     long long pix = (n * H + 2 * io) * W + 2 * jo;
     const float* b = y + pix * ldy + q * 4;
     float4 a[4] = {ld4(b), ld4(b + ldy), ld4(b + (long long)W * ldy), ld4(b + (long long)(W + 1) * ldy)};
@@ -607,6 +611,7 @@ int32_t unet_maxpool2x2_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, 
                                     int32_t c, float rate, uint64_t seed, void* stream) {
   if (!x || !y || (c & 3) || (h & 1) || (wd & 1) || ldx < c || (ldx & 3) || rate < 0 || rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "maxpool fwd: bad args (h,w even; c%%4==0)");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, y, n, h, wd, c, rate, seed);
   UNET_CHECK_LAUNCH(ctx, "maxpool fwd"); return UNET_OK;
 }
@@ -616,6 +621,7 @@ int32_t unet_maxpool2x2_dropout_bwd(unet_ctx* ctx, const float* x, int32_t ldx, 
                                     int32_t accumulate, void* stream) {
   if (!x || !dy || !dx || (c & 3) || (h & 1) || (wd & 1) || ((ldx | lddx) & 3) || rate < 0 || rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd: bad args");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   int grid = grid_for(total);
   if (accumulate) hipLaunchKernelGGL(pool_bwd_kernel<true>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
   else hipLaunchKernelGGL(pool_bwd_kernel<false>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
@@ -628,6 +634,7 @@ int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx* ctx, const float* x, int32_t
   if (!x || !bnp || !y || !pooled || !bn_c_ok(c) || (h & 1) || (wd & 1) || ldx < c || ldy < c || ((ldx | ldy) & 3) || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn_apply_maxpool fwd: bad args (h,w even; c%%4==0)");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed);
   UNET_CHECK_LAUNCH(ctx, "bn_apply_maxpool fwd"); return UNET_OK;
 }
@@ -638,6 +645,7 @@ int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32
   if (!ctx || !y || !dy || !dx || !gamma || !beta || !sums || (c & 3) || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldy | lddx) & 3) || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd + bn stats: bad args (c/4 must divide 256)");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   int grid = (int)std::min<long long>(cdiv64(total, TPB), POOL_BWD_STATS_BLOCKS); if (grid < 1) grid = 1;
   hipLaunchKernelGGL(pool_bwd_bnstats_kernel, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, ctx->bn_slots, n, h, wd, c, rate, seed);
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
