@@ -17,6 +17,8 @@
 // Weight-gradient: see wgrad_mfma_kernel below (split-K over pixels, deterministic 2-stage).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restr
                                                             int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
   constexpr int ROWF = 34 * 32;
   constexpr int AL = 3, BL = 2;                       // float4 staging registers per lane (272 / 256 items over 128 lanes)
-  __shared__ __attribute__((aligned(16))) float s_a[3 * ROWF];
+  __shared__ __attribute__((aligned(16))) float s_a[ROWF];                 // newest X row only (older rows live in the register window)
   __shared__ __attribute__((aligned(16))) float s_b[32 * 32];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -499,37 +501,48 @@ __global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restr
   };
   const float sgn = w ? -1.0f : 1.0f;
 
-  issue(0);
-  for (int t = 0; t < nsteps; ++t) {
-    const int yy = ya - 1 + t;
-    const int slot_w = ((yy + 3) % 3) * ROWF;
+  // Register-resident row window: the two transformed A operands of every tile pair (8 pairs x 2 slots) of the LAST THREE X rows
+  // stay in registers (48 VGPRs), so a row is read from LDS and transformed once instead of three times (as ky = 2, 1, 0 of three
+  // consecutive output rows): 5 instead of 11 LDS reads per 6 MFMAs.  LDS then only holds the newest X row and the dY row.
+  // The row loop is unrolled by 3 so the window slot of a step is a compile-time constant.
+  float win[3][8][2];
+  auto step = [&](int t, auto phc) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phc)::value;
 #pragma unroll
-    for (int k = 0; k < AL; ++k) *reinterpret_cast<f32x4*>(&s_a[slot_w + alds[k]]) = areg[k];
+    for (int k = 0; k < AL; ++k) *reinterpret_cast<f32x4*>(&s_a[alds[k]]) = areg[k];
 #pragma unroll
     for (int k = 0; k < BL; ++k) *reinterpret_cast<f32x4*>(&s_b[blds[k]]) = breg[k];
     __syncthreads();
-    if (t + 1 < nsteps) issue(t + 1);                      // next row's loads fly under this row's MFMAs
-    if (t >= 2) {
-      int slot_off[3];
+    if (t + 1 < nsteps) issue(t + 1);                      // next row's loads fly under this row's MFMAs (two rows ahead measured slower)
 #pragma unroll
-      for (int dr = 0; dr < 3; ++dr) slot_off[dr] = ((yy - 2 + dr + 3) % 3) * ROWF;   // rows y-1, y, y+1 with y = yy-1
-#pragma unroll 2
+    for (int pp = 0; pp < 8; ++pp) {                       // newest X row (= ky 2 of this step's output row) -> window slot PH
+      const float* r = &s_a[(2 * (2 * pp + hi) + w) * 32 + l31];          // px 0 <-> column x0-1: window px 2tt .. 2tt+3
+      const float e0 = r[0], e1 = r[32], e2 = r[64];
+      const float z = w ? e0 : e2;
+      win[PH][pp][0] = e0 - e2; win[PH][pp][1] = e1 + sgn * z;
+    }
+    if (t >= 2) {
+#pragma unroll
       for (int pp = 0; pp < 8; ++pp) {
         const int tt = 2 * pp + hi;                        // MFMA k-pair = 2 consecutive Winograd tiles of the strip
         const float dy0 = s_b[(2 * tt) * 32 + l31], dy1 = s_b[(2 * tt + 1) * 32 + l31];
         if (w == 0) bsum += dy0 + dy1;
         const float bm0 = w ? -dy1 : dy0, bm1 = dy0 + sgn * dy1;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const float* r = &s_a[slot_off[ky] + (2 * tt + w) * 32 + l31];    // ring px 0 <-> column x0-1: window px 2tt .. 2tt+3
-          const float e0 = r[0], e1 = r[32], e2 = r[64];
-          const float z = w ? e0 : e2;
-          acc[ky][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e2, bm0, acc[ky][0], 0, 0, 0);
-          acc[ky][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 + sgn * z, bm1, acc[ky][1], 0, 0, 0);
+        for (int ky = 0; ky < 3; ++ky) {                   // X row of tap ky was staged (2 - ky) steps ago
+          const int sl = (PH + 1 + ky) % 3;
+          acc[ky][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(win[sl][pp][0], bm0, acc[ky][0], 0, 0, 0);
+          acc[ky][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(win[sl][pp][1], bm1, acc[ky][1], 0, 0, 0);
         }
       }
     }
     __syncthreads();
+  };
+  issue(0);
+  for (int t = 0; t < nsteps; t += 3) {                     // window slot = t % 3: static inside the 3-step body
+    step(t, std::integral_constant<int, 0>{});
+    if (t + 1 < nsteps) step(t + 1, std::integral_constant<int, 1>{});
+    if (t + 2 < nsteps) step(t + 2, std::integral_constant<int, 2>{});
   }
 
   // partial tiles: slot j of wave w is Winograd index k = w ? 3 - j : j; quad transpose -> 16-byte stores (see wgrad_mfma_kernel)
