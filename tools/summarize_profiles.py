@@ -37,7 +37,7 @@ def collect(counter):
 
 
 def family(name):
-    if "conv_wino2d_kernel" in name or "conv_wino_kernel" in name:
+    if "conv_wino2d_kernel" in name or "conv_wino2d4_kernel" in name or "conv_wino_kernel" in name:
         return "dom"
     if "conv_mfma_kernel<0" in name:
         return "dom"
