@@ -26,10 +26,13 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 4
+#define UNET_ABI_VERSION 5
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
+/* bf16 storage element (raw bit pattern; round-to-nearest-even from fp32) of the mixed-precision path */
+typedef uint16_t unet_bf16;
+enum { UNET_DTYPE_F32 = 0, UNET_DTYPE_BF16 = 1 };
 
 /* status codes */
 enum { UNET_OK = 0, UNET_E_ARG = -1, UNET_E_HIP = -2, UNET_E_SHAPE = -3, UNET_E_STATE = -4, UNET_E_NODEV = -5 };
@@ -186,6 +189,60 @@ int32_t unet_zero(unet_ctx*, void* ptr, size_t bytes, void* stream);
 int32_t unet_copy_slice(unet_ctx*, const float* src, int32_t lds, float* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream);
 int32_t unet_accum_slices(unet_ctx*, const float* const* srcs, const int32_t* lds, int32_t nsrc, float* dst, int32_t ldd,
                           int64_t pixels, int32_t c, int32_t accumulate, void* stream);
+
+/* ---- bf16-storage variants of the ops above (ABI v5) ----------------------------------------------------------------
+ * Mixed precision of the same graph: activations and activation gradients are unet_bf16 in HBM (half the traffic), parameters,
+ * parameter gradients, BN sums (fp64), the head's probabilities / targets and all arithmetic stay fp32; convolutions run on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same argument meaning as the fp32 functions; `ld*` in ELEMENTS.
+ * Channel counts: conv3x3 cin % 16 == 0 (or the cin == 1 `first` entry points, whose image stays fp32), cout % 32 == 0;
+ * convT cin, cout % 32 == 0; other shapes return UNET_E_SHAPE.  w_ws: device scratch of unet_conv3x3_w_ws_floats(cin, cout)
+ * floats (re-laid-out bf16 weights).  BASELINE.json configs[3], configs[4] name bf16. */
+int32_t unet_cast_f32_to_bf16(unet_ctx*, const float* src, unet_bf16* dst, int64_t count, void* stream);   /* count % 4 == 0 */
+int32_t unet_cast_bf16_to_f32(unet_ctx*, const unet_bf16* src, float* dst, int64_t count, void* stream);
+int32_t unet_conv3x3_fwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int32_t n, int32_t h, int32_t wd,
+                              int32_t cin, int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, void* w_ws, void* stream);
+int32_t unet_conv3x3_first_fwd_bf16(unet_ctx*, const float* x, const float* w, const float* bias, unet_bf16* y, int32_t n, int32_t h,
+                                    int32_t wd, int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, void* stream);
+int32_t unet_conv3x3_bwd_data_bf16(unet_ctx*, const unet_bf16* dy, const float* w, const unet_bf16* mask_src, int32_t mask_mode, float mask_rate,
+                                   uint64_t mask_seed, unet_bf16* dx, void* w_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
+                                   void* stream);
+size_t unet_conv3x3_bwd_weights_ws_bytes_bf16(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout);
+int32_t unet_conv3x3_bwd_weights_bf16(unet_ctx*, const unet_bf16* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                                      int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream);
+int32_t unet_conv3x3_first_bwd_weights_bf16(unet_ctx*, const float* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                                            int32_t n, int32_t h, int32_t wd, int32_t cout, void* stream);
+int32_t unet_convT2x2_fwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int32_t ldy, int32_t n, int32_t h,
+                               int32_t wd, int32_t cin, int32_t cout, void* w_ws, void* stream);
+int32_t unet_convT2x2_bwd_data_bf16(unet_ctx*, const unet_bf16* dy, int32_t lddy, const float* w, const unet_bf16* relu_src, unet_bf16* dx,
+                                    int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* w_ws, void* stream);
+size_t unet_convT2x2_bwd_weights_ws_bytes_bf16(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout);
+int32_t unet_convT2x2_bwd_weights_bf16(unet_ctx*, const unet_bf16* x, const unet_bf16* dy, int32_t lddy, float* dw, float* db, void* ws,
+                                       size_t ws_bytes, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream);
+int32_t unet_bn_stats_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream);
+int32_t unet_bn_apply_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy, int64_t pixels, int32_t c,
+                           void* stream);
+int32_t unet_bn_bwd_stats_bf16(unet_ctx*, const unet_bf16* dy, int32_t lddy, const unet_bf16* x, int32_t ldx, const float* bnp, double* sums,
+                               int64_t pixels, int32_t c, void* stream);
+int32_t unet_bn_bwd_apply_bf16(unet_ctx*, const unet_bf16* dy, int32_t lddy, const unet_bf16* x, int32_t ldx, const float* bnp, const double* sums,
+                               double count, int32_t mask_mode, float mask_rate, uint64_t mask_seed, unet_bf16* dx, int32_t lddx,
+                               int64_t pixels, int32_t c, void* stream);
+int32_t unet_maxpool2x2_dropout_fwd_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, unet_bf16* y, int32_t n, int32_t h, int32_t wd, int32_t c,
+                                         float rate, uint64_t seed, void* stream);
+int32_t unet_maxpool2x2_dropout_bwd_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, const unet_bf16* dy, unet_bf16* dx, int32_t lddx, int32_t n,
+                                         int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, int32_t accumulate, void* stream);
+int32_t unet_bn_apply_maxpool_dropout_fwd_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy,
+                                               unet_bf16* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
+                                               void* stream);
+int32_t unet_maxpool2x2_dropout_bwd_bnstats_bf16(unet_ctx*, const unet_bf16* y, int32_t ldy, const unet_bf16* dy, unet_bf16* dx, int32_t lddx,
+                                                 const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd,
+                                                 int32_t c, float rate, uint64_t seed, void* stream);
+int32_t unet_head_fwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, float* p, const float* y_true, double* loss_sums,
+                           int64_t pixels, int32_t cin, void* stream);
+int32_t unet_head_bwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const float* p, const float* y_true, const double* loss_sums,
+                           double count, unet_bf16* dx, float* dw, float* db, int64_t pixels, int32_t cin, int32_t relu_mask, void* stream);
+int32_t unet_copy_slice_bf16(unet_ctx*, const unet_bf16* src, int32_t lds, unet_bf16* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream);
+int32_t unet_accum_slices_bf16(unet_ctx*, const unet_bf16* const* srcs, const int32_t* lds, int32_t nsrc, unet_bf16* dst, int32_t ldd,
+                               int64_t pixels, int32_t c, int32_t accumulate, void* stream);
 
 /* ---- dense tail of the slice classifier (task2_covid19_classifcation.py:770-776, `T2`) ------------------------------
  * Replaces: Flatten -> Dense(32, relu) -> Dropout(0.4) T2:772-775.  y[b,:] = dropout(act(x[b,:] W + bias)); x [batch,k] row-major

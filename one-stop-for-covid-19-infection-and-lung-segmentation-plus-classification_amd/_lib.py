@@ -10,10 +10,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA, ALGO_WINOGRAD = 0, 1, 2, 3
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
+DTYPE_F32, DTYPE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 MASK_NONE, MASK_RELU, MASK_ELU, MASK_ELU_DROP = 0, 1, 2, 3
 PROG_FWD_TRAIN, PROG_BWD, PROG_FWD_INFER = 0, 1, 2
@@ -47,25 +48,50 @@ _PROTOS = {
     "unet_convT2x2_bwd_data": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_convT2x2_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "unet_convT2x2_bwd_weights": (i32, [vp, vp, vp, i32, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]),
+    # bf16-storage variants (ABI v5): same argument lists minus the algorithm selector
+    "unet_cast_f32_to_bf16": (i32, [vp, vp, vp, i64, vp]),
+    "unet_cast_bf16_to_f32": (i32, [vp, vp, vp, i64, vp]),
+    "unet_conv3x3_fwd_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, vp, vp]),
+    "unet_conv3x3_first_fwd_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_conv3x3_bwd_data_bf16": (i32, [vp, vp, vp, vp, i32, f32, u64, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "unet_conv3x3_bwd_weights_ws_bytes_bf16": (sz, [i32, i32, i32, i32, i32]),
+    "unet_conv3x3_bwd_weights_bf16": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp]),
+    "unet_conv3x3_first_bwd_weights_bf16": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
+    "unet_convT2x2_fwd_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "unet_convT2x2_bwd_data_bf16": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "unet_convT2x2_bwd_weights_ws_bytes_bf16": (sz, [i32, i32, i32, i32, i32]),
+    "unet_convT2x2_bwd_weights_bf16": (i32, [vp, vp, vp, i32, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp]),
     "unet_bn_stats": (i32, [vp, vp, i32, vp, i64, i32, vp]),
+    "unet_bn_stats_bf16": (i32, [vp, vp, i32, vp, i64, i32, vp]),
     "unet_bn_finalize_train": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, i32, vp]),
     "unet_bn_finalize_infer": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "unet_bn_apply": (i32, [vp, vp, i32, vp, vp, i32, i64, i32, vp]),
+    "unet_bn_apply_bf16": (i32, [vp, vp, i32, vp, vp, i32, i64, i32, vp]),
     "unet_bn_bwd_stats": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, i32, vp]),
+    "unet_bn_bwd_stats_bf16": (i32, [vp, vp, i32, vp, i32, vp, vp, i64, i32, vp]),
     "unet_bn_bwd_param_grads": (i32, [vp, vp, vp, vp, i32, vp]),
     "unet_bn_bwd_apply": (i32, [vp, vp, i32, vp, i32, vp, vp, f64, i32, f32, u64, vp, i32, i64, i32, vp]),
+    "unet_bn_bwd_apply_bf16": (i32, [vp, vp, i32, vp, i32, vp, vp, f64, i32, f32, u64, vp, i32, i64, i32, vp]),
     "unet_maxpool2x2_dropout_fwd": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_maxpool2x2_dropout_fwd_bf16": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, u64, i32, vp]),
+    "unet_maxpool2x2_dropout_bwd_bf16": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, u64, i32, vp]),
     "unet_bn_apply_maxpool_dropout_fwd": (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_bn_apply_maxpool_dropout_fwd_bf16": (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd_bnstats": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_maxpool2x2_dropout_bwd_bnstats_bf16": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "unet_head_fwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "unet_loss_finalize": (i32, [vp, vp, f64, vp, vp]),
     "unet_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
+    "unet_head_bwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
     "unet_adam_keras": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     "unet_seg_metrics_sweep": (i32, [vp, vp, vp, vp, i32, vp, i64, vp]),
     "unet_zero": (i32, [vp, vp, sz, vp]),
     "unet_copy_slice": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
+    "unet_copy_slice_bf16": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
     "unet_accum_slices": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, i64, i32, i32, vp]),
+    "unet_accum_slices_bf16": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, i64, i32, i32, vp]),
     "unet_dense_ws_bytes": (sz, [i32, i32, i32]),
     "unet_dense_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, sz, vp]),
     "unet_dense_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

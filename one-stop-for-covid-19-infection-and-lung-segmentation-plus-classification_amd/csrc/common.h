@@ -70,6 +70,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
 
+// ---- bf16 storage (activations / activation gradients of the mixed-precision path; arithmetic stays fp32) -----------------
+// unet_bf16 (include/unet_hip.h) = raw 16-bit pattern.  Conversions are round-to-nearest-even (v_cvt_pk_bf16_f32), the same
+// rounding torch's .bfloat16() applies, so the oracle can quantise at the same points.
+typedef __bf16 unet_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 unet_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float unet_f32x2 __attribute__((ext_vector_type(2)));
+typedef float unet_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((unet_f32x2){lo, hi}, unet_bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+// 4 consecutive channels of an NHWC tensor as fp32, whatever the storage type (16-byte / 8-byte lane accesses)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const unet_bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+}
+__device__ __forceinline__ void st4(unet_bf16* p, float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const unet_bf16* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(unet_bf16* p, float v) { *p = (unet_bf16)(pack_bf16x2(v, 0.f) & 0xFFFFu); }
+
 // Philox-4x32-10 counter RNG (dropout keep-mask): counter = element-quad index, key = seed.
 __device__ __forceinline__ uint4 philox4x32(uint64_t ctr, uint64_t seed) {
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
@@ -158,3 +183,26 @@ int32_t k_convT_mfma_wgrad(unet_ctx*, const float* x, const float* dy, int lddy,
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_mfma_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws,
                              size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);
+// bf16-storage convolutions (kernels_bf16.hip); wimg = scratch for the re-laid-out bf16 weights (>= 9*cin*cout, resp. 4*cin*cout, elements)
+bool bf16_conv3x3_supported(int cin, int cout);
+bool bf16_convT_supported(int cin, int cout);
+bool bf16_wgrad_supported(int ca, int cb);
+int32_t k_conv3x3_bf16_fwd(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, const unet_bf16* mask, int mask_mode, unet_bf16* y, int n, int h,
+                           int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s);
+int32_t k_convT_bf16_fwd(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int ldy, int n, int h, int wd, int cin, int cout,
+                         unet_bf16* wimg, hipStream_t s);
+int32_t k_convT_bf16_dgrad(unet_ctx*, const unet_bf16* dy, int lddy, const float* w, const unet_bf16* mask, unet_bf16* dx, int n, int h, int wd, int cin,
+                           int cout, unet_bf16* wimg, hipStream_t s);
+size_t bf16_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
+size_t bf16_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
+int32_t k_conv3x3_bf16_wgrad(unet_ctx*, const unet_bf16* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
+                             int cin, int cout, hipStream_t s);
+int32_t k_convT_bf16_wgrad(unet_ctx*, const unet_bf16* x, const unet_bf16* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
+                           int wd, int cin, int cout, hipStream_t s);
+size_t wgrad_reduce_scratch_floats(int taps, int ca, int cb, int cbias, int nslabs);
+int32_t k_wgrad_reduce(unet_ctx*, float* part, int nslabs, int taps, int ca, int cb, int cbias, float* dw, float* db, hipStream_t s);
+// first layer (cin = 1): fp32 image in, bf16 activations out / bf16 gradient in (kernels_conv_naive.hip)
+int32_t k_conv3x3_c1_fwd_bf16(unet_ctx*, const float* x, const float* w, const float* bias, unet_bf16* y, int n, int h, int wd, int cout, int act,
+                              float rate, uint64_t seed, hipStream_t s);
+int32_t k_conv3x3_c1_wgrad_bf16(unet_ctx*, const float* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
+                                int cout, hipStream_t s);

@@ -1,0 +1,562 @@
+// Mixed-precision convolutions of the U-Net hot path: activations and activation gradients are stored as bf16 in HBM (half the
+// traffic of the fp32 path), parameters / parameter gradients / accumulators stay fp32, products run on
+// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense: 16x the fp32 MFMA rate, so these layers are HBM- or LDS-bound, not MFMA-bound).
+//
+// Forward / data gradient / transposed conv share one implicit-GEMM kernel (conv_bf16_kernel):
+//   D[m][pixel] = sum_k Wimg[m][k] * X[pixel][k]        A operand (32 x 16) = weights, B operand (16 x 32) = 32 pixels of a row
+//   so a lane ends up with 16 CONSECUTIVE output channels of ONE pixel (the A rows are stored permuted, cperm()) and the
+//   tile leaves as 32-byte runs per lane.  The weights are re-laid out once per launch into the exact LDS image the kernel
+//   reads ([group][chunk][k-step][tap][n-block][k-half][row][8], bf16) by wimg_kernel.
+//   workgroup = 4 waves, output tile 16 rows x 32 columns x (32*NB) channels, wave = 4 rows: per staged 16-channel chunk a
+//   wave issues 9 taps x 4 rows x NB MFMAs from 18 + 9*NB ds_read_b128 (the three ky taps share their pixel rows).
+//   LDS is double buffered (global -> registers under the MFMAs of the previous chunk -> LDS), one barrier per chunk.
+// Weight gradient (wgrad_bf16_kernel): K = pixels, both operands need 8 consecutive PIXELS of one channel per lane while NHWC
+//   keeps channels contiguous: the rows are staged as they come (16-byte pieces) and read back through the gfx950 LDS
+//   transpose read (ds_read_b64_tr_b16), two reads per operand.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef unet_bf16x8 bf16x8;
+typedef unet_f32x16 f32x16;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// A-tile row m <-> output channel: lane (hi, register r) of the MFMA result holds row (r&3) + 8*(r>>2) + 4*hi; storing channel
+// hi*16 + r in that row gives every lane 16 consecutive channels
+__host__ __device__ inline int cperm(int m) { return ((m >> 2) & 1) * 16 + (m & 3) + 4 * (m >> 3); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight image: img[(((((g*nchunks + chunk)*KS + ks)*T + tap)*NB + nb)*2 + half)*32 + m][j] = W(tap, k, mm)
+//   k = (chunk*KS + ks)*16 + half*8 + j,  mm = (g*NB + nb)*32 + cperm(m),  W(tap,k,mm) = w[tap_base(tap) + k*sk + mm*sm]
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wimg_kernel(const float* __restrict__ w, unet_bf16* __restrict__ img, int T, int KS, int NB, int nchunks,
+                                                   long long tap_stride, int tap_flip, long long sk, long long sm, long long total8) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long long)gridDim.x * 256) {
+    long long r = e;
+    const int m = (int)(r & 31); r >>= 5;
+    const int half = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r % NB); r /= NB;
+    const int tap = (int)(r % T); r /= T;
+    const int ks = (int)(r % KS); r /= KS;
+    const int chunk = (int)(r % nchunks); const int g = (int)(r / nchunks);
+    const long long k0 = ((long long)chunk * KS + ks) * 16 + half * 8;
+    const long long mm = ((long long)g * NB + nb) * 32 + cperm(m);
+    const float* src = w + (long long)(tap_flip ? T - 1 - tap : tap) * tap_stride + k0 * sk + mm * sm;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[j * sk];
+    *reinterpret_cast<uint4*>(img + e * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+  }
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// MODE 0: conv3x3 'same' (forward; data gradient with the flipped/transposed weight image)
+// MODE 1: convT2x2s2 forward  = per-pixel GEMM [pixels, Cin] x [Cin, 4*Cout] with a scatter epilogue into the (2i+a, 2j+b)
+//         positions of a channel slice (pixel stride ldy) of the concat buffer
+// MODE 2: convT2x2s2 data gradient = per-pixel GEMM over the virtual channels k = (ab, o): chunk -> (ab, o0) selects the
+//         parity plane (2i+a, 2j+b) of dU (pixel stride ldx) that is staged
+template <int MODE, int NB, bool GEN>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg,
+                                                           const float* __restrict__ bias, const unet_bf16* __restrict__ mask,
+                                                           unet_bf16* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
+                                                           int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y,
+                                                           int groups, int total_blocks) {
+  constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
+  constexpr int PR = MODE == 0 ? 18 : 16, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
+  constexpr int PLANE = NPIX * 32;                       // bytes of one 16-channel plane of the pixel patch
+  constexpr int IN_BYTES = KS * PLANE, W_BYTES = KS * T * NB * 2 * 32 * 16;
+  constexpr int PPIECES = KS * NPIX * 2, WPIECES = W_BYTES / 16;
+  constexpr int PL = (PPIECES + 255) / 256, WL = (WPIECES + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];            // [2][IN_BYTES] then [2][W_BYTES]
+  char* const s_in = smem; char* const s_w = smem + 2 * IN_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware block map: workgroup b runs on XCD b % 8; give every XCD a contiguous range of work items (channel groups of
+  // one spatial tile, then the neighbouring tiles) so that a patch is fetched into ONE L2
+  const int per = gridDim.x >> 3;
+  const int wi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (wi >= total_blocks) return;
+  const int g = wi % groups; int t = wi / groups;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y; const int n = t / tiles_y;
+  const int x0 = tx * 32, y0 = ty * 16;
+  const int HI = MODE == 2 ? 2 * H : H, WI = MODE == 2 ? 2 * W : W;
+  const int nchunks = K / (16 * KS);
+
+  f32x16 acc[4][NB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(x + (long long)n * HI * WI * ldx), 0, (int)((long long)HI * WI * ldx * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(wimg), 0, (int)((long long)groups * nchunks * W_BYTES), 0x00020000);
+  int poff[PL];
+#pragma unroll
+  for (int k = 0; k < PL; ++k) {
+    const int idx = tid + k * 256;
+    const int half = idx & 1, pp = idx >> 1, ks = pp / NPIX, pix = pp - ks * NPIX;
+    int gy, gx;
+    if (MODE == 0) { const int r = pix / PWD, c = pix - r * PWD; gy = y0 + r - 1; gx = x0 + c - 1; }
+    else { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); }
+    const bool ok = idx < PPIECES && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    if (MODE == 2) poff[k] = ok ? (((2 * gy) * WI + 2 * gx) * ldx + ks * 16 + half * 8) * 2 : UNET_OOB;
+    else poff[k] = ok ? ((gy * WI + gx) * ldx + ks * 16 + half * 8) * 2 : UNET_OOB;
+  }
+  unet_u32x4 preg[PL], wreg[WL];
+  auto issue_loads = [&](int chunk) __attribute__((always_inline)) {
+    int soff;
+    if (MODE == 2) { const int ct = K >> 2, k0 = chunk * 32, ab = k0 / ct, o0 = k0 - ab * ct; soff = (((ab >> 1) * WI + (ab & 1)) * ldx + o0) * 2; }
+    else soff = chunk * 16 * KS * 2;
+#pragma unroll
+    for (int k = 0; k < PL; ++k) preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, poff[k], soff, 0);
+    const int wsoff = (g * nchunks + chunk) * W_BYTES;
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const int idx = tid + k * 256;
+      wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, idx < WPIECES ? idx * 16 : UNET_OOB, wsoff, 0);
+    }
+  };
+  auto store_lds = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < PPIECES) *reinterpret_cast<unet_u32x4*>(s_in + buf * IN_BYTES + idx * 16) = preg[k];     // piece order == LDS order: [ks][pix][half]
+    }
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < WPIECES) *reinterpret_cast<unet_u32x4*>(s_w + buf * W_BYTES + idx * 16) = wreg[k];
+    }
+  };
+
+  issue_loads(0);
+  store_lds(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int cur = chunk & 1;
+    if (chunk + 1 < nchunks) issue_loads(chunk + 1);
+    const char* in = s_in + cur * IN_BYTES; const char* wt = s_w + cur * W_BYTES;
+    if (MODE == 0) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        bf16x8 px[6];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) px[rr] = lds_frag(in + (((wave * 4 + rr) * PWD + l31 + kx) * 32 + hi * 16));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          bf16x8 wf[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) wf[nb] = lds_frag(wt + ((((ky * 3 + kx) * NB + nb) * 2 + hi) * 512 + l31 * 16));
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], px[r + ky], acc[r][nb], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 px[4], wf[NB];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) px[r] = lds_frag(in + ks * PLANE + (((wave * 4 + r) * 32 + l31) * 32 + hi * 16));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wf[nb] = lds_frag(wt + (((ks * NB + nb) * 2 + hi) * 512 + l31 * 16));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], px[r], acc[r][nb], 0, 0, 0);
+      }
+    }
+    if (chunk + 1 < nchunks) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (l31, hi) holds, for pixel column l31 of each of its 4 rows, channels mb + 0..15
+  const int px_ = x0 + l31;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int mb = (g * NB + nb) * 32 + hi * 16;
+    int ab = 0, oc = mb;
+    if (MODE == 1) { const int ct = M >> 2; ab = mb / ct; oc = mb - ab * ct; }
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + oc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int py = y0 + wave * 4 + r;
+      if (py >= H || px_ >= W) continue;
+      long long o;
+      if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
+      else o = (((long long)n * H + py) * W + px_) * ldy + mb;
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = acc[r][nb][i] + bv[i];
+      if (MODE == 0 || MODE == 2) {
+        if (!GEN) {
+          if (act == ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+          }
+          if (mask_mode == MASK_RELU) {
+            const uint4 m0 = *reinterpret_cast<const uint4*>(mask + o), m1 = *reinterpret_cast<const uint4*>(mask + o + 8);
+            const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {            // bf16 > 0  <=>  sign clear and magnitude non-zero
+              v[2 * i] = ((mw[i] & 0x8000u) == 0 && (mw[i] & 0x7FFFu) != 0) ? v[2 * i] : 0.f;
+              v[2 * i + 1] = ((mw[i] & 0x80000000u) == 0 && (mw[i] & 0x7FFF0000u) != 0) ? v[2 * i + 1] : 0.f;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = apply_act(v[i], act);
+          if (mask_mode == MASK_NONE) {
+            if (rate > 0.0f) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 ks4 = keep_scale((o >> 2) + q, rate, seed);
+                v[q * 4] *= ks4.x; v[q * 4 + 1] *= ks4.y; v[q * 4 + 2] *= ks4.z; v[q * 4 + 3] *= ks4.w;
+              }
+            }
+          } else {
+            const uint4 m0 = *reinterpret_cast<const uint4*>(mask + o), m1 = *reinterpret_cast<const uint4*>(mask + o + 8);
+            const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
+              if (mask_mode == MASK_ELU_DROP) ks4 = keep_scale((o >> 2) + q, rate, seed);
+              v[q * 4] *= mask_factor(bf16_lo(mw[2 * q]), mask_mode, ks4.x, rate); v[q * 4 + 1] *= mask_factor(bf16_hi(mw[2 * q]), mask_mode, ks4.y, rate);
+              v[q * 4 + 2] *= mask_factor(bf16_lo(mw[2 * q + 1]), mask_mode, ks4.z, rate); v[q * 4 + 3] *= mask_factor(bf16_hi(mw[2 * q + 1]), mask_mode, ks4.w, rate);
+            }
+          }
+        }
+      }
+      *reinterpret_cast<uint4*>(y + o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      *reinterpret_cast<uint4*>(y + o + 8) = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+    }
+  }
+}
+
+template <int MODE, int NB>
+int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_bf16* wimg, const float* bias, const unet_bf16* mask, int mask_mode,
+                         unet_bf16* y, int ldy, int n, int h, int wd, int K, int M, int act, float rate, unsigned long long seed, hipStream_t s) {
+  constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
+  constexpr int NPIX = MODE == 0 ? 18 * 34 : 16 * 32;
+  constexpr int IN_BYTES = KS * NPIX * 32, W_BYTES = KS * T * NB * 2 * 32 * 16;
+  constexpr size_t smem = 2 * (size_t)(IN_BYTES + W_BYTES);
+  if (!mask) mask_mode = MASK_NONE;
+  if ((long long)(MODE == 2 ? 4 : 1) * h * wd * ldx * 2 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: one image must stay below 1 GiB (32-bit buffer offsets)");
+  const int tiles_x = (wd + 31) / 32, tiles_y = (h + 15) / 16, groups = M / (32 * NB);
+  const long long total = (long long)tiles_x * tiles_y * n * groups;
+  if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: too many tiles");
+  const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
+  const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU);
+  auto go = [&](auto kern) -> int32_t {
+    static bool attr_done = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
+    if (!attr_done) { UNET_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_done = true; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);
+    return UNET_OK;
+  };
+  int32_t r;
+  if (gen) r = go(conv_bf16_kernel<MODE, NB, (MODE == 0)>); else r = go(conv_bf16_kernel<MODE, NB, false>);
+  if (r) return r;
+  UNET_CHECK_LAUNCH(ctx, "conv_bf16");
+  return UNET_OK;
+}
+
+// weight image for (T taps, K contraction channels, M output channels); returns bytes written
+int32_t make_wimg(unet_ctx* ctx, const float* w, unet_bf16* img, int T, int KS, int NB, int K, int M, long long tap_stride, int tap_flip, long long sk,
+                  long long sm, hipStream_t s) {
+  const int nchunks = K / (16 * KS), groups = M / (32 * NB);
+  const long long total8 = (long long)groups * nchunks * KS * T * NB * 2 * 32;
+  const unsigned grid = (unsigned)std::min<long long>((total8 + 255) / 256, 2048);
+  hipLaunchKernelGGL(wimg_kernel, dim3(grid), dim3(256), 0, s, w, img, T, KS, NB, nchunks, tap_stride, tap_flip, sk, sm, total8);
+  UNET_CHECK_LAUNCH(ctx, "wimg");
+  return UNET_OK;
+}
+
+}  // namespace
+
+bool bf16_conv3x3_supported(int cin, int cout) { return cin >= 16 && (cin % 16) == 0 && cout >= 32 && (cout % 32) == 0; }
+bool bf16_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0; }
+
+// forward (flip = 0, w = [3][3][cin][cout]) or data gradient (flip = 1: w = the layer's forward weights [3][3][cout][cin], x = dy with
+// `cin` channels, y = dx with `cout` channels).  wimg: scratch of >= 9*cin*cout bf16.
+int32_t k_conv3x3_bf16_fwd(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, const unet_bf16* mask, int mask_mode, unet_bf16* y,
+                           int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s) {
+  if (!bf16_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 bf16: cin=%d (%%16) cout=%d (%%32) unsupported", cin, cout);
+  const int NB = (cout % 64) == 0 ? 2 : 1;
+  int32_t r;
+  if (!flip) r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 0, cout, 1, s);
+  else r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 1, 1, cin, s);      // W(tap,k,m) = w_f[8-tap][m][k], row length = cout_f = cin here
+  if (r) return r;
+  if (NB == 2) return launch_conv_bf16<0, 2>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
+  return launch_conv_bf16<0, 1>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
+}
+
+// u[n,2i+a,2j+b,o] = bias[o] + sum_c x[n,i,j,c] * K[a,b,o,c]   (Keras ConvT kernel [2][2][cout][cin])
+int32_t k_convT_bf16_fwd(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int ldy, int n, int h, int wd, int cin,
+                         int cout, unet_bf16* wimg, hipStream_t s) {
+  if (!bf16_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT bf16: cin=%d cout=%d unsupported", cin, cout);
+  int32_t r = make_wimg(ctx, w, wimg, 1, 2, 2, cin, 4 * cout, 0, 0, 1, cin, s);             // W(k = c, m = ab*cout + o) = K[m*cin + c]
+  if (r) return r;
+  return launch_conv_bf16<1, 2>(ctx, x, cin, wimg, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
+}
+
+// dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]; mask: ReLU of the producer of x
+int32_t k_convT_bf16_dgrad(unet_ctx* ctx, const unet_bf16* dy, int lddy, const float* w, const unet_bf16* mask, unet_bf16* dx, int n, int h, int wd,
+                           int cin, int cout, unet_bf16* wimg, hipStream_t s) {
+  if (!bf16_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT bf16: cin=%d cout=%d unsupported", cin, cout);
+  const int NB = (cin % 64) == 0 ? 2 : 1;
+  int32_t r = make_wimg(ctx, w, wimg, 1, 2, NB, 4 * cout, cin, 0, 0, cin, 1, s);            // W(k = ab*cout + o, m = c) = K[k*cin + c]
+  if (r) return r;
+  const int mm = mask ? MASK_RELU : MASK_NONE;
+  if (NB == 2) return launch_conv_bf16<2, 2>(ctx, dy, lddy, wimg, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
+  return launch_conv_bf16<2, 1>(ctx, dy, lddy, wimg, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
+}
+
+namespace {
+
+// =====================================================================================================================
+// Weight gradient.  dW[tap][ci][co] = sum_p X[p + tap][ci] * dY[p][co]   (conv3x3, TAPS = 9, X = layer input, halo 1)
+//                   dK[ab][o][c]    = sum_p dU[2p + ab][o] * X[p][c]     (convT2x2, TAPS = 4: A = dU parity planes, B = X)
+// GEMM per tap: D[a_ch][b_ch] += A^T B with K = pixels; split-K over (image, 32-column strip, row chunk), partial slabs
+// [split][tap][CA][CB] (+ bias sums) reduced in a fixed order by the fp32 path's reduce kernels (deterministic).
+// workgroup = 4 waves = WA x WB channel tiles of 32 x 32 (all taps: 144 accumulator registers per wave) x WR row phases; a step
+// stages 4 B rows (+ the 6 A rows they touch) in LDS as they come from HBM ([32-channel plane][row][pixel][32 ch]) and each
+// operand (8 consecutive pixels of one channel per lane) is fetched with two ds_read_b64_tr_b16.
+// =====================================================================================================================
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int MODE, int WA, int WB, int WR>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const unet_bf16* __restrict__ A, int ldA, const unet_bf16* __restrict__ B, int ldB,
+                                                            float* __restrict__ part, int N, int H, int W, int CA, int CB, int tiles_b,
+                                                            int strips, int rows_per_chunk, int chunks_per_strip, int nsplit, int npairs,
+                                                            long long pstride) {
+  static_assert(WA * WB * WR == 4, "4 waves");
+  constexpr int TAPS = MODE == 0 ? 9 : 4;
+  constexpr int R = MODE == 0 ? 4 : 2;                            // B rows per step
+  static_assert(WR <= R, "row phases");
+  constexpr int AROWS = MODE == 0 ? R + 2 : 2 * R, APX = MODE == 0 ? 34 : 64;      // A rows / pixels per row staged per step
+  constexpr int ASUB = AROWS * APX * 64, BSUB = R * 32 * 64;      // bytes of one 32-channel plane
+  constexpr int APIECES = WA * AROWS * APX * 4, BPIECES = WB * R * 32 * 4;
+  constexpr int AL = (APIECES + 255) / 256, BL = (BPIECES + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char s_a[WA * ASUB];
+  __shared__ __attribute__((aligned(16))) char s_b[WB * BSUB];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave % WR, wb = (wave / WR) % WB, wa = wave / (WR * WB);
+  // XCD-aware block map (as the fp32 kernels): all channel-tile pairs of one pixel split run on the same XCD back to back
+  const int sq = blockIdx.x >> 3;
+  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);
+  if (split >= nsplit) return;
+  const int ta = pair / tiles_b, tb = pair % tiles_b;
+  const int a0 = ta * 32 * WA, b0 = tb * 32 * WB;
+  const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
+  const int cs = t2 % strips, n = t2 / strips;
+  const int x0 = cs * 32;
+  const int ya = chunk * rows_per_chunk;
+  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
+  const int HA = MODE == 0 ? H : 2 * H, WA_ = MODE == 0 ? W : 2 * W;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bsum = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(A + (long long)n * HA * WA_ * ldA), 0, (int)((long long)HA * WA_ * ldA * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(B + (long long)n * H * W * ldB), 0, (int)((long long)H * W * ldB * 2), 0x00020000);
+  // staging plan: byte offset of the piece inside its image for step row 0 (may be negative for the halo row), and its row
+  int aoff[AL], arow[AL], boff[BL], brow[BL];
+#pragma unroll
+  for (int k = 0; k < AL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx & 3; int r = idx >> 2;
+    const int px = r % APX; r /= APX;
+    const int row = r % AROWS, sub = r / AROWS;
+    const int gx = MODE == 0 ? x0 + px - 1 : 2 * x0 + px;
+    const int ch = a0 + sub * 32 + q * 8;
+    const bool ok = idx < APIECES && gx >= 0 && gx < WA_ && ch < CA;
+    arow[k] = ok ? (MODE == 0 ? row - 1 : row) : (1 << 20);          // invalid -> row test fails below
+    aoff[k] = ((MODE == 0 ? row - 1 : row) * WA_ + gx) * ldA * 2 + ch * 2;
+  }
+#pragma unroll
+  for (int k = 0; k < BL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx & 3; int r = idx >> 2;
+    const int px = r & 31; r >>= 5;
+    const int row = r % R, sub = r / R;
+    const int gx = x0 + px, ch = b0 + sub * 32 + q * 8;
+    const bool ok = idx < BPIECES && gx < W && ch < CB;
+    brow[k] = ok ? row : (1 << 20);
+    boff[k] = (row * W + gx) * ldB * 2 + ch * 2;
+  }
+  unet_u32x4 areg[AL], breg[BL];
+  auto issue_loads = [&](int ys) __attribute__((always_inline)) {        // ys = first B row of the step
+    const int ysa = MODE == 0 ? ys : 2 * ys;
+#pragma unroll
+    for (int k = 0; k < AL; ++k) {
+      const int gy = ysa + arow[k];
+      const bool ok = gy >= 0 && gy < HA;
+      areg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? aoff[k] + ysa * WA_ * ldA * 2 : UNET_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < BL; ++k) {
+      const int gy = ys + brow[k];
+      breg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, gy < yb ? boff[k] + ys * W * ldB * 2 : UNET_OOB, 0, 0);   // rows past the chunk contribute 0
+    }
+  };
+  auto store_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < AL; ++k) { const int idx = tid + k * 256; if (idx < APIECES) *reinterpret_cast<unet_u32x4*>(s_a + idx * 16) = areg[k]; }    // piece order == LDS order
+#pragma unroll
+    for (int k = 0; k < BL; ++k) { const int idx = tid + k * 256; if (idx < BPIECES) *reinterpret_cast<unet_u32x4*>(s_b + idx * 16) = breg[k]; }
+  };
+
+  // transpose-read addressing: 16-lane group g4 reads [4 pixels][16 channels]; lane i -> pixel i>>2, channel quad i&3
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int tr_px = (g4 >> 1) * 8 + (i16 >> 2), tr_ch = ((g4 & 1) * 16 + (i16 & 3) * 4) * 2;
+  const char* const pa = s_a + wa * ASUB + tr_ch;
+  const char* const pb = s_b + wb * BSUB + tr_ch;
+
+  issue_loads(ya);
+  store_lds();
+  __syncthreads();
+  for (int ys = ya; ys < yb; ys += R) {
+    const bool more = ys + R < yb;
+    if (more) issue_loads(ys + R);
+#pragma unroll
+    for (int r = wr; r < R; r += WR) {
+#pragma unroll
+      for (int kst = 0; kst < 2; ++kst) {
+        const char* bp = pb + (r * 32 + kst * 16 + tr_px) * 64;
+        const bf16x8 bf = lds_tr_frag(bp, bp + 4 * 64);
+        if (MODE == 0 && wa == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum += (float)bf[j];
+        }
+        if (MODE == 0) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const char* ap = pa + ((r + ky) * APX + kst * 16 + tr_px + kx) * 64;
+              const bf16x8 af = lds_tr_frag(ap, ap + 4 * 64);
+              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ky * 3 + kx], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int ab = 0; ab < 4; ++ab) {          // A = dU: pixel (2y + a, 2x + b); consecutive k = consecutive x -> stride 2 pixels
+            const char* ap = pa + ((2 * r + (ab >> 1)) * APX + 2 * (kst * 16 + tr_px) + (ab & 1)) * 64;
+            const bf16x8 af = lds_tr_frag(ap, ap + 8 * 64);
+            if (wb == 0) {                          // bias gradient of the ConvT = sum of dU over all four parity planes
+#pragma unroll
+              for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+            }
+            acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ab], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (more) { store_lds(); __syncthreads(); }
+  }
+
+  // ---- write the partial slab of (split, row phase)
+  float* P = part + ((long long)split * WR + wr) * pstride;
+  const int ar = a0 + wa * 32, bc = b0 + wb * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = acc[t][r];
+    }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (MODE == 0) { if (wa == 0 && ta == 0 && lane < 32 && bc < CB) P[(long long)TAPS * CA * CB + bc] = bsum; }
+  else if (wb == 0 && tb == 0 && lane < 32 && ar + l31 < CA) P[(long long)TAPS * CA * CB + ar + l31] = bsum;
+}
+
+struct WgPlan { int WA, WB, WR, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs; size_t floats; };
+
+WgPlan plan_wgrad_bf16(int mode, int n, int h, int w, int ca, int cb) {
+  WgPlan p;
+  const int R = mode == 0 ? 4 : 2, taps = mode == 0 ? 9 : 4, cbias = mode == 0 ? cb : ca;
+  p.WA = (ca % 64) == 0 ? 2 : 1; p.WB = (cb % 64) == 0 ? 2 : 1;
+  p.WR = 4 / (p.WA * p.WB); if (p.WR > R) { p.WB = 2; p.WR = 4 / (p.WA * p.WB); }      // (a 64-wide B tile may overhang cb: masked)
+  p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
+  const long long pairs = (long long)p.tiles_a * p.tiles_b, per = (long long)taps * ca * cb;
+  const long long units = (long long)n * p.strips;
+  static const long long target = [] { const char* e = getenv("UNET_WGRAD_BF16_BLOCKS"); return e ? atoll(e) : 1024LL; }();   // 256 CUs x 2 resident workgroups x 2 rounds
+  long long want = (target + pairs - 1) / pairs;
+  const long long cap = std::max<long long>(1, (64LL << 20) / (per * p.WR));
+  want = std::min(want, cap);
+  long long cps = std::max<long long>(1, (want + units - 1) / units);
+  cps = std::min<long long>(cps, std::max<long long>(1, h / 8));
+  int rpc = (int)((h + cps - 1) / cps); rpc = (rpc + R - 1) / R * R;                // whole steps
+  p.rows_per_chunk = rpc; p.chunks_per_strip = (h + rpc - 1) / rpc;
+  p.nsplit = (int)(units * p.chunks_per_strip); p.nslabs = p.nsplit * p.WR;
+  p.floats = (size_t)p.nslabs * (per + cbias) + wgrad_reduce_scratch_floats(taps, ca, cb, cbias, p.nslabs);
+  return p;
+}
+
+template <int MODE>
+int32_t run_wgrad_bf16(unet_ctx* ctx, const unet_bf16* A, int ldA, const unet_bf16* B, int ldB, float* dw, float* db, void* ws, size_t ws_bytes, int n,
+                       int h, int w, int ca, int cb, hipStream_t s) {
+  const int taps = MODE == 0 ? 9 : 4, cbias = MODE == 0 ? cb : ca;
+  if ((long long)(MODE == 1 ? 4 : 1) * h * w * ldA * 2 >= (1LL << 30) || (long long)h * w * ldB * 2 >= (1LL << 30))
+    UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad bf16: one image must stay below 1 GiB (32-bit buffer offsets)");
+  const WgPlan p = plan_wgrad_bf16(MODE, n, h, w, ca, cb);
+  if (!ws || ws_bytes < p.floats * sizeof(float)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad bf16: workspace %zu < %zu bytes", ws_bytes, p.floats * sizeof(float));
+  float* part = static_cast<float*>(ws);
+  const long long S = (long long)taps * ca * cb + cbias;
+  const int npairs = p.tiles_a * p.tiles_b;
+  const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
+#define UNET_WG(WA_, WB_, WR_) hipLaunchKernelGGL((wgrad_bf16_kernel<MODE, WA_, WB_, WR_>), grid, dim3(256), 0, s, A, ldA, B, ldB, part, n, h, w, ca, cb, \
+                                                  p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S)
+  if (p.WA == 2 && p.WB == 2) UNET_WG(2, 2, 1);
+  else if (p.WA == 2) UNET_WG(2, 1, 2);
+  else if (p.WB == 2) UNET_WG(1, 2, 2);
+  else { if constexpr (MODE == 0) UNET_WG(1, 1, 4); else UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad bf16: internal plan error"); }
+#undef UNET_WG
+  UNET_CHECK_LAUNCH(ctx, "wgrad_bf16");
+  // a wave's bias lanes are only written by the (ta == 0 / tb == 0) tiles; every slab position is written by exactly one wave
+  return k_wgrad_reduce(ctx, part, p.nslabs, taps, ca, cb, cbias, dw, db, s);
+}
+
+}  // namespace
+
+bool bf16_wgrad_supported(int ca, int cb) { return ca >= 32 && (ca % 32) == 0 && cb >= 32 && (cb % 32) == 0; }
+size_t bf16_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return bf16_wgrad_supported(cin, cout) ? plan_wgrad_bf16(0, n, h, wd, cin, cout).floats * sizeof(float) : 0; }
+size_t bf16_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return bf16_convT_supported(cin, cout) ? plan_wgrad_bf16(1, n, h, wd, cout, cin).floats * sizeof(float) : 0; }
+
+int32_t k_conv3x3_bf16_wgrad(unet_ctx* ctx, const unet_bf16* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
+                             int cin, int cout, hipStream_t s) {
+  if (!bf16_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad bf16: cin=%d cout=%d unsupported (multiples of 32)", cin, cout);
+  return run_wgrad_bf16<0>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
+}
+
+// convT: A = dU (channels = cout, pixel stride lddy, 2h x 2w), B = x (channels = cin, h x w); dK is [4][cout][cin]
+int32_t k_convT_bf16_wgrad(unet_ctx* ctx, const unet_bf16* x, const unet_bf16* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
+                           int wd, int cin, int cout, hipStream_t s) {
+  if (!bf16_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad bf16: cin=%d cout=%d unsupported", cin, cout);
+  return run_wgrad_bf16<1>(ctx, dy, lddy, x, cin, dw, db, ws, ws_bytes, n, h, wd, cout, cin, s);
+}

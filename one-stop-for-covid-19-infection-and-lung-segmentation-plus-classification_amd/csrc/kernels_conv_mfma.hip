@@ -704,6 +704,36 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
 
 }  // namespace
 
+// Shared with the bf16 weight-gradient kernels (kernels_bf16.hip): fixed-order reduction of `nslabs` partial slabs of S = taps*ca*cb
+// + cbias floats each (scratch for the group sums directly behind the slabs: wgrad_reduce_scratch_floats)
+static void reduce_groups(long long per, int nslabs, int* groups, int* per_group) {
+  const long long out_blocks = std::max<long long>(1, per / 1024);
+  long long g = std::min<long long>(std::min<long long>(64, nslabs / 8), 1024 / out_blocks);
+  *groups = (int)std::max<long long>(1, g);
+  *per_group = (nslabs + *groups - 1) / *groups;
+  *groups = (nslabs + *per_group - 1) / *per_group;
+}
+size_t wgrad_reduce_scratch_floats(int taps, int ca, int cb, int cbias, int nslabs) {
+  int groups, per_group; reduce_groups((long long)taps * ca * cb, nslabs, &groups, &per_group);
+  return groups > 1 ? (size_t)groups * ((size_t)taps * ca * cb + cbias) : 0;
+}
+int32_t k_wgrad_reduce(unet_ctx* ctx, float* part, int nslabs, int taps, int ca, int cb, int cbias, float* dw, float* db, hipStream_t s) {
+  const long long per = (long long)taps * ca * cb, S = per + cbias;
+  int groups, per_group; reduce_groups(per, nslabs, &groups, &per_group);
+  const float* src = part; int count = nslabs;
+  if (groups > 1) {
+    float* part2 = part + (size_t)nslabs * S;
+    const unsigned gx = (unsigned)std::min<long long>((S / 4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(gx, groups), dim3(256), 0, s, part, part2, S / 4, S, nslabs, per_group, S);
+    src = part2; count = groups;
+  }
+  const int n4 = ca * cb / 4, nb4 = cbias / 4;
+  const int items = taps * n4 + nb4;
+  hipLaunchKernelGGL(reduce_final_kernel<false>, dim3((unsigned)std::min(2048, (items + 255) / 256)), dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
+  return UNET_OK;
+}
+
 bool mfma_conv3x3_supported(int cin, int cout) { return cin >= CK && (cin % CK) == 0 && cout >= 4 && (cout % 4) == 0; }
 bool mfma_wgrad_supported(int ca, int cb) { return ca >= 8 && (ca % 4) == 0 && cb >= 8 && (cb % 4) == 0; }
 

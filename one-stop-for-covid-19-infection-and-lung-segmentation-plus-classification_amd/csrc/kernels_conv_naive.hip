@@ -41,8 +41,9 @@ __global__ __launch_bounds__(TPB) void conv3x3_naive_kernel(const float* __restr
 
 // First layer, Cin = 1 (c1a, T1:859): HBM-bound (AI ~2 F/B).  8 lanes per pixel, each lane owns
 // 4 output channels with its 9x4 weights in registers; a wave writes 8 pixels = 1 KiB contiguous.
+template <typename T>
 __global__ __launch_bounds__(TPB) void conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         const float* __restrict__ bias, T* __restrict__ y,
                                                          int N, int H, int W, int Cout, int act, float rate, unsigned long long seed) {
   const int lpp = Cout >> 2;
   const int sub = threadIdx.x % lpp;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1_kernel(const float* __restrict
     }
     acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
     if (rate > 0.0f) { const float4 ks = keep_scale(p * lpp + sub, rate, seed); acc.x *= ks.x; acc.y *= ks.y; acc.z *= ks.z; acc.w *= ks.w; }
-    *reinterpret_cast<float4*>(y + p * Cout + sub * 4) = acc;
+    st4(y + p * Cout + sub * 4, acc);
   }
 }
 
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(TPB) void conv3x3_naive_wgrad_kernel(const float* _
 // accumulators [9 taps + bias] x float4, xor-shuffle + LDS tree per block, then block partials
 // [grid][10][Cout] that reduce_c1_kernel sums in a fixed order (deterministic).
 constexpr int C1_BLOCKS = 1024;
-__global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                                float* __restrict__ part, int N, int H, int W, int Cout) {
   const int lpp = Cout >> 2;
   const int sub = threadIdx.x % lpp;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __re
   for (long long p = g0; p < pixels; p += gs) {
     const unsigned pu = (unsigned)p, tq = pu / (unsigned)W;             // 32-bit index math (pixels < 2^31, checked by the launcher)
     const int j = (int)(pu - tq * (unsigned)W), i = (int)(tq % (unsigned)H);
-    const float4 g = *reinterpret_cast<const float4*>(dy + p * Cout + sub * 4);
+    const float4 g = ld4(dy + p * Cout + sub * 4);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int ii = i + a - 1;
@@ -253,14 +255,19 @@ int32_t k_conv3x3_naive_fwd(unet_ctx* ctx, const float* x, const float* w, const
   UNET_CHECK_LAUNCH(ctx, "conv3x3_naive_fwd"); return UNET_OK;
 }
 
-int32_t k_conv3x3_c1_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd,
+template <typename T>
+static int32_t c1_fwd_impl(unet_ctx* ctx, const float* x, const float* w, const float* bias, T* y, int n, int h, int wd,
                          int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   if ((cout & 3) || TPB % (cout / 4) || (long long)n * h * wd >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1: cout=%d / %d x %d x %d pixels unsupported", cout, n, h, wd);
   long long threads = (long long)n * h * wd * (cout / 4);
-  hipLaunchKernelGGL(conv3x3_c1_kernel, dim3(grid_for(threads / 2 + 1, 2048)), dim3(TPB), 0, s, x, w, bias, y, n, h, wd, cout, act, rate,
+  hipLaunchKernelGGL(conv3x3_c1_kernel<T>, dim3(grid_for(threads / 2 + 1, 2048)), dim3(TPB), 0, s, x, w, bias, y, n, h, wd, cout, act, rate,
                      (unsigned long long)seed);
   UNET_CHECK_LAUNCH(ctx, "conv3x3_c1_fwd"); return UNET_OK;
 }
+int32_t k_conv3x3_c1_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cout, int act, float rate,
+                         uint64_t seed, hipStream_t s) { return c1_fwd_impl(ctx, x, w, bias, y, n, h, wd, cout, act, rate, seed, s); }
+int32_t k_conv3x3_c1_fwd_bf16(unet_ctx* ctx, const float* x, const float* w, const float* bias, unet_bf16* y, int n, int h, int wd, int cout, int act,
+                              float rate, uint64_t seed, hipStream_t s) { return c1_fwd_impl(ctx, x, w, bias, y, n, h, wd, cout, act, rate, seed, s); }
 
 int32_t k_flip_transpose_w3x3(unet_ctx* ctx, const float* w, float* wt, int cin, int cout, hipStream_t s) {
   hipLaunchKernelGGL(flip_transpose_kernel, dim3(grid_for(9LL * cin * cout, 2048)), dim3(TPB), 0, s, w, wt, cin, cout);
@@ -309,16 +316,21 @@ int32_t k_convT_naive_wgrad(unet_ctx* ctx, const float* x, const float* dy, int 
 
 size_t c1_wgrad_ws_bytes(int cout) { return (size_t)(C1_BLOCKS + 32) * 10 * cout * sizeof(float); }
 
-int32_t k_conv3x3_c1_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
+template <typename T>
+static int32_t c1_wgrad_impl(unet_ctx* ctx, const float* x, const T* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                            int wd, int cout, hipStream_t s) {
   if ((cout & 3) || TPB % (cout / 4) || (cout / 4) > 64 || (long long)n * h * wd >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1_wgrad: cout=%d unsupported", cout);
   if (!ws || ws_bytes < c1_wgrad_ws_bytes(cout)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_c1_wgrad: workspace too small");
   long long groups = ((long long)n * h * wd * (cout / 4) + TPB - 1) / TPB;
   int blocks = (int)std::min<long long>(C1_BLOCKS, std::max<long long>(groups, 1));
-  hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
+  hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<T>, dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
   float* part = static_cast<float*>(ws); float* part2 = part + (size_t)C1_BLOCKS * 10 * cout;
   const int ngroups = (blocks + 31) / 32;
   hipLaunchKernelGGL(reduce_c1_kernel, dim3((10 * cout + 127) / 128, ngroups), dim3(128), 0, s, part, part2, nullptr, blocks, 32, cout, 0);
   hipLaunchKernelGGL(reduce_c1_kernel, dim3((10 * cout + 127) / 128, 1), dim3(128), 0, s, part2, dw, db, ngroups, ngroups, cout, 1);
   UNET_CHECK_LAUNCH(ctx, "conv3x3_c1_wgrad"); return UNET_OK;
 }
+int32_t k_conv3x3_c1_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cout,
+                           hipStream_t s) { return c1_wgrad_impl(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cout, s); }
+int32_t k_conv3x3_c1_wgrad_bf16(unet_ctx* ctx, const float* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
+                                int cout, hipStream_t s) { return c1_wgrad_impl(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cout, s); }

@@ -20,17 +20,15 @@ static const int BN_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 512;         
 static const int BN_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 1024;     // two tensors in       (1.06 -> 0.79)
 static const int POOL_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 768;    // read-modify-write    (0.73 -> 0.63)
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // ---------------------------------------------------------------------------------------
 // BatchNorm statistics.  MODE 0: (sum x, sum x^2).  MODE 1: (sum dy, sum dy*xhat).
 // lanes-per-pixel lpp = C/4; a block covers ppb = 256/lpp pixels per iteration.
 // fp32 per-thread partials (<= a few hundred terms each), block tree, fp64 global atomics.
 // ---------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(TPB) void bn_stats_kernel(const float* __restrict__ a, int lda,
-                                                       const float* __restrict__ x, int ldx,
+template <int MODE, typename T>
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(const T* __restrict__ a, int lda,
+                                                       const T* __restrict__ x, int ldx,
                                                        const float* __restrict__ bnp, double* sums,
                                                        long long pixels, int C) {
   const int lpp = C >> 2, ppb = TPB / lpp;
@@ -110,9 +108,10 @@ __global__ void bn_finalize_infer_kernel(const float* gamma, const float* beta, 
   bnp[c] = sc; bnp[C + c] = beta[c] - mm[c] * sc; bnp[2 * C + c] = mm[c]; bnp[3 * C + c] = istd;
 }
 
-__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, int ldx,
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(const T* __restrict__ x, int ldx,
                                                        const float* __restrict__ bnp,
-                                                       float* __restrict__ y, int ldy,
+                                                       T* __restrict__ y, int ldy,
                                                        long long pixels, int C) {
   const int lpp = C >> 2;
   if (TPB % lpp == 0) {          // a thread keeps its channel quad: parameters live in registers, no per-element 64-bit div/mod
@@ -149,12 +148,12 @@ __global__ void bn_bwd_param_grads_kernel(const double* sums, float* dgamma, flo
 
 // mask_mode: derivative of what produced the BN input x (MASK_RELU: T1:860; MASK_ELU / MASK_ELU_DROP: U-Net++ conv_block,
 // where x = dropout(elu(conv)) and the keep mask is recomputed from the Philox stream of that dropout)
-template <int MM>       // MASK_* of the producer of x, compile-time so the U-Net (ReLU) instance carries no Philox/ELU code
-__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy,
-                                                           const float* __restrict__ x, int ldx,
+template <int MM, typename T>       // MASK_* of the producer of x, compile-time so the U-Net (ReLU) instance carries no Philox/ELU code
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy,
+                                                           const T* __restrict__ x, int ldx,
                                                            const float* __restrict__ bnp,
                                                            const double* __restrict__ sums, double inv_count,
-                                                           float* __restrict__ dx, int lddx,
+                                                           T* __restrict__ dx, int lddx,
                                                            long long pixels, int C, float rate, unsigned long long seed) {
   constexpr int mask_mode = MM;
   const int lpp = C >> 2;
@@ -195,8 +194,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------
 // 2x2 max-pool (+ inverted dropout).  One thread = one pooled pixel x 4 channels.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__ x, int ldx,
-                                                       float* __restrict__ y, int N, int H, int W, int C,
+template <typename T>
+__global__ __launch_bounds__(TPB) void pool_fwd_kernel(const T* __restrict__ x, int ldx,
+                                                       T* __restrict__ y, int N, int H, int W, int C,
                                                        float rate, uint64_t seed) {
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__
     const unsigned iu = (unsigned)i, pu = iu / (unsigned)lpp, tu = pu / (unsigned)Wo;    // 32-bit index math (launchers check total < 2^31)
     const int q = (int)(iu - pu * (unsigned)lpp), jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
     const long long p = pu, n = tu / (unsigned)Ho;
-    const float* b = x + ((n * H + 2 * io) * W + 2 * jo) * (long long)ldx + q * 4;
+    const T* b = x + ((n * H + 2 * io) * W + 2 * jo) * (long long)ldx + q * 4;
     float4 a0 = ld4(b), a1 = ld4(b + ldx), a2 = ld4(b + (long long)W * ldx), a3 = ld4(b + (long long)(W + 1) * ldx);
     float4 m = make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)), fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
                            fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)), fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
@@ -221,9 +221,9 @@ __device__ __forceinline__ int argmax4(float a, float b, float c, float d) {
   return k;
 }
 
-template <bool ACC>
-__global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__ x, int ldx,
-                                                       const float* __restrict__ dy, float* dx, int lddx,
+template <bool ACC, typename T>
+__global__ __launch_bounds__(TPB) void pool_bwd_kernel(const T* __restrict__ x, int ldx,
+                                                       const T* __restrict__ dy, T* dx, int lddx,
                                                        int N, int H, int W, int C, float rate, uint64_t seed) {
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
@@ -232,13 +232,13 @@ __global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__
     const int q = (int)(iu - pu * (unsigned)lpp), jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
     const long long p = pu, n = tu / (unsigned)Ho;
     long long pix = (n * H + 2 * io) * W + 2 * jo;
-    const float* b = x + pix * ldx + q * 4;
+    const T* b = x + pix * ldx + q * 4;
     float4 a0 = ld4(b), a1 = ld4(b + ldx), a2 = ld4(b + (long long)W * ldx), a3 = ld4(b + (long long)(W + 1) * ldx);
     float4 g = ld4(dy + p * C + q * 4);
     if (rate > 0.0f) { float4 k = keep_scale(i, rate, seed); g.x *= k.x; g.y *= k.y; g.z *= k.z; g.w *= k.w; }
     int kx = argmax4(a0.x, a1.x, a2.x, a3.x), ky = argmax4(a0.y, a1.y, a2.y, a3.y);
     int kz = argmax4(a0.z, a1.z, a2.z, a3.z), kw = argmax4(a0.w, a1.w, a2.w, a3.w);
-    float* o = dx + pix * lddx + q * 4;
+    T* o = dx + pix * lddx + q * 4;
     const long long offs[4] = {0, lddx, (long long)W * lddx, (long long)(W + 1) * lddx};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -251,8 +251,9 @@ __global__ __launch_bounds__(TPB) void pool_bwd_kernel(const float* __restrict__
 
 // Fused encoder tail (T1:861-863): y = BN(x) written into the skip slice of the concat buffer AND
 // p = dropout(maxpool2x2(y)) in one pass -- saves re-reading y for the pool.
-__global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ bnp,
-                                                          float* __restrict__ y, int ldy, float* __restrict__ pooled, int N, int H,
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ bnp,
+                                                          T* __restrict__ y, int ldy, T* __restrict__ pooled, int N, int H,
                                                           int W, int C, float rate, uint64_t seed) {
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const float* __restric
     const int q = (int)(iu - pu * (unsigned)lpp), jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
     const long long p = pu, n = tu / (unsigned)Ho;
     const long long pix = (n * H + 2 * io) * W + 2 * jo;
-    const float* b = x + pix * ldx + q * 4;
+    const T* b = x + pix * ldx + q * 4;
     const float4 sc = ld4(bnp + q * 4), sh = ld4(bnp + C + q * 4);
     const long long offs[4] = {0, 1, (long long)W, (long long)W + 1};
     float4 m;
@@ -282,8 +283,9 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const float* __restric
 // backward statistics (sum d, sum d*xhat) of the finished gradient d, with xhat = (y - beta)/gamma recovered from the BN
 // OUTPUT y that the pool backward reads anyway -- saves the separate 2-tensor statistics pass (gamma == 0 is not supported
 // by this fused form: xhat cannot be recovered from a constant output).
-__global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dyp,
-                                                               float* dx, int lddx, const float* __restrict__ gamma,
+template <typename T>
+__global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dyp,
+                                                               T* dx, int lddx, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, double* sums, int N, int H, int W,
                                                                int C, float rate, uint64_t seed) {
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
@@ -298,13 +300,13 @@ __global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const float* __re
     const int jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
     const long long p = pu, n = tu / (unsigned)Ho;
     long long pix = (n * H + 2 * io) * W + 2 * jo;
-    const float* b = y + pix * ldy + q * 4;
+    const T* b = y + pix * ldy + q * 4;
     float4 a[4] = {ld4(b), ld4(b + ldy), ld4(b + (long long)W * ldy), ld4(b + (long long)(W + 1) * ldy)};
     float4 g = ld4(dyp + p * C + q * 4);
     if (rate > 0.0f) { float4 k = keep_scale(i, rate, seed); g.x *= k.x; g.y *= k.y; g.z *= k.z; g.w *= k.w; }
     int kx = argmax4(a[0].x, a[1].x, a[2].x, a[3].x), ky = argmax4(a[0].y, a[1].y, a[2].y, a[3].y);
     int kz = argmax4(a[0].z, a[1].z, a[2].z, a[3].z), kw = argmax4(a[0].w, a[1].w, a[2].w, a[3].w);
-    float* o = dx + pix * lddx + q * 4;
+    T* o = dx + pix * lddx + q * 4;
     const long long offs[4] = {0, lddx, (long long)W * lddx, (long long)(W + 1) * lddx};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -342,7 +344,8 @@ __device__ __forceinline__ float bce_elem(float p, float t, float* pc_out, bool*
   return fmaxf(z, 0.0f) - z * t + log1pf(expf(-fabsf(z)));
 }
 
-__global__ __launch_bounds__(TPB) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ pout,
                                                        const float* __restrict__ yt, double* sums,
                                                        long long pixels, int cin) {
@@ -389,10 +392,11 @@ __global__ void loss_finalize_kernel(const double* sums, double count, float* ou
   out[1] = (float)dice;
 }
 
-__global__ __launch_bounds__(TPB) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(TPB) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ pin, const float* __restrict__ yt,
                                                        const double* __restrict__ sums, double inv_count,
-                                                       float* __restrict__ dx, float* dw, float* db,
+                                                       T* __restrict__ dx, float* dw, float* db,
                                                        long long pixels, int cin, int relu_mask) {
   const int lpp = cin >> 2;
   const int sub = threadIdx.x & (lpp - 1);
@@ -498,7 +502,8 @@ __global__ __launch_bounds__(TPB) void metrics_sweep_kernel(const float* __restr
 }
 
 // dst[slice] = src[slice] (materialise a skip tensor inside a concat buffer) and dst[slice] (+)= sum of up to 4 gradient slices
-__global__ __launch_bounds__(TPB) void copy_slice_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+template <typename T>
+__global__ __launch_bounds__(TPB) void copy_slice_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd,
                                                          long long pixels, int C) {
   const int lpp = C >> 2; const long long total = pixels * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
@@ -506,8 +511,9 @@ __global__ __launch_bounds__(TPB) void copy_slice_kernel(const float* __restrict
     st4(dst + p * ldd + q * 4, ld4(src + p * lds + q * 4));
   }
 }
-struct SliceList { const float* p[4]; int ld[4]; int n; };
-__global__ __launch_bounds__(TPB) void accum_slices_kernel(SliceList sl, float* __restrict__ dst, int ldd, long long pixels, int C,
+template <typename T> struct SliceList { const T* p[4]; int ld[4]; int n; };
+template <typename T>
+__global__ __launch_bounds__(TPB) void accum_slices_kernel(SliceList<T> sl, T* __restrict__ dst, int ldd, long long pixels, int C,
                                                            int accumulate) {
   const int lpp = C >> 2; const long long total = pixels * lpp;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
@@ -543,11 +549,11 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 extern "C" {
 
-int32_t unet_bn_stats(unet_ctx* ctx, const float* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) {
+extern "C++" template <typename T> static int32_t bn_stats_impl(unet_ctx* ctx, const T* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) {
   if (!ctx || !x || !sums || !bn_c_ok(c) || ldx < c || (ldx & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: bad args c=%d ldx=%d", c, ldx);
   int ppb = TPB / (c / 4);
   int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(bn_stats_kernel<0>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c);
+  hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c);
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "bn_stats"); return UNET_OK;
 }
@@ -566,19 +572,19 @@ int32_t unet_bn_finalize_infer(unet_ctx* ctx, const float* gamma, const float* b
   UNET_CHECK_LAUNCH(ctx, "bn_finalize_infer"); return UNET_OK;
 }
 
-int32_t unet_bn_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy, int64_t pixels,
+extern "C++" template <typename T> static int32_t bn_apply_impl(unet_ctx* ctx, const T* x, int32_t ldx, const float* bnp, T* y, int32_t ldy, int64_t pixels,
                       int32_t c, void* stream) {
   if (!x || !bnp || !y || !bn_c_ok(c) || ldx < c || ldy < c || ((ldx | ldy) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_apply: bad args");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, y, ldy, (long long)pixels, c);
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, y, ldy, (long long)pixels, c);
   UNET_CHECK_LAUNCH(ctx, "bn_apply"); return UNET_OK;
 }
 
-int32_t unet_bn_bwd_stats(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp,
+extern "C++" template <typename T> static int32_t bn_bwd_stats_impl(unet_ctx* ctx, const T* dy, int32_t lddy, const T* x, int32_t ldx, const float* bnp,
                           double* sums, int64_t pixels, int32_t c, void* stream) {
   if (!ctx || !dy || !x || !bnp || !sums || !bn_c_ok(c) || ((ldx | lddy) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_stats: bad args");
   int ppb = TPB / (c / 4);
   int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_BWD_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, ctx->bn_slots, (long long)pixels, c);
+  hipLaunchKernelGGL((bn_stats_kernel<1, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, ctx->bn_slots, (long long)pixels, c);
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "bn_bwd_stats"); return UNET_OK;
 }
@@ -589,13 +595,13 @@ int32_t unet_bn_bwd_param_grads(unet_ctx* ctx, const double* sums, float* dgamma
   UNET_CHECK_LAUNCH(ctx, "bn_bwd_param_grads"); return UNET_OK;
 }
 
-int32_t unet_bn_bwd_apply(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp,
-                          const double* sums, double count, int32_t mask_mode, float mask_rate, uint64_t mask_seed, float* dx,
+extern "C++" template <typename T> static int32_t bn_bwd_apply_impl(unet_ctx* ctx, const T* dy, int32_t lddy, const T* x, int32_t ldx, const float* bnp,
+                          const double* sums, double count, int32_t mask_mode, float mask_rate, uint64_t mask_seed, T* dx,
                           int32_t lddx, int64_t pixels, int32_t c, void* stream) {
   if (!dy || !x || !bnp || !sums || !dx || !bn_c_ok(c) || count < 1 || ((ldx | lddy | lddx) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_apply: bad args");
   if (mask_mode < 0 || mask_mode > 3 || (mask_mode == MASK_ELU_DROP && (ldx != c || mask_rate < 0 || mask_rate >= 1))) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_apply: bad mask mode (MASK_ELU_DROP needs a dense x)");
 #define UNET_LAUNCH_BNBA(MM_)                                                                                                        \
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<MM_>, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<MM_, T>), dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, \
                      sums, 1.0 / count, dx, lddx, (long long)pixels, c, mask_rate, (unsigned long long)mask_seed)
   switch (mask_mode) {
     case MASK_NONE: UNET_LAUNCH_BNBA(MASK_NONE); break;
@@ -607,39 +613,39 @@ int32_t unet_bn_bwd_apply(unet_ctx* ctx, const float* dy, int32_t lddy, const fl
   UNET_CHECK_LAUNCH(ctx, "bn_bwd_apply"); return UNET_OK;
 }
 
-int32_t unet_maxpool2x2_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, float* y, int32_t n, int32_t h, int32_t wd,
+extern "C++" template <typename T> static int32_t maxpool_fwd_impl(unet_ctx* ctx, const T* x, int32_t ldx, T* y, int32_t n, int32_t h, int32_t wd,
                                     int32_t c, float rate, uint64_t seed, void* stream) {
   if (!x || !y || (c & 3) || (h & 1) || (wd & 1) || ldx < c || (ldx & 3) || rate < 0 || rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "maxpool fwd: bad args (h,w even; c%%4==0)");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, y, n, h, wd, c, rate, seed);
+  hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, y, n, h, wd, c, rate, seed);
   UNET_CHECK_LAUNCH(ctx, "maxpool fwd"); return UNET_OK;
 }
 
-int32_t unet_maxpool2x2_dropout_bwd(unet_ctx* ctx, const float* x, int32_t ldx, const float* dy, float* dx, int32_t lddx,
+extern "C++" template <typename T> static int32_t maxpool_bwd_impl(unet_ctx* ctx, const T* x, int32_t ldx, const T* dy, T* dx, int32_t lddx,
                                     int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
                                     int32_t accumulate, void* stream) {
   if (!x || !dy || !dx || (c & 3) || (h & 1) || (wd & 1) || ((ldx | lddx) & 3) || rate < 0 || rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd: bad args");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   int grid = grid_for(total);
-  if (accumulate) hipLaunchKernelGGL(pool_bwd_kernel<true>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
-  else hipLaunchKernelGGL(pool_bwd_kernel<false>, dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
+  if (accumulate) hipLaunchKernelGGL((pool_bwd_kernel<true, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
+  else hipLaunchKernelGGL((pool_bwd_kernel<false, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed);
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd"); return UNET_OK;
 }
 
-int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy,
-                                          float* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
+extern "C++" template <typename T> static int32_t bn_apply_maxpool_impl(unet_ctx* ctx, const T* x, int32_t ldx, const float* bnp, T* y, int32_t ldy,
+                                          T* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
                                           void* stream) {
   if (!x || !bnp || !y || !pooled || !bn_c_ok(c) || (h & 1) || (wd & 1) || ldx < c || ldy < c || ((ldx | ldy) & 3) || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn_apply_maxpool fwd: bad args (h,w even; c%%4==0)");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
-  hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed);
+  hipLaunchKernelGGL(bn_pool_fwd_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed);
   UNET_CHECK_LAUNCH(ctx, "bn_apply_maxpool fwd"); return UNET_OK;
 }
 
-int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32_t ldy, const float* dy, float* dx, int32_t lddx,
+extern "C++" template <typename T> static int32_t maxpool_bwd_bnstats_impl(unet_ctx* ctx, const T* y, int32_t ldy, const T* dy, T* dx, int32_t lddx,
                                             const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd,
                                             int32_t c, float rate, uint64_t seed, void* stream) {
   if (!ctx || !y || !dy || !dx || !gamma || !beta || !sums || (c & 3) || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldy | lddx) & 3) || rate < 0 || rate >= 1)
@@ -647,15 +653,15 @@ int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   int grid = (int)std::min<long long>(cdiv64(total, TPB), POOL_BWD_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(pool_bwd_bnstats_kernel, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, ctx->bn_slots, n, h, wd, c, rate, seed);
+  hipLaunchKernelGGL(pool_bwd_bnstats_kernel<T>, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, ctx->bn_slots, n, h, wd, c, rate, seed);
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd + bn stats"); return UNET_OK;
 }
 
-int32_t unet_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* p, const float* y_true,
+extern "C++" template <typename T> static int32_t head_fwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* bias, float* p, const float* y_true,
                       double* loss_sums, int64_t pixels, int32_t cin, void* stream) {
   if (!x || !w || !bias || !p || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || (y_true && !loss_sums)) UNET_FAIL(ctx, UNET_E_ARG, "head_fwd: bad args (cin/4 must be a power of two <= 64)");
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels * (cin / 4) / 4, TPB), HEAD_BLOCKS))), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels, cin);
+  hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels * (cin / 4) / 4, TPB), HEAD_BLOCKS))), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels, cin);
   UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
 }
 
@@ -665,11 +671,11 @@ int32_t unet_loss_finalize(unet_ctx* ctx, const double* loss_sums, double count,
   UNET_CHECK_LAUNCH(ctx, "loss_finalize"); return UNET_OK;
 }
 
-int32_t unet_head_bwd(unet_ctx* ctx, const float* x, const float* w, const float* p, const float* y_true,
-                      const double* loss_sums, double count, float* dx, float* dw, float* db, int64_t pixels, int32_t cin,
+extern "C++" template <typename T> static int32_t head_bwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* p, const float* y_true,
+                      const double* loss_sums, double count, T* dx, float* dw, float* db, int64_t pixels, int32_t cin,
                       int32_t relu_mask, void* stream) {
   if (!x || !w || !p || !y_true || !loss_sums || !dx || !dw || !db || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "head_bwd: bad args");
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(std::min(grid_for(pixels * (cin / 4) / 4), 1024)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin, relu_mask);
+  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(std::min(grid_for(pixels * (cin / 4) / 4), 1024)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin, relu_mask);
   UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
 }
 
@@ -688,18 +694,18 @@ int32_t unet_seg_metrics_sweep(unet_ctx* ctx, const float* p, const float* gt, c
   UNET_CHECK_LAUNCH(ctx, "metrics_sweep"); return UNET_OK;
 }
 
-int32_t unet_copy_slice(unet_ctx* ctx, const float* src, int32_t lds, float* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream) {
+extern "C++" template <typename T> static int32_t copy_slice_impl(unet_ctx* ctx, const T* src, int32_t lds, T* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream) {
   if (!src || !dst || (c & 3) || lds < c || ldd < c || ((lds | ldd) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "copy_slice: bad args");
-  hipLaunchKernelGGL(copy_slice_kernel, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), src, lds, dst, ldd, (long long)pixels, c);
+  hipLaunchKernelGGL(copy_slice_kernel<T>, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), src, lds, dst, ldd, (long long)pixels, c);
   UNET_CHECK_LAUNCH(ctx, "copy_slice"); return UNET_OK;
 }
 
-int32_t unet_accum_slices(unet_ctx* ctx, const float* const* srcs, const int32_t* lds, int32_t nsrc, float* dst, int32_t ldd, int64_t pixels,
+extern "C++" template <typename T> static int32_t accum_slices_impl(unet_ctx* ctx, const T* const* srcs, const int32_t* lds, int32_t nsrc, T* dst, int32_t ldd, int64_t pixels,
                           int32_t c, int32_t accumulate, void* stream) {
   if (!srcs || !lds || !dst || nsrc < 1 || nsrc > 4 || (c & 3) || ldd < c || (ldd & 3)) UNET_FAIL(ctx, UNET_E_ARG, "accum_slices: bad args (1..4 sources)");
-  SliceList sl; sl.n = nsrc;
+  SliceList<T> sl; sl.n = nsrc;
   for (int k = 0; k < 4; ++k) { sl.p[k] = k < nsrc ? srcs[k] : nullptr; sl.ld[k] = k < nsrc ? lds[k] : 0; if (k < nsrc && (!srcs[k] || lds[k] < c || (lds[k] & 3))) UNET_FAIL(ctx, UNET_E_ARG, "accum_slices: bad source %d", k); }
-  hipLaunchKernelGGL(accum_slices_kernel, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), sl, dst, ldd, (long long)pixels, c, accumulate);
+  hipLaunchKernelGGL(accum_slices_kernel<T>, dim3(grid_for(pixels * (c / 4))), dim3(TPB), 0, as_stream(stream), sl, dst, ldd, (long long)pixels, c, accumulate);
   UNET_CHECK_LAUNCH(ctx, "accum_slices"); return UNET_OK;
 }
 
@@ -715,6 +721,53 @@ int32_t unet_zero(unet_ctx* ctx, void* ptr, size_t bytes, void* stream) {
   }
   UNET_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, as_stream(stream)));
   return UNET_OK;
+}
+
+
+// C entry points of the storage-templated ops: fp32 and bf16 (activation pointers only; parameters, sums and the head's
+// probabilities / targets stay fp32 / fp64)
+int32_t unet_bn_stats(unet_ctx* ctx, const float* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) { return bn_stats_impl(ctx, x, ldx, sums, pixels, c, stream); }
+int32_t unet_bn_stats_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) { return bn_stats_impl(ctx, x, ldx, sums, pixels, c, stream); }
+int32_t unet_bn_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy, int64_t pixels, int32_t c, void* stream) { return bn_apply_impl(ctx, x, ldx, bnp, y, ldy, pixels, c, stream); }
+int32_t unet_bn_apply_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy, int64_t pixels, int32_t c, void* stream) { return bn_apply_impl(ctx, x, ldx, bnp, y, ldy, pixels, c, stream); }
+int32_t unet_bn_bwd_stats(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp, double* sums, int64_t pixels, int32_t c, void* stream) { return bn_bwd_stats_impl(ctx, dy, lddy, x, ldx, bnp, sums, pixels, c, stream); }
+int32_t unet_bn_bwd_stats_bf16(unet_ctx* ctx, const unet_bf16* dy, int32_t lddy, const unet_bf16* x, int32_t ldx, const float* bnp, double* sums, int64_t pixels, int32_t c, void* stream) { return bn_bwd_stats_impl(ctx, dy, lddy, x, ldx, bnp, sums, pixels, c, stream); }
+int32_t unet_bn_bwd_apply(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp, const double* sums, double count, int32_t mask_mode, float mask_rate, uint64_t mask_seed, float* dx, int32_t lddx, int64_t pixels, int32_t c, void* stream) { return bn_bwd_apply_impl(ctx, dy, lddy, x, ldx, bnp, sums, count, mask_mode, mask_rate, mask_seed, dx, lddx, pixels, c, stream); }
+int32_t unet_bn_bwd_apply_bf16(unet_ctx* ctx, const unet_bf16* dy, int32_t lddy, const unet_bf16* x, int32_t ldx, const float* bnp, const double* sums, double count, int32_t mask_mode, float mask_rate, uint64_t mask_seed, unet_bf16* dx, int32_t lddx, int64_t pixels, int32_t c, void* stream) { return bn_bwd_apply_impl(ctx, dy, lddy, x, ldx, bnp, sums, count, mask_mode, mask_rate, mask_seed, dx, lddx, pixels, c, stream); }
+int32_t unet_maxpool2x2_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, float* y, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_fwd_impl(ctx, x, ldx, y, n, h, wd, c, rate, seed, stream); }
+int32_t unet_maxpool2x2_dropout_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, unet_bf16* y, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_fwd_impl(ctx, x, ldx, y, n, h, wd, c, rate, seed, stream); }
+int32_t unet_maxpool2x2_dropout_bwd(unet_ctx* ctx, const float* x, int32_t ldx, const float* dy, float* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, int32_t accumulate, void* stream) { return maxpool_bwd_impl(ctx, x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed, accumulate, stream); }
+int32_t unet_maxpool2x2_dropout_bwd_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const unet_bf16* dy, unet_bf16* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, int32_t accumulate, void* stream) { return maxpool_bwd_impl(ctx, x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed, accumulate, stream); }
+int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy, float* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_apply_maxpool_impl(ctx, x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed, stream); }
+int32_t unet_bn_apply_maxpool_dropout_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy, unet_bf16* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_apply_maxpool_impl(ctx, x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed, stream); }
+int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32_t ldy, const float* dy, float* dx, int32_t lddx, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_bnstats_impl(ctx, y, ldy, dy, dx, lddx, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
+int32_t unet_maxpool2x2_dropout_bwd_bnstats_bf16(unet_ctx* ctx, const unet_bf16* y, int32_t ldy, const unet_bf16* dy, unet_bf16* dx, int32_t lddx, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_bnstats_impl(ctx, y, ldy, dy, dx, lddx, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
+int32_t unet_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* p, const float* y_true, double* loss_sums, int64_t pixels, int32_t cin, void* stream) { return head_fwd_impl(ctx, x, w, bias, p, y_true, loss_sums, pixels, cin, stream); }
+int32_t unet_head_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, float* p, const float* y_true, double* loss_sums, int64_t pixels, int32_t cin, void* stream) { return head_fwd_impl(ctx, x, w, bias, p, y_true, loss_sums, pixels, cin, stream); }
+int32_t unet_head_bwd(unet_ctx* ctx, const float* x, const float* w, const float* p, const float* y_true, const double* loss_sums, double count, float* dx, float* dw, float* db, int64_t pixels, int32_t cin, int32_t relu_mask, void* stream) { return head_bwd_impl(ctx, x, w, p, y_true, loss_sums, count, dx, dw, db, pixels, cin, relu_mask, stream); }
+int32_t unet_head_bwd_bf16(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* p, const float* y_true, const double* loss_sums, double count, unet_bf16* dx, float* dw, float* db, int64_t pixels, int32_t cin, int32_t relu_mask, void* stream) { return head_bwd_impl(ctx, x, w, p, y_true, loss_sums, count, dx, dw, db, pixels, cin, relu_mask, stream); }
+int32_t unet_copy_slice(unet_ctx* ctx, const float* src, int32_t lds, float* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream) { return copy_slice_impl(ctx, src, lds, dst, ldd, pixels, c, stream); }
+int32_t unet_copy_slice_bf16(unet_ctx* ctx, const unet_bf16* src, int32_t lds, unet_bf16* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream) { return copy_slice_impl(ctx, src, lds, dst, ldd, pixels, c, stream); }
+int32_t unet_accum_slices(unet_ctx* ctx, const float* const* srcs, const int32_t* lds, int32_t nsrc, float* dst, int32_t ldd, int64_t pixels, int32_t c, int32_t accumulate, void* stream) { return accum_slices_impl(ctx, srcs, lds, nsrc, dst, ldd, pixels, c, accumulate, stream); }
+int32_t unet_accum_slices_bf16(unet_ctx* ctx, const unet_bf16* const* srcs, const int32_t* lds, int32_t nsrc, unet_bf16* dst, int32_t ldd, int64_t pixels, int32_t c, int32_t accumulate, void* stream) { return accum_slices_impl(ctx, srcs, lds, nsrc, dst, ldd, pixels, c, accumulate, stream); }
+
+namespace {
+__global__ __launch_bounds__(TPB) void cast_f32_bf16_kernel(const float* __restrict__ src, unet_bf16* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) st4(dst + i * 4, ld4(src + i * 4));
+}
+__global__ __launch_bounds__(TPB) void cast_bf16_f32_kernel(const unet_bf16* __restrict__ src, float* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) st4(dst + i * 4, ld4(src + i * 4));
+}
+}  // namespace
+int32_t unet_cast_f32_to_bf16(unet_ctx* ctx, const float* src, unet_bf16* dst, int64_t count, void* stream) {
+  if (!src || !dst || count < 4 || (count & 3)) UNET_FAIL(ctx, UNET_E_ARG, "cast: count must be a positive multiple of 4");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(count / 4)), dim3(TPB), 0, as_stream(stream), src, dst, (long long)(count / 4));
+  UNET_CHECK_LAUNCH(ctx, "cast_f32_to_bf16"); return UNET_OK;
+}
+int32_t unet_cast_bf16_to_f32(unet_ctx* ctx, const unet_bf16* src, float* dst, int64_t count, void* stream) {
+  if (!src || !dst || count < 4 || (count & 3)) UNET_FAIL(ctx, UNET_E_ARG, "cast: count must be a positive multiple of 4");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(count / 4)), dim3(TPB), 0, as_stream(stream), src, dst, (long long)(count / 4));
+  UNET_CHECK_LAUNCH(ctx, "cast_bf16_to_f32"); return UNET_OK;
 }
 
 }  // extern "C"

@@ -194,6 +194,56 @@ int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy
   return k_convT_naive_wgrad(ctx, x, dy, lddy, dw, db, n, h, wd, cin, cout, as_stream(stream));
 }
 
+
+/* ---- bf16-storage variants (activations / activation gradients bf16, everything else fp32).  No algorithm selector: one MFMA
+ * kernel family (v_mfma_f32_32x32x16_bf16); unsupported channel counts fail with UNET_E_SHAPE. */
+int32_t unet_conv3x3_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int32_t n, int32_t h, int32_t wd,
+                              int32_t cin, int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, void* w_ws, void* stream) {
+  if (!ctx || !x || !w || !y || !w_ws || n < 1 || h < 1 || wd < 1 || act < 0 || act > 2 || drop_rate < 0 || drop_rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd_bf16: bad args");
+  return k_conv3x3_bf16_fwd(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, static_cast<unet_bf16*>(w_ws), 0, as_stream(stream));
+}
+int32_t unet_conv3x3_first_fwd_bf16(unet_ctx* ctx, const float* x, const float* w, const float* bias, unet_bf16* y, int32_t n, int32_t h, int32_t wd,
+                                    int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, void* stream) {
+  if (!ctx || !x || !w || !y || n < 1 || h < 1 || wd < 1 || act < 0 || act > 2 || drop_rate < 0 || drop_rate >= 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_first_fwd_bf16: bad args");
+  return k_conv3x3_c1_fwd_bf16(ctx, x, w, bias, y, n, h, wd, cout, act, drop_rate, drop_seed, as_stream(stream));
+}
+int32_t unet_conv3x3_bwd_data_bf16(unet_ctx* ctx, const unet_bf16* dy, const float* w, const unet_bf16* mask_src, int32_t mask_mode, float mask_rate,
+                                   uint64_t mask_seed, unet_bf16* dx, void* w_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream) {
+  if (!ctx || !dy || !w || !dx || !w_ws || n < 1 || h < 1 || wd < 1 || mask_mode < 0 || mask_mode > 3 || (mask_mode != MASK_NONE && !mask_src) || mask_rate < 0 || mask_rate >= 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data_bf16: bad args");
+  return k_conv3x3_bf16_fwd(ctx, dy, w, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, static_cast<unet_bf16*>(w_ws), 1, as_stream(stream));
+}
+size_t unet_conv3x3_bwd_weights_ws_bytes_bf16(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
+  if (cin == 1) return c1_wgrad_ws_bytes(cout);
+  return bf16_wgrad_ws_bytes(n, h, wd, cin, cout);
+}
+int32_t unet_conv3x3_bwd_weights_bf16(unet_ctx* ctx, const unet_bf16* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int32_t n,
+                                      int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream) {
+  if (!ctx || !x || !dy || !dw || !db || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_weights_bf16: bad args");
+  return k_conv3x3_bf16_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, as_stream(stream));
+}
+int32_t unet_conv3x3_first_bwd_weights_bf16(unet_ctx* ctx, const float* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int32_t n,
+                                            int32_t h, int32_t wd, int32_t cout, void* stream) {
+  if (!ctx || !x || !dy || !dw || !db || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_first_bwd_weights_bf16: bad args");
+  return k_conv3x3_c1_wgrad_bf16(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cout, as_stream(stream));
+}
+int32_t unet_convT2x2_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int32_t ldy, int32_t n, int32_t h,
+                               int32_t wd, int32_t cin, int32_t cout, void* w_ws, void* stream) {
+  if (!ctx || !x || !w || !y || !w_ws || ldy < cout || (ldy & 7) || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "convT_fwd_bf16: bad args");
+  return k_convT_bf16_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, static_cast<unet_bf16*>(w_ws), as_stream(stream));
+}
+int32_t unet_convT2x2_bwd_data_bf16(unet_ctx* ctx, const unet_bf16* dy, int32_t lddy, const float* w, const unet_bf16* relu_src, unet_bf16* dx, int32_t n,
+                                    int32_t h, int32_t wd, int32_t cin, int32_t cout, void* w_ws, void* stream) {
+  if (!ctx || !dy || !w || !dx || !w_ws || lddy < cout || (lddy & 7)) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_data_bf16: bad args");
+  return k_convT_bf16_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, static_cast<unet_bf16*>(w_ws), as_stream(stream));
+}
+size_t unet_convT2x2_bwd_weights_ws_bytes_bf16(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) { return bf16_convT_wgrad_ws_bytes(n, h, wd, cin, cout); }
+int32_t unet_convT2x2_bwd_weights_bf16(unet_ctx* ctx, const unet_bf16* x, const unet_bf16* dy, int32_t lddy, float* dw, float* db, void* ws, size_t ws_bytes,
+                                       int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream) {
+  if (!ctx || !x || !dy || !dw || !db || lddy < cout || (lddy & 7)) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_weights_bf16: bad args");
+  return k_convT_bf16_wgrad(ctx, x, dy, lddy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, as_stream(stream));
+}
+
 }  // extern "C"
 
 // =========================================================================================

@@ -1,0 +1,146 @@
+"""-m gpu: the bf16-storage ops (include/unet_hip.h, ABI v5) against the CPU oracle on bf16-exact inputs.
+
+Tolerances (written here, per the task's floating-point rule):
+  * tensors the op STORES as bf16 (conv / convT outputs, data gradients): every element is an fp32-accumulated value rounded
+    once to bf16 (8 significant bits): |err| <= 2^-9 relative per element  ->  norm-wise BF16_OUT = 4e-3;
+  * fp32 outputs computed from bf16 inputs (weight / bias gradients): products of bf16 values are exact in fp32, only the
+    summation order differs from the fp64 oracle  ->  F32_OUT = 2e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle.unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF16_OUT, F32_OUT = 4e-3, 2e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gpu_util import Ops
+    return Ops()
+
+
+def T64(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+
+def q(a):
+    """round to bf16 (nearest even, as the kernels do) and return (device bf16 tensor, fp32 numpy of the rounded values)"""
+    t = torch.from_numpy(np.ascontiguousarray(a, np.float32)).bfloat16()
+    return t.cuda(), t.float().numpy()
+
+
+def f32(t):
+    return t.float().cpu().numpy()
+
+
+CONV_SHAPES = [(1, 16, 32, 16, 32), (2, 9, 37, 32, 64), (1, 33, 34, 64, 32), (2, 16, 16, 128, 128), (1, 5, 70, 96, 64), (1, 40, 8, 48, 96),
+               (1, 64, 64, 32, 32)]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_fwd_bf16(ops, shape):
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(hash(shape) % 1000)
+    xd, x = q(rng.standard_normal((n, h, w, ci))); _, k = q(rng.standard_normal((3, 3, ci, co)) * 0.2)
+    b = rng.standard_normal(co).astype(np.float32)
+    for act in (1, 0):
+        y = ops.z(n, h, w, co, dtype=torch.bfloat16); y.fill_(7.0)
+        ops.ck(ops.lib.unet_conv3x3_fwd_bf16(ops.h, xd.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, act, 0.0, 0, ops.wws(ci, co), ops.s), "conv fwd bf16")
+        want = O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=bool(act)).numpy()
+        assert relerr(f32(y), want) < BF16_OUT
+        # rounding the oracle the same way leaves only the accumulation-order flips
+        wq = torch.from_numpy(want.astype(np.float32)).bfloat16().float().numpy()
+        assert (f32(y) != wq).mean() < 0.02
+
+
+# the data gradient swaps the roles of cin / cout, the weight gradient tiles both by 32: multiples of 32 on both sides
+@pytest.mark.parametrize("shape", [s for s in CONV_SHAPES if s[3] % 32 == 0] + [(1, 40, 8, 96, 96), (2, 12, 20, 256, 64)])
+def test_conv3x3_bwd_bf16(ops, shape):
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(7 + hash(shape) % 1000)
+    xd, x = q(rng.standard_normal((n, h, w, ci))); _, k = q(rng.standard_normal((3, 3, ci, co)) * 0.2)
+    dyd, dy = q(rng.standard_normal((n, h, w, co)))
+    xt, kt = T64(x).requires_grad_(True), T64(k).requires_grad_(True)
+    bt = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    O.conv3x3_bias_relu(xt, kt, bt, relu=False).backward(T64(dy))
+    for masked in (False, True):
+        dx = ops.z(n, h, w, ci, dtype=torch.bfloat16); dx.fill_(3.0)
+        ops.ck(ops.lib.unet_conv3x3_bwd_data_bf16(ops.h, dyd.data_ptr(), ops.d(k).data_ptr(), xd.data_ptr() if masked else None, 1 if masked else 0, 0.0, 0, dx.data_ptr(),
+                                                  ops.wws(ci, co), n, h, w, ci, co, ops.s), "conv bwd data bf16")
+        want = xt.grad.numpy() * ((x > 0) if masked else 1.0)
+        assert relerr(f32(dx), want) < BF16_OUT
+    nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes_bf16(n, h, w, ci, co)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    dw = ops.z(3, 3, ci, co); db = ops.z(co)
+    dw.fill_(123.0); db.fill_(-7.0)                                  # must be overwritten, not accumulated
+    ops.ck(ops.lib.unet_conv3x3_bwd_weights_bf16(ops.h, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, ops.s), "conv bwd w bf16")
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < F32_OUT
+    assert relerr(db.cpu().numpy(), bt.grad.numpy()) < F32_OUT
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 37, 32), (1, 64, 64, 32), (1, 5, 6, 64)])
+def test_conv3x3_first_layer_bf16(ops, shape):
+    """cin = 1: the fp32 image goes in, bf16 activations come out; the weight gradient reads the fp32 image and a bf16 gradient"""
+    from gpu_util import relerr
+    n, h, w, co = shape
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, h, w, 1)).astype(np.float32); k = (rng.standard_normal((3, 3, 1, co)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32); dyd, dy = q(rng.standard_normal((n, h, w, co)))
+    y = ops.z(n, h, w, co, dtype=torch.bfloat16)
+    ops.ck(ops.lib.unet_conv3x3_first_fwd_bf16(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, co, 1, 0.0, 0, ops.s), "c1 fwd bf16")
+    assert relerr(f32(y), O.conv3x3_bias_relu(T64(x), T64(k), T64(b)).numpy()) < BF16_OUT
+    xt, kt, bt = T64(x), T64(k).requires_grad_(True), torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    O.conv3x3_bias_relu(xt, kt, bt, relu=False).backward(T64(dy))
+    nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes_bf16(n, h, w, 1, co)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    dw = ops.z(3, 3, 1, co); db = ops.z(co)
+    ops.ck(ops.lib.unet_conv3x3_first_bwd_weights_bf16(ops.h, ops.d(x).data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, co, ops.s), "c1 wgrad bf16")
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < F32_OUT and relerr(db.cpu().numpy(), bt.grad.numpy()) < F32_OUT
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 4, 512, 256), (2, 8, 8, 64, 32), (1, 7, 9, 128, 64), (2, 5, 37, 64, 64), (1, 33, 34, 64, 32), (1, 16, 32, 256, 128)])
+def test_convT_bf16(ops, shape):
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(11)
+    xd, x = q(rng.standard_normal((n, h, w, ci))); _, k = q(rng.standard_normal((2, 2, co, ci)) * 0.2)
+    b = rng.standard_normal(co).astype(np.float32); _, dy = q(rng.standard_normal((n, 2 * h, 2 * w, co)))
+    ld = 2 * co
+    xt, kt, bt = T64(x).requires_grad_(True), T64(k).requires_grad_(True), T64(b).requires_grad_(True)
+    yt = O.convT2x2s2_bias(xt, kt, bt)
+    cat = ops.z(n, 2 * h, 2 * w, ld, dtype=torch.bfloat16); cat.fill_(9.0)
+    ops.ck(ops.lib.unet_convT2x2_fwd_bf16(ops.h, xd.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), cat.data_ptr(), ld, n, h, w, ci, co, ops.wws(ci, co), ops.s), "convT fwd bf16")
+    got = f32(cat)
+    assert relerr(got[..., :co], yt.detach().numpy()) < BF16_OUT and (got[..., co:] == 9.0).all()      # only the slice is written
+    yt.backward(T64(dy))
+    dcat = np.full((n, 2 * h, 2 * w, ld), 5.0, np.float32); dcat[..., :co] = dy
+    dcd, _ = q(dcat)
+    for masked in (False, True):
+        dx = ops.z(n, h, w, ci, dtype=torch.bfloat16)
+        ops.ck(ops.lib.unet_convT2x2_bwd_data_bf16(ops.h, dcd.data_ptr(), ld, ops.d(k).data_ptr(), xd.data_ptr() if masked else None, dx.data_ptr(), n, h, w, ci, co, ops.wws(ci, co), ops.s), "convT bwd data bf16")
+        assert relerr(f32(dx), xt.grad.numpy() * ((x > 0) if masked else 1.0)) < BF16_OUT
+    nb = ops.lib.unet_convT2x2_bwd_weights_ws_bytes_bf16(n, h, w, ci, co)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    dw = ops.z(2, 2, co, ci); db = ops.z(co); dw.fill_(3.0); db.fill_(-2.0)
+    ops.ck(ops.lib.unet_convT2x2_bwd_weights_bf16(ops.h, xd.data_ptr(), dcd.data_ptr(), ld, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, ops.s), "convT bwd w bf16")
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < F32_OUT and relerr(db.cpu().numpy(), bt.grad.numpy()) < F32_OUT
+
+
+def test_unsupported_channel_counts_fail_loudly(ops):
+    xd, _ = q(np.zeros((1, 8, 8, 8))); y = ops.z(1, 8, 8, 32, dtype=torch.bfloat16)
+    rc = ops.lib.unet_conv3x3_fwd_bf16(ops.h, xd.data_ptr(), ops.z(3, 3, 8, 32).data_ptr(), None, y.data_ptr(), 1, 8, 8, 8, 32, 0, 0.0, 0, ops.wws(8, 32), ops.s)
+    assert rc == -3          # UNET_E_SHAPE, not a silent fallback
+
+
+def test_cast_round_trip(ops):
+    x = np.random.default_rng(0).standard_normal(4096).astype(np.float32)
+    b = ops.z(4096, dtype=torch.bfloat16); back = ops.z(4096)
+    ops.ck(ops.lib.unet_cast_f32_to_bf16(ops.h, ops.d(x).data_ptr(), b.data_ptr(), 4096, ops.s), "cast")
+    ops.ck(ops.lib.unet_cast_bf16_to_f32(ops.h, b.data_ptr(), back.data_ptr(), 4096, ops.s), "cast back")
+    want = torch.from_numpy(x).bfloat16()
+    assert torch.equal(b.cpu(), want) and np.array_equal(back.cpu().numpy(), want.float().numpy())          # bit-exact: same RNE rounding as torch
