@@ -287,8 +287,11 @@ typedef struct unet_sync_point {
 /* arch: UNET_ARCH_UNET (T1:853-916), UNET_ARCH_UNETPP (task1_unet_plus_plus.py:858-950) or UNET_ARCH_CLASSIFIER (the Sequential
  * CNN of task2_covid19_classifcation.py:747-776: y_true / p_out are [n] floats, loss_ptr = (binary cross-entropy, f1)) */
 enum { UNET_ARCH_UNET = 0, UNET_ARCH_UNETPP = 1, UNET_ARCH_CLASSIFIER = 2 };
+/* dtype: UNET_DTYPE_F32, or UNET_DTYPE_BF16 = activations / activation gradients stored as bf16 inside the workspace (the image x,
+ * the targets, the probabilities p_out, parameters, gradients and optimizer state stay fp32; implemented for UNET_ARCH_UNET, in_ch 1) */
 int32_t unet_model_create(unet_ctx*, int32_t arch, int32_t in_ch, int32_t n, int32_t h, int32_t w,
-                          int32_t world_size, int32_t conv_algo, unet_model** out);
+                          int32_t world_size, int32_t conv_algo, int32_t dtype, unet_model** out);
+int32_t unet_model_dtype(const unet_model*);
 void unet_model_destroy(unet_model*);
 int64_t unet_model_param_count(const unet_model*);   /* trainable floats (7,762,401 for in_ch=1) */
 int64_t unet_model_state_count(const unet_model*);   /* BN moving mean/var floats (2,880) */
@@ -309,7 +312,7 @@ int32_t unet_model_run(unet_model*, int32_t prog, int32_t begin, int32_t end, vo
 /* device pointer to float[2] = (loss, dice_coeff) of the last forward with y_true bound */
 const float* unet_model_loss_ptr(const unet_model*);
 /* intermediate activation / gradient taps for tests ("c1a","bn1","p1","u6","cat6",...) */
-int32_t unet_model_tap(const unet_model*, const char* name, int32_t grad, const float** ptr,
+int32_t unet_model_tap(const unet_model*, const char* name, int32_t grad, const void** ptr,   /* element type: see unet_model_dtype */
                        int32_t* ld, int32_t* n, int32_t* h, int32_t* w, int32_t* c);
 /* profiling: per-op name and accumulated milliseconds since last reset (profiling on) */
 int32_t unet_model_op_info(const unet_model*, int32_t prog, int32_t op, const char** name,

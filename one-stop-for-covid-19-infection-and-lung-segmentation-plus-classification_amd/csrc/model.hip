@@ -267,6 +267,7 @@ struct Op {
 struct unet_model {
   unet_ctx* ctx = nullptr;
   int arch = 0, in_ch = 1, N = 0, H = 0, W = 0, world = 1, algo = 0;
+  int dt = UNET_DTYPE_F32;                             // storage type of activations / activation gradients
   std::vector<Layer> layers;
   std::map<std::string, TInfo> tinfo;
   int64_t n_params = 0, n_state = 0;
@@ -296,6 +297,10 @@ struct unet_model {
   const float* A(const std::string& n) const { auto& b = act.at(n); return wsf(b.off + b.chan_off); }
   float* Aw(const std::string& n) const { auto& b = act.at(n); return wsf(b.off + b.chan_off); }
   float* D(const std::string& n) const { auto& b = grad.at(n); return wsf(b.off + b.chan_off); }
+  // storage-type-agnostic addresses: buffer offsets are in 4-byte units, channel offsets in elements
+  void* bufptr(const Buf& b) const { return ws + b.off * 4 + b.chan_off * (dt ? 2 : 4); }
+  void* Av(const std::string& n) const { return bufptr(act.at(n)); }
+  void* Dv(const std::string& n) const { return bufptr(grad.at(n)); }
 };
 
 namespace {
@@ -346,11 +351,11 @@ void build_layers(unet_model* m) {
 }
 
 struct Carver {
-  size_t cur = 0;
+  size_t cur = 0; int dt = 0;          // dt: storage type of the activation buffers carved by mk()
   size_t take(size_t floats) { size_t o = cur; cur += (floats + 63) & ~size_t(63); return o; }
 };
 
-Buf mk(Carver& cv, int n, int h, int w, int c) { Buf b; b.off = cv.take((size_t)n * h * w * c); b.ld = c; b.n = n; b.h = h; b.w = w; b.c = c; return b; }
+Buf mk(Carver& cv, int n, int h, int w, int c) { Buf b; const size_t el = (size_t)n * h * w * c; b.off = cv.take(cv.dt ? (el + 1) / 2 : el); b.ld = c; b.n = n; b.h = h; b.w = w; b.c = c; return b; }
 Buf slice(const Buf& b, int c0, int c) { Buf s = b; s.chan_off = c0; s.c = c; return s; }
 
 void plan_scratch(unet_model* m, Carver& cv) {          // BN sums / params, loss scalars (the cross-rank sync buffers)
@@ -367,7 +372,7 @@ void plan_scratch(unet_model* m, Carver& cv) {          // BN sums / params, los
 }
 
 void plan_workspace(unet_model* m) {
-  Carver cv;
+  Carver cv; cv.dt = m->dt;
   const int N = m->N;
   plan_scratch(m, cv);
   // --- activations ---
@@ -430,13 +435,13 @@ void plan_workspace(unet_model* m) {
       if (l.name == "c5a" || l.name == "c5b") lvl = 4;
       else { int k = l.name[1] - '0'; lvl = (k <= 4) ? k - 1 : 9 - k; }
       int hs = s >> lvl, ts = t >> lvl;
-      wgb = std::max(wgb, unet_conv3x3_bwd_weights_ws_bytes(m->N, hs, ts, l.cin, l.cout));
+      wgb = std::max(wgb, m->dt ? unet_conv3x3_bwd_weights_ws_bytes_bf16(m->N, hs, ts, l.cin, l.cout) : unet_conv3x3_bwd_weights_ws_bytes(m->N, hs, ts, l.cin, l.cout));
     }
     for (auto& l : m->layers) {
       if (l.kind != 1) continue;
       int k = l.name[1] - '0';                 // u6..u9: input at level (10-k), i.e. spatial >> (10-k)
       int lvl = 10 - k;
-      wgb = std::max(wgb, mfma_convT_wgrad_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout));
+      wgb = std::max(wgb, m->dt ? bf16_convT_wgrad_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout) : mfma_convT_wgrad_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout));
     }
   }
   m->wgrad_ws_bytes = wgb;
@@ -458,6 +463,10 @@ void build_programs(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int N = m->N, algo = m->algo;
   const double gcount = (double)m->world;     // multiplies per-rank element counts into global counts
+  const int dt = m->dt;
+  const double eb = dt ? 2.0 : 4.0;           // bytes per stored activation element (roofline accounting)
+#define CBF(p) static_cast<const unet_bf16*>(p)
+#define WBF(p) static_cast<unet_bf16*>(p)
   auto& FT = m->prog[UNET_PROG_FWD_TRAIN];
   auto& FI = m->prog[UNET_PROG_FWD_INFER];
   auto& BW = m->prog[UNET_PROG_BWD];
@@ -471,8 +480,13 @@ void build_programs(unet_model* m) {
     auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
       const Buf ob = m->act.at(name);
       double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
-      double by = 4.0 * ((double)ob.n * ob.h * ob.w * (cin + cout) + 9.0 * cin * cout);
+      double by = eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout;
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
+        if (dt) {
+          if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_RELU, 0.0f, 0, s);
+          return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU,
+                                    0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
+        }
         const float* xin = in.empty() ? m->x : m->A(in);
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
                                     ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0);
@@ -483,7 +497,10 @@ void build_programs(unet_model* m) {
       const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
       const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
       if (training) {
-        ADD_OP(F, "bn_stats:" + name, 0, 4.0 * pixels * c, { return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s); });
+        ADD_OP(F, "bn_stats:" + name, 0, eb * pixels * c, {
+          if (dt) return unet_bn_stats_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+          return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+        });
         SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
         ADD_OP(F, "bn_finalize:" + name, 0, 0, {
           return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
@@ -494,7 +511,10 @@ void build_programs(unet_model* m) {
           return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
         });
       }
-      if (!fuse_pool) ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s); });
+      if (!fuse_pool) ADD_OP(F, "bn_apply:" + name, 0, 2 * eb * pixels * c, {
+        if (dt) return unet_bn_apply_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(out)), ob.ld, pixels, c, s);
+        return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s);
+      });
     };
     std::string prev = "";
     int cprev = m->in_ch;
@@ -507,7 +527,9 @@ void build_programs(unet_model* m) {
       const std::string pin = "bn" + ks, pout = "p" + ks, xin = "c" + ks + "b";
       const int tr = training;
       const size_t bo = m->bnp_off.at("bn" + ks);
-      ADD_OP(F, "bn_apply_pool:" + pout, 0, 4.0 * 2.25 * nel(ib), {
+      ADD_OP(F, "bn_apply_pool:" + pout, 0, eb * 2.25 * nel(ib), {
+        if (dt) return unet_bn_apply_maxpool_dropout_fwd_bf16(ctx, CBF(m->Av(xin)), xb.ld, m->wsf(bo), WBF(m->Av(pin)), ib.ld, WBF(m->Av(pout)), ib.n, ib.h, ib.w, ib.c,
+                                                              tr ? m->drop_rate : 0.0f, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
         return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(xin), xb.ld, m->wsf(bo), m->Aw(pin), ib.ld, m->Aw(pout), ib.n, ib.h, ib.w, ib.c,
                                                  tr ? m->drop_rate : 0.0f, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
       });
@@ -521,7 +543,8 @@ void build_programs(unet_model* m) {
       int c = dec[k - 6]; std::string ks = std::to_string(k);
       const Buf ib = m->act.at(prev), ub = m->act.at("u" + ks);
       const std::string uin = prev, un = "u" + ks; const int ci = cprev;
-      ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * ci * c * nel(ib) / ib.c, 4.0 * (nel(ib) + nel(ub)), {
+      ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * ci * c * nel(ib) / ib.c, eb * (nel(ib) + nel(ub)), {
+        if (dt) return k_convT_bf16_fwd(ctx, CBF(m->Av(uin)), m->P(un + "/kernel"), m->P(un + "/bias"), WBF(m->Av(un)), ub.ld, ib.n, ib.h, ib.w, ci, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
         return unet_convT2x2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, algo, s);
       });
       bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c, false);
@@ -531,8 +554,9 @@ void build_programs(unet_model* m) {
     }
     const Buf hb = m->act.at("c9b");
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
-    ADD_OP(F, "head_fwd", 2.0 * 32 * hp, 4.0 * hp * 34, {
+    ADD_OP(F, "head_fwd", 2.0 * 32 * hp, hp * (eb * 32 + 8.0), {
       if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_fwd: p_out not set (unet_model_set_io)");
+      if (dt) return unet_head_fwd_bf16(ctx, CBF(m->Av("c9b")), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt, m->yt ? m->wsd(m->off_loss_sums) : nullptr, hp, hb.c, s);
       return unet_head_fwd(ctx, m->A("c9b"), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt, m->yt ? m->wsd(m->off_loss_sums) : nullptr, hp, hb.c, s);
     });
     SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
@@ -556,8 +580,10 @@ void build_programs(unet_model* m) {
     });
     const Buf hb = m->act.at("c9b");
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
-    ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, 4.0 * hp * 66, {
+    ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, hp * (eb * 64 + 8.0), {
       if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
+      if (dt) return unet_head_bwd_bf16(ctx, CBF(m->Av("c9b")), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, WBF(m->Dv("c9b")),
+                                        m->G("out/kernel"), m->G("out/bias"), hp, hb.c, 1, s);
       return unet_head_bwd(ctx, m->A("c9b"), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, m->D("c9b"),
                            m->G("out/kernel"), m->G("out/bias"), hp, hb.c, 1, s);
     });
@@ -565,13 +591,20 @@ void build_programs(unet_model* m) {
     auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, bool mask_in) {
       const Buf ob = m->act.at(name);
       const double px = (double)ob.n * ob.h * ob.w;
-      ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+      ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
+        if (dt) {
+          if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
+          return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(in)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w,
+                                      cin, cout, s);
+        }
         const float* xin = in.empty() ? m->x : m->A(in);
         return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
                                       ob.n, ob.h, ob.w, cin, cout, algo, s);
       });
       if (want_dx) {
-        ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cout + cin + (mask_in ? cin : 0)) + 9.0 * cin * cout), {
+        ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? cin : 0)) + 4.0 * 9.0 * cin * cout, {
+          if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mask_in ? CBF(m->Av(in)) : nullptr, mask_in ? MASK_RELU : MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h,
+                                            ob.w, cout, cin, ACT_NONE, 0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
           return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), mask_in ? m->A(in) : nullptr, mask_in ? MASK_RELU : MASK_NONE, 0.0f, 0, m->D(in),
                                        m->wsf(m->off_wt), ob.n, ob.h, ob.w, cin, cout, algo, s);
         });
@@ -589,14 +622,17 @@ void build_programs(unet_model* m) {
           return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
         });
       } else {
-        ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
-          int32_t r = unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
+        ADD_OP(BW, "bn_bwd_stats:" + name, 0, 2 * eb * pixels * c, {
+          int32_t r = dt ? unet_bn_bwd_stats_bf16(ctx, CBF(m->Dv(dyname)), gb.ld, CBF(m->Av(xname)), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s)
+                         : unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
           if (r) return r;
           return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
         });
       }
       SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
-      ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
+      ADD_OP(BW, "bn_bwd_apply:" + name, 0, 3 * eb * pixels * c, {
+        if (dt) return unet_bn_bwd_apply_bf16(ctx, CBF(m->Dv(dyname)), gb.ld, CBF(m->Av(xname)), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount,
+                                              mask ? MASK_RELU : MASK_NONE, 0.0f, 0, WBF(m->Dv(dxname)), db.ld, pixels, c, s);
         return unet_bn_bwd_apply(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, mask ? MASK_RELU : MASK_NONE, 0.0f, 0,
                                  m->D(dxname), db.ld, pixels, c, s);
       });
@@ -615,11 +651,14 @@ void build_programs(unet_model* m) {
       bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, false);
       const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
       const std::string un = "u" + ks;
-      ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, 4.0 * (nel(ib) + nel(ug)), {
+      ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, eb * (nel(ib) + nel(ug)), {
+        if (dt) return k_convT_bf16_wgrad(ctx, CBF(m->Av(prev)), CBF(m->Dv(un)), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ib.n, ib.h,
+                                          ib.w, cprev, c, s);
         return unet_convT2x2_bwd_weights(ctx, m->A(prev), m->D(un), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
                                          ib.n, ib.h, ib.w, cprev, c, algo, s);
       });
-      ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, 4.0 * (2 * nel(ib) + nel(ug)), {
+      ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, eb * (2 * nel(ib) + nel(ug)), {
+        if (dt) return k_convT_bf16_dgrad(ctx, CBF(m->Dv(un)), ug.ld, m->P(un + "/kernel"), CBF(m->Av(prev)), WBF(m->Dv(prev)), ib.n, ib.h, ib.w, cprev, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
         return unet_convT2x2_bwd_data(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->A(prev), m->D(prev), ib.n, ib.h, ib.w, cprev, c, algo, s);
       });
       if (k == 7) bucket("u7/kernel", "out/bias");
@@ -633,7 +672,10 @@ void build_programs(unet_model* m) {
       const Buf xb = m->act.at("bn" + ks), gb = m->grad.at("bn" + ks);
       const std::string bnn = "bn" + ks, pn = "p" + ks;
       const size_t so = m->bn_bsum_off.at(bnn);
-      ADD_OP(BW, "pool_bwd_bnstats:" + pn, 0, 4.0 * 3.25 * nel(xb), {
+      ADD_OP(BW, "pool_bwd_bnstats:" + pn, 0, eb * 3.25 * nel(xb), {
+        if (dt) return unet_maxpool2x2_dropout_bwd_bnstats_bf16(ctx, CBF(m->Av(bnn)), xb.ld, CBF(m->Dv(pn)), WBF(m->Dv(bnn)), gb.ld, m->P(bnn + "/gamma"), m->P(bnn + "/beta"),
+                                                                m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c, m->drop_rate,
+                                                                m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
         return unet_maxpool2x2_dropout_bwd_bnstats(ctx, m->A(bnn), xb.ld, m->D(pn), m->D(bnn), gb.ld, m->P(bnn + "/gamma"), m->P(bnn + "/beta"),
                                                    m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c, m->drop_rate,
                                                    m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
@@ -645,6 +687,8 @@ void build_programs(unet_model* m) {
     }
     bucket("c1a/kernel", "bn4/beta");
   }
+#undef CBF
+#undef WBF
 }
 
 // =========================================================================================
@@ -1150,15 +1194,18 @@ void resolve_sync(unet_model* m) {
 extern "C" {
 
 int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n, int32_t h, int32_t w, int32_t world_size,
-                          int32_t conv_algo, unet_model** out) {
+                          int32_t conv_algo, int32_t dtype, unet_model** out) {
   if (!ctx || !out) return UNET_E_ARG;
   *out = nullptr;
+  if (dtype != UNET_DTYPE_F32 && dtype != UNET_DTYPE_BF16) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown dtype %d", dtype);
+  if (dtype == UNET_DTYPE_BF16 && (arch != UNET_ARCH_UNET || in_ch != 1))
+    UNET_FAIL(ctx, UNET_E_ARG, "model_create: bf16 storage is implemented for the U-Net graph with a 1-channel image (arch %d, in_ch %d asked)", arch, in_ch);
   if (arch != UNET_ARCH_UNET && arch != UNET_ARCH_UNETPP && arch != UNET_ARCH_CLASSIFIER) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown arch %d", arch);
   const int mult = arch == UNET_ARCH_UNET ? 16 : 8;      // 4 pool levels (T1:862-880) / 3 used pool levels (UPP: p4 is dead)
   if (in_ch < 1 || n < 1 || h < mult || w < mult || (h % mult) || (w % mult) || world_size < 1)
     UNET_FAIL(ctx, UNET_E_SHAPE, "model_create: need n>=1 and h,w multiples of %d; got n=%d h=%d w=%d", mult, n, h, w);
   unet_model* m = new unet_model();
-  m->ctx = ctx; m->arch = arch; m->in_ch = in_ch; m->N = n; m->H = h; m->W = w; m->world = world_size; m->algo = conv_algo;
+  m->ctx = ctx; m->arch = arch; m->in_ch = in_ch; m->N = n; m->H = h; m->W = w; m->world = world_size; m->algo = conv_algo; m->dt = dtype;
   if (arch == UNET_ARCH_UNET) { build_layers(m); plan_workspace(m); build_programs(m); }
   else if (arch == UNET_ARCH_UNETPP) { build_layers_pp(m); plan_workspace_pp(m); build_programs_pp(m); }
   else { build_layers_cls(m); plan_workspace_cls(m); build_programs_cls(m); }
@@ -1169,6 +1216,7 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
 void unet_model_destroy(unet_model* m) { delete m; }
 int64_t unet_model_param_count(const unet_model* m) { return m ? m->n_params : 0; }
 int64_t unet_model_state_count(const unet_model* m) { return m ? m->n_state : 0; }
+int32_t unet_model_dtype(const unet_model* m) { return m ? m->dt : UNET_E_ARG; }
 size_t unet_model_workspace_bytes(const unet_model* m, int32_t training) {
   if (!m) return 0;
   return (training ? m->ws_floats_train : m->ws_floats_infer) * sizeof(float);
@@ -1251,14 +1299,14 @@ int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, 
 
 const float* unet_model_loss_ptr(const unet_model* m) { return (m && m->ws) ? m->wsf(m->off_loss_out) : nullptr; }
 
-int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, const float** ptr, int32_t* ld, int32_t* n, int32_t* h,
+int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, const void** ptr, int32_t* ld, int32_t* n, int32_t* h,
                        int32_t* w, int32_t* c) {
   if (!m || !name || !m->ws) return UNET_E_ARG;
   auto& mp = grad ? m->grad : m->act;
   auto it = mp.find(name);
   if (it == mp.end()) return UNET_E_ARG;
   const Buf& b = it->second;
-  if (ptr) *ptr = m->wsf(b.off + b.chan_off);
+  if (ptr) *ptr = m->bufptr(b);
   if (ld) *ld = b.ld; if (n) *n = b.n; if (h) *h = b.h; if (w) *w = b.w; if (c) *c = b.c;
   return UNET_OK;
 }

@@ -30,9 +30,13 @@ class HipUNet:
 
     def __init__(self, h: int, w: int, in_ch: int = 1, device: int | None = None, conv_algo: int = _lib.ALGO_AUTO,
                  process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR,
-                 arch: str = "unet"):
+                 arch: str = "unet", dtype: str = "fp32"):
         torch = _torch()
         self.lib = _lib.load()
+        # dtype "bf16": activations / activation gradients stored as bf16 in the workspace (BASELINE.json configs[3], [4]); image,
+        # targets, probabilities, parameters, gradients and Adam state stay fp32
+        self.dtype = dtype
+        self._dtype_id = {"fp32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16}[dtype]
         if not torch.cuda.is_available():
             raise _lib.UNetHipError("HipUNet: no GPU visible to torch (torch.cuda.is_available() is False); "
                                     "the hot path has no CPU fallback")
@@ -81,7 +85,7 @@ class HipUNet:
     def _create_plan(self, n):
         m = _lib.vp()
         self.ctx.check(self.lib.unet_model_create(self.ctx.handle, self._arch_id, self.in_ch, n, self.h, self.w,
-                                                  self.world if self.sync_bn else 1, self.algo, C.byref(m)), "model_create")
+                                                  self.world if self.sync_bn else 1, self.algo, self._dtype_id, C.byref(m)), "model_create")
         return m
 
     def _plan(self, n: int):
@@ -260,9 +264,10 @@ class HipUNet:
                                                C.byref(ww), C.byref(cc)), f"tap({name})")
         off = ptr.value - self._ws.data_ptr()
         pix = nn.value * hh.value * ww.value
-        flat = self._ws[off:off + 4 * ((pix - 1) * ld.value + cc.value)].view(torch.float32)
+        esz, tdt = (2, torch.bfloat16) if self._dtype_id == _lib.DTYPE_BF16 else (4, torch.float32)
+        flat = self._ws[off:off + esz * ((pix - 1) * ld.value + cc.value)].view(tdt)
         v = torch.as_strided(flat, (pix, cc.value), (ld.value, 1))
-        return v.reshape(nn.value, hh.value, ww.value, cc.value).cpu().numpy()
+        return v.reshape(nn.value, hh.value, ww.value, cc.value).float().cpu().numpy()
 
     def op_profile(self, n, prog):
         """[(name, flops, bytes, ms, calls)] accumulated while ctx profiling was on."""

@@ -187,34 +187,56 @@ def convT2x2s2_bias(x, kernel, bias):
     return y.permute(0, 2, 3, 1)
 
 
-def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False):
+class _StoreBF16(torch.autograd.Function):
+    """Emulates the build's bf16-STORAGE mode (BASELINE.json configs[3]/[4] name bf16; the reference itself is fp32): a tensor that
+    the engine writes to HBM as bf16 is rounded to bf16 (nearest even) on the way forward, and so is its gradient on the way
+    back; all arithmetic in between stays in the oracle's precision.  Not part of the reference's algorithm: test
+    infrastructure for the mixed-precision path only."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def store_bf16(t):
+    return _StoreBF16.apply(t)
+
+
+def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, store=None):
     """Whole graph T1:853-916.  weights: dict name->array/tensor.  x: [N,H,W,Cin].
     keep_masks: None (dropout off / inference) or dict 'p1'..'p4' -> {0,1} arrays of the
-    pooled shapes.  Returns (p, acts, bn_batch_stats)."""
+    pooled shapes.  store: None, or store_bf16 to emulate bf16 storage of every activation the engine materialises
+    (conv / BN / pool / ConvT outputs and the concat buffers; the probabilities stay full precision).
+    Returns (p, acts, bn_batch_stats)."""
+    st = store if store is not None else (lambda t: t)
     W = {k: _t(v, dtype) for k, v in weights.items()}
     a = OrderedDict()
     stats = OrderedDict()
     h = _t(x, dtype)
     skips = {}
     for k in (1, 2, 3, 4):                                                   # T1:859-881
-        h = conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]); a[f"c{k}a"] = h
-        h = conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]); a[f"c{k}b"] = h
+        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"])); a[f"c{k}a"] = h
+        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"])); a[f"c{k}b"] = h
         h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
-        a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
+        h = st(h); a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
         skips[k] = h
-        h = maxpool2x2(h)
+        h = st(maxpool2x2(h))
         if training and keep_masks is not None:
-            h = dropout(h, _t(keep_masks[f"p{k}"], dtype))
+            h = st(dropout(h, _t(keep_masks[f"p{k}"], dtype)))
         a[f"p{k}"] = h
-    h = conv3x3_bias_relu(h, W["c5a/kernel"], W["c5a/bias"]); a["c5a"] = h    # T1:883-884
-    h = conv3x3_bias_relu(h, W["c5b/kernel"], W["c5b/bias"]); a["c5b"] = h
+    h = st(conv3x3_bias_relu(h, W["c5a/kernel"], W["c5a/bias"])); a["c5a"] = h    # T1:883-884
+    h = st(conv3x3_bias_relu(h, W["c5b/kernel"], W["c5b/bias"])); a["c5b"] = h
     for k, sk in zip((6, 7, 8, 9), (4, 3, 2, 1)):                            # T1:886-911
-        u = convT2x2s2_bias(h, W[f"u{k}/kernel"], W[f"u{k}/bias"]); a[f"u{k}"] = u
-        h = torch.cat([u, skips[sk]], dim=3)                                 # [up, skip]
+        u = st(convT2x2s2_bias(h, W[f"u{k}/kernel"], W[f"u{k}/bias"])); a[f"u{k}"] = u
+        h = st(torch.cat([u, skips[sk]], dim=3))                             # [up, skip]
         h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
-        a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
-        h = conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]); a[f"c{k}a"] = h
-        h = conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]); a[f"c{k}b"] = h
+        h = st(h); a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
+        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"])); a[f"c{k}a"] = h
+        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"])); a[f"c{k}b"] = h
     p = conv1x1_sigmoid(h, W["out/kernel"], W["out/bias"])                   # T1:913
     a["out"] = p
     return (p, a, stats) if want_acts else (p, None, stats)
@@ -268,13 +290,13 @@ def sm_scores(tp, spr, sgt, smooth=SM_SMOOTH):
 # ---------------------------------------------------------------------------------------
 # Training step (fwd -> loss -> autograd bwd -> Keras-form Adam) and evaluation
 # ---------------------------------------------------------------------------------------
-def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False):
+def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, store=None):
     """One training-mode fwd + bwd.  Returns dict(loss, dice, grads{name}, bn_stats, p[, acts, act_grads])."""
     names = trainable_names(np.asarray(x).shape[-1])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=True)
+    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=True, store=store)
     t = _t(y, dtype)
     loss = bce_dice_loss(t, p)
     dice = dice_coeff(t, p)

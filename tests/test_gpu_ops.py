@@ -240,7 +240,7 @@ def test_bad_arguments_are_reported_not_crashed(ops):
     rc = ops.lib.unet_bn_apply(ops.h, None, 32, None, None, 32, 10, 32, ops.s)
     assert rc == -1 and b"bn_apply" in ops.lib.unet_last_error(ops.h)
     m = __import__("ctypes").c_void_p()
-    assert ops.lib.unet_model_create(ops.h, 0, 1, 2, 30, 32, 1, 0, __import__("ctypes").byref(m)) == -3   # h not a multiple of 16
+    assert ops.lib.unet_model_create(ops.h, 0, 1, 2, 30, 32, 1, 0, 0, __import__("ctypes").byref(m)) == -3   # h not a multiple of 16
 
 
 @pytest.mark.parametrize("c", [32, 128, 512])
