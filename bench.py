@@ -19,6 +19,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, no TF32 on gfx950
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense v_mfma_f32_32x32x16_bf16
 HBM_PEAK_GBS = 8000.0
 
 
@@ -69,6 +71,8 @@ def main():
     ap.add_argument("--arch", default="unet", choices=["unet", "unetpp", "classifier"], help="unetpp = the U-Net++ graph (BASELINE "
                     "configs[3], at fp32; --size 256 --batch 32); classifier = the task-2 CNN (configs[4] at the reference's 1-channel fp32; "
                     "--size 224 --batch 256).  Neither is the headline metric")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="bf16 = activations / activation gradients stored as bf16 (U-Net graph only); "
+                    "NOT the headline metric, which BASELINE.json fixes at fp32")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,7 +112,7 @@ def main():
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
-                  arch=args.arch)
+                  arch=args.arch, dtype=args.dtype)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     for _ in range(args.warmup):
@@ -151,7 +155,7 @@ def main():
             if kind == "conv3x3_dgrad":
                 ci, co = co, ci
             ptr, ld, nn, hh, ww, cc = _tap_dims(eng, B, lname)
-            ratio = eng.lib.unet_conv3x3_exec_ratio(args.algo, hh, ww, ci, co)
+            ratio = 1.0 if args.dtype == "bf16" else eng.lib.unet_conv3x3_exec_ratio(args.algo, hh, ww, ci, co)
             fl_exec += o[1] * ratio; n_wino += int(ratio < 1.0)
         groups = {}
         for name, flops, by, tms, calls in ops:
@@ -162,7 +166,7 @@ def main():
         # this exact workload, calibration inside the file) -- only quoted for the configuration it was measured on
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0:
+        if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.dtype == "fp32":
             traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
         roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
@@ -176,6 +180,17 @@ def main():
                 "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                 "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3),
                 "op_ms_per_step": {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+        if args.dtype == "bf16":
+            # bf16 storage: the same launches priced against HBM (they move half the bytes and the bf16 MFMA rate is 16x the fp32 one)
+            gbs = sum(o[2] for o in dom) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            step_bytes = sum(o[2] for o in ops)
+            roof.update({"bound": "hbm", "kernel": "conv3x3 fwd + data-gradient launches: conv_bf16_kernel<0,...> (v_mfma_f32_32x32x16_bf16, direct)",
+                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "mfma_tflops": round(achieved, 1), "mfma_frac_of_bf16_peak": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "note": "achieved = algorithmic bytes (activations at 2 B/element, weights 4 B) of these launches / their time; mfma_* = their algorithmic FLOP rate",
+                         "step_algorithmic_bytes": round(step_bytes), "step_hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)})
+            for k in ("executed_tflops", "executed_frac"):
+                roof.pop(k, None)
 
     if rank == 0:
         total_imgs = B * world * args.steps
@@ -183,7 +198,7 @@ def main():
             "metric": ("CT images/sec (fwd+bwd) U-Net 512x512x1 bs16" if args.arch == "unet" else
                        f"CT images/sec (fwd+bwd) {'U-Net++' if args.arch == 'unetpp' else 'slice classifier'} {S}x{S}x1 bs{B}"), "value": round(total_imgs / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16 storage, f32 accumulate/params", "data": "synthetic",
             "config": {"workload": (f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
                                     if args.arch == "unet" else
                                     f"U-Net++ infection seg (task1_unet_plus_plus.py:858-950), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
@@ -192,7 +207,7 @@ def main():
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
                                    + {"unet": "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
-                       "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": {0: "auto: winograd F(2x2,3x3) / F(2,3) on mfma_f32_32x32x2, direct mfma otherwise", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd"}[args.algo],
+                       "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: winograd F(2x2,3x3) / F(2,3) on mfma_f32_32x32x2, direct mfma otherwise", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd"}[args.algo],
                        "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
