@@ -738,7 +738,7 @@ void build_layers_pp(unet_model* m) {
 }
 
 void plan_workspace_pp(unet_model* m) {
-  Carver cv;
+  Carver cv; cv.dt = m->dt;
   const int N = m->N;
   plan_scratch(m, cv);
   auto dims = [&](int lvl, int& hh, int& ww) { hh = m->H >> lvl; ww = m->W >> lvl; };
@@ -776,8 +776,8 @@ void plan_workspace_pp(unet_model* m) {
   }
   { Buf t; t.off = cv.take(tmp_up); m->act["tmp_up"] = t; }
   for (auto& l : m->layers) {
-    if (l.kind == 0) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, unet_conv3x3_bwd_weights_ws_bytes(N, ob.h, ob.w, l.cin, l.cout)); }
-    if (l.kind == 1) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, mfma_convT_wgrad_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout)); }
+    if (l.kind == 0) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, m->dt ? unet_conv3x3_bwd_weights_ws_bytes_bf16(N, ob.h, ob.w, l.cin, l.cout) : unet_conv3x3_bwd_weights_ws_bytes(N, ob.h, ob.w, l.cin, l.cout)); }
+    if (l.kind == 1) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, m->dt ? bf16_convT_wgrad_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout) : mfma_convT_wgrad_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout)); }
   }
   m->wgrad_ws_bytes = wgb;
   m->off_wgrad_ws = cv.take((wgb + 3) / 4);
@@ -788,6 +788,11 @@ void build_programs_pp(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int algo = m->algo;
   const double gcount = (double)m->world;
+  const int dt = m->dt;
+  const double eb = dt ? 2.0 : 4.0;           // bytes per stored activation element (roofline accounting)
+  const size_t esz = dt ? 2 : 4;
+#define CBF(p) static_cast<const unet_bf16*>(p)
+#define WBF(p) static_cast<unet_bf16*>(p)
   auto& BW = m->prog[UNET_PROG_BWD];
   const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
   std::map<std::string, int> lidx;
@@ -804,9 +809,14 @@ void build_programs_pp(unet_model* m) {
       const Buf ob = m->act.at(name);
       const uint64_t sd = seed_of(name);
       double px = (double)ob.n * ob.h * ob.w;
-      ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
-        const float* xin = in.empty() ? m->x : m->A(in);
+      ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
         const float r = (tr && m->drop_rate > 0.0f) ? rate : 0.0f;
+        if (dt) {
+          if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_ELU, r, m->drop_seed + sd, s);
+          return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_ELU, r,
+                                    m->drop_seed + sd, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
+        }
+        const float* xin = in.empty() ? m->x : m->A(in);
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
                                     ACT_ELU, r, m->drop_seed + sd, algo, s, m->wsf(m->off_wt), 0);
       });
@@ -817,7 +827,10 @@ void build_programs_pp(unet_model* m) {
       const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
       const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
       if (training) {
-        ADD_OP(F, "bn_stats:" + name, 0, 4.0 * pixels * c, { return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s); });
+        ADD_OP(F, "bn_stats:" + name, 0, eb * pixels * c, {
+          if (dt) return unet_bn_stats_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+          return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+        });
         SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
         ADD_OP(F, "bn_finalize:" + name, 0, 0, {
           return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
@@ -829,9 +842,13 @@ void build_programs_pp(unet_model* m) {
         });
       }
       if (pool.empty()) {
-        ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s); });
+        ADD_OP(F, "bn_apply:" + name, 0, 2 * eb * pixels * c, {
+          if (dt) return unet_bn_apply_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(out)), ob.ld, pixels, c, s);
+          return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s);
+        });
       } else {
-        ADD_OP(F, "bn_apply_pool:" + pool, 0, 4.0 * 2.25 * pixels * c, {
+        ADD_OP(F, "bn_apply_pool:" + pool, 0, eb * 2.25 * pixels * c, {
+          if (dt) return unet_bn_apply_maxpool_dropout_fwd_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(out)), ob.ld, WBF(m->Av(pool)), ib.n, ib.h, ib.w, c, 0.0f, 0, s);
           return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, m->Aw(pool), ib.n, ib.h, ib.w, c, 0.0f, 0, s);
         });
       }
@@ -850,13 +867,15 @@ void build_programs_pp(unet_model* m) {
         const std::string un = "u" + it.substr(1), src = nd->src, cat = "cat_" + it;
         const Buf sb = m->act.at(src), cb = m->act.at(cat);
         const int c = nd->c, csrc = pp_width(src);
-        ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, 4.0 * (nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+        ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, eb * (nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+          if (dt) return k_convT_bf16_fwd(ctx, CBF(m->Av(src)), m->P(un + "/kernel"), m->P(un + "/bias"), WBF(m->Av(un)), cb.ld, sb.n, sb.h, sb.w, csrc, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
           return unet_convT2x2_fwd(ctx, m->A(src), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), cb.ld, sb.n, sb.h, sb.w, csrc, c, algo, s);
         });
         int off = c;
         for (auto sk : nd->skips) {
           const std::string skn = sk; const Buf kb = m->act.at(skn); const int o = off, cw = kb.c;
-          ADD_OP(F, "copy_slice:" + skn + ">" + it, 0, 8.0 * nel(kb), {
+          ADD_OP(F, "copy_slice:" + skn + ">" + it, 0, 2 * eb * nel(kb), {
+            if (dt) return unet_copy_slice_bf16(ctx, CBF(m->Av(skn)), kb.ld, WBF(m->Av(cat)) + o, cb.ld, (int64_t)kb.n * kb.h * kb.w, cw, s);
             return unet_copy_slice(ctx, m->A(skn), kb.ld, m->Aw(cat) + o, cb.ld, (int64_t)kb.n * kb.h * kb.w, cw, s);
           });
           off += cw;
@@ -869,8 +888,9 @@ void build_programs_pp(unet_model* m) {
     }
     const Buf hb = m->act.at("x1_4");
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
-    ADD_OP(F, "head_fwd", 2.0 * 32 * hp, 4.0 * hp * 34, {
+    ADD_OP(F, "head_fwd", 2.0 * 32 * hp, hp * (eb * 32 + 8.0), {
       if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_fwd: p_out not set (unet_model_set_io)");
+      if (dt) return unet_head_fwd_bf16(ctx, CBF(m->Av("x1_4")), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt, m->yt ? m->wsd(m->off_loss_sums) : nullptr, hp, hb.c, s);
       return unet_head_fwd(ctx, m->A("x1_4"), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt, m->yt ? m->wsd(m->off_loss_sums) : nullptr, hp, hb.c, s);
     });
     SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
@@ -888,13 +908,15 @@ void build_programs_pp(unet_model* m) {
   ADD_OP(BW, "zero_bwd_sums", 0, 0, {
     int32_t r = unet_zero(ctx, m->wsf(m->off_bn_bsums), bs_bytes, s); if (r) return r;
     r = unet_zero(ctx, m->G("out/kernel"), (size_t)(m->tinfo.at("out/kernel").count + 1) * sizeof(float), s); if (r) return r;
-    for (auto& t : multi) { const Buf& b = m->grad.at(t); r = unet_zero(ctx, m->wsf(b.off), (size_t)b.n * b.h * b.w * b.c * sizeof(float), s); if (r) return r; }
+    for (auto& t : multi) { const Buf& b = m->grad.at(t); r = unet_zero(ctx, m->wsf(b.off), (((size_t)b.n * b.h * b.w * b.c * esz) + 15) & ~size_t(15), s); if (r) return r; }
     return UNET_OK;
   });
   const Buf hb = m->act.at("x1_4");
   const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
-  ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, 4.0 * hp * 66, {
+  ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, hp * (eb * 64 + 8.0), {
     if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
+    if (dt) return unet_head_bwd_bf16(ctx, CBF(m->Av("x1_4")), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, WBF(m->Dv("x1_4")),
+                                      m->G("out/kernel"), m->G("out/bias"), hp, hb.c, 0, s);
     return unet_head_bwd(ctx, m->A("x1_4"), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, m->D("x1_4"),
                          m->G("out/kernel"), m->G("out/bias"), hp, hb.c, 0, s);
   });
@@ -903,14 +925,17 @@ void build_programs_pp(unet_model* m) {
     const Buf gb = m->grad.at(dyname), xb = m->act.at(xname), db = m->grad.at(xname);
     const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
     const size_t so = m->bn_bsum_off.at(name), bo = m->bnp_off.at(name);
-    ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
-      int32_t r = unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
+    ADD_OP(BW, "bn_bwd_stats:" + name, 0, 2 * eb * pixels * c, {
+      int32_t r = dt ? unet_bn_bwd_stats_bf16(ctx, CBF(m->Dv(dyname)), gb.ld, CBF(m->Av(xname)), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s)
+                     : unet_bn_bwd_stats(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
       if (r) return r;
       return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
     });
     SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
-    ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
+    ADD_OP(BW, "bn_bwd_apply:" + name, 0, 3 * eb * pixels * c, {
       const bool drop = m->drop_rate > 0.0f && rate > 0.0f;
+      if (dt) return unet_bn_bwd_apply_bf16(ctx, CBF(m->Dv(dyname)), gb.ld, CBF(m->Av(xname)), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount,
+                                            (mask_mode == MASK_ELU_DROP && !drop) ? MASK_ELU : mask_mode, drop ? rate : 0.0f, m->drop_seed + sd, WBF(m->Dv(xname)), db.ld, pixels, c, s);
       return unet_bn_bwd_apply(ctx, m->D(dyname), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount,
                                (mask_mode == MASK_ELU_DROP && !drop) ? MASK_ELU : mask_mode, drop ? rate : 0.0f, m->drop_seed + sd, m->D(xname), db.ld,
                                pixels, c, s);
@@ -920,15 +945,21 @@ void build_programs_pp(unet_model* m) {
   auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, int mask_mode, float rate, uint64_t sd) {
     const Buf ob = m->act.at(name);
     const double px = (double)ob.n * ob.h * ob.w;
-    ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+    ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
+      if (dt) {
+        if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
+        return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(in)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, cout, s);
+      }
       const float* xin = in.empty() ? m->x : m->A(in);
       return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
                                     ob.n, ob.h, ob.w, cin, cout, algo, s);
     });
     if (want_dx) {
-      ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cout + cin + (mask_mode ? cin : 0)) + 9.0 * cin * cout), {
+      ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_mode ? cin : 0)) + 4.0 * 9.0 * cin * cout, {
         const bool drop = m->drop_rate > 0.0f && rate > 0.0f;
         const int mm = (mask_mode == MASK_ELU_DROP && !drop) ? MASK_ELU : mask_mode;
+        if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mm ? CBF(m->Av(in)) : nullptr, mm, WBF(m->Dv(in)), ob.n, ob.h, ob.w, cout, cin, ACT_NONE,
+                                          drop ? rate : 0.0f, m->drop_seed + sd, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
         return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), mm ? m->A(in) : nullptr, mm, drop ? rate : 0.0f, m->drop_seed + sd, m->D(in),
                                      m->wsf(m->off_wt), ob.n, ob.h, ob.w, cin, cout, algo, s);
       });
@@ -949,7 +980,8 @@ void build_programs_pp(unet_model* m) {
       if (k > 1) {
         const std::string pk = "p" + std::to_string(k - 1), ck = "c" + std::to_string(k - 1);
         const Buf xb = m->act.at(ck);
-        ADD_OP(BW, "pool_bwd:" + pk, 0, 4.0 * 3.25 * nel(xb), {
+        ADD_OP(BW, "pool_bwd:" + pk, 0, eb * 3.25 * nel(xb), {
+          if (dt) return unet_maxpool2x2_dropout_bwd_bf16(ctx, CBF(m->Av(ck)), xb.ld, CBF(m->Dv(pk)), WBF(m->Dv(ck)), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 1, s);
           return unet_maxpool2x2_dropout_bwd(ctx, m->A(ck), xb.ld, m->D(pk), m->D(ck), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 1, s);
         });
       }
@@ -967,12 +999,20 @@ void build_programs_pp(unet_model* m) {
       bn_bwd(it + "abn", it + "abn", it + "a", c, MASK_ELU_DROP, PP_BLOCK_DROP, seed_of(it + "a"));
       conv_bwd(it + "a", cat, cb.c, c, true, MASK_NONE, 0.0f, 0);
       const Buf ug = m->grad.at(un);
-      ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, 4.0 * (nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+      ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, eb * (nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+        if (dt) return k_convT_bf16_wgrad(ctx, CBF(m->Av(src)), CBF(m->Dv(un)), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, sb.n, sb.h, sb.w, csrc, c, s);
         return unet_convT2x2_bwd_weights(ctx, m->A(src), m->D(un), ug.ld, m->G(un + "/kernel"), m->G(un + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
                                          sb.n, sb.h, sb.w, csrc, c, algo, s);
       });
-      ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, 4.0 * (2 * nel(sb) + 4.0 * nel(sb) / sb.c * c), {
+      ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, eb * (2 * nel(sb) + 4.0 * nel(sb) / sb.c * c), {
         float* tmp = m->wsf(m->act.at("tmp_up").off);
+        if (dt) {
+          unet_bf16* tb = WBF(static_cast<void*>(tmp));
+          int32_t r = k_convT_bf16_dgrad(ctx, CBF(m->Dv(un)), ug.ld, m->P(un + "/kernel"), nullptr, tb, sb.n, sb.h, sb.w, csrc, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
+          if (r) return r;
+          const unet_bf16* srcs[1] = {tb}; const int32_t lds[1] = {csrc};
+          return unet_accum_slices_bf16(ctx, srcs, lds, 1, WBF(m->Dv(src)), m->grad.at(src).ld, (int64_t)sb.n * sb.h * sb.w, csrc, 1, s);
+        }
         int32_t r = unet_convT2x2_bwd_data(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), nullptr, tmp, sb.n, sb.h, sb.w, csrc, c, algo, s);
         if (r) return r;
         const float* srcs[1] = {tmp}; const int32_t lds[1] = {csrc};
@@ -981,7 +1021,11 @@ void build_programs_pp(unet_model* m) {
       int off = c;
       for (auto sk : nd->skips) {
         const std::string skn = sk; const Buf kb = m->act.at(skn); const int o = off, cw = kb.c;
-        ADD_OP(BW, "accum_slice:" + it + ">" + skn, 0, 12.0 * nel(kb), {
+        ADD_OP(BW, "accum_slice:" + it + ">" + skn, 0, 3 * eb * nel(kb), {
+          if (dt) {
+            const unet_bf16* srcs[1] = {CBF(m->Dv(cat)) + o}; const int32_t lds[1] = {cb.ld};
+            return unet_accum_slices_bf16(ctx, srcs, lds, 1, WBF(m->Dv(skn)), m->grad.at(skn).ld, (int64_t)kb.n * kb.h * kb.w, cw, 1, s);
+          }
           const float* srcs[1] = {m->D(cat) + o}; const int32_t lds[1] = {cb.ld};
           return unet_accum_slices(ctx, srcs, lds, 1, m->D(skn), m->grad.at(skn).ld, (int64_t)kb.n * kb.h * kb.w, cw, 1, s);
         });
@@ -990,6 +1034,8 @@ void build_programs_pp(unet_model* m) {
       if (it == "x1_4") bucket("u1_4/kernel", "out/bias");
     }
   }
+#undef CBF
+#undef WBF
 }
 
 // =========================================================================================
@@ -1198,8 +1244,8 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
   if (!ctx || !out) return UNET_E_ARG;
   *out = nullptr;
   if (dtype != UNET_DTYPE_F32 && dtype != UNET_DTYPE_BF16) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown dtype %d", dtype);
-  if (dtype == UNET_DTYPE_BF16 && (arch != UNET_ARCH_UNET || in_ch != 1))
-    UNET_FAIL(ctx, UNET_E_ARG, "model_create: bf16 storage is implemented for the U-Net graph with a 1-channel image (arch %d, in_ch %d asked)", arch, in_ch);
+  if (dtype == UNET_DTYPE_BF16 && (arch == UNET_ARCH_CLASSIFIER || in_ch != 1))
+    UNET_FAIL(ctx, UNET_E_ARG, "model_create: bf16 storage is implemented for the U-Net / U-Net++ graphs with a 1-channel image (arch %d, in_ch %d asked)", arch, in_ch);
   if (arch != UNET_ARCH_UNET && arch != UNET_ARCH_UNETPP && arch != UNET_ARCH_CLASSIFIER) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown arch %d", arch);
   const int mult = arch == UNET_ARCH_UNET ? 16 : 8;      // 4 pool levels (T1:862-880) / 3 used pool levels (UPP: p4 is dead)
   if (in_ch < 1 || n < 1 || h < mult || w < mult || (h % mult) || (w % mult) || world_size < 1)

@@ -117,7 +117,7 @@ def test_bf16_workspace_is_smaller_and_modes_are_rejected_loudly():
     assert wb < 0.75 * wa                                                  # activations + gradients halve, the split-K scratch does not (it dominates at 64 x 64)
     with pytest.raises(_lib.UNetHipError):
         from covidseg_amd.engine import HipUNet
-        HipUNet(64, 64, 1, arch="unetpp", dtype="bf16")
+        HipUNet(64, 64, 3, dtype="bf16")                                   # the first-layer kernel of the bf16 path is the cin = 1 one
 
 
 def test_bf16_full_size_512_step_runs_and_decreases_loss():
@@ -127,3 +127,34 @@ def test_bf16_full_size_512_step_runs_and_decreases_loss():
     eng.set_weights(O.init_weights(seed=0))
     l = np.array([eng.train_batch(x, y).cpu().numpy() for _ in range(5)])
     assert np.isfinite(l).all() and l[-1, 0] < l[0, 0]
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.3])
+def test_unetpp_bf16_against_the_fp32_engine(dropout):
+    """U-Net++ (BASELINE.json configs[3] names bf16): the nested-skip graph in bf16 storage against the fp32 engine, which
+    test_gpu_unetpp.py pins to the oracle.  Same weights, batch and dropout streams (the counter-based RNG indexes elements, not
+    bytes).  Forward tensors drift to the bf16 noise floor (<= 3e-2 by the last node), gradients carry the mask / argmax flips
+    explained at the top of this file."""
+    from covidseg_amd.engine import HipUNet
+    from covidseg_amd import weights as W
+    from covidseg_amd.data import synthetic_ct
+    x, y = synthetic_ct(4, 64, seed=5)
+    wts = W.init_weights(3, 1, "unetpp", (64, 64))
+    a = HipUNet(64, 64, 1, arch="unetpp", dropout_rate=dropout, seed=9); b = HipUNet(64, 64, 1, arch="unetpp", dropout_rate=dropout, seed=9, dtype="bf16")
+    a.set_weights(wts); b.set_weights(wts)
+    la, lb = a.forward_backward(x, y).cpu().numpy(), b.forward_backward(x, y).cpu().numpy()
+    assert np.abs(la - lb).max() < 2e-2
+    for name in ("c1a", "c1", "p1", "c3", "x3_2", "x2_3", "cat_x1_4", "x1_4"):
+        assert relerr(b.tap(4, name), a.tap(4, name)) < 3e-2, name
+    if dropout:
+        assert ((b.tap(4, "x1_4a") == 0) == (a.tap(4, "x1_4a") == 0)).mean() > 0.999            # same keep masks
+    ga, gb = a.get_grads(), b.get_grads()
+    for k in ga:
+        if k.startswith("u") and k.endswith("/bias"):
+            continue
+        assert cosine(gb[k], ga[k]) > 0.9, k
+    ta = np.array([a.train_batch(x, y).cpu().numpy() for _ in range(5)]); tb = np.array([b.train_batch(x, y).cpu().numpy() for _ in range(5)])
+    assert np.abs(ta - tb).max() < 3e-2 and tb[-1, 0] < tb[0, 0]
+    a.set_weights(wts); b.set_weights(wts)
+    pa, _ = a.predict_batch(x, y); pb, _ = b.predict_batch(x, y)
+    assert np.abs(pa.cpu().numpy() - pb.cpu().numpy()).max() < 3e-2
