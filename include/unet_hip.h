@@ -194,8 +194,8 @@ int32_t unet_accum_slices(unet_ctx*, const float* const* srcs, const int32_t* ld
  * Mixed precision of the same graph: activations and activation gradients are unet_bf16 in HBM (half the traffic), parameters,
  * parameter gradients, BN sums (fp64), the head's probabilities / targets and all arithmetic stay fp32; convolutions run on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same argument meaning as the fp32 functions; `ld*` in ELEMENTS.
- * Channel counts: conv3x3 cin % 16 == 0 (or the cin == 1 `first` entry points, whose image stays fp32), cout % 32 == 0;
- * convT cin, cout % 32 == 0; other shapes return UNET_E_SHAPE.  w_ws: device scratch of unet_conv3x3_w_ws_floats(cin, cout)
+ * Channel counts: conv3x3 forward cin % 16 == 0 (or the cin == 1 `first` entry points, whose image stays fp32) and cout % 16 == 0,
+ * so a layer that is also differentiated needs both multiples of 16; convT cin, cout % 32 == 0; other shapes return UNET_E_SHAPE.  w_ws: device scratch of unet_conv3x3_w_ws_floats(cin, cout)
  * floats (re-laid-out bf16 weights).  BASELINE.json configs[3], configs[4] name bf16. */
 int32_t unet_cast_f32_to_bf16(unet_ctx*, const float* src, unet_bf16* dst, int64_t count, void* stream);   /* count % 4 == 0 */
 int32_t unet_cast_bf16_to_f32(unet_ctx*, const unet_bf16* src, float* dst, int64_t count, void* stream);
@@ -240,6 +240,11 @@ int32_t unet_head_fwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const 
                            int64_t pixels, int32_t cin, void* stream);
 int32_t unet_head_bwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const float* p, const float* y_true, const double* loss_sums,
                            double count, unet_bf16* dx, float* dw, float* db, int64_t pixels, int32_t cin, int32_t relu_mask, void* stream);
+/* dense tail: the flattened activations x (and their gradient dx) are bf16, the 32 hidden units, dy and the weights stay fp32 */
+int32_t unet_dense_fwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, float* y, int32_t batch, int32_t k, int32_t n, int32_t act,
+                            float drop_rate, uint64_t drop_seed, void* ws, size_t ws_bytes, void* stream);
+int32_t unet_dense_bwd_bf16(unet_ctx*, const unet_bf16* x, const float* w, const float* dy, unet_bf16* dx, float* dw, int32_t batch, int32_t k, int32_t n,
+                            void* stream);
 int32_t unet_copy_slice_bf16(unet_ctx*, const unet_bf16* src, int32_t lds, unet_bf16* dst, int32_t ldd, int64_t pixels, int32_t c, void* stream);
 int32_t unet_accum_slices_bf16(unet_ctx*, const unet_bf16* const* srcs, const int32_t* lds, int32_t nsrc, unet_bf16* dst, int32_t ldd,
                                int64_t pixels, int32_t c, int32_t accumulate, void* stream);
@@ -288,7 +293,7 @@ typedef struct unet_sync_point {
  * CNN of task2_covid19_classifcation.py:747-776: y_true / p_out are [n] floats, loss_ptr = (binary cross-entropy, f1)) */
 enum { UNET_ARCH_UNET = 0, UNET_ARCH_UNETPP = 1, UNET_ARCH_CLASSIFIER = 2 };
 /* dtype: UNET_DTYPE_F32, or UNET_DTYPE_BF16 = activations / activation gradients stored as bf16 inside the workspace (the image x,
- * the targets, the probabilities p_out, parameters, gradients and optimizer state stay fp32; implemented for UNET_ARCH_UNET, in_ch 1) */
+ * the targets, the probabilities p_out, parameters, gradients and optimizer state stay fp32; in_ch must be 1) */
 int32_t unet_model_create(unet_ctx*, int32_t arch, int32_t in_ch, int32_t n, int32_t h, int32_t w,
                           int32_t world_size, int32_t conv_algo, int32_t dtype, unet_model** out);
 int32_t unet_model_dtype(const unet_model*);

@@ -94,7 +94,9 @@ _PROTOS = {
     "unet_accum_slices_bf16": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, i64, i32, i32, vp]),
     "unet_dense_ws_bytes": (sz, [i32, i32, i32]),
     "unet_dense_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, sz, vp]),
+    "unet_dense_fwd_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, sz, vp]),
     "unet_dense_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "unet_dense_bwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "unet_cls_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, f32, f32, vp, i32, i32, vp]),
     "unet_cls_loss_finalize": (i32, [vp, vp, f64, vp, vp]),
     "unet_cls_head_bwd": (i32, [vp, vp, vp, vp, vp, f32, f32, f64, f32, vp, vp, vp, vp, i32, i32, vp]),

@@ -33,7 +33,7 @@ __host__ __device__ inline int cperm(int m) { return ((m >> 2) & 1) * 16 + (m & 
 //   k = (chunk*KS + ks)*16 + half*8 + j,  mm = (g*NB + nb)*32 + cperm(m),  W(tap,k,mm) = w[tap_base(tap) + k*sk + mm*sm]
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wimg_kernel(const float* __restrict__ w, unet_bf16* __restrict__ img, int T, int KS, int NB, int nchunks,
-                                                   long long tap_stride, int tap_flip, long long sk, long long sm, long long total8) {
+                                                   long long tap_stride, int tap_flip, long long sk, long long sm, long long total8, int M) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long long)gridDim.x * 256) {
     long long r = e;
     const int m = (int)(r & 31); r >>= 5;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void wimg_kernel(const float* __restrict__ w, 
     const float* src = w + (long long)(tap_flip ? T - 1 - tap : tap) * tap_stride + k0 * sk + mm * sm;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[j * sk];
+    for (int j = 0; j < 8; ++j) v[j] = mm < M ? src[j * sk] : 0.0f;          // rows past M (a 32-row tile of a 16-channel layer) are zero
     *reinterpret_cast<uint4*>(img + e * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
   }
 }
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int mb = (g * NB + nb) * 32 + hi * 16;
+    if (mb >= M) continue;                                  // zero-padded rows of a tile that overhangs M (M % 16 == 0)
     int ab = 0, oc = mb;
     if (MODE == 1) { const int ct = M >> 2; ab = mb / ct; oc = mb - ab * ct; }
     float bv[16];
@@ -256,7 +257,7 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
   constexpr size_t smem = 2 * (size_t)(IN_BYTES + W_BYTES);
   if (!mask) mask_mode = MASK_NONE;
   if ((long long)(MODE == 2 ? 4 : 1) * h * wd * ldx * 2 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: one image must stay below 1 GiB (32-bit buffer offsets)");
-  const int tiles_x = (wd + 31) / 32, tiles_y = (h + 15) / 16, groups = M / (32 * NB);
+  const int tiles_x = (wd + 31) / 32, tiles_y = (h + 15) / 16, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
@@ -277,24 +278,24 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
 // weight image for (T taps, K contraction channels, M output channels); returns bytes written
 int32_t make_wimg(unet_ctx* ctx, const float* w, unet_bf16* img, int T, int KS, int NB, int K, int M, long long tap_stride, int tap_flip, long long sk,
                   long long sm, hipStream_t s) {
-  const int nchunks = K / (16 * KS), groups = M / (32 * NB);
+  const int nchunks = K / (16 * KS), groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total8 = (long long)groups * nchunks * KS * T * NB * 2 * 32;
   const unsigned grid = (unsigned)std::min<long long>((total8 + 255) / 256, 2048);
-  hipLaunchKernelGGL(wimg_kernel, dim3(grid), dim3(256), 0, s, w, img, T, KS, NB, nchunks, tap_stride, tap_flip, sk, sm, total8);
+  hipLaunchKernelGGL(wimg_kernel, dim3(grid), dim3(256), 0, s, w, img, T, KS, NB, nchunks, tap_stride, tap_flip, sk, sm, total8, M);
   UNET_CHECK_LAUNCH(ctx, "wimg");
   return UNET_OK;
 }
 
 }  // namespace
 
-bool bf16_conv3x3_supported(int cin, int cout) { return cin >= 16 && (cin % 16) == 0 && cout >= 32 && (cout % 32) == 0; }
+bool bf16_conv3x3_supported(int cin, int cout) { return cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0; }
 bool bf16_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0; }
 
 // forward (flip = 0, w = [3][3][cin][cout]) or data gradient (flip = 1: w = the layer's forward weights [3][3][cout][cin], x = dy with
 // `cin` channels, y = dx with `cout` channels).  wimg: scratch of >= 9*cin*cout bf16.
 int32_t k_conv3x3_bf16_fwd(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, const unet_bf16* mask, int mask_mode, unet_bf16* y,
                            int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s) {
-  if (!bf16_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 bf16: cin=%d (%%16) cout=%d (%%32) unsupported", cin, cout);
+  if (!bf16_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 bf16: cin=%d cout=%d unsupported (multiples of 16)", cin, cout);
   const int NB = (cout % 64) == 0 ? 2 : 1;
   int32_t r;
   if (!flip) r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 0, cout, 1, s);
@@ -544,13 +545,13 @@ int32_t run_wgrad_bf16(unet_ctx* ctx, const unet_bf16* A, int ldA, const unet_bf
 
 }  // namespace
 
-bool bf16_wgrad_supported(int ca, int cb) { return ca >= 32 && (ca % 32) == 0 && cb >= 32 && (cb % 32) == 0; }
+bool bf16_wgrad_supported(int ca, int cb) { return ca >= 16 && (ca % 8) == 0 && cb >= 16 && (cb % 8) == 0; }      // 32-wide tiles, overhang masked per 8-channel piece
 size_t bf16_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return bf16_wgrad_supported(cin, cout) ? plan_wgrad_bf16(0, n, h, wd, cin, cout).floats * sizeof(float) : 0; }
 size_t bf16_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return bf16_convT_supported(cin, cout) ? plan_wgrad_bf16(1, n, h, wd, cout, cin).floats * sizeof(float) : 0; }
 
 int32_t k_conv3x3_bf16_wgrad(unet_ctx* ctx, const unet_bf16* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
                              int cin, int cout, hipStream_t s) {
-  if (!bf16_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad bf16: cin=%d cout=%d unsupported (multiples of 32)", cin, cout);
+  if (!bf16_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad bf16: cin=%d cout=%d unsupported (multiples of 8, >= 16)", cin, cout);
   return run_wgrad_bf16<0>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
 }
 

@@ -14,7 +14,8 @@ constexpr int TPB = 256;
 constexpr int DK = 256;      // rows of W per workgroup (split-K chunk)
 
 // part[kc][b][o] = sum_{k in chunk kc} x[b][k] * W[k][o]
-__global__ __launch_bounds__(TPB) void dense_fwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(TPB) void dense_fwd_partial_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                                 float* __restrict__ part, int B, int K, int N) {
   extern __shared__ float smem[];
   float* s_w = smem;                 // [DK][N]
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(TPB) void dense_fwd_partial_kernel(const float* __r
   for (int i = tid; i < rows * DK / 4; i += TPB) {
     const int rr = (i * 4) / DK, kk = (i * 4) % DK;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b0 + rr < B && kk < kn) v = *reinterpret_cast<const float4*>(x + (long long)(b0 + rr) * K + k0 + kk);   // K % 4 == 0
+    if (b0 + rr < B && kk < kn) v = ld4(x + (long long)(b0 + rr) * K + k0 + kk);   // K % 4 == 0
     *reinterpret_cast<float4*>(s_x + i * 4) = v;
   }
   __syncthreads();
@@ -73,9 +74,9 @@ __global__ __launch_bounds__(TPB) void dense_fwd_reduce_kernel(const float* __re
 // One thread = one row k of W: dx[b][k] = sum_o dy[b][o] W[k][o]; dW[k][o] = sum_b x[b][k] dy[b][o].
 // dy rows are staged through LDS in tiles of DB rows and read as broadcasts; x and dx accesses are coalesced along k.
 constexpr int DB = 128;
-template <int N>
-__global__ __launch_bounds__(TPB) void dense_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
-                                                        float* __restrict__ dx, float* __restrict__ dw, int B, int K) {
+template <int N, typename T>
+__global__ __launch_bounds__(TPB) void dense_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                        T* __restrict__ dx, float* __restrict__ dw, int B, int K) {
   __shared__ __attribute__((aligned(16))) float s_dy[DB * N];
   const int k = blockIdx.x * TPB + threadIdx.x;
   const bool ok = k < K;
@@ -93,9 +94,9 @@ __global__ __launch_bounds__(TPB) void dense_bwd_kernel(const float* __restrict_
       *reinterpret_cast<float4*>(s_dy + i * 4) = *reinterpret_cast<const float4*>(dy + (long long)b0 * N + i * 4);
     __syncthreads();
     if (!ok) continue;
-    float xv = x[(long long)b0 * K + k];
+    float xv = ld1(x + (long long)b0 * K + k);
     for (int b = 0; b < nb; ++b) {
-      const float xn = (b + 1 < nb) ? x[(long long)(b0 + b + 1) * K + k] : 0.f;       // next row's load in flight during the FMAs
+      const float xn = (b + 1 < nb) ? ld1(x + (long long)(b0 + b + 1) * K + k) : 0.f;       // next row's load in flight during the FMAs
       float d = 0.f;
 #pragma unroll
       for (int o = 0; o < N; o += 4) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(TPB) void dense_bwd_kernel(const float* __restrict_
         d = fmaf(g.x, wr[o], d); d = fmaf(g.y, wr[o + 1], d); d = fmaf(g.z, wr[o + 2], d); d = fmaf(g.w, wr[o + 3], d);
         acc[o] = fmaf(xv, g.x, acc[o]); acc[o + 1] = fmaf(xv, g.y, acc[o + 1]); acc[o + 2] = fmaf(xv, g.z, acc[o + 2]); acc[o + 3] = fmaf(xv, g.w, acc[o + 3]);
       }
-      if (dx) dx[(long long)(b0 + b) * K + k] = d;
+      if (dx) st1(dx + (long long)(b0 + b) * K + k, d);
       xv = xn;
     }
   }
@@ -201,14 +202,14 @@ size_t unet_dense_ws_bytes(int32_t batch, int32_t k, int32_t n) {
   return (size_t)((k + DK - 1) / DK) * batch * n * sizeof(float);
 }
 
-int32_t unet_dense_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t k, int32_t n,
+extern "C++" template <typename T> static int32_t dense_fwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* bias, float* y, int32_t batch, int32_t k, int32_t n,
                        int32_t act, float drop_rate, uint64_t drop_seed, void* ws, size_t ws_bytes, void* stream) {
   if (!ctx || !x || !w || !y || batch < 1 || k < 4 || (k & 3) || !dense_n_ok(n) || act < 0 || act > 2 || drop_rate < 0 || drop_rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "dense_fwd: bad args (k %% 4 == 0, n a power of two in 4..32)");
   if (!ws || ws_bytes < unet_dense_ws_bytes(batch, k, n)) UNET_FAIL(ctx, UNET_E_ARG, "dense_fwd: workspace too small");
   const int chunks = (k + DK - 1) / DK, rows = TPB / n;
   const size_t lds = (size_t)(DK * n + rows * DK) * sizeof(float);
-  hipLaunchKernelGGL(dense_fwd_partial_kernel, dim3(chunks, (batch + rows - 1) / rows), dim3(TPB), lds, as_stream(stream), x, w, static_cast<float*>(ws), batch, k, n);
+  hipLaunchKernelGGL(dense_fwd_partial_kernel<T>, dim3(chunks, (batch + rows - 1) / rows), dim3(TPB), lds, as_stream(stream), x, w, static_cast<float*>(ws), batch, k, n);
   UNET_CHECK_LAUNCH(ctx, "dense_fwd_partial");
   const long long quads = (long long)batch * n / 4;
   hipLaunchKernelGGL(dense_fwd_reduce_kernel, dim3((unsigned)std::min<long long>((quads + TPB - 1) / TPB, 2048)), dim3(TPB), 0, as_stream(stream),
@@ -216,20 +217,35 @@ int32_t unet_dense_fwd(unet_ctx* ctx, const float* x, const float* w, const floa
   UNET_CHECK_LAUNCH(ctx, "dense_fwd_reduce");
   return UNET_OK;
 }
+int32_t unet_dense_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t k, int32_t n, int32_t act,
+                       float drop_rate, uint64_t drop_seed, void* ws, size_t ws_bytes, void* stream) {
+  return dense_fwd_impl(ctx, x, w, bias, y, batch, k, n, act, drop_rate, drop_seed, ws, ws_bytes, stream);
+}
+int32_t unet_dense_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, float* y, int32_t batch, int32_t k, int32_t n, int32_t act,
+                            float drop_rate, uint64_t drop_seed, void* ws, size_t ws_bytes, void* stream) {
+  return dense_fwd_impl(ctx, x, w, bias, y, batch, k, n, act, drop_rate, drop_seed, ws, ws_bytes, stream);
+}
 
-int32_t unet_dense_bwd(unet_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* dw, int32_t batch, int32_t k, int32_t n,
+extern "C++" template <typename T> static int32_t dense_bwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* dy, T* dx, float* dw, int32_t batch, int32_t k, int32_t n,
                        void* stream) {
   if (!ctx || !x || !w || !dy || !dw || batch < 1 || k < 1 || !dense_n_ok(n)) UNET_FAIL(ctx, UNET_E_ARG, "dense_bwd: bad args");
   const dim3 grid((k + TPB - 1) / TPB), block(TPB);
   hipStream_t s = as_stream(stream);
   switch (n) {
-    case 4: hipLaunchKernelGGL(dense_bwd_kernel<4>, grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
-    case 8: hipLaunchKernelGGL(dense_bwd_kernel<8>, grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
-    case 16: hipLaunchKernelGGL(dense_bwd_kernel<16>, grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
-    default: hipLaunchKernelGGL(dense_bwd_kernel<32>, grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
+    case 4: hipLaunchKernelGGL((dense_bwd_kernel<4, T>), grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
+    case 8: hipLaunchKernelGGL((dense_bwd_kernel<8, T>), grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
+    case 16: hipLaunchKernelGGL((dense_bwd_kernel<16, T>), grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
+    default: hipLaunchKernelGGL((dense_bwd_kernel<32, T>), grid, block, 0, s, x, w, dy, dx, dw, batch, k); break;
   }
   UNET_CHECK_LAUNCH(ctx, "dense_bwd");
   return UNET_OK;
+}
+int32_t unet_dense_bwd(unet_ctx* ctx, const float* x, const float* w, const float* dy, float* dx, float* dw, int32_t batch, int32_t k, int32_t n, void* stream) {
+  return dense_bwd_impl(ctx, x, w, dy, dx, dw, batch, k, n, stream);
+}
+int32_t unet_dense_bwd_bf16(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* dy, unet_bf16* dx, float* dw, int32_t batch, int32_t k, int32_t n,
+                            void* stream) {
+  return dense_bwd_impl(ctx, x, w, dy, dx, dw, batch, k, n, stream);
 }
 
 int32_t unet_cls_head_fwd(unet_ctx* ctx, const float* h, const float* w, const float* bias, float* p, const float* y_true, float class_w0,

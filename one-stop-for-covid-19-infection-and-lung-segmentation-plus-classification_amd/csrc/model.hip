@@ -1064,7 +1064,7 @@ void build_layers_cls(unet_model* m) {
 }
 
 void plan_workspace_cls(unet_model* m) {
-  Carver cv;
+  Carver cv; cv.dt = m->dt;
   const int N = m->N;
   plan_scratch(m, cv);
   int hh = m->H, ww = m->W;
@@ -1075,16 +1075,20 @@ void plan_workspace_cls(unet_model* m) {
     m->act["p" + ks] = mk(cv, N, hh / 2, ww / 2, c);
     hh /= 2; ww /= 2;
   }
-  m->act["h1"] = mk(cv, N, 1, 1, CLS_HIDDEN);
+  { Buf b; b.off = cv.take((size_t)N * CLS_HIDDEN); b.ld = b.c = CLS_HIDDEN; b.n = N; b.h = b.w = 1; m->act["h1"] = b; }      // the hidden units stay fp32 in every mode
   const int K = hh * ww * CLS_C[2];
   m->dense_ws_bytes = unet_dense_ws_bytes(N, K, CLS_HIDDEN);
   m->off_dense_ws = cv.take((m->dense_ws_bytes + 3) / 4);
   for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)16 * l.cin * l.cout);
   m->off_wt = cv.take(wt0);
   m->ws_floats_infer = cv.cur;
-  for (auto& kv : m->act) { const Buf& b = kv.second; m->grad[kv.first] = mk(cv, b.n, b.h, b.w, b.c); }
+  for (auto& kv : m->act) {
+    const Buf& b = kv.second;
+    if (kv.first == "h1") { Buf g = b; g.off = cv.take((size_t)N * CLS_HIDDEN); m->grad[kv.first] = g; }
+    else m->grad[kv.first] = mk(cv, b.n, b.h, b.w, b.c);
+  }
   for (auto& l : m->layers)
-    if (l.kind == 0) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, unet_conv3x3_bwd_weights_ws_bytes(N, ob.h, ob.w, l.cin, l.cout)); }
+    if (l.kind == 0) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, m->dt ? unet_conv3x3_bwd_weights_ws_bytes_bf16(N, ob.h, ob.w, l.cin, l.cout) : unet_conv3x3_bwd_weights_ws_bytes(N, ob.h, ob.w, l.cin, l.cout)); }
   m->wgrad_ws_bytes = wgb;
   m->off_wgrad_ws = cv.take((wgb + 3) / 4);
   m->ws_floats_train = cv.cur;
@@ -1094,6 +1098,10 @@ void build_programs_cls(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int algo = m->algo;
   const double gcount = (double)m->world;
+  const int dt = m->dt;
+  const double eb = dt ? 2.0 : 4.0;
+#define CBF(p) static_cast<const unet_bf16*>(p)
+#define WBF(p) static_cast<unet_bf16*>(p)
   const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
   const Buf fb = m->act.at("p3");
   const int N = m->N, K = fb.h * fb.w * fb.c;
@@ -1107,7 +1115,12 @@ void build_programs_cls(unet_model* m) {
     auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
       const Buf ob = m->act.at(name);
       double px = (double)ob.n * ob.h * ob.w;
-      ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+      ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
+        if (dt) {
+          if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_RELU, 0.0f, 0, s);
+          return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0,
+                                    WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
+        }
         const float* xin = in.empty() ? m->x : m->A(in);
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
                                     ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0);
@@ -1118,7 +1131,10 @@ void build_programs_cls(unet_model* m) {
       const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
       const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
       if (training) {
-        ADD_OP(F, "bn_stats:" + name, 0, 4.0 * pixels * c, { return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s); });
+        ADD_OP(F, "bn_stats:" + name, 0, eb * pixels * c, {
+          if (dt) return unet_bn_stats_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+          return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+        });
         SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
         ADD_OP(F, "bn_finalize:" + name, 0, 0, {
           return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
@@ -1130,9 +1146,13 @@ void build_programs_cls(unet_model* m) {
         });
       }
       if (pool.empty()) {
-        ADD_OP(F, "bn_apply:" + name, 0, 8.0 * pixels * c, { return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(name), ob.ld, pixels, c, s); });
+        ADD_OP(F, "bn_apply:" + name, 0, 2 * eb * pixels * c, {
+          if (dt) return unet_bn_apply_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(name)), ob.ld, pixels, c, s);
+          return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(name), ob.ld, pixels, c, s);
+        });
       } else {
-        ADD_OP(F, "bn_apply_pool:" + pool, 0, 4.0 * 2.25 * pixels * c, {
+        ADD_OP(F, "bn_apply_pool:" + pool, 0, eb * 2.25 * pixels * c, {
+          if (dt) return unet_bn_apply_maxpool_dropout_fwd_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(name)), ob.ld, WBF(m->Av(pool)), ib.n, ib.h, ib.w, c, 0.0f, 0, s);
           return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(name), ob.ld, m->Aw(pool), ib.n, ib.h, ib.w, c, 0.0f, 0, s);
         });
       }
@@ -1146,8 +1166,10 @@ void build_programs_cls(unet_model* m) {
       bn("bn" + ks + "b", "c" + ks + "b", c, "p" + ks);
       cprev = c;
     }
-    ADD_OP(F, "dense_fwd:fc1", 2.0 * N * K * CLS_HIDDEN, 4.0 * ((double)N * K + (double)K * CLS_HIDDEN), {
+    ADD_OP(F, "dense_fwd:fc1", 2.0 * N * K * CLS_HIDDEN, eb * (double)N * K + 4.0 * (double)K * CLS_HIDDEN, {
       const float r = (tr && m->drop_rate > 0.0f) ? CLS_DROP : 0.0f;
+      if (dt) return unet_dense_fwd_bf16(ctx, CBF(m->Av("p3")), m->P("fc1/kernel"), m->P("fc1/bias"), m->Aw("h1"), N, K, CLS_HIDDEN, ACT_RELU, r, m->drop_seed + fc_seed,
+                                         m->wsf(m->off_dense_ws), m->dense_ws_bytes, s);
       return unet_dense_fwd(ctx, m->A("p3"), m->P("fc1/kernel"), m->P("fc1/bias"), m->Aw("h1"), N, K, CLS_HIDDEN, ACT_RELU, r, m->drop_seed + fc_seed,
                             m->wsf(m->off_dense_ws), m->dense_ws_bytes, s);
     });
@@ -1174,7 +1196,8 @@ void build_programs_cls(unet_model* m) {
     return unet_cls_head_bwd(ctx, m->A("h1"), m->P("fc2/kernel"), m->pout, m->yt, m->cw0, m->cw1, (double)N * gcount,
                              m->drop_rate > 0.0f ? CLS_DROP : 0.0f, m->D("h1"), m->G("fc2/kernel"), m->G("fc2/bias"), m->G("fc1/bias"), N, CLS_HIDDEN, s);
   });
-  ADD_OP(BW, "dense_bwd:fc1", 4.0 * N * K * CLS_HIDDEN, 4.0 * (2.0 * N * K + 2.0 * K * CLS_HIDDEN), {
+  ADD_OP(BW, "dense_bwd:fc1", 4.0 * N * K * CLS_HIDDEN, eb * 2.0 * N * K + 4.0 * 2.0 * K * CLS_HIDDEN, {
+    if (dt) return unet_dense_bwd_bf16(ctx, CBF(m->Av("p3")), m->P("fc1/kernel"), m->D("h1"), WBF(m->Dv("p3")), m->G("fc1/kernel"), N, K, CLS_HIDDEN, s);
     return unet_dense_bwd(ctx, m->A("p3"), m->P("fc1/kernel"), m->D("h1"), m->D("p3"), m->G("fc1/kernel"), N, K, CLS_HIDDEN, s);
   });
   { const TInfo a = m->tinfo.at("fc1/kernel"), b = m->tinfo.at("fc2/bias"); SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off}); }
@@ -1182,13 +1205,16 @@ void build_programs_cls(unet_model* m) {
     const Buf gb = m->grad.at(name), xb = m->act.at(xname), db = m->grad.at(xname);
     const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
     const size_t so = m->bn_bsum_off.at(name), bo = m->bnp_off.at(name);
-    ADD_OP(BW, "bn_bwd_stats:" + name, 0, 8.0 * pixels * c, {
-      int32_t r = unet_bn_bwd_stats(ctx, m->D(name), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
+    ADD_OP(BW, "bn_bwd_stats:" + name, 0, 2 * eb * pixels * c, {
+      int32_t r = dt ? unet_bn_bwd_stats_bf16(ctx, CBF(m->Dv(name)), gb.ld, CBF(m->Av(xname)), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s)
+                     : unet_bn_bwd_stats(ctx, m->D(name), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, pixels, c, s);
       if (r) return r;
       return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(name + "/gamma"), m->G(name + "/beta"), c, s);
     });
     SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
-    ADD_OP(BW, "bn_bwd_apply:" + name, 0, 12.0 * pixels * c, {
+    ADD_OP(BW, "bn_bwd_apply:" + name, 0, 3 * eb * pixels * c, {
+      if (dt) return unet_bn_bwd_apply_bf16(ctx, CBF(m->Dv(name)), gb.ld, CBF(m->Av(xname)), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, MASK_RELU, 0.0f, 0,
+                                            WBF(m->Dv(xname)), db.ld, pixels, c, s);
       return unet_bn_bwd_apply(ctx, m->D(name), gb.ld, m->A(xname), xb.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, MASK_RELU, 0.0f, 0,
                                m->D(xname), db.ld, pixels, c, s);
     });
@@ -1196,13 +1222,19 @@ void build_programs_cls(unet_model* m) {
   auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx) {
     const Buf ob = m->act.at(name);
     const double px = (double)ob.n * ob.h * ob.w;
-    ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cin + cout) + 9.0 * cin * cout), {
+    ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
+      if (dt) {
+        if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
+        return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(in)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, cout, s);
+      }
       const float* xin = in.empty() ? m->x : m->A(in);
       return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
                                     ob.n, ob.h, ob.w, cin, cout, algo, s);
     });
     if (want_dx) {
-      ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, 4.0 * (px * (cout + cin) + 9.0 * cin * cout), {
+      ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin) + 4.0 * 9.0 * cin * cout, {
+        if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, nullptr, MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0,
+                                          WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
         return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), nullptr, MASK_NONE, 0.0f, 0, m->D(in), m->wsf(m->off_wt), ob.n, ob.h, ob.w, cin,
                                      cout, algo, s);
       });
@@ -1212,7 +1244,8 @@ void build_programs_cls(unet_model* m) {
     const int c = CLS_C[k - 1], cin = k == 1 ? m->in_ch : CLS_C[k - 2];
     const std::string ks = std::to_string(k), ca = "c" + ks + "a", cb = "c" + ks + "b", ba = "bn" + ks + "a", bb = "bn" + ks + "b", pk = "p" + ks;
     const Buf xb = m->act.at(bb);
-    ADD_OP(BW, "pool_bwd:" + pk, 0, 4.0 * 2.25 * nel(xb), {
+    ADD_OP(BW, "pool_bwd:" + pk, 0, eb * 2.25 * nel(xb), {
+      if (dt) return unet_maxpool2x2_dropout_bwd_bf16(ctx, CBF(m->Av(bb)), xb.ld, CBF(m->Dv(pk)), WBF(m->Dv(bb)), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 0, s);
       return unet_maxpool2x2_dropout_bwd(ctx, m->A(bb), xb.ld, m->D(pk), m->D(bb), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 0, s);
     });
     bn_bwd(bb, cb, c);
@@ -1221,6 +1254,8 @@ void build_programs_cls(unet_model* m) {
     conv_bwd(ca, k == 1 ? "" : "p" + std::to_string(k - 1), cin, c, k > 1);
   }
   { const TInfo a = m->tinfo.at("c1a/kernel"), b = m->tinfo.at("bn3b/beta"); SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off}); }
+#undef CBF
+#undef WBF
 }
 
 void resolve_sync(unet_model* m) {
@@ -1244,8 +1279,8 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
   if (!ctx || !out) return UNET_E_ARG;
   *out = nullptr;
   if (dtype != UNET_DTYPE_F32 && dtype != UNET_DTYPE_BF16) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown dtype %d", dtype);
-  if (dtype == UNET_DTYPE_BF16 && (arch == UNET_ARCH_CLASSIFIER || in_ch != 1))
-    UNET_FAIL(ctx, UNET_E_ARG, "model_create: bf16 storage is implemented for the U-Net / U-Net++ graphs with a 1-channel image (arch %d, in_ch %d asked)", arch, in_ch);
+  if (dtype == UNET_DTYPE_BF16 && in_ch != 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "model_create: bf16 storage needs a 1-channel image (the first-layer kernel keeps the image fp32); in_ch %d asked", in_ch);
   if (arch != UNET_ARCH_UNET && arch != UNET_ARCH_UNETPP && arch != UNET_ARCH_CLASSIFIER) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown arch %d", arch);
   const int mult = arch == UNET_ARCH_UNET ? 16 : 8;      // 4 pool levels (T1:862-880) / 3 used pool levels (UPP: p4 is dead)
   if (in_ch < 1 || n < 1 || h < mult || w < mult || (h % mult) || (w % mult) || world_size < 1)

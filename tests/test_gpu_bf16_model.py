@@ -158,3 +158,26 @@ def test_unetpp_bf16_against_the_fp32_engine(dropout):
     a.set_weights(wts); b.set_weights(wts)
     pa, _ = a.predict_batch(x, y); pb, _ = b.predict_batch(x, y)
     assert np.abs(pa.cpu().numpy() - pb.cpu().numpy()).max() < 3e-2
+
+
+def test_classifier_bf16_against_the_fp32_engine():
+    """task-2 classifier (BASELINE.json configs[4] names bf16) in bf16 storage against the fp32 engine (pinned to the oracle in
+    test_gpu_classifier.py): 16-channel layers run the 32-row MFMA tiles half empty, the 32 hidden units stay fp32."""
+    from covidseg_amd.engine import HipUNet
+    from covidseg_amd import weights as W
+    from covidseg_amd.data import synthetic_classification
+    x, y = synthetic_classification(12, 64, seed=2); y = y.astype(np.float32)
+    wts = W.init_weights(4, 1, "classifier", (64, 64))
+    a = HipUNet(64, 64, 1, arch="classifier", dropout_rate=0.0); b = HipUNet(64, 64, 1, arch="classifier", dropout_rate=0.0, dtype="bf16")
+    a.set_weights(wts); b.set_weights(wts)
+    la, lb = a.forward_backward(x, y).cpu().numpy(), b.forward_backward(x, y).cpu().numpy()
+    assert abs(la[0] - lb[0]) < 2e-2
+    for name in ("c1a", "bn1b", "p1", "c2b", "p3", "h1"):
+        assert relerr(b.tap(12, name), a.tap(12, name)) < 3e-2, name
+    ga, gb = a.get_grads(), b.get_grads()
+    for k in ga:
+        if k.startswith("c") and k.endswith("/bias"):
+            continue                       # a conv bias in front of a BatchNorm: true gradient 0
+        assert cosine(gb[k], ga[k]) > 0.9, k
+    ta = np.array([a.train_batch(x, y).cpu().numpy() for _ in range(6)]); tb = np.array([b.train_batch(x, y).cpu().numpy() for _ in range(6)])
+    assert np.abs(ta[:, 0] - tb[:, 0]).max() < 5e-2 and tb[-1, 0] < tb[0, 0]

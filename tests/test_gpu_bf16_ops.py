@@ -37,7 +37,7 @@ def f32(t):
 
 
 CONV_SHAPES = [(1, 16, 32, 16, 32), (2, 9, 37, 32, 64), (1, 33, 34, 64, 32), (2, 16, 16, 128, 128), (1, 5, 70, 96, 64), (1, 40, 8, 48, 96),
-               (1, 64, 64, 32, 32)]
+               (1, 64, 64, 32, 32), (2, 28, 28, 16, 16), (1, 20, 36, 32, 16), (1, 8, 8, 16, 48)]          # 16-channel layers: the task-2 classifier
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
@@ -57,8 +57,8 @@ def test_conv3x3_fwd_bf16(ops, shape):
         assert (f32(y) != wq).mean() < 0.02
 
 
-# the data gradient swaps the roles of cin / cout, the weight gradient tiles both by 32: multiples of 32 on both sides
-@pytest.mark.parametrize("shape", [s for s in CONV_SHAPES if s[3] % 32 == 0] + [(1, 40, 8, 96, 96), (2, 12, 20, 256, 64)])
+# the data gradient swaps the roles of cin / cout: multiples of 16 on both sides
+@pytest.mark.parametrize("shape", [s for s in CONV_SHAPES if s[3] != 48] + [(1, 40, 8, 96, 96), (2, 12, 20, 256, 64)])
 def test_conv3x3_bwd_bf16(ops, shape):
     from gpu_util import relerr
     n, h, w, ci, co = shape
@@ -129,6 +129,22 @@ def test_convT_bf16(ops, shape):
     dw = ops.z(2, 2, co, ci); db = ops.z(co); dw.fill_(3.0); db.fill_(-2.0)
     ops.ck(ops.lib.unet_convT2x2_bwd_weights_bf16(ops.h, xd.data_ptr(), dcd.data_ptr(), ld, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, ops.s), "convT bwd w bf16")
     assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < F32_OUT and relerr(db.cpu().numpy(), bt.grad.numpy()) < F32_OUT
+
+
+def test_dense_bf16(ops):
+    """Flatten -> Dense(32): bf16 activations in, fp32 hidden units out; backward returns a bf16 dx and fp32 dW"""
+    from gpu_util import relerr
+    b, k, n = 6, 3136, 32
+    rng = np.random.default_rng(5)
+    xd, x = q(rng.standard_normal((b, k))); w = (rng.standard_normal((k, n)) * 0.05).astype(np.float32); bias = rng.standard_normal(n).astype(np.float32)
+    dy = rng.standard_normal((b, n)).astype(np.float32)
+    nb = ops.lib.unet_dense_ws_bytes(b, k, n); ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    y = ops.z(b, n)
+    ops.ck(ops.lib.unet_dense_fwd_bf16(ops.h, xd.data_ptr(), ops.d(w).data_ptr(), ops.d(bias).data_ptr(), y.data_ptr(), b, k, n, 1, 0.0, 0, ws.data_ptr(), nb, ops.s), "dense fwd bf16")
+    assert relerr(y.cpu().numpy(), np.maximum(x.astype(np.float64) @ w + bias, 0)) < F32_OUT
+    dx = ops.z(b, k, dtype=torch.bfloat16); dw = ops.z(k, n)
+    ops.ck(ops.lib.unet_dense_bwd_bf16(ops.h, xd.data_ptr(), ops.d(w).data_ptr(), ops.d(dy).data_ptr(), dx.data_ptr(), dw.data_ptr(), b, k, n, ops.s), "dense bwd bf16")
+    assert relerr(f32(dx), dy.astype(np.float64) @ w.T) < BF16_OUT and relerr(dw.cpu().numpy(), x.astype(np.float64).T @ dy) < F32_OUT
 
 
 def test_unsupported_channel_counts_fail_loudly(ops):
