@@ -349,7 +349,7 @@ template <int MODE, int WA, int WB, int WR>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const unet_bf16* __restrict__ A, int ldA, const unet_bf16* __restrict__ B, int ldB,
                                                             float* __restrict__ part, int N, int H, int W, int CA, int CB, int tiles_b,
                                                             int strips, int rows_per_chunk, int chunks_per_strip, int nsplit, int npairs,
-                                                            long long pstride) {
+                                                            long long pstride, int units, int upb) {
   static_assert(WA * WB * WR == 4, "4 waves");
   constexpr int TAPS = MODE == 0 ? 9 : 4;
   constexpr int R = MODE == 0 ? 4 : 2;                            // B rows per step
@@ -358,8 +358,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const unet_bf16* __r
   constexpr int ASUB = AROWS * APX * 64, BSUB = R * 32 * 64;      // bytes of one 32-channel plane
   constexpr int APIECES = WA * AROWS * APX * 4, BPIECES = WB * R * 32 * 4;
   constexpr int AL = (APIECES + 255) / 256, BL = (BPIECES + 255) / 256;
-  __shared__ __attribute__((aligned(16))) char s_a[WA * ASUB];
-  __shared__ __attribute__((aligned(16))) char s_b[WB * BSUB];
+  constexpr int RED = WR > 1 ? 2 * TAPS * 16 * 64 * 4 : 0;        // two accumulator images for the row-phase reduction
+  constexpr int STAGE = WA * ASUB + WB * BSUB;
+  __shared__ __attribute__((aligned(16))) char smem[STAGE > RED ? STAGE : RED];
+  __shared__ float s_bs[4][64];
+  char* const s_a = smem; char* const s_b = smem + WA * ASUB;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave % WR, wb = (wave / WR) % WB, wa = wave / (WR * WB);
@@ -369,9 +372,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const unet_bf16* __r
   if (split >= nsplit) return;
   const int ta = pair / tiles_b, tb = pair % tiles_b;
   const int a0 = ta * 32 * WA, b0 = tb * 32 * WB;
-  const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
-  const int cs = t2 % strips, n = t2 / strips;
-  const int x0 = cs * 32;
+  // a split = one row chunk of `upb` consecutive (image, 32-column strip) units
+  const int chunk = split % chunks_per_strip; const int ublk = split / chunks_per_strip;
   const int ya = chunk * rows_per_chunk;
   const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
   const int HA = MODE == 0 ? H : 2 * H, WA_ = MODE == 0 ? W : 2 * W;
@@ -383,106 +385,137 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const unet_bf16* __r
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   float bsum = 0.0f;
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(A + (long long)n * HA * WA_ * ldA), 0, (int)((long long)HA * WA_ * ldA * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(B + (long long)n * H * W * ldB), 0, (int)((long long)H * W * ldB * 2), 0x00020000);
-  // staging plan: byte offset of the piece inside its image for step row 0 (may be negative for the halo row), and its row
-  int aoff[AL], arow[AL], boff[BL], brow[BL];
-#pragma unroll
-  for (int k = 0; k < AL; ++k) {
-    const int idx = tid + k * 256;
-    const int q = idx & 3; int r = idx >> 2;
-    const int px = r % APX; r /= APX;
-    const int row = r % AROWS, sub = r / AROWS;
-    const int gx = MODE == 0 ? x0 + px - 1 : 2 * x0 + px;
-    const int ch = a0 + sub * 32 + q * 8;
-    const bool ok = idx < APIECES && gx >= 0 && gx < WA_ && ch < CA;
-    arow[k] = ok ? (MODE == 0 ? row - 1 : row) : (1 << 20);          // invalid -> row test fails below
-    aoff[k] = ((MODE == 0 ? row - 1 : row) * WA_ + gx) * ldA * 2 + ch * 2;
-  }
-#pragma unroll
-  for (int k = 0; k < BL; ++k) {
-    const int idx = tid + k * 256;
-    const int q = idx & 3; int r = idx >> 2;
-    const int px = r & 31; r >>= 5;
-    const int row = r % R, sub = r / R;
-    const int gx = x0 + px, ch = b0 + sub * 32 + q * 8;
-    const bool ok = idx < BPIECES && gx < W && ch < CB;
-    brow[k] = ok ? row : (1 << 20);
-    boff[k] = (row * W + gx) * ldB * 2 + ch * 2;
-  }
-  unet_u32x4 areg[AL], breg[BL];
-  auto issue_loads = [&](int ys) __attribute__((always_inline)) {        // ys = first B row of the step
-    const int ysa = MODE == 0 ? ys : 2 * ys;
-#pragma unroll
-    for (int k = 0; k < AL; ++k) {
-      const int gy = ysa + arow[k];
-      const bool ok = gy >= 0 && gy < HA;
-      areg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? aoff[k] + ysa * WA_ * ldA * 2 : UNET_OOB, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < BL; ++k) {
-      const int gy = ys + brow[k];
-      breg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, gy < yb ? boff[k] + ys * W * ldB * 2 : UNET_OOB, 0, 0);   // rows past the chunk contribute 0
-    }
-  };
-  auto store_lds = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < AL; ++k) { const int idx = tid + k * 256; if (idx < APIECES) *reinterpret_cast<unet_u32x4*>(s_a + idx * 16) = areg[k]; }    // piece order == LDS order
-#pragma unroll
-    for (int k = 0; k < BL; ++k) { const int idx = tid + k * 256; if (idx < BPIECES) *reinterpret_cast<unet_u32x4*>(s_b + idx * 16) = breg[k]; }
-  };
-
   // transpose-read addressing: 16-lane group g4 reads [4 pixels][16 channels]; lane i -> pixel i>>2, channel quad i&3
   const int i16 = lane & 15, g4 = lane >> 4;
   const int tr_px = (g4 >> 1) * 8 + (i16 >> 2), tr_ch = ((g4 & 1) * 16 + (i16 & 3) * 4) * 2;
   const char* const pa = s_a + wa * ASUB + tr_ch;
   const char* const pb = s_b + wb * BSUB + tr_ch;
 
-  issue_loads(ya);
-  store_lds();
-  __syncthreads();
-  for (int ys = ya; ys < yb; ys += R) {
-    const bool more = ys + R < yb;
-    if (more) issue_loads(ys + R);
+  const int u1 = (ublk + 1) * upb < units ? (ublk + 1) * upb : units;
+  for (int unit = ublk * upb; unit < u1; ++unit) {
+    const int cs = unit % strips, n = unit / strips;
+    const int x0 = cs * 32;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(A + (long long)n * HA * WA_ * ldA), 0, (int)((long long)HA * WA_ * ldA * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(B + (long long)n * H * W * ldB), 0, (int)((long long)H * W * ldB * 2), 0x00020000);
+    // staging plan, one register per piece: byte offset of the piece for staged row 0 (a multiple of 16) | staged row (bits 0-2) |
+    // invalid column / channel (bit 3)
+    int aoff[AL], boff[BL];
 #pragma unroll
-    for (int r = wr; r < R; r += WR) {
+    for (int k = 0; k < AL; ++k) {
+      const int idx = tid + k * 256;
+      const int q = idx & 3; int r = idx >> 2;
+      const int px = r % APX; r /= APX;
+      const int row = r % AROWS, sub = r / AROWS;
+      const int gx = MODE == 0 ? x0 + px - 1 : 2 * x0 + px;
+      const int ch = a0 + sub * 32 + q * 8;
+      const bool ok = idx < APIECES && gx >= 0 && gx < WA_ && ch < CA;
+      aoff[k] = ok ? (((row * WA_ + gx) * ldA * 2 + ch * 2) | row) : 8;
+    }
 #pragma unroll
-      for (int kst = 0; kst < 2; ++kst) {
-        const char* bp = pb + (r * 32 + kst * 16 + tr_px) * 64;
-        const bf16x8 bf = lds_tr_frag(bp, bp + 4 * 64);
-        if (MODE == 0 && wa == 0) {
+    for (int k = 0; k < BL; ++k) {
+      const int idx = tid + k * 256;
+      const int q = idx & 3; int r = idx >> 2;
+      const int px = r & 31; r >>= 5;
+      const int row = r % R, sub = r / R;
+      const int gx = x0 + px, ch = b0 + sub * 32 + q * 8;
+      const bool ok = idx < BPIECES && gx < W && ch < CB;
+      boff[k] = ok ? (((row * W + gx) * ldB * 2 + ch * 2) | row) : 8;
+    }
+    unet_u32x4 areg[AL], breg[BL];
+    auto issue_loads = [&](int ys) __attribute__((always_inline)) {        // ys = first B row of the step
+      const int ysa = MODE == 0 ? ys - 1 : 2 * ys;                       // image row of staged A row 0 (conv3x3: the halo row above)
+      const int abase = ysa * WA_ * ldA * 2, bbase = ys * W * ldB * 2;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bsum += (float)bf[j];
-        }
-        if (MODE == 0) {
+      for (int k = 0; k < AL; ++k) {
+        const int v = aoff[k], gy = ysa + (v & 7);
+        const bool ok = !(v & 8) && gy >= 0 && gy < HA;
+        areg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? (v & ~15) + abase : UNET_OOB, 0, 0);
+      }
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
+      for (int k = 0; k < BL; ++k) {
+        const int v = boff[k], gy = ys + (v & 7);
+        breg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (!(v & 8) && gy < yb) ? (v & ~15) + bbase : UNET_OOB, 0, 0);   // rows past the chunk contribute 0
+      }
+    };
+    auto store_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const char* ap = pa + ((r + ky) * APX + kst * 16 + tr_px + kx) * 64;
-              const bf16x8 af = lds_tr_frag(ap, ap + 4 * 64);
-              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ky * 3 + kx], 0, 0, 0);
+      for (int k = 0; k < AL; ++k) { const int idx = tid + k * 256; if (idx < APIECES) *reinterpret_cast<unet_u32x4*>(s_a + idx * 16) = areg[k]; }    // piece order == LDS order
+#pragma unroll
+      for (int k = 0; k < BL; ++k) { const int idx = tid + k * 256; if (idx < BPIECES) *reinterpret_cast<unet_u32x4*>(s_b + idx * 16) = breg[k]; }
+    };
+
+    issue_loads(ya);
+    store_lds();
+    __syncthreads();
+    for (int ys = ya; ys < yb; ys += R) {
+      const bool more = ys + R < yb;
+      if (more) issue_loads(ys + R);
+#pragma unroll
+      for (int r = wr; r < R; r += WR) {
+#pragma unroll
+        for (int kst = 0; kst < 2; ++kst) {
+          const char* bp = pb + (r * 32 + kst * 16 + tr_px) * 64;
+          const bf16x8 bf = lds_tr_frag(bp, bp + 4 * 64);
+          if (MODE == 0 && wa == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += (float)bf[j];
+          }
+          if (MODE == 0) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) {
+                const char* ap = pa + ((r + ky) * APX + kst * 16 + tr_px + kx) * 64;
+                const bf16x8 af = lds_tr_frag(ap, ap + 4 * 64);
+                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ky * 3 + kx], 0, 0, 0);
+              }
+          } else {
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {          // A = dU: pixel (2y + a, 2x + b); consecutive k = consecutive x -> stride 2 pixels
+              const char* ap = pa + ((2 * r + (ab >> 1)) * APX + 2 * (kst * 16 + tr_px) + (ab & 1)) * 64;
+              const bf16x8 af = lds_tr_frag(ap, ap + 8 * 64);
+              if (wb == 0) {                          // bias gradient of the ConvT = sum of dU over all four parity planes
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+              }
+              acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ab], 0, 0, 0);
             }
-        } else {
-#pragma unroll
-          for (int ab = 0; ab < 4; ++ab) {          // A = dU: pixel (2y + a, 2x + b); consecutive k = consecutive x -> stride 2 pixels
-            const char* ap = pa + ((2 * r + (ab >> 1)) * APX + 2 * (kst * 16 + tr_px) + (ab & 1)) * 64;
-            const bf16x8 af = lds_tr_frag(ap, ap + 8 * 64);
-            if (wb == 0) {                          // bias gradient of the ConvT = sum of dU over all four parity planes
-#pragma unroll
-              for (int j = 0; j < 8; ++j) bsum += (float)af[j];
-            }
-            acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ab], 0, 0, 0);
           }
         }
       }
+      __syncthreads();
+      if (more) { store_lds(); __syncthreads(); }
     }
-    __syncthreads();
-    if (more) { store_lds(); __syncthreads(); }
   }
 
-  // ---- write the partial slab of (split, row phase)
-  float* P = part + ((long long)split * WR + wr) * pstride;
+  // ---- row phases of one channel tile are summed inside the workgroup (fixed order, through LDS): one slab per split
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (WR > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    const int grp = wave / WR;                                      // (wa, wb) tile of this wave; WR/2 * (4/WR) = 2 images at most
+    s_bs[wave][lane] = bsum;
+#pragma unroll
+    for (int stride = WR / 2; stride >= 1; stride >>= 1) {
+      float* img = red + (size_t)(grp * stride + (wr % stride)) * (TAPS * 16 * 64);
+      if (wr >= stride && wr < 2 * stride) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) img[(t * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (wr < stride) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += img[(t * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (wr == 0) { bsum = s_bs[wave][lane]; for (int k = 1; k < WR; ++k) bsum += s_bs[wave + k][lane]; }
+  }
+  if (wr != 0) return;
+  float* P = part + (long long)split * pstride;
   const int ar = a0 + wa * 32, bc = b0 + wb * 32 + l31;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
@@ -491,12 +524,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const unet_bf16* __r
       const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = acc[t][r];
     }
-  bsum += __shfl_xor(bsum, 32, 64);
   if (MODE == 0) { if (wa == 0 && ta == 0 && lane < 32 && bc < CB) P[(long long)TAPS * CA * CB + bc] = bsum; }
   else if (wb == 0 && tb == 0 && lane < 32 && ar + l31 < CA) P[(long long)TAPS * CA * CB + ar + l31] = bsum;
 }
 
-struct WgPlan { int WA, WB, WR, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs; size_t floats; };
+struct WgPlan { int WA, WB, WR, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs, units, upb; size_t floats; };
 
 WgPlan plan_wgrad_bf16(int mode, int n, int h, int w, int ca, int cb) {
   WgPlan p;
@@ -506,15 +538,19 @@ WgPlan plan_wgrad_bf16(int mode, int n, int h, int w, int ca, int cb) {
   p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
   const long long pairs = (long long)p.tiles_a * p.tiles_b, per = (long long)taps * ca * cb;
   const long long units = (long long)n * p.strips;
-  static const long long target = [] { const char* e = getenv("UNET_WGRAD_BF16_BLOCKS"); return e ? atoll(e) : 1024LL; }();   // 256 CUs x 2 resident workgroups x 2 rounds
-  long long want = (target + pairs - 1) / pairs;
-  const long long cap = std::max<long long>(1, (64LL << 20) / (per * p.WR));
+  static const long long target = [] { const char* e = getenv("UNET_WGRAD_BF16_BLOCKS"); return e ? atoll(e) : 512LL; }();   // 256 CUs x 2 resident workgroups (1024 measured 15 % slower: twice the partial-slab traffic)
+  long long want = std::max<long long>(1, target / pairs);          // pixel splits wanted
+  const long long cap = std::max<long long>(1, (64LL << 20) / per);
   want = std::min(want, cap);
-  long long cps = std::max<long long>(1, (want + units - 1) / units);
+  // fewer splits than units: a workgroup walks `upb` consecutive units (halves / quarters the partial-slab traffic of the deep layers,
+  // whose slabs are megabytes); more: the rows of a unit are cut into chunks
+  p.units = (int)units; p.upb = (int)std::max<long long>(1, units / want);
+  const long long ublocks = (units + p.upb - 1) / p.upb;
+  long long cps = std::max<long long>(1, want / ublocks);
   cps = std::min<long long>(cps, std::max<long long>(1, h / 8));
   int rpc = (int)((h + cps - 1) / cps); rpc = (rpc + R - 1) / R * R;                // whole steps
   p.rows_per_chunk = rpc; p.chunks_per_strip = (h + rpc - 1) / rpc;
-  p.nsplit = (int)(units * p.chunks_per_strip); p.nslabs = p.nsplit * p.WR;
+  p.nsplit = (int)(ublocks * p.chunks_per_strip); p.nslabs = p.nsplit;
   p.floats = (size_t)p.nslabs * (per + cbias) + wgrad_reduce_scratch_floats(taps, ca, cb, cbias, p.nslabs);
   return p;
 }
@@ -532,7 +568,7 @@ int32_t run_wgrad_bf16(unet_ctx* ctx, const unet_bf16* A, int ldA, const unet_bf
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
 #define UNET_WG(WA_, WB_, WR_) hipLaunchKernelGGL((wgrad_bf16_kernel<MODE, WA_, WB_, WR_>), grid, dim3(256), 0, s, A, ldA, B, ldB, part, n, h, w, ca, cb, \
-                                                  p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S)
+                                                  p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb)
   if (p.WA == 2 && p.WB == 2) UNET_WG(2, 2, 1);
   else if (p.WA == 2) UNET_WG(2, 1, 2);
   else if (p.WB == 2) UNET_WG(1, 2, 2);
