@@ -59,14 +59,15 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_
 //         positions of a channel slice (pixel stride ldy) of the concat buffer
 // MODE 2: convT2x2s2 data gradient = per-pixel GEMM over the virtual channels k = (ab, o): chunk -> (ab, o0) selects the
 //         parity plane (2i+a, 2j+b) of dU (pixel stride ldx) that is staged
-template <int MODE, int NB, bool GEN>
+template <int MODE, int NB, bool GEN, int RW>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg,
                                                            const float* __restrict__ bias, const unet_bf16* __restrict__ mask,
                                                            unet_bf16* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y,
                                                            int groups, int total_blocks) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
-  constexpr int PR = MODE == 0 ? 18 : 16, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
+  constexpr int TH = 4 * RW;                             // tile rows: RW per wave
+  constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
   constexpr int PLANE = NPIX * 32;                       // bytes of one 16-channel plane of the pixel patch
   constexpr int IN_BYTES = KS * PLANE, W_BYTES = KS * T * NB * 2 * 32 * 16;
   constexpr int PPIECES = KS * NPIX * 2, WPIECES = W_BYTES / 16;
@@ -84,13 +85,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
   const int g = wi % groups; int t = wi / groups;
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y; const int n = t / tiles_y;
-  const int x0 = tx * 32, y0 = ty * 16;
+  const int x0 = tx * 32, y0 = ty * TH;
   const int HI = MODE == 2 ? 2 * H : H, WI = MODE == 2 ? 2 * W : W;
   const int nchunks = K / (16 * KS);
 
-  f32x16 acc[4][NB];
+  f32x16 acc[RW][NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -147,16 +148,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
     if (MODE == 0) {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        bf16x8 px[6];
+        bf16x8 px[RW + 2];
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) px[rr] = lds_frag(in + (((wave * 4 + rr) * PWD + l31 + kx) * 32 + hi * 16));
+        for (int rr = 0; rr < RW + 2; ++rr) px[rr] = lds_frag(in + (((wave * RW + rr) * PWD + l31 + kx) * 32 + hi * 16));
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           bf16x8 wf[NB];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) wf[nb] = lds_frag(wt + ((((ky * 3 + kx) * NB + nb) * 2 + hi) * 512 + l31 * 16));
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < RW; ++r)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], px[r + ky], acc[r][nb], 0, 0, 0);
         }
@@ -164,13 +165,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
     } else {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 px[4], wf[NB];
+        bf16x8 px[RW], wf[NB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) px[r] = lds_frag(in + ks * PLANE + (((wave * 4 + r) * 32 + l31) * 32 + hi * 16));
+        for (int r = 0; r < RW; ++r) px[r] = lds_frag(in + ks * PLANE + (((wave * RW + r) * 32 + l31) * 32 + hi * 16));
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) wf[nb] = lds_frag(wt + (((ks * NB + nb) * 2 + hi) * 512 + l31 * 16));
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], px[r], acc[r][nb], 0, 0, 0);
       }
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
       bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int py = y0 + wave * 4 + r;
+    for (int r = 0; r < RW; ++r) {
+      const int py = y0 + wave * RW + r;
       if (py >= H || px_ >= W) continue;
       long long o;
       if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
@@ -248,16 +249,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
   }
 }
 
-template <int MODE, int NB>
+template <int MODE, int NB, int RW = 4>
 int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_bf16* wimg, const float* bias, const unet_bf16* mask, int mask_mode,
                          unet_bf16* y, int ldy, int n, int h, int wd, int K, int M, int act, float rate, unsigned long long seed, hipStream_t s) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
-  constexpr int NPIX = MODE == 0 ? 18 * 34 : 16 * 32;
+  constexpr int TH = 4 * RW;
+  constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
   constexpr int IN_BYTES = KS * NPIX * 32, W_BYTES = KS * T * NB * 2 * 32 * 16;
   constexpr size_t smem = 2 * (size_t)(IN_BYTES + W_BYTES);
   if (!mask) mask_mode = MASK_NONE;
   if ((long long)(MODE == 2 ? 4 : 1) * h * wd * ldx * 2 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: one image must stay below 1 GiB (32-bit buffer offsets)");
-  const int tiles_x = (wd + 31) / 32, tiles_y = (h + 15) / 16, groups = (M + 32 * NB - 1) / (32 * NB);
+  const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
@@ -269,7 +271,7 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
     return UNET_OK;
   };
   int32_t r;
-  if (gen) r = go(conv_bf16_kernel<MODE, NB, (MODE == 0)>); else r = go(conv_bf16_kernel<MODE, NB, false>);
+  if (gen) r = go(conv_bf16_kernel<MODE, NB, (MODE == 0), RW>); else r = go(conv_bf16_kernel<MODE, NB, false, RW>);
   if (r) return r;
   UNET_CHECK_LAUNCH(ctx, "conv_bf16");
   return UNET_OK;
@@ -296,13 +298,22 @@ bool bf16_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) ==
 int32_t k_conv3x3_bf16_fwd(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, const unet_bf16* mask, int mask_mode, unet_bf16* y,
                            int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s) {
   if (!bf16_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 bf16: cin=%d cout=%d unsupported (multiples of 16)", cin, cout);
-  const int NB = (cout % 64) == 0 ? 2 : 1;
+  // tile choice.  Wide layers (>= 128 output channels) are MFMA / LDS bound: 64-channel x 16-row tiles (most operand reuse, 2 workgroups
+  // per CU).  32-channel layers are short-K and HBM bound: 32-channel x 8-row tiles need 40 KB of LDS and 89 registers, so 4 workgroups
+  // per CU hide the load latency of each other's prologues (c1b / c9b: -15 %; 64-channel layers measured neutral to worse).  UNET_BF16_TILE = "<nb><rw>" overrides (measurements).
+  static const int force = [] { const char* e = getenv("UNET_BF16_TILE"); return e ? atoi(e) : 0; }();
+  static const int narrow_max = [] { const char* e = getenv("UNET_BF16_NARROW_MAX"); return e ? atoi(e) : 32; }();
+  int NB = (cout % 64) == 0 ? 2 : 1, RW = 4;
+  if (cout <= narrow_max) { NB = 1; RW = 2; }
+  if (force) { NB = force / 10; RW = force % 10; if ((cout % 64) != 0) NB = 1; }
   int32_t r;
   if (!flip) r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 0, cout, 1, s);
   else r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 1, 1, cin, s);      // W(tap,k,m) = w_f[8-tap][m][k], row length = cout_f = cin here
   if (r) return r;
-  if (NB == 2) return launch_conv_bf16<0, 2>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
-  return launch_conv_bf16<0, 1>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
+  if (NB == 2 && RW == 4) return launch_conv_bf16<0, 2, 4>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
+  if (NB == 2) return launch_conv_bf16<0, 2, 2>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
+  if (RW == 4) return launch_conv_bf16<0, 1, 4>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
+  return launch_conv_bf16<0, 1, 2>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
 }
 
 // u[n,2i+a,2j+b,o] = bias[o] + sum_c x[n,i,j,c] * K[a,b,o,c]   (Keras ConvT kernel [2][2][cout][cin])
