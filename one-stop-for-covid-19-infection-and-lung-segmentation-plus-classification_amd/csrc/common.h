@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <set>
 #include <string>
 
 #include "../../include/unet_hip.h"
@@ -18,6 +19,7 @@ struct unet_ctx {
   int num_cu = 256;
   int profiling = 0;
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS x UNET_BN_SLOT_DOUBLES, all zero between launches
+  std::set<const void*> big_lds_kernels;   // kernels already opted in to > 64 KiB of dynamic LDS on this context's device
   std::string err;
 };
 

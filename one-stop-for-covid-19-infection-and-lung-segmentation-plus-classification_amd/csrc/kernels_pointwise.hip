@@ -15,6 +15,7 @@ constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident blocks; grid-stride be
 // Workgroups of the reduction kernels.  Every workgroup ends in 2C fp64 atomics (spread over UNET_BN_SLOTS copies of the target), so
 // more workgroups buy memory-level parallelism and pay atomic traffic; measured optima per kernel (UNET_BN_BLOCKS overrides all three):
 static const int HEAD_BLOCKS = [] { const char* e = getenv("UNET_HEAD_BLOCKS"); return e ? atoi(e) : 8192; }();   // head_fwd: one load in flight per thread, wants many workgroups (0.20 -> 0.18 ms); head_bwd ends in 33 atomics on two cache lines: 1024 (0.25 -> 0.215)
+static const int HEAD_LPP_KERNEL = [] { const char* e = getenv("UNET_HEAD_LPP"); return e ? atoi(e) : 1; }();        // A/B switch for measurements
 static const int BN_BLOCKS_ENV = [] { const char* e = getenv("UNET_BN_BLOCKS"); return e ? atoi(e) : 0; }();
 static const int BN_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 512;          // one tensor in        (0.86 -> 0.68 ms per step with the slots)
 static const int BN_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 1024;     // two tensors in       (1.06 -> 0.79)
@@ -386,6 +387,58 @@ __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
+// Same op, LPP lanes per pixel known at compile time: a lane group walks LPP pixels per iteration (LPP independent loads in flight)
+// and lane `sub` then does the sigmoid / BCE / Dice arithmetic of pixel `sub` -- in the kernel above only one lane in LPP does that
+// (transcendental-bound: the same 0.18 ms in fp32 and in bf16); here every lane does, and the probability stores are contiguous.
+template <typename T, int LPP>
+__global__ __launch_bounds__(TPB) void head_fwd_lpp_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ pout,
+                                                           const float* __restrict__ yt, double* sums, long long pixels) {
+  constexpr int cin = LPP * 4;
+  const int sub = threadIdx.x & (LPP - 1);
+  const float4 wv = ld4(w + sub * 4);
+  const float b = bias[0];
+  float sb = 0, stp = 0, st = 0, sp = 0;
+  const long long g0 = ((long long)blockIdx.x * TPB + threadIdx.x) / LPP * LPP;          // first pixel of this lane group
+  const long long gstride = (long long)gridDim.x * TPB;                                  // pixels per sweep of the whole grid
+  const long long iters = (pixels + gstride - 1) / gstride;                               // uniform trip count: shuffles stay converged
+  for (long long it = 0; it < iters; ++it) {
+    const long long base = g0 + it * gstride;
+    float4 v[LPP];
+#pragma unroll
+    for (int k = 0; k < LPP; ++k) v[k] = base + k < pixels ? ld4(x + (base + k) * cin + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < LPP; ++k) {
+      float d = v[k].x * wv.x + v[k].y * wv.y + v[k].z * wv.z + v[k].w * wv.w;
+#pragma unroll
+      for (int o = LPP >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      mine = (k == sub) ? d : mine;
+    }
+    const long long p = base + sub;
+    if (p < pixels) {
+      const float pr = 1.0f / (1.0f + expf(-(mine + b)));
+      pout[p] = pr;
+      if (yt) {
+        float t = yt[p], pc; bool inr;
+        sb += bce_elem(pr, t, &pc, &inr); stp += t * pr; st += t; sp += pr;
+      }
+    }
+  }
+  if (yt) {
+    __shared__ float red[4][TPB / 64];
+    sb = wave_sum(sb); stp = wave_sum(stp); st = wave_sum(st); sp = wave_sum(sp);
+    int wv_ = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv_] = sb; red[1][wv_] = stp; red[2][wv_] = st; red[3][wv_] = sp; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      float s = 0;
+      for (int k = 0; k < TPB / 64; ++k) s += red[threadIdx.x][k];
+      atomicAdd(sums + threadIdx.x, (double)s);
+    }
+  }
+}
+
 __global__ void loss_finalize_kernel(const double* sums, double count, float* out) {
   double dice = (2.0 * sums[1] + 1.0) / (sums[2] + sums[3] + 1.0);
   out[0] = (float)(0.5 * (sums[0] / count) + 0.5 * (1.0 - dice));
@@ -661,6 +714,12 @@ extern "C++" template <typename T> static int32_t maxpool_bwd_bnstats_impl(unet_
 extern "C++" template <typename T> static int32_t head_fwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* bias, float* p, const float* y_true,
                       double* loss_sums, int64_t pixels, int32_t cin, void* stream) {
   if (!x || !w || !bias || !p || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || (y_true && !loss_sums)) UNET_FAIL(ctx, UNET_E_ARG, "head_fwd: bad args (cin/4 must be a power of two <= 64)");
+  if (cin == 32 && HEAD_LPP_KERNEL) {            // the U-Net / U-Net++ heads
+    static const int lpp_blocks = [] { const char* e = getenv("UNET_HEAD_LPP_BLOCKS"); return e ? atoi(e) : 2048; }();     // 8 loads in flight per lane: 2048 workgroups measured best (0.119 ms fp32 / 0.085 bf16; 8192: 0.141)
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels, TPB * 2), lpp_blocks));
+    hipLaunchKernelGGL((head_fwd_lpp_kernel<T, 8>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels);
+    UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
+  }
   hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels * (cin / 4) / 4, TPB), HEAD_BLOCKS))), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels, cin);
   UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
 }
