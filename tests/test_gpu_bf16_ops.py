@@ -160,3 +160,29 @@ def test_cast_round_trip(ops):
     ops.ck(ops.lib.unet_cast_bf16_to_f32(ops.h, b.data_ptr(), back.data_ptr(), 4096, ops.s), "cast back")
     want = torch.from_numpy(x).bfloat16()
     assert torch.equal(b.cpu(), want) and np.array_equal(back.cpu().numpy(), want.float().numpy())          # bit-exact: same RNE rounding as torch
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 512, 32, 32), (1, 512, 512, 64, 32), (4, 64, 64, 256, 128)])
+def test_full_size_bf16_conv_agrees_with_the_fp32_kernels(ops, shape):
+    """BASELINE-size tensors (the oracle would take minutes): the bf16 kernels against the fp32 GPU kernels -- which the oracle pins --
+    on the same bf16-exact inputs.  Exercises the large grids (XCD block map, > 65535 workgroups, multi-unit wgrad splits)."""
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    g = torch.Generator(device="cuda").manual_seed(1)
+    xb = torch.randn((n, h, w, ci), device="cuda", generator=g).bfloat16(); dyb = torch.randn((n, h, w, co), device="cuda", generator=g).bfloat16()
+    kb = (torch.randn((3, 3, ci, co), device="cuda", generator=g) * 0.1).bfloat16().float(); b = torch.randn(co, device="cuda", generator=g)
+    x32, dy32 = xb.float(), dyb.float()
+    y = ops.z(n, h, w, co, dtype=torch.bfloat16); yr = ops.z(n, h, w, co)
+    ops.ck(ops.lib.unet_conv3x3_fwd_bf16(ops.h, xb.data_ptr(), kb.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, ops.wws(ci, co), ops.s), "fwd bf16")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, x32.data_ptr(), kb.data_ptr(), b.data_ptr(), yr.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 2, None, ops.s), "fwd fp32 direct")
+    assert float((y.float() - yr).norm() / yr.norm()) < BF16_OUT
+    dx = ops.z(n, h, w, ci, dtype=torch.bfloat16); dxr = ops.z(n, h, w, ci)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data_bf16(ops.h, dyb.data_ptr(), kb.data_ptr(), xb.data_ptr(), 1, 0.0, 0, dx.data_ptr(), ops.wws(ci, co), n, h, w, ci, co, ops.s), "dgrad bf16")
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, dy32.data_ptr(), kb.data_ptr(), x32.data_ptr(), 1, 0.0, 0, dxr.data_ptr(), ops.z(16 * ci * co).data_ptr(), n, h, w, ci, co, 2, ops.s), "dgrad fp32")
+    assert float((dx.float() - dxr).norm() / dxr.norm()) < BF16_OUT
+    nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes_bf16(n, h, w, ci, co); nr = ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co)
+    ws = torch.empty(max(nb, nr, 16), dtype=torch.uint8, device="cuda")
+    dw, db, dwr, dbr = ops.z(3, 3, ci, co), ops.z(co), ops.z(3, 3, ci, co), ops.z(co)
+    ops.ck(ops.lib.unet_conv3x3_bwd_weights_bf16(ops.h, xb.data_ptr(), dyb.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ci, co, ops.s), "wgrad bf16")
+    ops.ck(ops.lib.unet_conv3x3_bwd_weights(ops.h, x32.data_ptr(), dy32.data_ptr(), dwr.data_ptr(), dbr.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ci, co, 2, ops.s), "wgrad fp32")
+    assert float((dw - dwr).norm() / dwr.norm()) < F32_OUT and float((db - dbr).norm() / dbr.norm()) < F32_OUT
