@@ -575,6 +575,147 @@ __global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restr
   if (w == 0 && ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * pstride + b0 + l31] = bsum;
 }
 
+// Weight gradient in the 2-D Winograd domain F(2x2,3x3): 16 instead of 24 (F(2,3) along x) or 36 (direct) MFMAs per 2x2 output tile.
+//   dU[xi][nu][ci][co] = sum over 2x2 output tiles of V[xi][nu][ci] * dM[xi][nu][co],   V = B^T d B (4x4 input tile d),  dM = A dY A^T,
+//   dW = G^T dU G (16 -> 9, applied by reduce_final_kernel<2>).
+// Workgroup = 4 waves, wave = xi (the y index): it forms ITS row combination of the 4-row input window (R = rowP + sgn * rowQ: 0-2, 1+2,
+// 2-1, 1-3) and of the dY row pair (S = c0 * dy_r0 + c1 * dy_r1: dy0, dy0+dy1, dy0-dy1, -dy1), then the x transforms in registers, and
+// owns the four nu accumulator tiles (64 registers).  A step = one output ROW PAIR of a 32-column strip = 16 tiles = 8 MFMA k-pairs per
+// (xi, nu).  LDS keeps the rows TRANSPOSED ([channel][pixel], pitch 34: conflict-free ds_read_b64), so a lane fetches the 4 columns of
+// its tile with two 8-byte reads per row: 6 reads per 4 MFMAs.  X rows live in a 4-slot ring (two new rows per step), the next step's
+// rows are register-prefetched under the MFMAs.
+__global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
+                                                              float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
+                                                              int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
+                                                              int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
+  constexpr int PIT = 34, ROW = 32 * PIT;
+  constexpr int XP = 2 * 34 * 8, YP = 2 * 32 * 8;          // 16-byte pieces per batch: two X rows (34 px), two dY rows (32 px)
+  constexpr int XL = (XP + 255) / 256, YL = YP / 256;
+  __shared__ __attribute__((aligned(16))) float s_x[4 * ROW];
+  __shared__ __attribute__((aligned(16))) float s_y[2 * ROW];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int npairs = tiles_a_x_b, sq = blockIdx.x >> 3;
+  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);      // XCD-aware block map, as wgrad_wino_kernel
+  if (split >= nsplit) return;
+  const int ta = pair / tiles_b, tb = pair % tiles_b;
+  const int a0 = ta * 32, b0 = tb * 32;
+  const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
+  const int cs = t2 % strips, n = t2 / strips;
+  const int x0 = cs * 32;
+  const int ya = chunk * rows_per_chunk;                                          // even (plan_wgrad rounds the chunk height up)
+  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
+  const int npr = (yb - ya + 1) >> 1;                                             // row pairs of this chunk
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  float bsum = 0.0f;
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + (long long)n * H * W * ldA, (long long)H * W * ldA * 4);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + (long long)n * H * W * ldB, (long long)H * W * ldB * 4);
+
+  int xoff[XL], xlds[XL], yoff[YL], ylds[YL];               // column part of the global offset; LDS float index | row-in-batch << 20
+#pragma unroll
+  for (int k = 0; k < XL; ++k) {
+    const int idx = min(tid + 256 * k, XP - 1);             // surplus lanes redo the last piece
+    const int i = idx / 272, rem = idx - i * 272, pix = rem >> 3, q = rem & 7, gx = x0 - 1 + pix;
+    xoff[k] = (gx >= 0 && gx < W && a0 + q * 4 < CA) ? (gx * ldA + a0 + q * 4) * 4 : UNET_COL_OOB;
+    xlds[k] = (q * 4 * PIT + pix) | (i << 20);
+  }
+#pragma unroll
+  for (int k = 0; k < YL; ++k) {
+    const int idx = tid + 256 * k;
+    const int i = idx >> 8, rem = idx & 255, pix = rem >> 3, q = rem & 7, gx = x0 + pix;
+    yoff[k] = (gx < W && b0 + q * 4 < CB) ? (gx * ldB + b0 + q * 4) * 4 : UNET_COL_OOB;
+    ylds[k] = (i * ROW + q * 4 * PIT + pix) | (i << 20);
+  }
+  f32x4 xreg[XL], yreg[YL];
+  // batch b = X rows ya-1+2b, ya+2b  and (b >= 1) the dY rows of pair b-1
+  auto issue = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < XL; ++k) {
+      const int yr = ya - 1 + 2 * b + (xlds[k] >> 20);
+      xreg[k] = buf_ld4(rs_a, xoff[k] + ((yr >= 0 && yr < H) ? yr * W * ldA * 4 : UNET_OOB));
+    }
+#pragma unroll
+    for (int k = 0; k < YL; ++k) {
+      const int yd = ya + 2 * (b - 1) + (ylds[k] >> 20);
+      yreg[k] = buf_ld4(rs_b, yoff[k] + ((b >= 1 && yd < yb) ? yd * W * ldB * 4 : UNET_OOB));
+    }
+  };
+  auto store = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < XL; ++k) {
+      float* d = s_x + ((2 * b + (xlds[k] >> 20)) & 3) * ROW + (xlds[k] & 0xFFFFF);
+      d[0] = xreg[k][0]; d[PIT] = xreg[k][1]; d[2 * PIT] = xreg[k][2]; d[3 * PIT] = xreg[k][3];
+    }
+    if (b >= 1) {
+#pragma unroll
+      for (int k = 0; k < YL; ++k) {
+        float* d = s_y + (ylds[k] & 0xFFFFF);
+        d[0] = yreg[k][0]; d[PIT] = yreg[k][1]; d[2 * PIT] = yreg[k][2]; d[3 * PIT] = yreg[k][3];
+      }
+    }
+  };
+  // wave-uniform row combinations: X window rows (P, Q) with sign, dY rows with (c0, c1)
+  const int rowP = (w == 0) ? 0 : (w == 2 ? 2 : 1), rowQ = (w == 0 || w == 1) ? 2 : (w == 2 ? 1 : 3);
+  const float sgx = (w == 1) ? 1.0f : -1.0f;
+  const float c0 = (w == 3) ? 0.0f : 1.0f, c1 = (w == 0) ? 0.0f : (w == 1 ? 1.0f : -1.0f);
+
+  issue(0); store(0); issue(1);
+  for (int s = 0; s < npr; ++s) {
+    store(s + 1);
+    __syncthreads();
+    if (s + 2 <= npr) issue(s + 2);
+    const float* rp = s_x + ((2 * s + rowP) & 3) * ROW + l31 * PIT + 2 * hi;
+    const float* rq = s_x + ((2 * s + rowQ) & 3) * ROW + l31 * PIT + 2 * hi;
+    const float* y0 = s_y + l31 * PIT + 2 * hi;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {                       // MFMA k-pair = tiles 2pp (lanes 0-31) and 2pp+1 (lanes 32-63)
+      const float2 p01 = *reinterpret_cast<const float2*>(rp + 4 * pp), p23 = *reinterpret_cast<const float2*>(rp + 4 * pp + 2);
+      const float2 q01 = *reinterpret_cast<const float2*>(rq + 4 * pp), q23 = *reinterpret_cast<const float2*>(rq + 4 * pp + 2);
+      const float2 da = *reinterpret_cast<const float2*>(y0 + 4 * pp), db = *reinterpret_cast<const float2*>(y0 + ROW + 4 * pp);
+      const float e0 = fmaf(sgx, q01.x, p01.x), e1 = fmaf(sgx, q01.y, p01.y), e2 = fmaf(sgx, q23.x, p23.x), e3 = fmaf(sgx, q23.y, p23.y);
+      const float s0 = c0 * da.x + c1 * db.x, s1 = c0 * da.y + c1 * db.y;
+      if (w == 1) bsum += s0 + s1;                         // wave 1 sees dy_r0 + dy_r1: the bias gradient rides along
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e2, s0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 + e2, s0 + s1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2 - e1, s0 - s1, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 - e3, -s1, acc[3], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // partial tiles dU[xi = w][nu]; quad transpose -> 16-byte stores (see wgrad_mfma_kernel)
+  float* P = part + (long long)split * pstride;
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) {
+    const int tap = w * 4 + nu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v0 = acc[nu][4 * g + 0], v1 = acc[nu][4 * g + 1], v2 = acc[nu][4 * g + 2], v3 = acc[nu][4 * g + 3];
+      {
+        const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
+        const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
+        if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
+      }
+      {
+        const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
+        const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
+        if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
+      }
+      const int i = e + 8 * g + 4 * hi;
+      if (a0 + i < CA && b0 + q4 < CB) *reinterpret_cast<float4*>(&P[((long long)tap * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
+    }
+  }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (w == 1 && ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * pstride + b0 + l31] = bsum;
+}
+
 // Sum the split-K partials in a fixed order.  Two levels so that a tiny output (e.g. 9x32x32) with
 // thousands of splits still spreads over the chip: level 1 reduces groups of splits (grid.y = groups),
 // level 2 reduces the group sums.  4 independent accumulators keep 4 loads in flight per thread.
@@ -605,11 +746,11 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 // Last reduction level, weights and bias in ONE launch.  src = `count` slabs of `stride` floats, each [taps][ca*cb] weight partials
 // followed by the bias partials.  WINO: the slab is in the Winograd domain dU[ky][k] (12 taps); the 12 -> 9 transform (transpose of
 // the weight transform G: dg0 = dU0 + (dU1+dU2)/2, dg1 = (dU1-dU2)/2, dg2 = (dU1+dU2)/2 + dU3) is applied on the fly.
-template <bool WINO>
+template <int WINO>       // 0: plain, 1: 12 -> 9 (F(2,3) along x), 2: 16 -> 9 (F(2x2,3x3))
 __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ src, long long stride, int count, int n4 /* ca*cb/4 */, int taps,
                                                            int nb4 /* bias floats / 4 */, float* __restrict__ dw, float* __restrict__ db) {
   const long long st = (long long)n4 * 4;
-  const int nw = (WINO ? 3 : taps) * n4;
+  const int nw = (WINO == 2 ? 1 : WINO == 1 ? 3 : taps) * n4;
   auto sum = [&](long long off) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     int c = 0;
@@ -622,7 +763,29 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
   };
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nw + nb4; i += gridDim.x * 256) {
     if (i >= nw) { *reinterpret_cast<float4*>(db + (long long)(i - nw) * 4) = sum((long long)taps * st + (long long)(i - nw) * 4); continue; }
-    if (!WINO) { *reinterpret_cast<float4*>(dw + (long long)i * 4) = sum((long long)i * 4); continue; }
+    if (WINO == 0) { *reinterpret_cast<float4*>(dw + (long long)i * 4) = sum((long long)i * 4); continue; }
+    if (WINO == 2) {                                   // dW = G^T dU G: rows (xi -> ky) then columns (nu -> kx), per (ci, co) quad i
+      float4 t[3][4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const float4 u0 = sum((long long)(0 * 4 + nu) * st + (long long)i * 4), u1 = sum((long long)(1 * 4 + nu) * st + (long long)i * 4);
+        const float4 u2 = sum((long long)(2 * 4 + nu) * st + (long long)i * 4), u3 = sum((long long)(3 * 4 + nu) * st + (long long)i * 4);
+        const float4 hs = make_float4(0.5f * (u1.x + u2.x), 0.5f * (u1.y + u2.y), 0.5f * (u1.z + u2.z), 0.5f * (u1.w + u2.w));
+        t[0][nu] = make_float4(u0.x + hs.x, u0.y + hs.y, u0.z + hs.z, u0.w + hs.w);
+        t[1][nu] = make_float4(0.5f * (u1.x - u2.x), 0.5f * (u1.y - u2.y), 0.5f * (u1.z - u2.z), 0.5f * (u1.w - u2.w));
+        t[2][nu] = make_float4(hs.x + u3.x, hs.y + u3.y, hs.z + u3.z, hs.w + u3.w);
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float4 a0 = t[ky][0], a1 = t[ky][1], a2 = t[ky][2], a3 = t[ky][3];
+        const float4 hs = make_float4(0.5f * (a1.x + a2.x), 0.5f * (a1.y + a2.y), 0.5f * (a1.z + a2.z), 0.5f * (a1.w + a2.w));
+        float* q = dw + (long long)ky * 3 * st + (long long)i * 4;
+        *reinterpret_cast<float4*>(q) = make_float4(a0.x + hs.x, a0.y + hs.y, a0.z + hs.z, a0.w + hs.w);
+        *reinterpret_cast<float4*>(q + st) = make_float4(0.5f * (a1.x - a2.x), 0.5f * (a1.y - a2.y), 0.5f * (a1.z - a2.z), 0.5f * (a1.w - a2.w));
+        *reinterpret_cast<float4*>(q + 2 * st) = make_float4(hs.x + a3.x, hs.y + a3.y, hs.z + a3.z, hs.w + a3.w);
+      }
+      continue;
+    }
     const int ky = i / n4, j = i - ky * n4;
     const long long o = (long long)ky * 4 * st + (long long)j * 4;
     const float4 u0 = sum(o), u1 = sum(o + st), u2 = sum(o + 2 * st), u3 = sum(o + 3 * st);
@@ -636,7 +799,7 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
 
 struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_chunk, chunks_per_strip, groups, per_group; size_t part_floats, bias_floats, part2_floats; };
 
-WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
+WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias, bool even_rows = false) {
   WgradPlan p;
   p.tiles_a = (ca + 31) / 32; p.tiles_b = (cb + 31) / 32; p.strips = (w + 31) / 32;      // a tile may overhang (channels % 32 != 0)
   const long long pairs = (long long)p.tiles_a * p.tiles_b;
@@ -651,6 +814,7 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
   long long cps = std::max<long long>(1, (want + units - 1) / units);
   cps = std::min<long long>(cps, std::max<long long>(1, h / 8));
   p.rows_per_chunk = (int)((h + cps - 1) / cps);
+  if (even_rows) p.rows_per_chunk += p.rows_per_chunk & 1;                 // the F(2x2,3x3) kernel walks row pairs
   p.chunks_per_strip = (h + p.rows_per_chunk - 1) / p.rows_per_chunk;
   p.nsplit = (int)(units * p.chunks_per_strip);
   p.part_floats = (size_t)p.nsplit * per; p.bias_floats = (size_t)p.nsplit * cbias;
@@ -667,17 +831,20 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
 template <int MODE>
 int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ldB, float* dw, float* db, void* ws, size_t ws_bytes, int n,
                   int h, int w, int ca, int cb, hipStream_t s) {
-  const int taps = MODE == 0 ? 9 : (MODE == 1 ? 4 : 12); const int cbias = MODE != 1 ? cb : ca;
+  const int taps = MODE == 0 ? 9 : (MODE == 1 ? 4 : (MODE == 2 ? 12 : 16)); const int cbias = MODE != 1 ? cb : ca;
   if ((long long)(MODE == 1 ? 4 : 1) * h * w * ldA * 4 >= (1LL << 30) || (long long)h * w * ldB * 4 >= (1LL << 30))
     UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad mfma: one image must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
-  const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias);
+  const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias, MODE == 3);
   const long long per = (long long)taps * ca * cb, S = per + cbias;      // one split's partial slab: weights, then bias sums
   const size_t need = (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
   if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   float* part = static_cast<float*>(ws); float* part_b = part + per;
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));            // see the block map in the kernels
-  if constexpr (MODE == 2)
+  if constexpr (MODE == 3)
+    hipLaunchKernelGGL(wgrad_wino2d_kernel, grid, dim3(256), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk,
+                       p.chunks_per_strip, p.nsplit, npairs, S);
+  else if constexpr (MODE == 2)
     hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(128), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk,
                        p.chunks_per_strip, p.nsplit, npairs, S);
   else
@@ -694,10 +861,11 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
     src = part2; count = p.groups;
   }
   const int n4 = ca * cb / 4, nb4 = cbias / 4;
-  const int items = (MODE == 2 ? 3 : taps) * n4 + nb4;
+  const int items = (MODE == 3 ? 1 : MODE == 2 ? 3 : taps) * n4 + nb4;
   const dim3 gf((unsigned)std::min(2048, (items + 255) / 256));
-  if (MODE == 2) hipLaunchKernelGGL(reduce_final_kernel<true>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
-  else hipLaunchKernelGGL(reduce_final_kernel<false>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  if (MODE == 3) hipLaunchKernelGGL(reduce_final_kernel<2>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  else if (MODE == 2) hipLaunchKernelGGL(reduce_final_kernel<1>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  else hipLaunchKernelGGL(reduce_final_kernel<0>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
 }
@@ -729,7 +897,7 @@ int32_t k_wgrad_reduce(unet_ctx* ctx, float* part, int nslabs, int taps, int ca,
   }
   const int n4 = ca * cb / 4, nb4 = cbias / 4;
   const int items = taps * n4 + nb4;
-  hipLaunchKernelGGL(reduce_final_kernel<false>, dim3((unsigned)std::min(2048, (items + 255) / 256)), dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3((unsigned)std::min(2048, (items + 255) / 256)), dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
 }
@@ -767,13 +935,15 @@ int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float
 
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // large enough for the direct AND the Winograd form
   if (!mfma_wgrad_supported(cin, cout)) return 0;
-  const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout), q = plan_wgrad(12, n, h, wd, cin, cout, cout);
-  return std::max((p.part_floats + p.bias_floats + p.part2_floats), (q.part_floats + q.bias_floats + q.part2_floats)) * sizeof(float);
+  const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout), q = plan_wgrad(12, n, h, wd, cin, cout, cout), r = plan_wgrad(16, n, h, wd, cin, cout, cout, true);
+  return std::max(std::max(p.part_floats + p.bias_floats + p.part2_floats, q.part_floats + q.bias_floats + q.part2_floats), r.part_floats + r.bias_floats + r.part2_floats) * sizeof(float);
 }
 
 int32_t k_conv3x3_wino_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                              int wd, int cin, int cout, hipStream_t s) {
   if (!mfma_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad winograd: cin=%d cout=%d unsupported", cin, cout);
+  static const int form = [] { const char* e = getenv("UNET_WINO_WGRAD_2D"); return e ? atoi(e) : 1; }();      // A/B switch: 0 = F(2,3) along x
+  if (form && h >= 2) return run_wgrad<3>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   return run_wgrad<2>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
 }
 
