@@ -583,7 +583,8 @@ __global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restr
 // owns the four nu accumulator tiles (64 registers).  A step = one output ROW PAIR of a 32-column strip = 16 tiles = 8 MFMA k-pairs per
 // (xi, nu).  LDS keeps the rows TRANSPOSED ([channel][pixel], pitch 34: conflict-free ds_read_b64), so a lane fetches the 4 columns of
 // its tile with two 8-byte reads per row: 6 reads per 4 MFMAs.  X rows live in a 4-slot ring (two new rows per step), the next step's
-// rows are register-prefetched under the MFMAs.
+// rows are register-prefetched under the MFMAs.  (A two-wave form -- wave 0: xi = 1, 2 from rows 1, 2; wave 1: xi = 0, 3 -- reads a third
+// less from LDS but needs 128 accumulator registers per wave: 2 instead of 3 waves per SIMD, measured 10 % slower.)
 __global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
                                                               float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
                                                               int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
