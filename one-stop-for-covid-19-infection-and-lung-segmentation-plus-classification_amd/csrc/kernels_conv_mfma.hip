@@ -798,6 +798,51 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
   }
 }
 
+// Final level for the F(2x2,3x3) weight gradient: 16 Winograd taps -> 9 kernel taps, dW = G^T dU G.  A workgroup = 16 (ci, co) quads x
+// 16 taps: every thread sums ITS (tap, quad) over the slabs (16x the parallelism of one thread per quad: the 32 x 32-channel layers
+// have only 256 quads), the 16 x 16 sums meet in LDS and 144 threads apply the two 4 -> 3 transforms.  Extra workgroups sum the bias.
+__global__ __launch_bounds__(256) void reduce_final_wino2d_kernel(const float* __restrict__ src, long long stride, int count, int n4, int nb4,
+                                                                  int wblocks, float* __restrict__ dw, float* __restrict__ db) {
+  const long long st = (long long)n4 * 4;
+  auto sum = [&](long long off) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    int c = 0;
+    for (; c + 1 < count; c += 2) {
+      const float4 u = *reinterpret_cast<const float4*>(src + (long long)c * stride + off), v = *reinterpret_cast<const float4*>(src + (long long)(c + 1) * stride + off);
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (c < count) { const float4 u = *reinterpret_cast<const float4*>(src + (long long)c * stride + off); a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  };
+  if ((int)blockIdx.x >= wblocks) {                      // bias gradient: plain sums
+    const int i = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (i < nb4) *reinterpret_cast<float4*>(db + (long long)i * 4) = sum(16 * st + (long long)i * 4);
+    return;
+  }
+  __shared__ float4 s_u[16][16];
+  const int tq = threadIdx.x & 15, tap = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + tq;
+  s_u[tap][tq] = j < n4 ? sum((long long)tap * st + (long long)j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  if (threadIdx.x >= 144) return;
+  const int q = threadIdx.x & 15, kk = threadIdx.x >> 4, ky = kk / 3, kx = kk - ky * 3;
+  const int jq = blockIdx.x * 16 + q;
+  if (jq >= n4) return;
+  // rows of G^T: (1, 1/2, 1/2, 0), (0, 1/2, -1/2, 0), (0, 1/2, 1/2, 1)
+  const float gy[4] = {ky == 0 ? 1.f : 0.f, 0.5f, ky == 1 ? -0.5f : 0.5f, ky == 2 ? 1.f : 0.f};
+  const float gx[4] = {kx == 0 ? 1.f : 0.f, 0.5f, kx == 1 ? -0.5f : 0.5f, kx == 2 ? 1.f : 0.f};
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const float c = gy[xi] * gx[nu];
+      const float4 u = s_u[xi * 4 + nu][q];
+      r.x = fmaf(c, u.x, r.x); r.y = fmaf(c, u.y, r.y); r.z = fmaf(c, u.z, r.z); r.w = fmaf(c, u.w, r.w);
+    }
+  *reinterpret_cast<float4*>(dw + (long long)kk * st + (long long)jq * 4) = r;
+}
+
 struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_chunk, chunks_per_strip, groups, per_group; size_t part_floats, bias_floats, part2_floats; };
 
 WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias, bool even_rows = false) {
@@ -864,7 +909,10 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
   const int n4 = ca * cb / 4, nb4 = cbias / 4;
   const int items = (MODE == 3 ? 1 : MODE == 2 ? 3 : taps) * n4 + nb4;
   const dim3 gf((unsigned)std::min(2048, (items + 255) / 256));
-  if (MODE == 3) hipLaunchKernelGGL(reduce_final_kernel<2>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  if (MODE == 3) {
+    const int wblocks = (n4 + 15) / 16;
+    hipLaunchKernelGGL(reduce_final_wino2d_kernel, dim3((unsigned)(wblocks + (nb4 + 255) / 256)), dim3(256), 0, s, src, S, count, n4, nb4, wblocks, dw, db);
+  }
   else if (MODE == 2) hipLaunchKernelGGL(reduce_final_kernel<1>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
   else hipLaunchKernelGGL(reduce_final_kernel<0>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
