@@ -577,7 +577,7 @@ __global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restr
 
 // Weight gradient in the 2-D Winograd domain F(2x2,3x3): 16 instead of 24 (F(2,3) along x) or 36 (direct) MFMAs per 2x2 output tile.
 //   dU[xi][nu][ci][co] = sum over 2x2 output tiles of V[xi][nu][ci] * dM[xi][nu][co],   V = B^T d B (4x4 input tile d),  dM = A dY A^T,
-//   dW = G^T dU G (16 -> 9, applied by reduce_final_kernel<2>).
+//   dW = G^T dU G (16 -> 9, applied by reduce_final_wino2d_kernel).
 // Workgroup = 4 waves, wave = xi (the y index): it forms ITS row combination of the 4-row input window (R = rowP + sgn * rowQ: 0-2, 1+2,
 // 2-1, 1-3) and of the dY row pair (S = c0 * dy_r0 + c1 * dy_r1: dy0, dy0+dy1, dy0-dy1, -dy1), then the x transforms in registers, and
 // owns the four nu accumulator tiles (64 registers).  A step = one output ROW PAIR of a 32-column strip = 16 tiles = 8 MFMA k-pairs per
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const float* __res
   constexpr int XP = 2 * 34 * 8, YP = 2 * 32 * 8;          // 16-byte pieces per batch: two X rows (34 px), two dY rows (32 px)
   constexpr int XL = (XP + 255) / 256, YL = YP / 256;
   __shared__ __attribute__((aligned(16))) float s_x[4 * ROW];
-  __shared__ __attribute__((aligned(16))) float s_y[2 * ROW];
+  __shared__ __attribute__((aligned(16))) float s_y[4 * ROW];                  // the four dY row combinations dy0, dy0+dy1, dy0-dy1, dy1, formed while staging
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int npairs = tiles_a_x_b, sq = blockIdx.x >> 3;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const float* __res
     const int idx = tid + 256 * k;
     const int i = idx >> 8, rem = idx & 255, pix = rem >> 3, q = rem & 7, gx = x0 + pix;
     yoff[k] = (gx < W && b0 + q * 4 < CB) ? (gx * ldB + b0 + q * 4) * 4 : UNET_COL_OOB;
-    ylds[k] = (i * ROW + q * 4 * PIT + pix) | (i << 20);
+    ylds[k] = (q * 4 * PIT + pix) | (i << 20);
   }
   f32x4 xreg[XL], yreg[YL];
   // batch b = X rows ya-1+2b, ya+2b  and (b >= 1) the dY rows of pair b-1
@@ -652,18 +652,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const float* __res
       float* d = s_x + ((2 * b + (xlds[k] >> 20)) & 3) * ROW + (xlds[k] & 0xFFFFF);
       d[0] = xreg[k][0]; d[PIT] = xreg[k][1]; d[2 * PIT] = xreg[k][2]; d[3 * PIT] = xreg[k][3];
     }
-    if (b >= 1) {
+    if (b >= 1) {                                          // piece k = row k of the pair, same (pixel, channel quad) for both: combine here, once,
+      float* d = s_y + (ylds[0] & 0xFFFFF);                // instead of in every wave of the main loop
 #pragma unroll
-      for (int k = 0; k < YL; ++k) {
-        float* d = s_y + (ylds[k] & 0xFFFFF);
-        d[0] = yreg[k][0]; d[PIT] = yreg[k][1]; d[2 * PIT] = yreg[k][2]; d[3 * PIT] = yreg[k][3];
+      for (int j = 0; j < 4; ++j) {
+        const float a = yreg[0][j], c = yreg[1][j];
+        d[j * PIT] = a; d[ROW + j * PIT] = a + c; d[2 * ROW + j * PIT] = a - c; d[3 * ROW + j * PIT] = c;
       }
     }
   };
   // wave-uniform row combinations: X window rows (P, Q) with sign, dY rows with (c0, c1)
   const int rowP = (w == 0) ? 0 : (w == 2 ? 2 : 1), rowQ = (w == 0 || w == 1) ? 2 : (w == 2 ? 1 : 3);
   const float sgx = (w == 1) ? 1.0f : -1.0f;
-  const float c0 = (w == 3) ? 0.0f : 1.0f, c1 = (w == 0) ? 0.0f : (w == 1 ? 1.0f : -1.0f);
 
   issue(0); store(0); issue(1);
   for (int s = 0; s < npr; ++s) {
@@ -672,19 +672,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const float* __res
     if (s + 2 <= npr) issue(s + 2);
     const float* rp = s_x + ((2 * s + rowP) & 3) * ROW + l31 * PIT + 2 * hi;
     const float* rq = s_x + ((2 * s + rowQ) & 3) * ROW + l31 * PIT + 2 * hi;
-    const float* y0 = s_y + l31 * PIT + 2 * hi;
+    const float* ys = s_y + w * ROW + l31 * PIT + 2 * hi;    // this wave's dY combination (xi = 3 reads +dy1: its sign is applied by the final reduction)
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {                       // MFMA k-pair = tiles 2pp (lanes 0-31) and 2pp+1 (lanes 32-63)
       const float2 p01 = *reinterpret_cast<const float2*>(rp + 4 * pp), p23 = *reinterpret_cast<const float2*>(rp + 4 * pp + 2);
       const float2 q01 = *reinterpret_cast<const float2*>(rq + 4 * pp), q23 = *reinterpret_cast<const float2*>(rq + 4 * pp + 2);
-      const float2 da = *reinterpret_cast<const float2*>(y0 + 4 * pp), db = *reinterpret_cast<const float2*>(y0 + ROW + 4 * pp);
+      const float2 sv = *reinterpret_cast<const float2*>(ys + 4 * pp);
       const float e0 = fmaf(sgx, q01.x, p01.x), e1 = fmaf(sgx, q01.y, p01.y), e2 = fmaf(sgx, q23.x, p23.x), e3 = fmaf(sgx, q23.y, p23.y);
-      const float s0 = c0 * da.x + c1 * db.x, s1 = c0 * da.y + c1 * db.y;
+      const float s0 = sv.x, s1 = sv.y;
       if (w == 1) bsum += s0 + s1;                         // wave 1 sees dy_r0 + dy_r1: the bias gradient rides along
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e2, s0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 + e2, s0 + s1, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2 - e1, s0 - s1, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 - e3, -s1, acc[3], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 - e3, s1, acc[3], 0, 0, 0);       // dM3 = -s1: sign applied by the final reduction
     }
     __syncthreads();
   }
@@ -747,11 +747,11 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 // Last reduction level, weights and bias in ONE launch.  src = `count` slabs of `stride` floats, each [taps][ca*cb] weight partials
 // followed by the bias partials.  WINO: the slab is in the Winograd domain dU[ky][k] (12 taps); the 12 -> 9 transform (transpose of
 // the weight transform G: dg0 = dU0 + (dU1+dU2)/2, dg1 = (dU1-dU2)/2, dg2 = (dU1+dU2)/2 + dU3) is applied on the fly.
-template <int WINO>       // 0: plain, 1: 12 -> 9 (F(2,3) along x), 2: 16 -> 9 (F(2x2,3x3))
+template <int WINO>       // 0: plain, 1: 12 -> 9 (F(2,3) along x); the 16 -> 9 form of F(2x2,3x3) is reduce_final_wino2d_kernel
 __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ src, long long stride, int count, int n4 /* ca*cb/4 */, int taps,
                                                            int nb4 /* bias floats / 4 */, float* __restrict__ dw, float* __restrict__ db) {
   const long long st = (long long)n4 * 4;
-  const int nw = (WINO == 2 ? 1 : WINO == 1 ? 3 : taps) * n4;
+  const int nw = (WINO == 1 ? 3 : taps) * n4;
   auto sum = [&](long long off) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     int c = 0;
@@ -765,28 +765,6 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nw + nb4; i += gridDim.x * 256) {
     if (i >= nw) { *reinterpret_cast<float4*>(db + (long long)(i - nw) * 4) = sum((long long)taps * st + (long long)(i - nw) * 4); continue; }
     if (WINO == 0) { *reinterpret_cast<float4*>(dw + (long long)i * 4) = sum((long long)i * 4); continue; }
-    if (WINO == 2) {                                   // dW = G^T dU G: rows (xi -> ky) then columns (nu -> kx), per (ci, co) quad i
-      float4 t[3][4];
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const float4 u0 = sum((long long)(0 * 4 + nu) * st + (long long)i * 4), u1 = sum((long long)(1 * 4 + nu) * st + (long long)i * 4);
-        const float4 u2 = sum((long long)(2 * 4 + nu) * st + (long long)i * 4), u3 = sum((long long)(3 * 4 + nu) * st + (long long)i * 4);
-        const float4 hs = make_float4(0.5f * (u1.x + u2.x), 0.5f * (u1.y + u2.y), 0.5f * (u1.z + u2.z), 0.5f * (u1.w + u2.w));
-        t[0][nu] = make_float4(u0.x + hs.x, u0.y + hs.y, u0.z + hs.z, u0.w + hs.w);
-        t[1][nu] = make_float4(0.5f * (u1.x - u2.x), 0.5f * (u1.y - u2.y), 0.5f * (u1.z - u2.z), 0.5f * (u1.w - u2.w));
-        t[2][nu] = make_float4(hs.x + u3.x, hs.y + u3.y, hs.z + u3.z, hs.w + u3.w);
-      }
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const float4 a0 = t[ky][0], a1 = t[ky][1], a2 = t[ky][2], a3 = t[ky][3];
-        const float4 hs = make_float4(0.5f * (a1.x + a2.x), 0.5f * (a1.y + a2.y), 0.5f * (a1.z + a2.z), 0.5f * (a1.w + a2.w));
-        float* q = dw + (long long)ky * 3 * st + (long long)i * 4;
-        *reinterpret_cast<float4*>(q) = make_float4(a0.x + hs.x, a0.y + hs.y, a0.z + hs.z, a0.w + hs.w);
-        *reinterpret_cast<float4*>(q + st) = make_float4(0.5f * (a1.x - a2.x), 0.5f * (a1.y - a2.y), 0.5f * (a1.z - a2.z), 0.5f * (a1.w - a2.w));
-        *reinterpret_cast<float4*>(q + 2 * st) = make_float4(hs.x + a3.x, hs.y + a3.y, hs.z + a3.z, hs.w + a3.w);
-      }
-      continue;
-    }
     const int ky = i / n4, j = i - ky * n4;
     const long long o = (long long)ky * 4 * st + (long long)j * 4;
     const float4 u0 = sum(o), u1 = sum(o + st), u2 = sum(o + 2 * st), u3 = sum(o + 3 * st);
@@ -829,8 +807,9 @@ __global__ __launch_bounds__(256) void reduce_final_wino2d_kernel(const float* _
   const int jq = blockIdx.x * 16 + q;
   if (jq >= n4) return;
   // rows of G^T: (1, 1/2, 1/2, 0), (0, 1/2, -1/2, 0), (0, 1/2, 1/2, 1)
-  const float gy[4] = {ky == 0 ? 1.f : 0.f, 0.5f, ky == 1 ? -0.5f : 0.5f, ky == 2 ? 1.f : 0.f};
-  const float gx[4] = {kx == 0 ? 1.f : 0.f, 0.5f, kx == 1 ? -0.5f : 0.5f, kx == 2 ? 1.f : 0.f};
+  // (the kernel accumulates xi = 3 and nu = 3 with the opposite sign -- it skips the negations of -dy1 and -s1 --: folded in here)
+  const float gy[4] = {ky == 0 ? 1.f : 0.f, 0.5f, ky == 1 ? -0.5f : 0.5f, ky == 2 ? -1.f : 0.f};
+  const float gx[4] = {kx == 0 ? 1.f : 0.f, 0.5f, kx == 1 ? -0.5f : 0.5f, kx == 2 ? -1.f : 0.f};
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi)
