@@ -585,7 +585,7 @@ __global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restr
 // its tile with two 8-byte reads per row: 6 reads per 4 MFMAs.  X rows live in a 4-slot ring (two new rows per step), the next step's
 // rows are register-prefetched under the MFMAs.  (A two-wave form -- wave 0: xi = 1, 2 from rows 1, 2; wave 1: xi = 0, 3 -- reads a third
 // less from LDS but needs 128 accumulator registers per wave: 2 instead of 3 waves per SIMD, measured 10 % slower.)
-__global__ __launch_bounds__(256, 2) void wgrad_wino2d_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
+__global__ __launch_bounds__(256, 4) void wgrad_wino2d_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
                                                               float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
                                                               int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
                                                               int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
@@ -832,7 +832,10 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias, b
   // K-split: every (image, 32-column strip) is cut into row chunks; aim at ~4096 waves (2 waves/SIMD x 256 CUs x 2 rounds),
   // at least 8 rows per chunk (the 3x3 ring re-reads 2 halo rows per chunk), at most 192 MiB of partials
   const long long units = (long long)n * p.strips;
-  static const long long target = [] { const char* e = getenv("UNET_WGRAD_BLOCKS"); return e ? atoll(e) : 1536LL; }();      // = one resident round of the two-wave kernel (256 CUs x 6): measured best of 1536..6144
+  static const long long target_env = [] { const char* e = getenv("UNET_WGRAD_BLOCKS"); return e ? atoll(e) : 0LL; }();
+  // one resident round: 256 CUs x 6 two-wave workgroups (1-D Winograd / direct kernels; measured best of 1536..6144), x 4 four-wave
+  // workgroups of the F(2x2,3x3) kernel (1024: best of 768..3072)
+  const long long target = target_env ? target_env : (even_rows ? 1024LL : 1536LL);
   long long want = (target + pairs - 1) / pairs;
   const long long cap = std::max<long long>(1, (48LL << 20) / per);
   want = std::min(want, cap);
