@@ -372,3 +372,23 @@ def test_winograd_matches_direct_mfma_at_full_size(ops, shape):
         res[algo] = [t.cpu().numpy() for t in (y, dx, dw, db)]
     for a, c, nm in zip(res[2], res[3], ("y", "dx", "dw", "db")):
         assert relerr(c, a) < 1e-5, nm
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_wgrad_random_shapes_all_algorithms_agree(ops, seed):
+    """odd heights / widths / channel counts (tile overhang, single-row chunks, odd last row pair): the 2-D Winograd, direct MFMA and
+    vector weight-gradient kernels against each other (the vector kernel is the one the oracle pins at every CONV_SHAPES entry)"""
+    rng = np.random.default_rng(1000 + seed)
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 41)), int(rng.integers(1, 71))
+    ci, co = int(rng.choice([8, 12, 16, 24, 32, 40, 64, 96])), int(rng.choice([8, 12, 16, 24, 32, 40, 64, 96]))
+    x = torch.randn((n, h, w, ci), device="cuda"); dy = torch.randn((n, h, w, co), device="cuda")
+    outs = []
+    for algo in (1, 2, 0):
+        nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+        dw = ops.z(3, 3, ci, co); db = ops.z(co); dw.fill_(7.0)
+        ops.ck(ops.lib.unet_conv3x3_bwd_weights(ops.h, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, algo, ops.s), f"wgrad algo {algo}")
+        outs.append((dw.clone(), db.clone()))
+    for dw, db in outs[1:]:
+        assert float((dw - outs[0][0]).norm() / (outs[0][0].norm() + 1e-20)) < 3e-5, (n, h, w, ci, co)
+        assert float((db - outs[0][1]).norm() / (outs[0][1].norm() + 1e-20)) < 3e-5, (n, h, w, ci, co)
