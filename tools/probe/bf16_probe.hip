@@ -1,3 +1,6 @@
+// Probe of the three gfx950 facts the bf16 kernels rely on (run once on the box, all reported 0 mismatches):
+//   ds_read_b64_tr_b16 lane/element mapping, the v_mfma_f32_32x32x16_bf16 operand layout, v_cvt_pk_bf16_f32 = round-to-nearest-even.
+// build: hipcc --offload-arch=gfx950 -O2 -o bf16_probe tools/probe/bf16_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
