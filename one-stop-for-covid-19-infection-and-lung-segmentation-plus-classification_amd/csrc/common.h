@@ -43,6 +43,16 @@ struct unet_ctx {
     if (_e != hipSuccess) UNET_FAIL(ctx, UNET_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS, once per (context = device, kernel): the attribute is per device, so a
+// process that drives several devices through several contexts sets it on each.
+static inline int32_t unet_big_lds(unet_ctx* ctx, const void* kernel, size_t bytes, const char* what) {
+  if (ctx->big_lds_kernels.count(kernel)) return UNET_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) UNET_FAIL(ctx, UNET_E_HIP, "%s: cannot reserve %zu bytes of LDS", what, bytes);
+  ctx->big_lds_kernels.insert(kernel);
+  return UNET_OK;
+}
+#define UNET_BIG_LDS(ctx, kern, bytes, what) do { int32_t _r = unet_big_lds(ctx, reinterpret_cast<const void*>(kern), bytes, what); if (_r) return _r; } while (0)
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

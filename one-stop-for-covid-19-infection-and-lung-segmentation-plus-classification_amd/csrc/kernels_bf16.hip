@@ -265,11 +265,7 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
   const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU);
   auto go = [&](auto kern) -> int32_t {
-    const void* kp = reinterpret_cast<const void*>(kern);          // > 64 KiB of dynamic LDS needs an opt-in, once per kernel and device
-    if (smem > 65536 && !ctx->big_lds_kernels.count(kp)) {
-      UNET_HIP(ctx, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      ctx->big_lds_kernels.insert(kp);
-    }
+    if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_bf16");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);
     return UNET_OK;
   };

@@ -702,13 +702,8 @@ int32_t launch_wino2d4(unet_ctx* ctx, const float* x, const float* u, const floa
   const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));
   const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * (CKV + 4)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));
   const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d4_kernel<WTT, false, CKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d4_kernel<WTT, true, CKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d4: cannot reserve %zu bytes of LDS", lds);
-    attr_done = true;
-  }
+  UNET_BIG_LDS(ctx, (conv_wino2d4_kernel<WTT, false, CKV>), lds, "conv_wino2d4");
+  UNET_BIG_LDS(ctx, (conv_wino2d4_kernel<WTT, true, CKV>), lds, "conv_wino2d4");
   if (gen) hipLaunchKernelGGL((conv_wino2d4_kernel<WTT, true, CKV>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
   else hipLaunchKernelGGL((conv_wino2d4_kernel<WTT, false, CKV>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
   UNET_CHECK_LAUNCH(ctx, "conv_wino2d4");
@@ -728,27 +723,16 @@ int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float
   const int breg = breg_env >= 0 ? breg_env : (WC == 2 ? 1 : 0);
   const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * CKP + (breg ? 0 : 16 * CK * TN)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));   // >= the epilogue exchange
   const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
-  static bool attr_done = false;
-  if (!attr_done) {
-    const int big = (int)((size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float));
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
-      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %d bytes of LDS", big);
-    attr_done = true;
+  {
+    const size_t big = (size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float);
+    UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, false, false, 8>), big, "conv_wino2d"); UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, true, false, 8>), big, "conv_wino2d");
+    UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, false, true, 8>), big, "conv_wino2d"); UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, true, true, 8>), big, "conv_wino2d");
   }
   static const int ck16_env = [] { const char* e = getenv("UNET_WINO_CK16"); return e ? atoi(e) : 1; }();
   const bool ck16 = ck16_env && breg && (cin % 16) == 0;
   if (ck16) {
     const size_t lds16 = std::max((size_t)((TH + 2) * 4 * WT * 20) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));
-    static bool attr16 = false;
-    if (!attr16) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, false, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2d_kernel<WTT, WM, WC, true, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess)
-        UNET_FAIL(ctx, UNET_E_HIP, "conv_wino2d: cannot reserve %zu bytes of LDS", lds16);
-      attr16 = true;
-    }
+    UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, false, true, 16>), lds16, "conv_wino2d"); UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, true, true, 16>), lds16, "conv_wino2d");
     if (gen) hipLaunchKernelGGL((conv_wino2d_kernel<WTT, WM, WC, true, true, 16>), grid, dim3(256), lds16, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
     else hipLaunchKernelGGL((conv_wino2d_kernel<WTT, WM, WC, false, true, 16>), grid, dim3(256), lds16, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
     UNET_CHECK_LAUNCH(ctx, "conv_wino2d");
@@ -770,13 +754,7 @@ int32_t launch_wino(unet_ctx* ctx, const float* x, const float* u, const float* 
   const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));       // see the block -> tile map in the kernel
   constexpr size_t lds = (size_t)((TH + 2) * 4 * WT * CKP + 12 * CK * TN) * sizeof(float);
   const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
-  static bool attr_done = false;                     // > 64 KiB of dynamic LDS needs the opt-in (per kernel instance; set both)
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<TN, TH, WR, WC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<TN, TH, WR, WC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      UNET_FAIL(ctx, UNET_E_HIP, "conv_wino: cannot reserve %zu bytes of LDS", lds);
-    attr_done = true;
-  }
+  UNET_BIG_LDS(ctx, (conv_wino_kernel<TN, TH, WR, WC, false>), lds, "conv_wino"); UNET_BIG_LDS(ctx, (conv_wino_kernel<TN, TH, WR, WC, true>), lds, "conv_wino");
   if (gen) hipLaunchKernelGGL((conv_wino_kernel<TN, TH, WR, WC, true>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
   else hipLaunchKernelGGL((conv_wino_kernel<TN, TH, WR, WC, false>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
   UNET_CHECK_LAUNCH(ctx, "conv_wino");
