@@ -317,8 +317,9 @@ int32_t unet_model_run(unet_model*, int32_t prog, int32_t begin, int32_t end, vo
 /* device pointer to float[2] = (loss, dice_coeff) of the last forward with y_true bound */
 const float* unet_model_loss_ptr(const unet_model*);
 /* intermediate activation / gradient taps for tests ("c1a","bn1","p1","u6","cat6",...) */
-int32_t unet_model_tap(const unet_model*, const char* name, int32_t grad, const void** ptr,   /* element type: see unet_model_dtype */
+int32_t unet_model_tap(const unet_model*, const char* name, int32_t grad, const void** ptr,   /* element size: unet_model_tap_elem_bytes */
                        int32_t* ld, int32_t* n, int32_t* h, int32_t* w, int32_t* c);
+int32_t unet_model_tap_elem_bytes(const unet_model*, const char* name, int32_t grad);   /* 4 (float) or 2 (unet_bf16) */
 /* profiling: per-op name and accumulated milliseconds since last reset (profiling on) */
 int32_t unet_model_op_info(const unet_model*, int32_t prog, int32_t op, const char** name,
                            double* flops, double* bytes, double* ms, int64_t* calls);

@@ -102,6 +102,7 @@ _PROTOS = {
     "unet_cls_head_bwd": (i32, [vp, vp, vp, vp, vp, f32, f32, f64, f32, vp, vp, vp, vp, i32, i32, vp]),
     "unet_model_create": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     "unet_model_dtype": (i32, [vp]),
+    "unet_model_tap_elem_bytes": (i32, [vp, C.c_char_p, i32]),
     "unet_model_destroy": (None, [vp]),
     "unet_model_param_count": (i64, [vp]),
     "unet_model_state_count": (i64, [vp]),

@@ -253,7 +253,7 @@ namespace {
 
 struct Layer { std::string name; int kind; int cin, cout; };   // kind 0 conv3, 1 convT, 2 bn, 3 conv1, 4 dense
 struct TInfo { int is_state; int64_t off, count; };
-struct Buf { size_t off = 0; int ld = 0, n = 0, h = 0, w = 0, c = 0; size_t chan_off = 0; };   // float offsets into workspace
+struct Buf { size_t off = 0; int ld = 0, n = 0, h = 0, w = 0, c = 0; size_t chan_off = 0; int f32 = 0; };   // offsets in 4-byte units into the workspace; f32: stays fp32 in bf16-storage mode
 
 struct Op {
   std::string name;
@@ -298,7 +298,8 @@ struct unet_model {
   float* Aw(const std::string& n) const { auto& b = act.at(n); return wsf(b.off + b.chan_off); }
   float* D(const std::string& n) const { auto& b = grad.at(n); return wsf(b.off + b.chan_off); }
   // storage-type-agnostic addresses: buffer offsets are in 4-byte units, channel offsets in elements
-  void* bufptr(const Buf& b) const { return ws + b.off * 4 + b.chan_off * (dt ? 2 : 4); }
+  int elem_bytes(const Buf& b) const { return (dt && !b.f32) ? 2 : 4; }
+  void* bufptr(const Buf& b) const { return ws + b.off * 4 + b.chan_off * elem_bytes(b); }
   void* Av(const std::string& n) const { return bufptr(act.at(n)); }
   void* Dv(const std::string& n) const { return bufptr(grad.at(n)); }
 };
@@ -1075,7 +1076,7 @@ void plan_workspace_cls(unet_model* m) {
     m->act["p" + ks] = mk(cv, N, hh / 2, ww / 2, c);
     hh /= 2; ww /= 2;
   }
-  { Buf b; b.off = cv.take((size_t)N * CLS_HIDDEN); b.ld = b.c = CLS_HIDDEN; b.n = N; b.h = b.w = 1; m->act["h1"] = b; }      // the hidden units stay fp32 in every mode
+  { Buf b; b.off = cv.take((size_t)N * CLS_HIDDEN); b.ld = b.c = CLS_HIDDEN; b.n = N; b.h = b.w = 1; b.f32 = 1; m->act["h1"] = b; }      // the hidden units stay fp32 in every mode
   const int K = hh * ww * CLS_C[2];
   m->dense_ws_bytes = unet_dense_ws_bytes(N, K, CLS_HIDDEN);
   m->off_dense_ws = cv.take((m->dense_ws_bytes + 3) / 4);
@@ -1390,6 +1391,14 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
   if (ptr) *ptr = m->bufptr(b);
   if (ld) *ld = b.ld; if (n) *n = b.n; if (h) *h = b.h; if (w) *w = b.w; if (c) *c = b.c;
   return UNET_OK;
+}
+
+/* bytes per element of a tap (4, or 2 for bf16-stored tensors) */
+int32_t unet_model_tap_elem_bytes(const unet_model* m, const char* name, int32_t grad) {
+  if (!m || !name) return UNET_E_ARG;
+  auto& mp = grad ? m->grad : m->act;
+  auto it = mp.find(name);
+  return it == mp.end() ? UNET_E_ARG : m->elem_bytes(it->second);
 }
 
 int32_t unet_model_op_info(const unet_model* m, int32_t prog, int32_t op, const char** name, double* flops, double* bytes, double* ms,

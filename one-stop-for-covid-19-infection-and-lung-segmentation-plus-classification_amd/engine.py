@@ -264,7 +264,8 @@ class HipUNet:
                                                C.byref(ww), C.byref(cc)), f"tap({name})")
         off = ptr.value - self._ws.data_ptr()
         pix = nn.value * hh.value * ww.value
-        esz, tdt = (2, torch.bfloat16) if (self._dtype_id == _lib.DTYPE_BF16 and name != "h1") else (4, torch.float32)     # the classifier's hidden units stay fp32
+        esz = self.lib.unet_model_tap_elem_bytes(plan["m"], name.encode(), int(grad))
+        tdt = torch.bfloat16 if esz == 2 else torch.float32
         flat = self._ws[off:off + esz * ((pix - 1) * ld.value + cc.value)].view(tdt)
         v = torch.as_strided(flat, (pix, cc.value), (ld.value, 1))
         return v.reshape(nn.value, hh.value, ww.value, cc.value).float().cpu().numpy()
