@@ -273,6 +273,18 @@ int32_t unet_cls_head_bwd(unet_ctx*, const float* h, const float* w, const float
                           double count, float drop_rate, float* dh, float* dw, float* db, float* dbias_prev, int32_t batch, int32_t n,
                           void* stream);
 
+/* ---- image steps in front of the path: byte / integer work, bit-exact against oracle/preprocess_oracle.py ----
+ * Replaces: `img = (img - xmin)/(xmax - xmin)` T1:336-337 + `np.uint8(test_img*255)` T1:165-166 (float64 arithmetic, truncation);
+ *           `cv2.createCLAHE(clipLimit=3.0, tileGridSize=(8,8)).apply(img)` T1:168-169 (OpenCV clahe.cpp restated; cv2 is not in
+ *           this image: parity unpinned); `cts/255` T1:520.  Images are dense [n][h][w] (single channel). */
+size_t unet_pre_minmax_ws_bytes(int32_t n);
+int32_t unet_pre_minmax_to_u8(unet_ctx*, const float* img, uint8_t* out, int32_t n, int64_t pixels_per_image, void* ws, size_t ws_bytes, void* stream);
+int32_t unet_pre_unit_to_u8(unet_ctx*, const float* img, uint8_t* out, int64_t count, void* stream);
+int32_t unet_pre_u8_to_unit(unet_ctx*, const uint8_t* src, float* dst, int64_t count, void* stream);
+size_t unet_pre_clahe_ws_bytes(int32_t n, int32_t tiles_x, int32_t tiles_y);
+int32_t unet_pre_clahe_u8(unet_ctx*, const uint8_t* src, uint8_t* dst, int32_t n, int32_t h, int32_t w, float clip_limit, int32_t tiles_x,
+                          int32_t tiles_y, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Model level.  Replaces the Keras Model built at T1:853-916 and driven by
  * compile/fit/evaluate/predict (T1:1053-1061, 1101, 1137).  A model is a fixed-shape plan:

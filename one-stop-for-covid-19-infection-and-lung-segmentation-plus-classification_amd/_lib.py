@@ -100,6 +100,13 @@ _PROTOS = {
     "unet_cls_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, f32, f32, vp, i32, i32, vp]),
     "unet_cls_loss_finalize": (i32, [vp, vp, f64, vp, vp]),
     "unet_cls_head_bwd": (i32, [vp, vp, vp, vp, vp, f32, f32, f64, f32, vp, vp, vp, vp, i32, i32, vp]),
+    # image steps in front of the path (kernels_pre.hip)
+    "unet_pre_minmax_ws_bytes": (sz, [i32]),
+    "unet_pre_minmax_to_u8": (i32, [vp, vp, vp, i32, i64, vp, sz, vp]),
+    "unet_pre_unit_to_u8": (i32, [vp, vp, vp, i64, vp]),
+    "unet_pre_u8_to_unit": (i32, [vp, vp, vp, i64, vp]),
+    "unet_pre_clahe_ws_bytes": (sz, [i32, i32, i32]),
+    "unet_pre_clahe_u8": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, i32, vp, sz, vp]),
     "unet_model_create": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     "unet_model_dtype": (i32, [vp]),
     "unet_model_tap_elem_bytes": (i32, [vp, C.c_char_p, i32]),
