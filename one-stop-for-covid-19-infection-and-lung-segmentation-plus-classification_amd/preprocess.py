@@ -82,3 +82,11 @@ def u8_to_unit(img_u8):
     out = torch.empty(x.shape, dtype=torch.float32, device="cuda")
     ctx.check(lib.unet_pre_u8_to_unit(ctx.handle, x.data_ptr(), out.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream), "pre_u8_to_unit")
     return out.cpu().numpy()
+
+
+def prepare_cts(raw_slices):
+    """The per-slice chain of read_nii(..., 'cts') without the resize / crop steps (T1:336-337 -> 348 -> 520): min-max normalise,
+    clahe_enhancer, /255.  [N,H,W] raw (e.g. Hounsfield) slices in, [N,H,W,1] float32 in [0,1] out -- the shape the runners take."""
+    u8 = clahe_u8(min_max_to_u8(raw_slices), 3.0, (8, 8))
+    a = u8_to_unit(u8)
+    return a[..., None] if a.ndim == 3 else a[None, ..., None]

@@ -46,3 +46,15 @@ def test_min_max_to_u8_bit_exact(shape):
     for g, im in zip(got, hu):
         assert np.array_equal(g, P.minmax_to_u8(im))
         assert g.min() == 0 and g.max() == 255
+
+
+def test_prepare_cts_chain_matches_the_reference_order_of_operations():
+    """min-max -> clahe_enhancer -> /255 (T1:336-337, 348, 520) composed on the GPU == composed with the CPU restatement"""
+    from covidseg_amd import preprocess as G
+    rng = np.random.default_rng(9)
+    raw = rng.normal(-500, 350, (2, 256, 256)).astype(np.float32)
+    got = G.prepare_cts(raw)
+    assert got.shape == (2, 256, 256, 1) and got.dtype == np.float32
+    for g, im in zip(got[..., 0], raw):
+        a = im.astype(np.float64); mm = (a - a.min()) / (a.max() - a.min())
+        assert np.array_equal(g, P.u8_to_unit(P.clahe_enhancer(mm)))
