@@ -462,7 +462,7 @@ double nel(const Buf& b) { return (double)b.n * b.h * b.w * b.c; }
 
 void build_programs(unet_model* m) {
   unet_ctx* ctx = m->ctx;
-  const int N = m->N, algo = m->algo;
+  const int algo = m->algo;
   const double gcount = (double)m->world;     // multiplies per-rank element counts into global counts
   const int dt = m->dt;
   const double eb = dt ? 2.0 : 4.0;           // bytes per stored activation element (roofline accounting)
