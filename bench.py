@@ -165,8 +165,8 @@ def main():
         # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE; collected offline at
         # this exact workload, calibration inside the file) -- only quoted for the configuration it was measured on
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.dtype == "fp32":
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if args.dtype == "fp32" else "r01_pmc_traffic_bf16.json")
+        if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet":
             traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
         roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
@@ -185,7 +185,8 @@ def main():
             gbs = sum(o[2] for o in dom) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             step_bytes = sum(o[2] for o in ops)
             roof.update({"bound": "hbm", "kernel": "conv3x3 fwd + data-gradient launches: conv_bf16_kernel<0,...> (v_mfma_f32_32x32x16_bf16, direct)",
-                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic_bf16.json)",
                          "mfma_tflops": round(achieved, 1), "mfma_frac_of_bf16_peak": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                          "note": "achieved = algorithmic bytes (activations at 2 B/element, weights 4 B) of these launches / their time; mfma_* = their algorithmic FLOP rate",
                          "step_algorithmic_bytes": round(step_bytes), "step_hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)})

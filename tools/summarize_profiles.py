@@ -39,10 +39,10 @@ def collect(counter):
 def family(name):
     if "conv_wino2d_kernel" in name or "conv_wino2d4_kernel" in name or "conv_wino_kernel" in name:
         return "dom"
-    if "conv_mfma_kernel<0" in name:
+    if "conv_mfma_kernel<0" in name or "conv_bf16_kernel<0" in name:
         return "dom"
     if "bn_apply_kernel" in name:
-        return "bn_apply"
+        return "bn_apply"          # fp32: 8 B per element, bf16 storage: 4 B
     if "adam_kernel" in name:
         return "adam"
     return None
