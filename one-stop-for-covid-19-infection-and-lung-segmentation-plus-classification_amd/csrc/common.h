@@ -161,6 +161,10 @@ int32_t k_conv3x3_wino_wgrad(unet_ctx*, const float* x, const float* dy, float* 
                              int cin, int cout, hipStream_t s);      // kernels_conv_mfma.hip (shares the split-K machinery)
 size_t wino_u_floats(int cin, int cout);
 int32_t k_wino_weights(unet_ctx*, const float* w, float* u, int cin, int cout, int flip, int h, hipStream_t s);
+constexpr int UNET_WINO_PREP_MAX = 40;
+struct unet_wino_prep { const float* w; float* u; int cin, cout, flip, two_d; };
+struct unet_wino_prep_list { unet_wino_prep item[UNET_WINO_PREP_MAX]; int n; };          // passed by value as a kernel argument (1.3 KiB)
+int32_t k_wino_weights_multi(unet_ctx*, unet_wino_prep_list* L, const int* h, hipStream_t s);
 int32_t k_conv3x3_wino_fwd(unet_ctx*, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n,
                            int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,

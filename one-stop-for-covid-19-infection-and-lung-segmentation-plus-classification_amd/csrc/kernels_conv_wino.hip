@@ -33,7 +33,7 @@ constexpr int WT = 32;    // Winograd tiles per MFMA M-tile
 // u[ky][k][ci][co] (12 x Cin' x Cout') from the Keras kernel w[ky][kx][cin][cout].
 // flip = 0: forward (Cin' = cin, Cout' = cout).  flip = 1: data gradient, the convolution of dy with the flipped/transposed
 // kernel g[ky][kx][c'][o'] = w[2-ky][2-kx][o'][c']  (Cin' = cout, Cout' = cin).
-__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int flip, int two_d) {
+__device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int flip, int two_d) {
   const int ci2 = flip ? cout : cin, co2 = flip ? cin : cout;
   const int total = ci2 * co2;
   const long long st = (long long)ci2 * co2;
@@ -68,6 +68,14 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
       }
     }
   }
+}
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int flip, int two_d) {
+  wino_weight_body(w, u, cin, cout, flip, two_d);
+}
+// all layers of a program in ONE launch (blockIdx.y = layer): the per-layer launches were 34 x 6 us of launch latency per step
+__global__ void wino_weight_multi_kernel(unet_wino_prep_list L) {
+  const unet_wino_prep& p = L.item[blockIdx.y];
+  wino_weight_body(p.w, p.u, p.cin, p.cout, p.flip, p.two_d);
 }
 
 template <int TN, int TH, int WR, int WC, bool GEN>
@@ -777,6 +785,20 @@ int wino_tile_cols(int wd) {
   return u32 > 1.1 * u64 ? 32 : 64;
 }
 bool wino_uses_2d(int h, int cout) { return use_2d(h, cout); }
+
+// one launch for several layers: item k = (weights, scratch, cin, cout, flip, image rows) exactly as k_wino_weights takes them
+int32_t k_wino_weights_multi(unet_ctx* ctx, unet_wino_prep_list* L, const int* h, hipStream_t s) {
+  if (L->n < 1) return UNET_OK;
+  long long most = 1;
+  for (int k = 0; k < L->n; ++k) {
+    unet_wino_prep& p = L->item[k];
+    p.two_d = use_2d(h[k], p.flip ? p.cin : p.cout) ? 1 : 0;
+    most = std::max(most, (long long)p.cin * p.cout);
+  }
+  hipLaunchKernelGGL(wino_weight_multi_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 256), (unsigned)L->n), dim3(256), 0, s, *L);
+  UNET_CHECK_LAUNCH(ctx, "wino_weights_multi");
+  return UNET_OK;
+}
 
 // transformed weights for k_conv3x3_wino_fwd on an image of `h` rows (the 2-D form is picked per shape, both sides must agree)
 int32_t k_wino_weights(unet_ctx* ctx, const float* w, float* u, int cin, int cout, int flip, int h, hipStream_t s) {

@@ -83,8 +83,9 @@ static bool use_wino(int algo, int wd, int cin, int cout, const float* uws) {
 // weights [3][3][cout][cin] of the layer and the roles of cin/cout below are already swapped (cin = channels of dy).
 static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                                     float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, int algo,
-                                    hipStream_t s, float* uws = nullptr, int flip = 0) {
+                                    hipStream_t s, float* uws = nullptr, int flip = 0, const float* prepared = nullptr) {
   if (use_wino(algo, wd, cin, cout, uws)) {
+    if (prepared) return k_conv3x3_wino_fwd(ctx, x, prepared, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);     // transformed by the program's batch launch
     int32_t r = flip ? k_wino_weights(ctx, w, uws, cout, cin, 1, h, s) : k_wino_weights(ctx, w, uws, cin, cout, 0, h, s);
     if (r) return r;
     return k_conv3x3_wino_fwd(ctx, x, uws, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
@@ -285,6 +286,8 @@ struct unet_model {
   size_t off_bn_bsums = 0;                            // all bwd BN sums (double)
   std::map<std::string, size_t> bn_sum_off, bn_bsum_off, bnp_off;   // per-BN offsets (doubles / floats)
   size_t off_loss_sums = 0, off_loss_out = 0, off_wt = 0, off_wgrad_ws = 0; size_t wgrad_ws_bytes = 0;
+  std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the Winograd-transformed weights (forward / data-gradient form),
+                                                      // filled by ONE batched launch at the start of a program
   std::vector<Op> prog[3];
   std::vector<unet_sync_point> sync[3];
   struct SyncRef { int after_op, kind; bool in_ws; size_t off_bytes; int64_t count; };
@@ -401,7 +404,9 @@ void plan_workspace(unet_model* m) {
     m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
   }
   { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)16 * l.cin * l.cout); m->off_wt = cv.take(wt); }   // transformed-weight scratch
+  if (!m->dt) for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take((size_t)16 * l.cin * l.cout);
   m->ws_floats_infer = cv.cur;
+  if (!m->dt) for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take((size_t)16 * l.cin * l.cout);
   // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
     const std::string& nm = kv.first; const Buf& b = kv.second;
@@ -472,12 +477,28 @@ void build_programs(unet_model* m) {
   auto& FI = m->prog[UNET_PROG_FWD_INFER];
   auto& BW = m->prog[UNET_PROG_BWD];
   const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
+  // layers whose 3x3 weights the Winograd kernels consume (decided per layer by use_wino exactly as the conv dispatch does)
+  struct PrepItem { std::string name; int cin, cout, h, w; };
+  std::vector<PrepItem> prep_items;
+  if (!dt) for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) { const Buf& ob = m->act.at(l.name); prep_items.push_back({l.name, l.cin, l.cout, ob.h, ob.w}); }
+  auto prep_weights = [=](int flip, hipStream_t s) -> int32_t {
+    unet_wino_prep_list L; L.n = 0; int hs[UNET_WINO_PREP_MAX];
+    for (auto& it : prep_items) {
+      const int ci = flip ? it.cout : it.cin, co = flip ? it.cin : it.cout;          // channels the launch consumes / produces
+      if (flip && it.name == "c1a") continue;
+      if (!use_wino(algo, it.w, ci, co, m->wsf(m->off_wt)) || L.n >= UNET_WINO_PREP_MAX) continue;
+      L.item[L.n] = {m->P(it.name + "/kernel"), m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)), it.cin, it.cout, flip, 0};
+      hs[L.n++] = it.h;
+    }
+    return k_wino_weights_multi(ctx, &L, hs, s);
+  };
 
   // ------------------------------------------------------------------ forward (train / infer)
   for (int training = 1; training >= 0; --training) {
     auto& F = training ? FT : FI;
     auto& SY = m->syncref[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
     ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
+    if (!dt) ADD_OP(F, "wino_weights:fwd", 0, 0, { return prep_weights(0, s); });       // all Winograd weight transforms of the program in one launch
     auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
       const Buf ob = m->act.at(name);
       double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
@@ -489,8 +510,9 @@ void build_programs(unet_model* m) {
                                     0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
         }
         const float* xin = in.empty() ? m->x : m->A(in);
+        const auto pf = m->wprep_f.find(name);
         return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
-                                    ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0);
+                                    ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second));
       });
     };
     auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c, bool fuse_pool) {
@@ -581,6 +603,7 @@ void build_programs(unet_model* m) {
     });
     const Buf hb = m->act.at("c9b");
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
+    if (!dt) ADD_OP(BW, "wino_weights:bwd", 0, 0, { return prep_weights(1, s); });
     ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, hp * (eb * 64 + 8.0), {
       if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
       if (dt) return unet_head_bwd_bf16(ctx, CBF(m->Av("c9b")), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, WBF(m->Dv("c9b")),
@@ -606,8 +629,9 @@ void build_programs(unet_model* m) {
         ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? cin : 0)) + 4.0 * 9.0 * cin * cout, {
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mask_in ? CBF(m->Av(in)) : nullptr, mask_in ? MASK_RELU : MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h,
                                             ob.w, cout, cin, ACT_NONE, 0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
-          return unet_conv3x3_bwd_data(ctx, m->D(name), m->P(name + "/kernel"), mask_in ? m->A(in) : nullptr, mask_in ? MASK_RELU : MASK_NONE, 0.0f, 0, m->D(in),
-                                       m->wsf(m->off_wt), ob.n, ob.h, ob.w, cin, cout, algo, s);
+          const auto pb = m->wprep_b.find(name);
+          return conv3x3_fwd_dispatch(ctx, m->D(name), m->P(name + "/kernel"), nullptr, mask_in ? m->A(in) : nullptr, mask_in ? MASK_RELU : MASK_NONE, m->D(in), ob.n, ob.h,
+                                      ob.w, cout, cin, ACT_NONE, 0.0f, 0, algo, s, m->wsf(m->off_wt), 1, pb == m->wprep_b.end() ? nullptr : m->wsf(pb->second));
         });
       }
     };
