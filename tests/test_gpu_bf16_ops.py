@@ -186,3 +186,31 @@ def test_full_size_bf16_conv_agrees_with_the_fp32_kernels(ops, shape):
     ops.ck(ops.lib.unet_conv3x3_bwd_weights_bf16(ops.h, xb.data_ptr(), dyb.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ci, co, ops.s), "wgrad bf16")
     ops.ck(ops.lib.unet_conv3x3_bwd_weights(ops.h, x32.data_ptr(), dy32.data_ptr(), dwr.data_ptr(), dbr.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, ci, co, 2, ops.s), "wgrad fp32")
     assert float((dw - dwr).norm() / dwr.norm()) < F32_OUT and float((db - dbr).norm() / dbr.norm()) < F32_OUT
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40, 32, 64), (1, 16, 16, 64, 32)])
+def test_bf16_general_epilogue_elu_dropout_and_masks_agree_with_fp32_kernels(ops, shape):
+    """U-Net++ epilogue variants of the bf16 conv (ELU, fused Philox dropout, ELU / ELU+dropout data-gradient masks) against the fp32
+    kernels on the same bf16-exact inputs: the keep decisions must be IDENTICAL (the counter RNG indexes elements, not bytes)."""
+    n, h, w, ci, co = shape
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xb = torch.randn((n, h, w, ci), device="cuda", generator=g).bfloat16(); kb = (torch.randn((3, 3, ci, co), device="cuda", generator=g) * 0.15).bfloat16().float()
+    b = torch.randn(co, device="cuda", generator=g) * 0.1
+    for rate, seed in ((0.0, 0), (0.4, 1234)):
+        y = ops.z(n, h, w, co, dtype=torch.bfloat16); yr = ops.z(n, h, w, co)
+        ops.ck(ops.lib.unet_conv3x3_fwd_bf16(ops.h, xb.data_ptr(), kb.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 2, rate, seed, ops.wws(ci, co), ops.s), "fwd elu bf16")
+        x32 = xb.float()
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, x32.data_ptr(), kb.data_ptr(), b.data_ptr(), yr.data_ptr(), n, h, w, ci, co, 2, rate, seed, 2, None, ops.s), "fwd elu fp32")
+        assert torch.equal(y == 0, yr == 0) or rate == 0.0                     # same dropped elements
+        assert float((y.float() - yr).norm() / yr.norm()) < BF16_OUT
+        # data gradient through this layer's input side: mask = stored (dropped-out) ELU output of the producer
+        dyb = torch.randn((n, h, w, co), device="cuda", generator=g).bfloat16()
+        mode = 3 if rate > 0 else 2                                             # MASK_ELU_DROP / MASK_ELU
+        # the mask tensor must be a valid output of the same epilogue: reuse y of a conv whose output has `ci` channels
+        mb = ops.z(n, h, w, ci, dtype=torch.bfloat16); k2 = (torch.randn((3, 3, ci, ci), device="cuda", generator=g) * 0.15).bfloat16().float()
+        ops.ck(ops.lib.unet_conv3x3_fwd_bf16(ops.h, xb.data_ptr(), k2.data_ptr(), None, mb.data_ptr(), n, h, w, ci, ci, 2, rate, seed + 7, ops.wws(ci, ci), ops.s), "mask producer")
+        dx = ops.z(n, h, w, ci, dtype=torch.bfloat16); dxr = ops.z(n, h, w, ci)
+        ops.ck(ops.lib.unet_conv3x3_bwd_data_bf16(ops.h, dyb.data_ptr(), kb.data_ptr(), mb.data_ptr(), mode, rate, seed + 7, dx.data_ptr(), ops.wws(ci, co), n, h, w, ci, co, ops.s), "dgrad bf16")
+        dy32, m32, wt = dyb.float(), mb.float(), ops.z(16 * ci * co)          # keep the fp32 copies alive: the C ABI only sees raw pointers
+        ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, dy32.data_ptr(), kb.data_ptr(), m32.data_ptr(), mode, rate, seed + 7, dxr.data_ptr(), wt.data_ptr(), n, h, w, ci, co, 2, ops.s), "dgrad fp32")
+        assert float((dx.float() - dxr).norm() / dxr.norm()) < BF16_OUT
