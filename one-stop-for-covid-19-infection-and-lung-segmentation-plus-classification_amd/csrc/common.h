@@ -204,7 +204,11 @@ bool bf16_conv3x3_supported(int cin, int cout);
 bool bf16_convT_supported(int cin, int cout);
 bool bf16_wgrad_supported(int ca, int cb);
 int32_t k_conv3x3_bf16_fwd(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, const unet_bf16* mask, int mask_mode, unet_bf16* y, int n, int h,
-                           int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s);
+                           int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s,
+                           const unet_bf16* prepared = nullptr);
+struct unet_wimg_prep { const float* w; unet_bf16* img; long long tap_stride, sk, sm, total8; int nb, nchunks, flip, m; };
+struct unet_wimg_prep_list { unet_wimg_prep item[UNET_WINO_PREP_MAX]; int n; };       // passed by value as a kernel argument (2.2 KiB)
+int32_t k_wimg_multi(unet_ctx*, unet_wimg_prep_list* L, const int* cin, const int* cout, hipStream_t s);
 int32_t k_convT_bf16_fwd(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int ldy, int n, int h, int wd, int cin, int cout,
                          unet_bf16* wimg, hipStream_t s);
 int32_t k_convT_bf16_dgrad(unet_ctx*, const unet_bf16* dy, int lddy, const float* w, const unet_bf16* mask, unet_bf16* dx, int n, int h, int wd, int cin,

@@ -32,8 +32,8 @@ __host__ __device__ inline int cperm(int m) { return ((m >> 2) & 1) * 16 + (m & 
 // weight image: img[(((((g*nchunks + chunk)*KS + ks)*T + tap)*NB + nb)*2 + half)*32 + m][j] = W(tap, k, mm)
 //   k = (chunk*KS + ks)*16 + half*8 + j,  mm = (g*NB + nb)*32 + cperm(m),  W(tap,k,mm) = w[tap_base(tap) + k*sk + mm*sm]
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wimg_kernel(const float* __restrict__ w, unet_bf16* __restrict__ img, int T, int KS, int NB, int nchunks,
-                                                   long long tap_stride, int tap_flip, long long sk, long long sm, long long total8, int M) {
+__device__ __forceinline__ void wimg_body(const float* __restrict__ w, unet_bf16* __restrict__ img, int T, int KS, int NB, int nchunks,
+                                          long long tap_stride, int tap_flip, long long sk, long long sm, long long total8, int M) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long long)gridDim.x * 256) {
     long long r = e;
     const int m = (int)(r & 31); r >>= 5;
@@ -50,6 +50,15 @@ __global__ __launch_bounds__(256) void wimg_kernel(const float* __restrict__ w, 
     for (int j = 0; j < 8; ++j) v[j] = mm < M ? src[j * sk] : 0.0f;          // rows past M (a 32-row tile of a 16-channel layer) are zero
     *reinterpret_cast<uint4*>(img + e * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
   }
+}
+__global__ __launch_bounds__(256) void wimg_kernel(const float* __restrict__ w, unet_bf16* __restrict__ img, int T, int KS, int NB, int nchunks,
+                                                   long long tap_stride, int tap_flip, long long sk, long long sm, long long total8, int M) {
+  wimg_body(w, img, T, KS, NB, nchunks, tap_stride, tap_flip, sk, sm, total8, M);
+}
+// the weight images of all conv3x3 layers of a program in ONE launch (blockIdx.y = layer)
+__global__ __launch_bounds__(256) void wimg_multi_kernel(unet_wimg_prep_list L) {
+  const unet_wimg_prep& p = L.item[blockIdx.y];
+  wimg_body(p.w, p.img, 9, 1, p.nb, p.nchunks, p.tap_stride, p.flip, p.sk, p.sm, p.total8, p.m);
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -292,23 +301,49 @@ int32_t make_wimg(unet_ctx* ctx, const float* w, unet_bf16* img, int T, int KS, 
 bool bf16_conv3x3_supported(int cin, int cout) { return cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0; }
 bool bf16_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0; }
 
+static void bf16_conv_tile(int cout, int* NB, int* RW) {       // see the tile-choice note in k_conv3x3_bf16_fwd
+  static const int force = [] { const char* e = getenv("UNET_BF16_TILE"); return e ? atoi(e) : 0; }();
+  static const int narrow_max = [] { const char* e = getenv("UNET_BF16_NARROW_MAX"); return e ? atoi(e) : 32; }();
+  *NB = (cout % 64) == 0 ? 2 : 1; *RW = 4;
+  if (cout <= narrow_max) { *NB = 1; *RW = 2; }
+  if (force) { *NB = force / 10; *RW = force % 10; if ((cout % 64) != 0) *NB = 1; }
+}
+
+// item k: weights w (the layer's forward kernel), image scratch, (cin, cout) as k_conv3x3_bf16_fwd takes them (already swapped for flip = 1)
+int32_t k_wimg_multi(unet_ctx* ctx, unet_wimg_prep_list* L, const int* cin, const int* cout, hipStream_t s) {
+  if (L->n < 1) return UNET_OK;
+  long long most = 1;
+  for (int k = 0; k < L->n; ++k) {
+    unet_wimg_prep& p = L->item[k];
+    int NB, RW; bf16_conv_tile(cout[k], &NB, &RW);
+    p.nb = NB; p.nchunks = cin[k] / 16; p.m = cout[k];
+    const int groups = (cout[k] + 32 * NB - 1) / (32 * NB);
+    p.total8 = (long long)groups * p.nchunks * 9 * NB * 2 * 32;
+    p.tap_stride = (long long)cin[k] * cout[k];
+    if (!p.flip) { p.sk = cout[k]; p.sm = 1; } else { p.sk = 1; p.sm = cin[k]; }
+    most = std::max(most, p.total8);
+  }
+  hipLaunchKernelGGL(wimg_multi_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 512), (unsigned)L->n), dim3(256), 0, s, *L);
+  UNET_CHECK_LAUNCH(ctx, "wimg_multi");
+  return UNET_OK;
+}
+
 // forward (flip = 0, w = [3][3][cin][cout]) or data gradient (flip = 1: w = the layer's forward weights [3][3][cout][cin], x = dy with
 // `cin` channels, y = dx with `cout` channels).  wimg: scratch of >= 9*cin*cout bf16.
 int32_t k_conv3x3_bf16_fwd(unet_ctx* ctx, const unet_bf16* x, const float* w, const float* bias, const unet_bf16* mask, int mask_mode, unet_bf16* y,
-                           int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s) {
+                           int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s,
+                           const unet_bf16* prepared) {
   if (!bf16_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 bf16: cin=%d cout=%d unsupported (multiples of 16)", cin, cout);
   // tile choice.  Wide layers (>= 128 output channels) are MFMA / LDS bound: 64-channel x 16-row tiles (most operand reuse, 2 workgroups
   // per CU).  32-channel layers are short-K and HBM bound: 32-channel x 8-row tiles need 40 KB of LDS and 89 registers, so 4 workgroups
   // per CU hide the load latency of each other's prologues (c1b / c9b: -15 %; 64-channel layers measured neutral to worse).  UNET_BF16_TILE = "<nb><rw>" overrides (measurements).
-  static const int force = [] { const char* e = getenv("UNET_BF16_TILE"); return e ? atoi(e) : 0; }();
-  static const int narrow_max = [] { const char* e = getenv("UNET_BF16_NARROW_MAX"); return e ? atoi(e) : 32; }();
-  int NB = (cout % 64) == 0 ? 2 : 1, RW = 4;
-  if (cout <= narrow_max) { NB = 1; RW = 2; }
-  if (force) { NB = force / 10; RW = force % 10; if ((cout % 64) != 0) NB = 1; }
-  int32_t r;
-  if (!flip) r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 0, cout, 1, s);
-  else r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 1, 1, cin, s);      // W(tap,k,m) = w_f[8-tap][m][k], row length = cout_f = cin here
-  if (r) return r;
+  int NB, RW; bf16_conv_tile(cout, &NB, &RW);
+  if (!prepared) {
+    int32_t r;
+    if (!flip) r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 0, cout, 1, s);
+    else r = make_wimg(ctx, w, wimg, 9, 1, NB, cin, cout, (long long)cin * cout, 1, 1, cin, s);      // W(tap,k,m) = w_f[8-tap][m][k], row length = cout_f = cin here
+    if (r) return r;
+  } else wimg = const_cast<unet_bf16*>(prepared);          // laid out by k_wimg_multi at the start of the program
   if (NB == 2 && RW == 4) return launch_conv_bf16<0, 2, 4>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
   if (NB == 2) return launch_conv_bf16<0, 2, 2>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);
   if (RW == 4) return launch_conv_bf16<0, 1, 4>(ctx, x, cin, wimg, bias, mask, mask_mode, y, cout, n, h, wd, cin, cout, act, rate, seed, s);

@@ -404,9 +404,10 @@ void plan_workspace(unet_model* m) {
     m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
   }
   { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)16 * l.cin * l.cout); m->off_wt = cv.take(wt); }   // transformed-weight scratch
-  if (!m->dt) for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take((size_t)16 * l.cin * l.cout);
+  // per-layer scratch of the prepared weights: 16 Winograd taps (fp32) or the 9-tap bf16 image
+  for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
   m->ws_floats_infer = cv.cur;
-  if (!m->dt) for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take((size_t)16 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
   // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
     const std::string& nm = kv.first; const Buf& b = kv.second;
@@ -480,7 +481,16 @@ void build_programs(unet_model* m) {
   // layers whose 3x3 weights the Winograd kernels consume (decided per layer by use_wino exactly as the conv dispatch does)
   struct PrepItem { std::string name; int cin, cout, h, w; };
   std::vector<PrepItem> prep_items;
-  if (!dt) for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) { const Buf& ob = m->act.at(l.name); prep_items.push_back({l.name, l.cin, l.cout, ob.h, ob.w}); }
+  for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) { const Buf& ob = m->act.at(l.name); prep_items.push_back({l.name, l.cin, l.cout, ob.h, ob.w}); }
+  auto prep_weights_bf16 = [=](int flip, hipStream_t s) -> int32_t {          // bf16 storage: the MFMA weight images of all conv3x3 layers
+    unet_wimg_prep_list L; L.n = 0; int ci[UNET_WINO_PREP_MAX], co[UNET_WINO_PREP_MAX];
+    for (auto& it : prep_items) {
+      if (L.n >= UNET_WINO_PREP_MAX) break;
+      L.item[L.n] = unet_wimg_prep{m->P(it.name + "/kernel"), static_cast<unet_bf16*>(static_cast<void*>(m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)))), 0, 0, 0, 0, 0, 0, flip, 0};
+      ci[L.n] = flip ? it.cout : it.cin; co[L.n] = flip ? it.cin : it.cout; ++L.n;
+    }
+    return k_wimg_multi(ctx, &L, ci, co, s);
+  };
   auto prep_weights = [=](int flip, hipStream_t s) -> int32_t {
     unet_wino_prep_list L; L.n = 0; int hs[UNET_WINO_PREP_MAX];
     for (auto& it : prep_items) {
@@ -499,6 +509,7 @@ void build_programs(unet_model* m) {
     auto& SY = m->syncref[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
     ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
     if (!dt) ADD_OP(F, "wino_weights:fwd", 0, 0, { return prep_weights(0, s); });       // all Winograd weight transforms of the program in one launch
+    else ADD_OP(F, "weight_images:fwd", 0, 0, { return prep_weights_bf16(0, s); });
     auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
       const Buf ob = m->act.at(name);
       double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
@@ -507,7 +518,7 @@ void build_programs(unet_model* m) {
         if (dt) {
           if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_RELU, 0.0f, 0, s);
           return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU,
-                                    0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
+                                    0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s, CBF(static_cast<void*>(m->wsf(m->wprep_f.at(name)))));
         }
         const float* xin = in.empty() ? m->x : m->A(in);
         const auto pf = m->wprep_f.find(name);
@@ -604,6 +615,7 @@ void build_programs(unet_model* m) {
     const Buf hb = m->act.at("c9b");
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
     if (!dt) ADD_OP(BW, "wino_weights:bwd", 0, 0, { return prep_weights(1, s); });
+    else ADD_OP(BW, "weight_images:bwd", 0, 0, { return prep_weights_bf16(1, s); });
     ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, hp * (eb * 64 + 8.0), {
       if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
       if (dt) return unet_head_bwd_bf16(ctx, CBF(m->Av("c9b")), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, WBF(m->Dv("c9b")),
@@ -628,7 +640,7 @@ void build_programs(unet_model* m) {
       if (want_dx) {
         ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? cin : 0)) + 4.0 * 9.0 * cin * cout, {
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mask_in ? CBF(m->Av(in)) : nullptr, mask_in ? MASK_RELU : MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h,
-                                            ob.w, cout, cin, ACT_NONE, 0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
+                                            ob.w, cout, cin, ACT_NONE, 0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s, CBF(static_cast<void*>(m->wsf(m->wprep_b.at(name)))));
           const auto pb = m->wprep_b.find(name);
           return conv3x3_fwd_dispatch(ctx, m->D(name), m->P(name + "/kernel"), nullptr, mask_in ? m->A(in) : nullptr, mask_in ? MASK_RELU : MASK_NONE, m->D(in), ob.n, ob.h,
                                       ob.w, cout, cin, ACT_NONE, 0.0f, 0, algo, s, m->wsf(m->off_wt), 1, pb == m->wprep_b.end() ? nullptr : m->wsf(pb->second));
