@@ -673,9 +673,6 @@ __global__ __launch_bounds__(256, 4) void wgrad_wino2d_kernel(const float* __res
     const float* rp = s_x + ((2 * s + rowP) & 3) * ROW + l31 * PIT + 2 * hi;
     const float* rq = s_x + ((2 * s + rowQ) & 3) * ROW + l31 * PIT + 2 * hi;
     const float* ys = s_y + w * ROW + l31 * PIT + 2 * hi;    // this wave's dY combination (xi = 3 reads +dy1: its sign is applied by the final reduction)
-#ifdef UNET_IGLP_WG2D
-    __builtin_amdgcn_iglp_opt(UNET_IGLP_WG2D - 1);
-#endif
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {                       // MFMA k-pair = tiles 2pp (lanes 0-31) and 2pp+1 (lanes 32-63)
       const float2 p01 = *reinterpret_cast<const float2*>(rp + 4 * pp), p23 = *reinterpret_cast<const float2*>(rp + 4 * pp + 2);

@@ -617,9 +617,6 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
     __syncthreads();
     if (c0 + CKV < Cin) issue_loads(c0 + CKV);
     __builtin_amdgcn_s_setprio(2);
-#ifdef UNET_IGLP_W2D4
-    __builtin_amdgcn_iglp_opt(UNET_IGLP_W2D4 - 1);
-#endif
 #pragma unroll
     for (int sub = 0; sub < CKV / 8; ++sub) {
       const int cb = c0 + sub * 8;
