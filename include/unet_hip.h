@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 5
+#define UNET_ABI_VERSION 6
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -284,6 +284,15 @@ int32_t unet_pre_u8_to_unit(unet_ctx*, const uint8_t* src, float* dst, int64_t c
 size_t unet_pre_clahe_ws_bytes(int32_t n, int32_t tiles_x, int32_t tiles_y);
 int32_t unet_pre_clahe_u8(unet_ctx*, const uint8_t* src, uint8_t* dst, int32_t n, int32_t h, int32_t w, float clip_limit, int32_t tiles_x,
                           int32_t tiles_y, void* ws, size_t ws_bytes, void* stream);
+/* cv2.resize on uint8 crops (OpenCV resize.cpp, 8-bit path, restated: parity unpinned).  Replaces
+ *   `cv2.resize(img[y:y+h, x:x+w], dsize=(125,250), interpolation=cv2.INTER_AREA)`  T1:235-238, 354-357, 364-367  (interp = 3)
+ *   `cv2.resize(cts[i], dsize=(new_dim,new_dim), interpolation=cv2.INTER_LINEAR)`    T1:486-488                     (interp = 1)
+ * src: dense [n][sh][sw]; rects: HOST array [n][4] = (x, y, w, h) per image in cv2.boundingRect order, or NULL for the whole image;
+ * image i is written to the dh x dw window at column dst_x0 of dst[i] (rows of dst_ld bytes), so the two lung crops of a slice
+ * land side by side without a concatenate (T1:358).  Interpolation values are cv2's (INTER_LINEAR = 1, INTER_AREA = 3). */
+enum { UNET_RESIZE_LINEAR = 1, UNET_RESIZE_AREA = 3 };
+int32_t unet_pre_resize_u8(unet_ctx*, const uint8_t* src, int32_t n, int32_t sh, int32_t sw, const int32_t* rects, uint8_t* dst, int32_t dh,
+                           int32_t dw, int32_t dst_ld, int32_t dst_x0, int32_t interp, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Model level.  Replaces the Keras Model built at T1:853-916 and driven by

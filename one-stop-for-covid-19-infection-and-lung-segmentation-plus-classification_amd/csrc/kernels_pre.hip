@@ -117,6 +117,91 @@ __global__ __launch_bounds__(TPB) void clahe_blend_kernel(const uint8_t* __restr
 }
 
 inline unsigned blocks_for(long long items, int cap) { long long b = (items + TPB - 1) / TPB; return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b)); }
+// ---- cv2.resize on uint8 crops (resize.cpp hal::resize, 8-bit single channel), one thread per destination pixel ------------------------
+// Every thread rebuilds the few table entries it needs (OpenCV precomputes them per row / column): same doubles, same float32
+// operations in the same order, so the result is the bit pattern oracle/preprocess_oracle.py:resize_u8 produces.
+constexpr int RESIZE_RECTS = 96;                                   // rectangles per launch, passed by value
+struct resize_rects { int x[RESIZE_RECTS], y[RESIZE_RECTS], w[RESIZE_RECTS], h[RESIZE_RECTS]; };
+
+// computeResizeAreaTab for one destination index: optional partial cell on the left (s1 - 1), full cells [s1, s2), optional partial on the right (s2)
+struct area_span { int s1, s2; float a_left, a_mid, a_right; bool left, right; };
+__device__ __forceinline__ area_span area_cells(int d, double scale, int ssize) {
+  area_span r;
+  const double f1 = d * scale, f2 = f1 + scale;
+  const double cell = fmin(scale, ssize - f1);
+  int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+  s2 = min(s2, ssize - 1);
+  s1 = min(s1, s2);
+  r.s1 = s1; r.s2 = s2;
+  r.left = (s1 - f1) > 1e-3;
+  r.a_left = (float)((s1 - f1) / cell);
+  r.a_mid = (float)(1.0 / cell);
+  r.right = (f2 - s2) > 1e-3;
+  r.a_right = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell);
+  return r;
+}
+__device__ __forceinline__ int sat_short(float v) { return max(-32768, min(32767, __float2int_rn(v))); }
+// the bilinear coefficient pair of one destination index (INTER_RESIZE_COEF_BITS = 11); `clamp` = the x-axis treatment of the borders
+__device__ __forceinline__ void linear_coef(int d, int ssize, double scale, double inv_scale, bool area_mode, bool clamp, int* so, int* c0, int* c1) {
+  int s; float f;
+  if (!area_mode) { f = (float)((d + 0.5) * scale - 0.5); s = (int)floorf(f); f = f - (float)s; }
+  else { s = (int)floor(d * scale); f = (float)((d + 1) - (s + 1) * inv_scale); f = f <= 0.f ? 0.f : f - floorf(f); }
+  if (clamp) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  }
+  *so = s; *c0 = sat_short((1.f - f) * 2048.f); *c1 = sat_short(f * 2048.f);
+}
+
+__global__ __launch_bounds__(TPB) void resize_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, resize_rects rc, int img0, uint8_t* __restrict__ dst, int dh,
+                                                       int dw, int dst_ld, int dst_x0, int interp) {
+  const int li = blockIdx.y;
+  const int rx = rc.x[li], ry = rc.y[li], rw = rc.w[li], rh = rc.h[li];
+  const int idx = blockIdx.x * TPB + threadIdx.x;
+  if (idx >= dh * dw) return;
+  const int dy = idx / dw, dx = idx - dy * dw;
+  const uint8_t* S = src + (long long)(img0 + li) * sh * sw + (long long)ry * sw + rx;
+  const double inv_x = (double)dw / rw, inv_y = (double)dh / rh;
+  const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;
+  const int isx = (int)rint(scale_x), isy = (int)rint(scale_y);
+  const bool fast = fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16;
+  if (interp == UNET_RESIZE_LINEAR && fast && isx == 2 && isy == 2) interp = UNET_RESIZE_AREA;
+  int out;
+  if (interp == UNET_RESIZE_AREA && scale_x >= 1.0 && scale_y >= 1.0) {
+    if (fast) {
+      int sum = 0;
+      for (int ky = 0; ky < isy; ++ky)
+        for (int kx = 0; kx < isx; ++kx) sum += S[(long long)(dy * isy + ky) * sw + dx * isx + kx];
+      out = __float2int_rn((float)sum * (1.f / (float)(isx * isy)));
+    } else {
+      const area_span xs = area_cells(dx, scale_x, rw), ys = area_cells(dy, scale_y, rh);
+      float acc = 0.f; bool first = true;
+      const int y_lo = ys.left ? ys.s1 - 1 : ys.s1, y_hi = ys.right ? ys.s2 : ys.s2 - 1;
+      for (int sy = y_lo; sy <= y_hi; ++sy) {
+        const float beta = (sy < ys.s1) ? ys.a_left : (sy < ys.s2 ? ys.a_mid : ys.a_right);
+        const uint8_t* row = S + (long long)sy * sw;
+        float buf = 0.f;
+        if (xs.left) buf = buf + (float)row[xs.s1 - 1] * xs.a_left;
+        for (int sx = xs.s1; sx < xs.s2; ++sx) buf = buf + (float)row[sx] * xs.a_mid;
+        if (xs.right) buf = buf + (float)row[xs.s2] * xs.a_right;
+        acc = first ? beta * buf : acc + beta * buf;
+        first = false;
+      }
+      out = __float2int_rn(acc);
+    }
+  } else {
+    const bool area_mode = interp == UNET_RESIZE_AREA;
+    int sx, a0, a1, sy, b0, b1;
+    linear_coef(dx, rw, scale_x, inv_x, area_mode, true, &sx, &a0, &a1);
+    linear_coef(dy, rh, scale_y, inv_y, area_mode, false, &sy, &b0, &b1);
+    const int x1 = min(sx + 1, rw - 1);
+    const int r0 = max(0, min(sy, rh - 1)), r1 = max(0, min(sy + 1, rh - 1));
+    const uint8_t* p0 = S + (long long)r0 * sw; const uint8_t* p1 = S + (long long)r1 * sw;
+    const int h0 = p0[sx] * a0 + p0[x1] * a1, h1 = p1[sx] * a0 + p1[x1] * a1;
+    out = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+  }
+  dst[(long long)(img0 + li) * dh * dst_ld + (long long)dy * dst_ld + dst_x0 + dx] = (uint8_t)max(0, min(255, out));
+}
 }  // namespace
 
 extern "C" {
@@ -165,6 +250,30 @@ int32_t unet_pre_clahe_u8(unet_ctx* ctx, const uint8_t* src, uint8_t* dst, int32
   hipLaunchKernelGGL(clahe_blend_kernel, dim3(blocks_for((long long)n * h * w, 4096)), dim3(TPB), 0, s, src, lut, dst, n, h, w, tiles_x, tiles_y, 1.0f / (float)tw,
                      1.0f / (float)th);
   UNET_CHECK_LAUNCH(ctx, "pre_clahe_u8"); return UNET_OK;
+}
+
+int32_t unet_pre_resize_u8(unet_ctx* ctx, const uint8_t* src, int32_t n, int32_t sh, int32_t sw, const int32_t* rects, uint8_t* dst, int32_t dh, int32_t dw,
+                           int32_t dst_ld, int32_t dst_x0, int32_t interp, void* stream) {
+  if (!ctx || !src || !dst || n < 1 || sh < 1 || sw < 1 || dh < 1 || dw < 1 || dst_x0 < 0 || dst_ld < dst_x0 + dw) UNET_FAIL(ctx, UNET_E_ARG, "pre_resize_u8: bad args");
+  if (interp != UNET_RESIZE_LINEAR && interp != UNET_RESIZE_AREA) UNET_FAIL(ctx, UNET_E_ARG, "pre_resize_u8: interpolation %d (only INTER_LINEAR = 1 and INTER_AREA = 3)", interp);
+  if ((long long)dh * dw > 0x7FFFFFFFLL) UNET_FAIL(ctx, UNET_E_SHAPE, "pre_resize_u8: destination too large");
+  for (int i = 0; rects && i < n; ++i) {                             // rects is a HOST array: x, y, w, h per image (cv2.boundingRect order)
+    const int32_t* r = rects + 4 * i;
+    if (r[0] < 0 || r[1] < 0 || r[2] < 1 || r[3] < 1 || (long long)r[0] + r[2] > sw || (long long)r[1] + r[3] > sh)
+      UNET_FAIL(ctx, UNET_E_SHAPE, "pre_resize_u8: rectangle %d = (%d, %d, %d, %d) is empty or leaves the %d x %d image", i, r[0], r[1], r[2], r[3], sh, sw);
+  }
+  hipStream_t s = as_stream(stream);
+  for (int i0 = 0; i0 < n; i0 += RESIZE_RECTS) {
+    const int cnt = (n - i0) < RESIZE_RECTS ? (n - i0) : RESIZE_RECTS;
+    resize_rects rc;
+    for (int i = 0; i < cnt; ++i) {
+      if (rects) { const int32_t* r = rects + 4 * (i0 + i); rc.x[i] = r[0]; rc.y[i] = r[1]; rc.w[i] = r[2]; rc.h[i] = r[3]; }
+      else { rc.x[i] = 0; rc.y[i] = 0; rc.w[i] = sw; rc.h[i] = sh; }
+    }
+    hipLaunchKernelGGL(resize_u8_kernel, dim3((unsigned)(((long long)dh * dw + TPB - 1) / TPB), (unsigned)cnt), dim3(TPB), 0, s, src, sh, sw, rc, i0, dst, dh, dw, dst_ld,
+                       dst_x0, interp);
+  }
+  UNET_CHECK_LAUNCH(ctx, "pre_resize_u8"); return UNET_OK;
 }
 
 }  // extern "C"

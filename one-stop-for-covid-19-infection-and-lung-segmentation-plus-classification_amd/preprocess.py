@@ -4,9 +4,12 @@
     img = (img - xmin)/(xmax - xmin)                         T1:336-337   -> min_max_normalize / min_max_to_u8
     clahe_enhancer(test_img, demo)                           T1:163-202   -> clahe_enhancer (same name and arguments; `demo` plots nothing here)
     cts = cts / 255                                          T1:520       -> u8_to_unit
+    cv2.resize(img[b:b+d, a:a+c], (125,250), INTER_AREA) x2 + np.concatenate   T1:354-358, 364-368 -> crop_resize_fuse
+    cv2.resize(cts[i], (new_dim,new_dim), INTER_LINEAR)      T1:486-488   -> resize
 
-They call the C ABI (`unet_pre_*`, csrc/kernels_pre.hip); like the rest of the product there is no CPU fallback.  Resizing and the
-contour-based lung cropper (cv2.resize / cv2.findContours, T1:211-270, 335) stay on the host side of a user's pipeline: out of scope.
+They call the C ABI (`unet_pre_*`, csrc/kernels_pre.hip); like the rest of the product there is no CPU fallback.  The contour search that
+produces the lung rectangles (cv2.findContours / contourArea / boundingRect inside `cropper`, T1:219-233: serial border following) stays on
+the host side of a user's pipeline; its output -- two (x, y, w, h) rectangles per slice -- is what crop_resize_fuse takes.
 """
 from __future__ import annotations
 
@@ -84,9 +87,66 @@ def u8_to_unit(img_u8):
     return out.cpu().numpy()
 
 
-def prepare_cts(raw_slices):
-    """The per-slice chain of read_nii(..., 'cts') without the resize / crop steps (T1:336-337 -> 348 -> 520): min-max normalise,
-    clahe_enhancer, /255.  [N,H,W] raw (e.g. Hounsfield) slices in, [N,H,W,1] float32 in [0,1] out -- the shape the runners take."""
+INTER_LINEAR, INTER_AREA = 1, 3           # cv2's values
+
+
+def _resize_into(lib, ctx, x, rects, out, x0, dw, interpolation):
+    torch = _torch()
+    n, sh, sw = x.shape
+    r = None
+    if rects is not None:
+        r = np.ascontiguousarray(np.asarray(rects, np.int64).reshape(n, 4).astype(np.int32))
+    ctx.check(lib.unet_pre_resize_u8(ctx.handle, x.data_ptr(), n, sh, sw, r.ctypes.data if r is not None else None, out.data_ptr(), out.shape[1], dw, out.shape[2], x0,
+                                     int(interpolation), torch.cuda.current_stream().cuda_stream), "pre_resize_u8")
+
+
+def resize(img_u8, dsize, interpolation=INTER_LINEAR):
+    """cv2.resize(img, dsize=(width, height), interpolation=cv2.INTER_LINEAR | cv2.INTER_AREA) for uint8 slice(s) (T1:486-488)."""
+    torch = _torch(); lib, ctx = _ctx()
+    a, single = _as_batch(img_u8)
+    x = torch.from_numpy(np.ascontiguousarray(a, np.uint8)).cuda()
+    dw, dh = int(dsize[0]), int(dsize[1])
+    out = torch.empty((x.shape[0], dh, dw), dtype=torch.uint8, device="cuda")
+    _resize_into(lib, ctx, x, None, out, 0, dw, interpolation)
+    r = out.cpu().numpy()
+    return r[0] if single else r
+
+
+def crop_resize_fuse(img_u8, rects1, rects2, size=(125, 250), interpolation=INTER_AREA):
+    """T1:354-358 / 364-368: per slice, the two lung rectangles (x, y, w, h) -- `all_points1[i]`, `all_points2[i]` -- cut out, each resized
+    to `size` = (width 125, height 250) with INTER_AREA and put side by side: [N,H,W] uint8 -> [N,250,250] uint8 (no concatenate pass: both
+    crops are written into their half of the output)."""
+    torch = _torch(); lib, ctx = _ctx()
+    a, single = _as_batch(img_u8)
+    x = torch.from_numpy(np.ascontiguousarray(a, np.uint8)).cuda()
+    dw, dh = int(size[0]), int(size[1])
+    out = torch.empty((x.shape[0], dh, 2 * dw), dtype=torch.uint8, device="cuda")
+    _resize_into(lib, ctx, x, rects1, out, 0, dw, interpolation)
+    _resize_into(lib, ctx, x, rects2, out, dw, dw, interpolation)
+    r = out.cpu().numpy()
+    return r[0] if single else r
+
+
+def prepare_cts(raw_slices, rects1=None, rects2=None, new_dim=None):
+    """The per-slice chain of read_nii(..., 'cts') (T1:336-337 -> 348 -> 354-358 -> 486 -> 520): min-max normalise, clahe_enhancer, then -- when
+    the lung rectangles are given -- crop + INTER_AREA resize + fuse and the INTER_LINEAR resize to new_dim (224 in the reference), /255.
+    [N,H,W] raw (e.g. Hounsfield) slices in, [N,h,w,1] float32 in [0,1] out -- the shape the runners take."""
     u8 = clahe_u8(min_max_to_u8(raw_slices), 3.0, (8, 8))
+    if rects1 is not None:
+        u8 = crop_resize_fuse(u8, rects1, rects2)
+    if new_dim is not None:
+        u8 = resize(u8, (int(new_dim), int(new_dim)), INTER_LINEAR)
+    a = u8_to_unit(u8)
+    return a[..., None] if a.ndim == 3 else a[None, ..., None]
+
+
+def prepare_infections(raw_masks, rects1=None, rects2=None, new_dim=None):
+    """read_nii(..., 'infections') (T1:336-337, 360-368, 488, 521): min-max, np.uint8(img*255), crop + resize + fuse, resize, /255 -- the soft
+    labels the loss is trained on."""
+    u8 = min_max_to_u8(raw_masks)
+    if rects1 is not None:
+        u8 = crop_resize_fuse(u8, rects1, rects2)
+    if new_dim is not None:
+        u8 = resize(u8, (int(new_dim), int(new_dim)), INTER_LINEAR)
     a = u8_to_unit(u8)
     return a[..., None] if a.ndim == 3 else a[None, ..., None]

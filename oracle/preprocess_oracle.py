@@ -94,3 +94,122 @@ def clahe_u8(src, clip_limit=3.0, tiles=(8, 8)):
 def clahe_enhancer(test_img, demo=0):
     """T1:163-202 without the plots: a [0,1] float slice in, the CLAHE-enhanced uint8 slice out."""
     return clahe_u8(to_u8(test_img), 3.0, (8, 8))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# cv2.resize on uint8 single-channel images: INTER_AREA (T1:236-238, 355-367: lung crops -> 125 x 250) and INTER_LINEAR (T1:486-488:
+# the fused 250 x 250 image -> new_dim x new_dim).  PARITY UNPINNED like CLAHE (cv2 absent): restates opencv/modules/imgproc/src/
+# resize.cpp (hal::resize, 8-bit path) as remembered:
+#   * inv_scale = dsize / ssize (double), scale = 1 / inv_scale (NOT ssize / dsize: the two can differ in the last bit);
+#   * INTER_AREA with both scales >= 1: integer scales -> box sum * (1.f / area) rounded half-even (the generic resizeAreaFast_ body;
+#     OpenCV's SIMD 2x2 special case rounds half-up instead -- build dependent, the generic form is what is restated);
+#     otherwise the DecimateAlpha tables of computeResizeAreaTab and float32 accumulation in table order (x first, then rows);
+#   * INTER_AREA with an up-scaling axis falls into the bilinear code with the "area" coefficients
+#     (sx = floor(dx * scale), fx = (dx + 1) - (sx + 1) * inv_scale, clamped / wrapped as in the source);
+#   * bilinear on 8-bit data is fixed point: coefficients saturate_cast<short>(c * 2048), horizontal pass exact in int32, vertical
+#     pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+INTER_LINEAR, INTER_AREA = 1, 3            # the cv2 constants
+_DBL_EPS = np.finfo(np.float64).eps
+
+
+def _area_tab(ssize, dsize, scale):
+    """computeResizeAreaTab: list of (di, si, alpha float32) in table order."""
+    tab = []
+    for dx in range(dsize):
+        fsx1 = dx * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1, sx2 = int(np.ceil(fsx1)), int(np.floor(fsx2))
+        sx2 = min(sx2, ssize - 1)
+        sx1 = min(sx1, sx2)
+        if sx1 - fsx1 > 1e-3:
+            tab.append((dx, sx1 - 1, F((sx1 - fsx1) / cell)))
+        for sx in range(sx1, sx2):
+            tab.append((dx, sx, F(1.0 / cell)))
+        if fsx2 - sx2 > 1e-3:
+            tab.append((dx, sx2, F(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+    return tab
+
+
+def _linear_tab(ssize, dsize, scale, inv_scale, area_mode, clamp):
+    """(ofs, c0, c1): source index and the two 11-bit coefficients per destination index.  `clamp` is the x-axis behaviour (index and
+    fraction clamped at both ends); the y axis keeps the raw index and the rows are clipped when they are read."""
+    ofs, c0, c1 = np.zeros(dsize, np.int64), np.zeros(dsize, np.int64), np.zeros(dsize, np.int64)
+    for d in range(dsize):
+        if not area_mode:
+            f = F((d + 0.5) * scale - 0.5)
+            s = int(np.floor(f))
+            f = F(f - F(s))
+        else:
+            s = int(np.floor(d * scale))
+            f = F((d + 1) - (s + 1) * inv_scale)
+            f = F(0) if f <= 0 else F(f - F(np.floor(f)))
+        if clamp:
+            if s < 0:
+                f, s = F(0), 0
+            if s >= ssize - 1:
+                f, s = F(0), ssize - 1
+        ofs[d] = s
+        c0[d] = int(np.clip(np.rint(F(F(1) - f) * F(2048)), -32768, 32767))
+        c1[d] = int(np.clip(np.rint(f * F(2048)), -32768, 32767))
+    return ofs, c0, c1
+
+
+def resize_u8(img, dsize, interpolation=INTER_LINEAR):
+    """cv2.resize(img, dsize=(width, height), interpolation=...) for a 2-D uint8 image."""
+    src = np.ascontiguousarray(img, np.uint8)
+    assert src.ndim == 2 and src.size > 0
+    sh, sw = src.shape
+    dw, dh = int(dsize[0]), int(dsize[1])
+    inv_x, inv_y = dw / sw, dh / sh
+    scale_x, scale_y = 1.0 / inv_x, 1.0 / inv_y
+    isx, isy = int(np.rint(scale_x)), int(np.rint(scale_y))
+    fast = abs(scale_x - isx) < _DBL_EPS and abs(scale_y - isy) < _DBL_EPS
+    if interpolation == INTER_LINEAR and fast and isx == 2 and isy == 2:
+        interpolation = INTER_AREA
+    if interpolation == INTER_AREA and scale_x >= 1 and scale_y >= 1:
+        if fast:
+            s = np.zeros((dh, dw), np.int64)
+            for ky in range(isy):
+                for kx in range(isx):
+                    s += src[ky:ky + dh * isy:isy, kx:kx + dw * isx:isx]
+            v = s.astype(F) * F(F(1) / F(isx * isy))                      # int * float scale, then saturate_cast<uchar> = round half even
+            return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+        xtab, ytab = _area_tab(sw, dw, scale_x), _area_tab(sh, dh, scale_y)
+        buf = np.zeros((sh, dw), F)
+        s32 = src.astype(F)
+        for di, si, a in xtab:                                             # buf[dxn] += S[si] * alpha, in table order, every source row at once
+            buf[:, di] = buf[:, di] + s32[:, si] * a
+        out = np.zeros((dh, dw), np.uint8)
+        acc, prev = None, -1
+        for di, si, b in ytab:
+            if di != prev:
+                if prev >= 0:
+                    out[prev] = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+                acc, prev = b * buf[si], di
+            else:
+                acc = acc + b * buf[si]
+        out[prev] = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+        return out
+    if interpolation not in (INTER_LINEAR, INTER_AREA):
+        raise ValueError("only INTER_LINEAR and INTER_AREA are restated")
+    area_mode = interpolation == INTER_AREA
+    xo, a0, a1 = _linear_tab(sw, dw, scale_x, inv_x, area_mode, True)
+    yo, b0, b1 = _linear_tab(sh, dh, scale_y, inv_y, area_mode, False)
+    s64 = src.astype(np.int64)
+    x1 = np.minimum(xo + 1, sw - 1)
+    rows = s64[:, xo] * a0[None, :] + s64[:, x1] * a1[None, :]            # horizontal pass: exact integers (pixel * 2048 scale)
+    r0 = np.clip(yo, 0, sh - 1)
+    r1 = np.clip(yo + 1, 0, sh - 1)
+    v = ((b0[:, None] * (rows[r0] >> 4)) >> 16) + ((b1[:, None] * (rows[r1] >> 4)) >> 16)
+    return np.clip((v + 2) >> 2, 0, 255).astype(np.uint8)
+
+
+def crop_resize_fuse(img_u8, rect1, rect2, interpolation=INTER_AREA):
+    """T1:354-358 (cts) / T1:364-368 (infections): the two lung rectangles (x, y, w, h) of a slice, each resized to 125 x 250 and put side
+    by side -> 250 x 250."""
+    a, b, c, d = rect1
+    e, f, g, h = rect2
+    i1 = resize_u8(img_u8[b:b + d, a:a + c], (125, 250), interpolation)
+    i2 = resize_u8(img_u8[f:f + h, e:e + g], (125, 250), interpolation)
+    return np.concatenate((i1, i2), axis=1)

@@ -58,3 +58,62 @@ def test_prepare_cts_chain_matches_the_reference_order_of_operations():
     for g, im in zip(got[..., 0], raw):
         a = im.astype(np.float64); mm = (a - a.min()) / (a.max() - a.min())
         assert np.array_equal(g, P.u8_to_unit(P.clahe_enhancer(mm)))
+
+
+def _smooth(shape, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    a = 120 + 90 * np.sin(yy / rng.uniform(8, 40)) * np.cos(xx / rng.uniform(8, 40)) + rng.normal(0, 6, shape)
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("src,dsize", [((250, 250), (224, 224)), ((250, 250), (512, 512)), ((300, 180), (125, 250)), ((91, 57), (200, 33)), ((64, 64), (64, 64)),
+                                       ((500, 250), (125, 250)), ((300, 180), (90, 150)), ((7, 5), (3, 2)), ((1, 9), (4, 4))])
+def test_resize_bit_exact_linear_and_area(src, dsize):
+    """cv2.resize restated (T1:486-488 INTER_LINEAR, T1:236 INTER_AREA): down-scaling, up-scaling (INTER_AREA then runs the bilinear code with
+    its own coefficients), integer scales (the box-sum path; 2x2 INTER_LINEAR is redirected to it), identity, tiny images"""
+    from covidseg_amd import preprocess as G
+    imgs = np.stack([_smooth(src, 1), (np.random.default_rng(2).random(src) * 255).astype(np.uint8), np.full(src, 201, np.uint8)])
+    for interp in (P.INTER_LINEAR, P.INTER_AREA):
+        got = G.resize(imgs, dsize, interp)
+        assert got.shape == (3, dsize[1], dsize[0]) and got.dtype == np.uint8
+        for g, im in zip(got, imgs):
+            assert np.array_equal(g, P.resize_u8(im, dsize, interp)), (src, dsize, interp)
+        assert np.all(got[2] == 201)                                   # weights sum to one: constants stay constant
+    assert np.array_equal(G.resize(imgs[0], dsize), got_single := P.resize_u8(imgs[0], dsize, P.INTER_LINEAR)) and got_single.ndim == 2
+
+
+def test_crop_resize_fuse_per_slice_rectangles_and_errors():
+    from covidseg_amd import preprocess as G, _lib
+    rng = np.random.default_rng(3)
+    n = 100                                                            # more rectangles than one launch carries
+    imgs = np.stack([_smooth((256, 256), 10 + i) for i in range(4)])[rng.integers(0, 4, n)]
+    r1 = np.stack([rng.integers(0, 60, n), rng.integers(0, 40, n), rng.integers(40, 130, n), rng.integers(100, 216, n)], 1)          # narrow ones up-scale in x
+    r2 = np.stack([rng.integers(120, 140, n), rng.integers(0, 30, n), rng.integers(60, 116, n), rng.integers(150, 226, n)], 1)
+    got = G.crop_resize_fuse(imgs, r1, r2)
+    assert got.shape == (n, 250, 250)
+    for i in range(n):
+        assert np.array_equal(got[i], P.crop_resize_fuse(imgs[i], tuple(r1[i]), tuple(r2[i]))), i
+    with pytest.raises(_lib.UNetHipError, match="rectangle"):
+        G.crop_resize_fuse(imgs[:1], [[200, 0, 100, 50]], [[0, 0, 10, 10]])
+    with pytest.raises(_lib.UNetHipError, match="interpolation"):
+        G.resize(imgs[0], (10, 10), 2)                                 # INTER_CUBIC is not restated
+
+
+def test_full_cts_and_infection_chain_with_rectangles():
+    """read_nii for 'cts' and 'infections' end to end (T1:336-368, 486-488, 520-521) on the GPU == composed with the CPU restatement"""
+    from covidseg_amd import preprocess as G
+    rng = np.random.default_rng(11)
+    raw = rng.normal(-500, 350, (3, 512, 512)).astype(np.float32)
+    msk = (rng.random((3, 512, 512)) > 0.97).astype(np.float32) * rng.integers(1, 4, (3, 1, 1))
+    r1 = [(60, 90, 170, 330), (40, 100, 120, 300), (70, 80, 200, 350)]
+    r2 = [(280, 95, 180, 320), (270, 100, 190, 310), (300, 60, 150, 260)]
+    got = G.prepare_cts(raw, r1, r2, new_dim=224)
+    gotm = G.prepare_infections(msk, r1, r2, new_dim=224)
+    assert got.shape == gotm.shape == (3, 224, 224, 1)
+    for i in range(3):
+        a = raw[i].astype(np.float64); mm = (a - a.min()) / (a.max() - a.min())
+        e = P.resize_u8(P.crop_resize_fuse(P.clahe_enhancer(mm), r1[i], r2[i]), (224, 224), P.INTER_LINEAR)
+        assert np.array_equal(got[i, ..., 0], P.u8_to_unit(e))
+        e = P.resize_u8(P.crop_resize_fuse(P.minmax_to_u8(msk[i]), r1[i], r2[i]), (224, 224), P.INTER_LINEAR)
+        assert np.array_equal(gotm[i, ..., 0], P.u8_to_unit(e))
