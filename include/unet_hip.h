@@ -110,6 +110,14 @@ int32_t unet_convT2x2_bwd_weights(unet_ctx*, const float* x, const float* dy, in
  * CONTEXT owns: issue them on one stream at a time per context; use one context per stream otherwise. */
 int32_t unet_bn_stats(unet_ctx*, const float* x, int32_t ldx, double* sums, int64_t pixels,
                       int32_t c, void* stream);
+/* Statistics of the decoder's BatchNormalization over concatenate([u, c]) (T1:887-888, 894-895, 901-902, 908-909) when the skip half `c`
+ * is the output of an encoder BatchNormalization of the same step: over the batch that output has mean beta and variance
+ * gamma^2 var/(var + eps) exactly, so only the c_up channels of `u` (x_up, row stride ldx) are read; the c_skip pairs come from the
+ * source layer's sums (src_sums = its double[2*c_skip] AFTER any cross-rank reduction, src_count = its global element count) and
+ * parameters.  sums: double[2*(c_up+c_skip)] = (sums, sums of squares) of the concat, ACCUMULATED like unet_bn_stats; the analytic half is
+ * scaled by `pixels` (this rank's count) so a cross-rank SUM of `sums` stays correct. */
+int32_t unet_bn_stats_concat(unet_ctx*, const float* x_up, int32_t ldx, const double* src_sums, double src_count, const float* src_gamma,
+                             const float* src_beta, double* sums, int64_t pixels, int32_t c_up, int32_t c_skip, void* stream);
 int32_t unet_bn_finalize_train(unet_ctx*, const double* sums, double count, const float* gamma,
                                const float* beta, float* moving_mean, float* moving_var,
                                float* bnp, int32_t c, void* stream);
@@ -219,6 +227,8 @@ size_t unet_convT2x2_bwd_weights_ws_bytes_bf16(int32_t n, int32_t h, int32_t wd,
 int32_t unet_convT2x2_bwd_weights_bf16(unet_ctx*, const unet_bf16* x, const unet_bf16* dy, int32_t lddy, float* dw, float* db, void* ws,
                                        size_t ws_bytes, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream);
 int32_t unet_bn_stats_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream);
+int32_t unet_bn_stats_concat_bf16(unet_ctx*, const unet_bf16* x_up, int32_t ldx, const double* src_sums, double src_count, const float* src_gamma,
+                                  const float* src_beta, double* sums, int64_t pixels, int32_t c_up, int32_t c_skip, void* stream);
 int32_t unet_bn_apply_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy, int64_t pixels, int32_t c,
                            void* stream);
 int32_t unet_bn_bwd_stats_bf16(unet_ctx*, const unet_bf16* dy, int32_t lddy, const unet_bf16* x, int32_t ldx, const float* bnp, double* sums,

@@ -63,6 +63,8 @@ _PROTOS = {
     "unet_convT2x2_bwd_weights_bf16": (i32, [vp, vp, vp, i32, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp]),
     "unet_bn_stats": (i32, [vp, vp, i32, vp, i64, i32, vp]),
     "unet_bn_stats_bf16": (i32, [vp, vp, i32, vp, i64, i32, vp]),
+    "unet_bn_stats_concat": (i32, [vp, vp, i32, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
+    "unet_bn_stats_concat_bf16": (i32, [vp, vp, i32, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
     "unet_bn_finalize_train": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, i32, vp]),
     "unet_bn_finalize_infer": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     "unet_bn_apply": (i32, [vp, vp, i32, vp, vp, i32, i64, i32, vp]),

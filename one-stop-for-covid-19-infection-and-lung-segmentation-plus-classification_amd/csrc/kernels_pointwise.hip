@@ -595,6 +595,33 @@ __global__ void bn_slot_fold_kernel(double* __restrict__ slots, double* __restri
   sums[i] += s;
 }
 
+// Statistics of a concat([up, skip]) whose skip half is the OUTPUT of an earlier training-mode BatchNorm: y = gamma * xhat + beta has, over the
+// batch, mean(y) = beta and var(y) = gamma^2 * var / (var + eps) exactly, so its (sum, sum of squares) follow from the source layer's sums
+// without reading the tensor.  Thread i < c_up folds the measured sums of the up half out of the slot copies (as bn_slot_fold_kernel), thread
+// c_up + j writes the analytic pair of skip channel j.  Layout of `sums`: [c_up + c_skip sums][c_up + c_skip sums of squares].
+__global__ void bn_fold_concat_kernel(double* __restrict__ slots, double* __restrict__ sums, int c_up, int c_skip, const double* __restrict__ src_sums,
+                                      double src_count, const float* __restrict__ src_gamma, const float* __restrict__ src_beta, double pixels, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c2 = c_up + c_skip;
+  if (i < c_up) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < UNET_BN_SLOTS; ++k) {
+      double* p = slots + (size_t)k * UNET_BN_SLOT_DOUBLES + i;
+      s1 += p[0]; p[0] = 0.0; s2 += p[c_up]; p[c_up] = 0.0;
+    }
+    sums[i] += s1; sums[c2 + i] += s2;
+  } else if (i < c2) {
+    const int j = i - c_up;
+    const double mean = src_sums[j] / src_count;
+    double var = src_sums[c_skip + j] / src_count - mean * mean;
+    if (var < 0) var = 0;
+    const double g = (double)src_gamma[j], b = (double)src_beta[j];
+    sums[i] += pixels * b;
+    sums[c2 + i] += pixels * (g * g * var / (var + (double)eps) + b * b);
+  }
+}
+
 inline bool bn_c_ok(int c) { return c >= 4 && (c % 4) == 0 && (c / 4) <= TPB; }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -609,6 +636,18 @@ extern "C++" template <typename T> static int32_t bn_stats_impl(unet_ctx* ctx, c
   hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c);
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "bn_stats"); return UNET_OK;
+}
+
+extern "C++" template <typename T> static int32_t bn_stats_concat_impl(unet_ctx* ctx, const T* x_up, int32_t ldx, const double* src_sums, double src_count, const float* src_gamma,
+                                                                       const float* src_beta, double* sums, int64_t pixels, int32_t c_up, int32_t c_skip, void* stream) {
+  if (!ctx || !x_up || !sums || !src_sums || !src_gamma || !src_beta || !bn_c_ok(c_up) || c_skip < 1 || ldx < c_up || (ldx & 3) || src_count < 1 || pixels < 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "bn_stats_concat: bad args c_up=%d c_skip=%d ldx=%d", c_up, c_skip, ldx);
+  int ppb = TPB / (c_up / 4);
+  int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x_up, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c_up);
+  hipLaunchKernelGGL(bn_fold_concat_kernel, dim3((c_up + c_skip + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, c_up, c_skip, src_sums, src_count, src_gamma,
+                     src_beta, (double)pixels, 1e-3f);
+  UNET_CHECK_LAUNCH(ctx, "bn_stats_concat"); return UNET_OK;
 }
 
 int32_t unet_bn_finalize_train(unet_ctx* ctx, const double* sums, double count, const float* gamma, const float* beta,
@@ -787,6 +826,14 @@ int32_t unet_zero(unet_ctx* ctx, void* ptr, size_t bytes, void* stream) {
 // probabilities / targets stay fp32 / fp64)
 int32_t unet_bn_stats(unet_ctx* ctx, const float* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) { return bn_stats_impl(ctx, x, ldx, sums, pixels, c, stream); }
 int32_t unet_bn_stats_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) { return bn_stats_impl(ctx, x, ldx, sums, pixels, c, stream); }
+int32_t unet_bn_stats_concat(unet_ctx* ctx, const float* x_up, int32_t ldx, const double* src_sums, double src_count, const float* src_gamma, const float* src_beta, double* sums,
+                             int64_t pixels, int32_t c_up, int32_t c_skip, void* stream) {
+  return bn_stats_concat_impl(ctx, x_up, ldx, src_sums, src_count, src_gamma, src_beta, sums, pixels, c_up, c_skip, stream);
+}
+int32_t unet_bn_stats_concat_bf16(unet_ctx* ctx, const unet_bf16* x_up, int32_t ldx, const double* src_sums, double src_count, const float* src_gamma, const float* src_beta,
+                                  double* sums, int64_t pixels, int32_t c_up, int32_t c_skip, void* stream) {
+  return bn_stats_concat_impl(ctx, x_up, ldx, src_sums, src_count, src_gamma, src_beta, sums, pixels, c_up, c_skip, stream);
+}
 int32_t unet_bn_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy, int64_t pixels, int32_t c, void* stream) { return bn_apply_impl(ctx, x, ldx, bnp, y, ldy, pixels, c, stream); }
 int32_t unet_bn_apply_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy, int64_t pixels, int32_t c, void* stream) { return bn_apply_impl(ctx, x, ldx, bnp, y, ldy, pixels, c, stream); }
 int32_t unet_bn_bwd_stats(unet_ctx* ctx, const float* dy, int32_t lddy, const float* x, int32_t ldx, const float* bnp, double* sums, int64_t pixels, int32_t c, void* stream) { return bn_bwd_stats_impl(ctx, dy, lddy, x, ldx, bnp, sums, pixels, c, stream); }

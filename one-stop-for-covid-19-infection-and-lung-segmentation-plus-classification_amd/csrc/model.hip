@@ -466,6 +466,12 @@ double nel(const Buf& b) { return (double)b.n * b.h * b.w * b.c; }
     (vec).push_back(std::move(_o));                           \
   } while (0)
 
+// decoder BatchNorm statistics: skip half analytic, up half measured (unet_bn_stats_concat); 0 = read the whole concat as before
+static bool bn_concat_analytic() {
+  static const int on = [] { const char* e = getenv("UNET_BN_CONCAT_ANALYTIC"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
+  return on != 0;
+}
+
 void build_programs(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int algo = m->algo;
@@ -526,15 +532,27 @@ void build_programs(unet_model* m) {
                                     ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second));
       });
     };
-    auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c, bool fuse_pool) {
+    // skip_src: the encoder BatchNorm whose output is the second half of the concat `in` -- its statistics are analytic (unet_bn_stats_concat)
+    auto bn = [&](const std::string& name, const std::string& in, const std::string& out, int c, bool fuse_pool, const std::string& skip_src = "") {
       const Buf ib = m->act.at(in), ob = m->act.at(out);
       const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
       const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
       if (training) {
-        ADD_OP(F, "bn_stats:" + name, 0, eb * pixels * c, {
-          if (dt) return unet_bn_stats_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
-          return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
-        });
+        if (!skip_src.empty() && bn_concat_analytic()) {
+          const size_t sso = m->bn_sum_off.at(skip_src);
+          const int cu = c / 2, cs = c - c / 2;
+          ADD_OP(F, "bn_stats:" + name, 0, eb * pixels * cu, {
+            if (dt) return unet_bn_stats_concat_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsd(m->off_bn_sums) + sso, (double)pixels * gcount, m->P(skip_src + "/gamma"),
+                                                     m->P(skip_src + "/beta"), m->wsd(m->off_bn_sums) + so, pixels, cu, cs, s);
+            return unet_bn_stats_concat(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + sso, (double)pixels * gcount, m->P(skip_src + "/gamma"), m->P(skip_src + "/beta"),
+                                        m->wsd(m->off_bn_sums) + so, pixels, cu, cs, s);
+          });
+        } else {
+          ADD_OP(F, "bn_stats:" + name, 0, eb * pixels * c, {
+            if (dt) return unet_bn_stats_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+            return unet_bn_stats(ctx, m->A(in), ib.ld, m->wsd(m->off_bn_sums) + so, pixels, c, s);
+          });
+        }
         SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
         ADD_OP(F, "bn_finalize:" + name, 0, 0, {
           return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
@@ -581,7 +599,7 @@ void build_programs(unet_model* m) {
         if (dt) return k_convT_bf16_fwd(ctx, CBF(m->Av(uin)), m->P(un + "/kernel"), m->P(un + "/bias"), WBF(m->Av(un)), ub.ld, ib.n, ib.h, ib.w, ci, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
         return unet_convT2x2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, algo, s);
       });
-      bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c, false);
+      bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c, false, "bn" + std::to_string(10 - k));      // cat_k = [u_k, bn_{10-k} output]
       conv("c" + ks + "a", "bn" + ks, 2 * c, c);
       conv("c" + ks + "b", "c" + ks + "a", c, c);
       prev = "c" + ks + "b"; cprev = c;

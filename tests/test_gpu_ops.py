@@ -276,6 +276,48 @@ def test_fused_bn_pool_fwd_and_pool_bwd_bnstats(ops, c):
         assert relerr(sb.cpu().numpy(), sa.cpu().numpy()) < 1e-5           # xhat recovered from y = gamma*xhat+beta vs from x
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 20, 32, 32), (1, 8, 8, 256, 256), (3, 10, 6, 64, 16)])
+def test_bn_stats_concat_analytic_skip_half(ops, shape):
+    """decoder BN over concatenate([u, c]) (T1:887-888): the skip half c is an encoder BN output, so its (sum, sum of squares) are analytic
+    (mean beta, variance gamma^2 var/(var+eps)); unet_bn_stats_concat reads only the up half and must agree with unet_bn_stats over the whole
+    concat to fp32 storage rounding -- also with a non-zero accumulator and with the two-rank count convention"""
+    from gpu_util import relerr
+    n, h, w, cu, cs = shape
+    rng = np.random.default_rng(cu + cs)
+    pixels = n * h * w
+    xe = (rng.standard_normal((n, h, w, cs)) * rng.uniform(0.3, 3.0, cs) + rng.uniform(-2, 2, cs)).astype(np.float32)        # encoder conv output
+    ge = rng.uniform(0.5, 1.5, cs).astype(np.float32); be = (rng.standard_normal(cs) * 0.5).astype(np.float32)
+    up = (rng.standard_normal((n, h, w, cu)) * 1.7 + 0.3).astype(np.float32)
+    ld = cu + cs
+    cat = ops.z(n, h, w, ld)
+    cat[..., :cu] = ops.d(up)
+    es = ops.z(2 * cs, dtype=torch.float64); bnp = ops.z(4 * cs)
+    ops.ck(ops.lib.unet_bn_stats(ops.h, ops.d(xe).data_ptr(), cs, es.data_ptr(), pixels, cs, ops.s), "enc stats")
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, es.data_ptr(), float(pixels), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), ops.z(cs).data_ptr(), ops.z(cs).data_ptr(),
+                                          bnp.data_ptr(), cs, ops.s), "enc fin")
+    ops.ck(ops.lib.unet_bn_apply(ops.h, ops.d(xe).data_ptr(), cs, bnp.data_ptr(), cat.data_ptr() + 4 * cu, ld, pixels, cs, ops.s), "enc apply")
+    want = ops.z(2 * ld, dtype=torch.float64); got = ops.z(2 * ld, dtype=torch.float64)
+    if ld // 4 <= 256:
+        ops.ck(ops.lib.unet_bn_stats(ops.h, cat.data_ptr(), ld, want.data_ptr(), pixels, ld, ops.s), "full stats")
+        wn = want.cpu().numpy()
+    else:                                                    # 512 channels: wider than one unet_bn_stats launch takes -- fp64 on the host
+        c64 = cat.cpu().numpy().astype(np.float64).reshape(-1, ld)
+        wn = np.concatenate([c64.sum(0), (c64 * c64).sum(0)])
+    ops.ck(ops.lib.unet_bn_stats_concat(ops.h, cat.data_ptr(), ld, es.data_ptr(), float(pixels), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), got.data_ptr(), pixels, cu, cs, ops.s),
+           "concat stats")
+    gn = got.cpu().numpy()
+    assert relerr(gn[:cu], wn[:cu]) < 1e-6 and relerr(gn[ld:ld + cu], wn[ld:ld + cu]) < 1e-6                    # measured half: the same kernel
+    mean_g, mean_w = gn[:ld] / pixels, wn[:ld] / pixels
+    var_g, var_w = gn[ld:] / pixels - mean_g ** 2, wn[ld:] / pixels - mean_w ** 2
+    assert np.abs(mean_g - mean_w).max() < 2e-6 * max(1.0, np.abs(cat.cpu().numpy()).max()) and relerr(var_g, var_w) < 2e-5
+    # accumulates (a second call doubles the sums); with the source statistics global over two ranks' worth of pixels the analytic half scales by THIS rank's count
+    es2 = (es * 2).contiguous()
+    ops.ck(ops.lib.unet_bn_stats_concat(ops.h, cat.data_ptr(), ld, es2.data_ptr(), float(2 * pixels), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), got.data_ptr(), pixels, cu, cs, ops.s),
+           "concat stats again")
+    assert relerr(got.cpu().numpy(), 2 * gn) < 1e-12
+    assert ops.lib.unet_bn_stats_concat(ops.h, cat.data_ptr(), ld, es.data_ptr(), 0.0, ops.d(ge).data_ptr(), ops.d(be).data_ptr(), got.data_ptr(), pixels, cu, cs, ops.s) != 0
+
+
 @pytest.mark.parametrize("algo", [0, 1])
 @pytest.mark.parametrize("shape", [(2, 10, 14, 32, 64), (1, 8, 8, 96, 32), (2, 12, 12, 1, 32), (1, 6, 6, 192, 64)])
 def test_conv3x3_elu_dropout_and_mask_modes(ops, shape, algo):
