@@ -142,6 +142,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //   MASK_RELU: 1[m>0]      MASK_ELU: m>0 ? 1 : m+1  (elu' expressed through its output)
 //   MASK_ELU_DROP: m = dropout(elu(z)): keep ? s * elu'(m/s) : 0, keep/s recomputed from the Philox stream
 enum { MASK_NONE = 0, MASK_RELU = 1, MASK_ELU = 2, MASK_ELU_DROP = 3 };
+// internal to the F(2x2,3x3) forward kernels: `mask` is not a mask but the border-class bias table of a conv whose input BatchNorm was
+// folded into its weights (k_bn_fold_prepare): [16][Cout], class = 4 * (row == 0 | (row == H-1) << 1) + (col == 0 | (col == W-1) << 1)
+enum { MASK_BIAS_TAB = 4 };
 __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep_scale component */, float rate) {
   if (mode == MASK_RELU) return m > 0.0f ? 1.0f : 0.0f;
   if (mode == MASK_ELU) return m > 0.0f ? 1.0f : m + 1.0f;
@@ -156,6 +159,16 @@ __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep
 // Winograd F(2,3)-along-x kernels (kernels_conv_wino.hip): u = transformed weights [12][cin'][cout'] in caller scratch
 bool wino_conv3x3_supported(int cin, int cout);
 bool wino_uses_2d(int h, int cout);
+// conv3x3(BN-affine(x)) with the affine folded into the conv: w_scaled[tap][c][o] = w * scale[c], table[16][cout] = the bias
+// per border class (bias + the shift's contribution through the taps that stay inside the image); the forward then runs on the RAW x with
+// (bias = table, mask = table, mask_mode = MASK_BIAS_TAB) -- 2-D Winograd kernels only (wino_uses_2d) -- and the weight gradient on raw x is
+// corrected afterwards: dw = scale[c] * dw_raw + shift[c] * S[tap][o] (k_wgrad_bn_fold_fix; S from db and the border sums of dy).
+size_t bn_fold_scratch_floats(int cin, int cout);      // [w_scaled 9*cin*cout][table 16*cout][partials]
+int32_t k_bn_fold_prepare(unet_ctx*, const float* w, const float* bias, const float* scale, const float* shift, int cin, int cout, float* scratch, hipStream_t s);
+size_t wgrad_bn_fold_scratch_floats(int n, int cout);
+bool wgrad_bn_fold_supported(int cout);
+int32_t k_wgrad_bn_fold_fix(unet_ctx*, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db, float* scratch,
+                            hipStream_t s);
 int wino_tile_cols(int wd);                                          // 64 or 32 columns per row tile of the 2-D kernel                                 // F(2x2,3x3) instead of F(2,3)-along-x for this output shape
 int32_t k_conv3x3_wino_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
                              int cin, int cout, hipStream_t s);      // kernels_conv_mfma.hip (shares the split-K machinery)

@@ -970,6 +970,82 @@ size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // 
   return std::max(std::max(p.part_floats + p.bias_floats + p.part2_floats, q.part_floats + q.bias_floats + q.part2_floats), r.part_floats + r.bias_floats + r.part2_floats) * sizeof(float);
 }
 
+// ---- weight gradient of a conv whose input BatchNorm was folded into it (common.h: k_bn_fold_prepare) --------------------------------------
+// The gradient kernels ran on the raw x; with z = scale[c] * x + shift[c] inside the image and 0 outside,
+//   dW[a][b][c][o] = scale[c] * dW_raw[a][b][c][o] + shift[c] * S[a][b][o],   S[a][b][o] = sum of dy[.., o] over the pixels whose tap (a, b) stays inside
+// = db[o] minus the border row / column the tap excludes plus the corner both exclude.
+namespace {
+// out[n * SEG + seg][8][C]: sums of dy over (segment seg of) row 0, row H-1, column 0, column W-1 and the corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
+// of image n.  grid (8 * SEG, N)
+constexpr int BORDER_SEG = 4;
+__global__ __launch_bounds__(256) void border_sums_kernel(const float* __restrict__ dy, float* __restrict__ out, int H, int W, int C) {
+  __shared__ float s_p[256];
+  const int kind = blockIdx.x & 7, seg = blockIdx.x >> 3, n = blockIdx.y;
+  const int co = threadIdx.x % C, sl = threadIdx.x / C, nsl = 256 / C;
+  const float* img = dy + (long long)n * H * W * C;
+  float acc = 0.f;
+  if (kind < 2) {
+    const float* r = img + (long long)(kind ? H - 1 : 0) * W * C;
+    const int per = (W + BORDER_SEG - 1) / BORDER_SEG, j1 = min(W, (seg + 1) * per);
+    for (int j = seg * per + sl; j < j1; j += nsl) acc += r[(long long)j * C + co];
+  } else if (kind < 4) {
+    const float* q = img + (long long)(kind == 3 ? W - 1 : 0) * C;
+    const int per = (H + BORDER_SEG - 1) / BORDER_SEG, i1 = min(H, (seg + 1) * per);
+    for (int i = seg * per + sl; i < i1; i += nsl) acc += q[(long long)i * W * C + co];
+  } else if (sl == 0 && seg == 0) { const int i = (kind & 2) ? H - 1 : 0, j = (kind & 1) ? W - 1 : 0; acc = img[((long long)i * W + j) * C + co]; }
+  s_p[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0) { for (int k = 1; k < nsl; ++k) acc += s_p[k * C + co]; out[(((long long)n * BORDER_SEG + seg) * 8 + kind) * C + co] = acc; }
+}
+// S[tap][o] from db and the border sums (NS = images x segments of them).  grid (9, C / 64), 256 threads = 64 channels x 4 slices of NS
+__global__ __launch_bounds__(256) void fold_tap_sums_kernel(const float* __restrict__ border, const float* __restrict__ db, float* __restrict__ S, int NS, int C) {
+  __shared__ float s_r[3][4][64];
+  const int tap = blockIdx.x, a = tap / 3, b = tap - a * 3, l = threadIdx.x & 63, sl = threadIdx.x >> 6, o = blockIdx.y * 64 + l;
+  const int er = a == 0 ? 0 : (a == 2 ? 1 : -1), ec = b == 0 ? 0 : (b == 2 ? 1 : -1);      // excluded row (0: first, 1: last), column
+  float kr = 0.f, kc = 0.f, kk = 0.f;
+  if (o < C)
+    for (int n = sl; n < NS; n += 4) {
+      const float* p = border + (long long)n * 8 * C + o;
+      if (er >= 0) kr += p[er * C];
+      if (ec >= 0) kc += p[(2 + ec) * C];
+      if (er >= 0 && ec >= 0) kk += p[(4 + er * 2 + ec) * C];
+    }
+  s_r[0][sl][l] = kr; s_r[1][sl][l] = kc; s_r[2][sl][l] = kk;
+  __syncthreads();
+  if (sl == 0 && o < C) {
+    kr = (s_r[0][0][l] + s_r[0][1][l]) + (s_r[0][2][l] + s_r[0][3][l]);
+    kc = (s_r[1][0][l] + s_r[1][1][l]) + (s_r[1][2][l] + s_r[1][3][l]);
+    kk = (s_r[2][0][l] + s_r[2][1][l]) + (s_r[2][2][l] + s_r[2][3][l]);
+    S[tap * C + o] = ((db[o] - kr) - kc) + kk;
+  }
+}
+__global__ void fold_fix_kernel(float* __restrict__ dw, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ S, int cin, int cout4,
+                                long long total4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % cout4); const long long r = i / cout4; const int c = (int)(r % cin), tap = (int)(r / cin);
+    const float sc = scale[c], sh = shift[c];
+    const float4 sv = reinterpret_cast<const float4*>(S)[tap * cout4 + q];
+    float4 v = reinterpret_cast<float4*>(dw)[i];
+    v.x = fmaf(sc, v.x, sh * sv.x); v.y = fmaf(sc, v.y, sh * sv.y); v.z = fmaf(sc, v.z, sh * sv.z); v.w = fmaf(sc, v.w, sh * sv.w);
+    reinterpret_cast<float4*>(dw)[i] = v;
+  }
+}
+}  // namespace
+
+bool wgrad_bn_fold_supported(int cout) { return cout >= 4 && cout <= 256 && 256 % cout == 0; }
+size_t wgrad_bn_fold_scratch_floats(int n, int cout) { return (size_t)(n > 0 ? n : 0) * BORDER_SEG * 8 * cout + 9 * (size_t)cout; }
+int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
+                            float* scratch, hipStream_t s) {
+  if (!dy || !scale || !shift || !dw || !db || !scratch || !wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: bad args (cout=%d)", cout);
+  float* border = scratch; float* S = scratch + (size_t)n * BORDER_SEG * 8 * cout;
+  hipLaunchKernelGGL(border_sums_kernel, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
+  hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, border, db, S, n * BORDER_SEG, cout);
+  const long long total4 = 9LL * cin * cout / 4;
+  hipLaunchKernelGGL(fold_fix_kernel, dim3((unsigned)std::min<long long>((total4 + 255) / 256, 2048)), dim3(256), 0, s, dw, scale, shift, S, cin, cout / 4, total4);
+  UNET_CHECK_LAUNCH(ctx, "wgrad_bn_fold_fix");
+  return UNET_OK;
+}
+
 int32_t k_conv3x3_wino_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                              int wd, int cin, int cout, hipStream_t s) {
   if (!mfma_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad winograd: cin=%d cout=%d unsupported", cin, cout);

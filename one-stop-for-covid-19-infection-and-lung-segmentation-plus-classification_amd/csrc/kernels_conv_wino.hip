@@ -496,7 +496,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
       const int mt = e + 8 * g + 4 * hi;                      // M index of this value: row pair mt / WT, tile mt % WT
       const int px = x0 + 2 * (mt % WT) + half, py = y0 + 2 * (wm * RPW + mt / WT) + kh;
       if (py >= H || px >= W || co >= Cout) continue;
-      float4 o4 = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
+      float4 bs = bb;
+      if (mask_mode == MASK_BIAS_TAB) {                       // folded input BatchNorm: border pixels see fewer taps of the shift
+        const int cls = (((py == 0) | ((py == H - 1) << 1)) << 2) | ((px == 0) | ((px == W - 1) << 1));
+        if (cls) bs = *reinterpret_cast<const float4*>(mask + (long long)cls * Cout + co);
+      }
+      float4 o4 = make_float4(v0 + bs.x, v1 + bs.y, v2 + bs.z, v3 + bs.w);
       const long long o = (((long long)n * H + py) * W + px) * Cout + co;
       if (!GEN) {
         if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
@@ -678,7 +683,12 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
     const int mt = e + 8 * g + 4 * hi;
     const int px = x0 + 2 * (mt % WT) + half, py = y0 + 2 * (mt / WT) + orow;
     if (py >= H || px >= W || co >= Cout) continue;
-    float4 o4 = make_float4(v0 + bb.x, v1 + bb.y, v2 + bb.z, v3 + bb.w);
+    float4 bs = bb;
+    if (mask_mode == MASK_BIAS_TAB) {                         // folded input BatchNorm: border pixels see fewer taps of the shift
+      const int cls = (((py == 0) | ((py == H - 1) << 1)) << 2) | ((px == 0) | ((px == W - 1) << 1));
+      if (cls) bs = *reinterpret_cast<const float4*>(mask + (long long)cls * Cout + co);
+    }
+    float4 o4 = make_float4(v0 + bs.x, v1 + bs.y, v2 + bs.z, v3 + bs.w);
     const long long o = (((long long)n * H + py) * W + px) * Cout + co;
     if (!GEN) {
       if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
@@ -710,7 +720,7 @@ int32_t launch_wino2d4(unet_ctx* ctx, const float* x, const float* u, const floa
   const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
   const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));
   const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * (CKV + 4)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));
-  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
   UNET_BIG_LDS(ctx, (conv_wino2d4_kernel<WTT, false, CKV>), lds, "conv_wino2d4");
   UNET_BIG_LDS(ctx, (conv_wino2d4_kernel<WTT, true, CKV>), lds, "conv_wino2d4");
   if (gen) hipLaunchKernelGGL((conv_wino2d4_kernel<WTT, true, CKV>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
@@ -731,7 +741,7 @@ int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float
   static const int breg_env = [] { const char* e = getenv("UNET_WINO_BREG"); return e ? atoi(e) : -1; }();
   const int breg = breg_env >= 0 ? breg_env : (WC == 2 ? 1 : 0);
   const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * CKP + (breg ? 0 : 16 * CK * TN)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));   // >= the epilogue exchange
-  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU;
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
   {
     const size_t big = (size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float);
     UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, false, false, 8>), big, "conv_wino2d"); UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, true, false, 8>), big, "conv_wino2d");
@@ -779,6 +789,59 @@ inline int wino_2d_mode() {          // UNET_WINO2D: 0 = F(2,3) along x only, 1 
   static const int v = [] { const char* e = getenv("UNET_WINO2D"); return e ? atoi(e) : 1; }();
   return v;
 }
+// ---- BatchNorm on the INPUT of a conv folded into the conv (k_bn_fold_prepare) ------------------------------------------------------------
+namespace {
+__global__ void bn_fold_scale_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ ws, int cin, int cout4, long long total4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / cout4) % cin);
+    const float sc = scale[c];
+    float4 v = reinterpret_cast<const float4*>(w)[i];
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    reinterpret_cast<float4*>(ws)[i] = v;
+  }
+}
+// T[tap][o] = sum_c w[tap][c][o] * shift[c] in two levels: grid (cout / 64, 9 taps, slices of 32 input channels) writes part[slice][tap][o]
+// (256 threads = 64 couts x 4 channel sub-slices), then one workgroup per 64 couts sums the slices and combines the taps per border class:
+// table[cls][o] = bias[o] + sum of T[a][b][o] over the taps (a, b) that stay inside the image for class cls.
+__global__ __launch_bounds__(256) void bn_fold_taps_kernel(const float* __restrict__ w, const float* __restrict__ shift, float* __restrict__ part, int cin, int cout) {
+  __shared__ float s_part[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, tap = blockIdx.y, c0 = blockIdx.z * 32;
+  float acc = 0.f;
+  if (o < cout) {
+    const float* p = w + ((long long)tap * cin) * cout + o;
+    for (int c = c0 + sl; c < min(c0 + 32, cin); c += 4) acc = fmaf(p[(long long)c * cout], shift[c], acc);
+  }
+  s_part[sl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sl == 0 && o < cout)
+    part[((long long)blockIdx.z * 9 + tap) * cout + o] = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+}
+// grid cout / 64, 576 threads = 9 taps x 64 couts: every thread sums ITS tap over the slices, the nine meet in LDS, the first 64 threads write the 16 classes
+__global__ __launch_bounds__(576) void bn_fold_table_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ table, int slices, int cout) {
+  __shared__ float s_t[9][64];
+  const int l = threadIdx.x & 63, tap = threadIdx.x >> 6, o = blockIdx.x * 64 + l;
+  float a = 0.f;
+  if (o < cout) for (int k = 0; k < slices; ++k) a += part[((long long)k * 9 + tap) * cout + o];
+  s_t[tap][l] = a;
+  __syncthreads();
+  if (tap != 0 || o >= cout) return;
+  const float b0 = bias ? bias[o] : 0.f;
+#pragma unroll
+  for (int cls = 0; cls < 16; ++cls) {
+    const int rs = cls >> 2, cs = cls & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        const bool out = (ta == 0 && (rs & 1)) || (ta == 2 && (rs & 2)) || (tb == 0 && (cs & 1)) || (tb == 2 && (cs & 2));
+        if (!out) v += s_t[ta * 3 + tb][l];
+      }
+    table[(long long)cls * cout + o] = b0 + v;
+  }
+}
+}  // namespace
+
 static bool use_2d(int h, int cout) { return wino_2d_mode() && h >= 2 && cout % 32 == 0; }
 // columns per row tile the 2-D kernel uses for an image of width wd: 64, or 32 when that fills the last tile much better
 int wino_tile_cols(int wd) {
@@ -786,6 +849,20 @@ int wino_tile_cols(int wd) {
   return u32 > 1.1 * u64 ? 32 : 64;
 }
 bool wino_uses_2d(int h, int cout) { return use_2d(h, cout); }
+
+size_t bn_fold_scratch_floats(int cin, int cout) { return (size_t)9 * cin * cout + 16 * (size_t)cout + (size_t)((cin + 31) / 32) * 9 * cout; }
+// scratch = [w_scaled 9*cin*cout][table 16*cout][tap partials]: bn_fold_scratch_floats(cin, cout)
+int32_t k_bn_fold_prepare(unet_ctx* ctx, const float* w, const float* bias, const float* scale, const float* shift, int cin, int cout, float* scratch, hipStream_t s) {
+  if (!w || !scale || !shift || !scratch || cin < 1 || cout < 4 || (cout & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_fold_prepare: bad args");
+  float* w_scaled = scratch; float* table = scratch + (size_t)9 * cin * cout; float* part = table + 16 * (size_t)cout;
+  const long long total4 = 9LL * cin * cout / 4;
+  const int slices = (cin + 31) / 32;
+  hipLaunchKernelGGL(bn_fold_scale_kernel, dim3((unsigned)std::min<long long>((total4 + 255) / 256, 2048)), dim3(256), 0, s, w, scale, w_scaled, cin, cout / 4, total4);
+  hipLaunchKernelGGL(bn_fold_taps_kernel, dim3((unsigned)((cout + 63) / 64), 9, (unsigned)slices), dim3(256), 0, s, w, shift, part, cin, cout);
+  hipLaunchKernelGGL(bn_fold_table_kernel, dim3((unsigned)((cout + 63) / 64)), dim3(576), 0, s, part, bias, table, slices, cout);
+  UNET_CHECK_LAUNCH(ctx, "bn_fold_prepare");
+  return UNET_OK;
+}
 
 // one launch for several layers: item k = (weights, scratch, cin, cout, flip, image rows) exactly as k_wino_weights takes them
 int32_t k_wino_weights_multi(unet_ctx* ctx, unet_wino_prep_list* L, const int* h, hipStream_t s) {
@@ -833,6 +910,7 @@ int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const 
     if (cout % 64 == 0) return launch_wino2d<32, 1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
     return launch_wino2d<32, 2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   }
+  if (mask_mode == MASK_BIAS_TAB) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3 winograd: the folded-BatchNorm bias table needs the F(2x2,3x3) kernels (h=%d cout=%d)", h, cout);
   // One image row per wave (64 accumulator registers) -> 3 workgroups per CU: occupancy pays more than sharing the weight operand
   // between two rows did (the <64,4,2,2> / <32,8,4,1> tiles measured 1-8 % slower on every U-Net layer).
   if (cout % 64 == 0) return launch_wino<64, 2, 2, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);

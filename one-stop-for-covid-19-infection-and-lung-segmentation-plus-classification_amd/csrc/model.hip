@@ -63,6 +63,18 @@ static bool use_mfma(int algo, int cin, int cout) {
 }
 
 // Winograd pays when its 64-column row tiles are reasonably full; `uws` = scratch for the transformed weights (may be null)
+// decoder BatchNorm statistics: skip half analytic, up half measured (unet_bn_stats_concat); 0 = read the whole concat as before
+static bool bn_concat_analytic() {
+  static const int on = [] { const char* e = getenv("UNET_BN_CONCAT_ANALYTIC"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
+  return on != 0;
+}
+
+// decoder BatchNorm folded into the conv behind it (no normalised copy of the concat); 0 = materialise it with bn_apply as before
+static bool bn_fold_enabled() {
+  static const int on = [] { const char* e = getenv("UNET_BN_FOLD"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
+  return on != 0;
+}
+
 static bool use_wino(int algo, int wd, int cin, int cout, const float* uws) {
   if (!uws || !wino_conv3x3_supported(cin, cout)) return false;
   if (algo == UNET_ALGO_WINOGRAD) return true;
@@ -152,6 +164,38 @@ int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, co
   // data gradient = 3x3 convolution of dy (cout channels) with the flipped/transposed kernel -> cin channels
   return conv3x3_fwd_dispatch(ctx, dy, w, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
                               as_stream(stream), wt_ws, 1);
+}
+
+/* ---- conv3x3 over a BatchNorm-affine input without the normalised tensor (the decoder blocks BN -> Conv, T1:888-889 ...) ---- */
+int32_t unet_conv3x3_bnfold_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
+  static float dummy;
+  return (h >= 1 && wd >= 1 && cin >= 1 && cout >= 1 && use_wino(algo, wd, cin, cout, &dummy) && wino_uses_2d(h, cout) && wgrad_bn_fold_supported(cout)) ? 1 : 0;
+}
+size_t unet_conv3x3_bnfold_ws_floats(int32_t n, int32_t cin, int32_t cout) {
+  if (n < 1 || cin < 1 || cout < 1) return 0;
+  return bn_fold_scratch_floats(cin, cout) + (size_t)16 * cin * cout + wgrad_bn_fold_scratch_floats(n, cout);
+}
+int32_t unet_conv3x3_bnfold_fwd(unet_ctx* ctx, const float* x, const float* bnp, const float* w, const float* bias, float* y, int32_t n, int32_t h, int32_t wd,
+                                int32_t cin, int32_t cout, int32_t act, int32_t algo, float* ws, void* stream) {
+  if (!ctx || !x || !bnp || !w || !y || !ws || n < 1 || act < 0 || act > ACT_RELU) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bnfold_fwd: bad args");
+  if (!unet_conv3x3_bnfold_supported(algo, h, wd, cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bnfold_fwd: no folded form for h=%d w=%d cin=%d cout=%d (unet_conv3x3_bnfold_supported)", h, wd, cin, cout);
+  hipStream_t s = as_stream(stream);
+  float* u = ws + bn_fold_scratch_floats(cin, cout);
+  int32_t r = k_bn_fold_prepare(ctx, w, bias, bnp, bnp + cin, cin, cout, ws, s);
+  if (r) return r;
+  r = k_wino_weights(ctx, ws, u, cin, cout, 0, h, s);
+  if (r) return r;
+  const float* tab = ws + (size_t)9 * cin * cout;
+  return k_conv3x3_wino_fwd(ctx, x, u, tab, tab, MASK_BIAS_TAB, y, n, h, wd, cin, cout, act, 0.0f, 0, s);
+}
+int32_t unet_conv3x3_bnfold_bwd_weights(unet_ctx* ctx, const float* x, const float* bnp, const float* dy, float* dw, float* db, void* gws, size_t gws_bytes, float* ws,
+                                        int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+  if (!ctx || !x || !bnp || !dy || !dw || !db || !ws || n < 1 || h < 1 || wd < 1 || cin < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bnfold_bwd_weights: bad args");
+  if (!wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bnfold_bwd_weights: cout=%d (needs a divisor of 256)", cout);
+  hipStream_t s = as_stream(stream);
+  int32_t r = conv3x3_wgrad_dispatch(ctx, x, dy, dw, db, gws, gws_bytes, n, h, wd, cin, cout, algo, s);
+  if (r) return r;
+  return k_wgrad_bn_fold_fix(ctx, dy, n, h, wd, cin, cout, bnp, bnp + cin, dw, db, ws + bn_fold_scratch_floats(cin, cout) + (size_t)16 * cin * cout, s);
 }
 
 size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
@@ -288,6 +332,10 @@ struct unet_model {
   size_t off_loss_sums = 0, off_loss_out = 0, off_wt = 0, off_wgrad_ws = 0; size_t wgrad_ws_bytes = 0;
   std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the Winograd-transformed weights (forward / data-gradient form),
                                                       // filled by ONE batched launch at the start of a program
+  // U-Net fp32: convs whose input BatchNorm is folded into them: conv name -> scratch of (scaled weights, bias table) / of the
+  // weight-gradient correction; folded_bn maps the BatchNorm's activation name to (its input buffer, its channel count): never written by the programs
+  std::map<std::string, size_t> fold_off, fold_g_off;
+  std::map<std::string, std::pair<std::string, int>> folded_bn;
   std::vector<Op> prog[3];
   std::vector<unet_sync_point> sync[3];
   struct SyncRef { int after_op, kind; bool in_ws; size_t off_bytes; int64_t count; };
@@ -406,7 +454,18 @@ void plan_workspace(unet_model* m) {
   { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)16 * l.cin * l.cout); m->off_wt = cv.take(wt); }   // transformed-weight scratch
   // per-layer scratch of the prepared weights: 16 Winograd taps (fp32) or the 9-tap bf16 image
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
+  // decoder BatchNorm folded into the conv that consumes it: whenever that conv runs on the F(2x2,3x3) kernels (the only ones with the border-class bias)
+  if (!m->dt && bn_fold_enabled()) {
+    for (int k = 6; k <= 9; ++k) {
+      const std::string ks = std::to_string(k), cn = "c" + ks + "a";
+      const Buf ob = m->act.at(cn); const int cin = 2 * ob.c, cout = ob.c;
+      if (!use_wino(m->algo, ob.w, cin, cout, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, cout) || !wgrad_bn_fold_supported(cout)) continue;
+      m->fold_off[cn] = cv.take(bn_fold_scratch_floats(cin, cout));
+      m->folded_bn["bn" + ks] = {"cat" + ks, cin};
+    }
+  }
   m->ws_floats_infer = cv.cur;
+  for (auto& kv : m->fold_off) m->fold_g_off[kv.first] = cv.take(wgrad_bn_fold_scratch_floats(N, m->act.at(kv.first).c));
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
   // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
@@ -466,12 +525,6 @@ double nel(const Buf& b) { return (double)b.n * b.h * b.w * b.c; }
     (vec).push_back(std::move(_o));                           \
   } while (0)
 
-// decoder BatchNorm statistics: skip half analytic, up half measured (unet_bn_stats_concat); 0 = read the whole concat as before
-static bool bn_concat_analytic() {
-  static const int on = [] { const char* e = getenv("UNET_BN_CONCAT_ANALYTIC"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
-  return on != 0;
-}
-
 void build_programs(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int algo = m->algo;
@@ -502,6 +555,7 @@ void build_programs(unet_model* m) {
     for (auto& it : prep_items) {
       const int ci = flip ? it.cout : it.cin, co = flip ? it.cin : it.cout;          // channels the launch consumes / produces
       if (flip && it.name == "c1a") continue;
+      if (!flip && m->fold_off.count(it.name)) continue;          // prepared after its BatchNorm's finalize (bn_fold_prepare)
       if (!use_wino(algo, it.w, ci, co, m->wsf(m->off_wt)) || L.n >= UNET_WINO_PREP_MAX) continue;
       L.item[L.n] = {m->P(it.name + "/kernel"), m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)), it.cin, it.cout, flip, 0};
       hs[L.n++] = it.h;
@@ -563,7 +617,7 @@ void build_programs(unet_model* m) {
           return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
         });
       }
-      if (!fuse_pool) ADD_OP(F, "bn_apply:" + name, 0, 2 * eb * pixels * c, {
+      if (!fuse_pool && !m->folded_bn.count(name)) ADD_OP(F, "bn_apply:" + name, 0, 2 * eb * pixels * c, {
         if (dt) return unet_bn_apply_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(out)), ob.ld, pixels, c, s);
         return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s);
       });
@@ -600,6 +654,20 @@ void build_programs(unet_model* m) {
         return unet_convT2x2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, algo, s);
       });
       bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c, false, "bn" + std::to_string(10 - k));      // cat_k = [u_k, bn_{10-k} output]
+      if (m->fold_off.count("c" + ks + "a")) {                // BatchNorm folded into the conv: scaled weights + border-class bias, raw concat in
+        const std::string cn = "c" + ks + "a", xn = "cat" + ks, bnn = "bn" + ks;
+        const Buf ob = m->act.at(cn); const int cin = 2 * c, cout = c;
+        const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn), uo = m->wprep_f.at(cn);
+        ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * cin * cout * 2, 4.0 * 9 * cin * cout * 4, {
+          int32_t r = k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + cin, cin, cout, m->wsf(fo), s);
+          if (r) return r;
+          return k_wino_weights(ctx, m->wsf(fo), m->wsf(uo), cin, cout, 0, ob.h, s);
+        });
+        ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout, {
+          const float* tab = m->wsf(fo) + (size_t)9 * cin * cout;
+          return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(uo), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0, s);
+        });
+      } else
       conv("c" + ks + "a", "bn" + ks, 2 * c, c);
       conv("c" + ks + "b", "c" + ks + "a", c, c);
       prev = "c" + ks + "b"; cprev = c;
@@ -642,19 +710,27 @@ void build_programs(unet_model* m) {
                            m->G("out/kernel"), m->G("out/bias"), hp, hb.c, 1, s);
     });
     // conv backward: wgrad (x, dy) then dgrad (dy -> dx, optional relu mask = activation that produced x)
-    auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, bool mask_in) {
+    // xraw: the conv's input BatchNorm is folded (fold_off): the weight gradient runs on the raw tensor `xraw` and is corrected afterwards
+    auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, bool mask_in, const std::string& xraw = "") {
       const Buf ob = m->act.at(name);
       const double px = (double)ob.n * ob.h * ob.w;
+      const std::string xsrc = xraw.empty() ? in : xraw;
       ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
         if (dt) {
           if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
           return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(in)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w,
                                       cin, cout, s);
         }
-        const float* xin = in.empty() ? m->x : m->A(in);
+        const float* xin = xsrc.empty() ? m->x : m->A(xsrc);
         return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
                                       ob.n, ob.h, ob.w, cin, cout, algo, s);
       });
+      if (!xraw.empty()) {
+        const size_t go = m->fold_g_off.at(name), bo = m->bnp_off.at(in);
+        ADD_OP(BW, "wgrad_bn_fold_fix:" + name, 2.0 * 9 * cin * cout, 8.0 * 9 * cin * cout, {
+          return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s);
+        });
+      }
       if (want_dx) {
         ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? cin : 0)) + 4.0 * 9.0 * cin * cout, {
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mask_in ? CBF(m->Av(in)) : nullptr, mask_in ? MASK_RELU : MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h,
@@ -702,7 +778,7 @@ void build_programs(unet_model* m) {
       std::string prev = (k == 6) ? "c5b" : "c" + std::to_string(k - 1) + "b";
       int cprev = (k == 6) ? 512 : dec[k - 7];
       conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
-      conv_bwd("c" + ks + "a", "bn" + ks, 2 * c, c, true, false);
+      conv_bwd("c" + ks + "a", "bn" + ks, 2 * c, c, true, false, m->fold_off.count("c" + ks + "a") ? "cat" + ks : "");
       bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, false);
       const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
       const std::string un = "u" + ks;
@@ -1442,6 +1518,15 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
   auto it = mp.find(name);
   if (it == mp.end()) return UNET_E_ARG;
   const Buf& b = it->second;
+  const auto fb = m->folded_bn.find(name);
+  if (!grad && fb != m->folded_bn.end()) {
+    // the programs never write this tensor (its BatchNorm is folded into the next conv): a tap materialises it from the layer's input and the
+    // scale / shift of the last forward, on the null stream, and waits for it
+    const Buf& xb = m->act.at(fb->second.first);
+    int32_t r = unet_bn_apply(m->ctx, m->A(fb->second.first), xb.ld, m->wsf(m->bnp_off.at(name)), const_cast<float*>(m->A(name)), b.ld, (int64_t)b.n * b.h * b.w, fb->second.second, nullptr);
+    if (r) return r;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return UNET_E_HIP;
+  }
   if (ptr) *ptr = m->bufptr(b);
   if (ld) *ld = b.ld; if (n) *n = b.n; if (h) *h = b.h; if (w) *w = b.w; if (c) *c = b.c;
   return UNET_OK;

@@ -76,6 +76,11 @@ def test_live_oracle_all_grads_and_taps(hw, n):
     eng.set_weights(wts)
     ld = eng.forward_backward(x, y).cpu().numpy()
     assert abs(ld[0] - r["loss"]) < 1e-5 and abs(ld[1] - r["dice"]) < 1e-5
+    if w_ >= 32:
+        # the wide case runs the folded decoder BatchNorms (no bn_apply pass, scaled weights + border-class bias, corrected weight gradient):
+        # everything below -- c9a's output, its kernel gradient, the taps of bn9 (materialised on demand) -- is checked THROUGH that path
+        fwd = [o[0] for o in eng.op_profile(n, 0)]; bwd = [o[0] for o in eng.op_profile(n, 1)]
+        assert "bn_fold_prepare:c9a" in fwd and "bn_apply:bn9" not in fwd and "wgrad_bn_fold_fix:c9a" in bwd, fwd
     for name in ("c1a", "c1b", "bn1", "p1", "c3b", "bn4", "p4", "c5b", "u6", "bn6", "c6a", "u9", "bn9", "c9b"):
         assert relerr(eng.tap(n, name), r["acts"][name]) < 2e-5, name
     # A ReLU whose pre-activation rounds to the other side of 0 in fp32 is a discontinuity, not an error: ONE such

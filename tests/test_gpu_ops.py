@@ -318,6 +318,49 @@ def test_bn_stats_concat_analytic_skip_half(ops, shape):
     assert ops.lib.unet_bn_stats_concat(ops.h, cat.data_ptr(), ld, es.data_ptr(), 0.0, ops.d(ge).data_ptr(), ops.d(be).data_ptr(), got.data_ptr(), pixels, cu, cs, ops.s) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 64, 64, 32), (1, 9, 70, 128, 64), (3, 2, 33, 32, 32), (2, 12, 40, 512, 256), (1, 64, 64, 16, 128), (2, 5, 1, 32, 64)])
+def test_conv3x3_bnfold_matches_bn_apply_then_conv(ops, shape):
+    """decoder BN -> Conv (T1:888-889): the BatchNorm folded into the conv (scaled weights + a bias per border class, weight gradient corrected
+    from db and the border sums of dy) against the fp64 oracle of conv3x3(zero-padded BN(x)), forward and weight gradient -- odd sizes, two-row and
+    one-column images (first and last row / column coincide), 512 -> 256 channels"""
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    if not ops.lib.unet_conv3x3_bnfold_supported(0, h, w, ci, co):
+        pytest.skip("no folded form for this shape")
+    rng = np.random.default_rng(h * w + ci)
+    x = (rng.standard_normal((n, h, w, ci)) * rng.uniform(0.5, 2.0, ci) + rng.uniform(-1.5, 1.5, ci)).astype(np.float32)
+    k = (rng.standard_normal((3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32); b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.4, 1.6, ci).astype(np.float32); shift = (rng.standard_normal(ci) * 0.7).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
+    bnp = ops.d(np.concatenate([scale, shift, np.zeros(2 * ci, np.float32)]))
+    ws = ops.z(int(ops.lib.unet_conv3x3_bnfold_ws_floats(n, ci, co)))
+    y = ops.z(n, h, w, co)
+    ops.ck(ops.lib.unet_conv3x3_bnfold_fwd(ops.h, ops.d(x).data_ptr(), bnp.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0, ws.data_ptr(), ops.s), "fold fwd")
+    zt = T64(x) * T64(scale) + T64(shift)
+    kt = T64(k).requires_grad_(True); bt = T64(b).requires_grad_(True)
+    yt = O.conv3x3_bias_relu(zt, kt, bt, True)
+    assert relerr(y.cpu().numpy(), yt.detach().numpy()) < TOL
+    # every border class is hit exactly: compare the first / last rows and columns on their own
+    yn, yw = y.cpu().numpy(), yt.detach().numpy()
+    for sl in (np.s_[:, 0], np.s_[:, -1], np.s_[:, :, 0], np.s_[:, :, -1]):
+        assert relerr(yn[sl], yw[sl]) < 5e-5
+    # weight gradient (dy taken as already masked)
+    pre = O.conv3x3_bias_relu(zt, kt, bt, False)
+    pre.backward(T64(dy))
+    gb = int(ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co)); gws = ops.z(max(gb // 4, 4))
+    dw = ops.z(3, 3, ci, co); db = ops.z(co)
+    ops.ck(ops.lib.unet_conv3x3_bnfold_bwd_weights(ops.h, ops.d(x).data_ptr(), bnp.data_ptr(), ops.d(dy).data_ptr(), dw.data_ptr(), db.data_ptr(), gws.data_ptr(), gb, ws.data_ptr(),
+                                                   n, h, w, ci, co, 0, ops.s), "fold wgrad")
+    assert relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < 5e-5
+    gmax = np.abs(kt.grad.numpy()).max()                     # per tap, against the gradient's scale: on a one-column image the side taps are exactly 0
+    for a in range(3):
+        for bb in range(3):
+            assert np.abs(dw.cpu().numpy()[a, bb] - kt.grad.numpy()[a, bb]).max() < 1e-4 * gmax, (a, bb)
+    assert ops.lib.unet_conv3x3_bnfold_supported(1, h, w, ci, co) == 0          # the direct kernels have no border-class bias
+    assert ops.lib.unet_conv3x3_bnfold_fwd(ops.h, ops.d(x).data_ptr(), bnp.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 1, ws.data_ptr(), ops.s) == -3
+
+
 @pytest.mark.parametrize("algo", [0, 1])
 @pytest.mark.parametrize("shape", [(2, 10, 14, 32, 64), (1, 8, 8, 96, 32), (2, 12, 12, 1, 32), (1, 6, 6, 192, 64)])
 def test_conv3x3_elu_dropout_and_mask_modes(ops, shape, algo):
