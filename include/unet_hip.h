@@ -83,14 +83,17 @@ int32_t unet_conv3x3_bwd_data(unet_ctx*, const float* dy, const float* w, const 
  * row or column sees fewer taps of the shift (16 classes, exact).  The forward then reads the raw x.  The weight gradient runs on the raw
  * x as well and is corrected: dw = scale[c] dw_raw + shift[c] S[tap][o], S = db minus the border row / column sums of dy the tap
  * excludes (plus the corner).  Only where unet_conv3x3_bnfold_supported() says so (the F(2x2,3x3) forward kernels; cout a divisor of
- * 256); ws: unet_conv3x3_bnfold_ws_floats floats, shared by the two calls of a step; gws: as unet_conv3x3_bwd_weights. */
+ * 256); ws: unet_conv3x3_bnfold_ws_floats floats, shared by the two calls of a step; gws: as unet_conv3x3_bwd_weights.
+ * bn_bwd_sums (optional, with the kernel w and bnp = scale, shift, mean, invstd): the BatchNorm's backward sums double[2*cin] =
+ * (sum dz, sum dz*xhat) as unet_bn_bwd_stats accumulates them, but WITHOUT reading dz or x -- dz is this conv's data gradient, so
+ * sum_p dz_c = sum_{tap,o} w[tap][c][o] S[tap][o] and sum_p dz_c x_c = sum_{tap,o} w[tap][c][o] dw_raw[tap][c][o]. */
 int32_t unet_conv3x3_bnfold_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
 size_t unet_conv3x3_bnfold_ws_floats(int32_t n, int32_t cin, int32_t cout);
 int32_t unet_conv3x3_bnfold_fwd(unet_ctx*, const float* x, const float* bnp, const float* w, const float* bias, float* y, int32_t n, int32_t h,
                                 int32_t wd, int32_t cin, int32_t cout, int32_t act, int32_t algo, float* ws, void* stream);
-int32_t unet_conv3x3_bnfold_bwd_weights(unet_ctx*, const float* x, const float* bnp, const float* dy, float* dw, float* db, void* gws,
-                                        size_t gws_bytes, float* ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
-                                        int32_t algo, void* stream);
+int32_t unet_conv3x3_bnfold_bwd_weights(unet_ctx*, const float* x, const float* bnp, const float* dy, const float* w, float* dw, float* db,
+                                        double* bn_bwd_sums, void* gws, size_t gws_bytes, float* ws, int32_t n, int32_t h, int32_t wd,
+                                        int32_t cin, int32_t cout, int32_t algo, void* stream);
 /* dw[a,b,c,o] = sum x[n,i+a-1,j+b-1,c]*dy[n,i,j,o];  db[o] = sum dy.  dy already ReLU-masked.
  * ws: split-K scratch (unet_conv3x3_bwd_weights_ws_bytes). dw/db are OVERWRITTEN. */
 size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout);

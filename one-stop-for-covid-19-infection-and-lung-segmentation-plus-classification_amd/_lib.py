@@ -66,7 +66,7 @@ _PROTOS = {
     "unet_conv3x3_bnfold_supported": (i32, [i32, i32, i32, i32, i32]),
     "unet_conv3x3_bnfold_ws_floats": (sz, [i32, i32, i32]),
     "unet_conv3x3_bnfold_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
-    "unet_conv3x3_bnfold_bwd_weights": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "unet_conv3x3_bnfold_bwd_weights": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_bn_stats_concat": (i32, [vp, vp, i32, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
     "unet_bn_stats_concat_bf16": (i32, [vp, vp, i32, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
     "unet_bn_finalize_train": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, i32, vp]),

@@ -1019,6 +1019,29 @@ __global__ __launch_bounds__(256) void fold_tap_sums_kernel(const float* __restr
     S[tap * C + o] = ((db[o] - kr) - kc) + kk;
   }
 }
+// (sum dz, sum dz * xhat) of the folded BatchNorm's backward WITHOUT reading dz or x: dz is the data gradient of this conv, so per input channel c
+//   sum_p dz_c(p)        = sum_{tap,o} W[tap][c][o] * S[tap][o]
+//   sum_p dz_c(p) x_c(p) = sum_{tap,o} W[tap][c][o] * dW_raw[tap][c][o]        (dW_raw = the weight gradient on the raw x, before the correction)
+// and sum dz * xhat = istd * (sum dz x - mean * sum dz).  grid cin, 256 threads over the 9 * cout (tap, o) pairs; added into sums[2 * cin] (doubles).
+__global__ __launch_bounds__(256) void fold_bn_bwd_sums_kernel(const float* __restrict__ w, const float* __restrict__ dw_raw, const float* __restrict__ S,
+                                                               const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ sums, int cin, int cout) {
+  __shared__ double s_a[256], s_b[256];
+  const int c = blockIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < 9 * cout; i += 256) {
+    const int tap = i / cout, o = i - tap * cout;
+    const long long j = ((long long)tap * cin + c) * cout + o;
+    const float wv = w[j];
+    a = fmaf(wv, dw_raw[j], a); b = fmaf(wv, S[i], b);
+  }
+  s_a[threadIdx.x] = (double)a; s_b[threadIdx.x] = (double)b;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { s_a[threadIdx.x] += s_a[threadIdx.x + st]; s_b[threadIdx.x] += s_b[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[c] += s_b[0]; sums[cin + c] += (double)istd[c] * (s_a[0] - (double)mean[c] * s_b[0]); }
+}
 __global__ void fold_fix_kernel(float* __restrict__ dw, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ S, int cin, int cout4,
                                 long long total4) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
@@ -1034,12 +1057,17 @@ __global__ void fold_fix_kernel(float* __restrict__ dw, const float* __restrict_
 
 bool wgrad_bn_fold_supported(int cout) { return cout >= 4 && cout <= 256 && 256 % cout == 0; }
 size_t wgrad_bn_fold_scratch_floats(int n, int cout) { return (size_t)(n > 0 ? n : 0) * BORDER_SEG * 8 * cout + 9 * (size_t)cout; }
+// w / mean / istd / bn_bwd_sums (all or none): also accumulate the folded BatchNorm's backward sums (sum dz, sum dz * xhat) -- from W, the raw dw and S
 int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                            float* scratch, hipStream_t s) {
+                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
   if (!dy || !scale || !shift || !dw || !db || !scratch || !wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: bad args (cout=%d)", cout);
   float* border = scratch; float* S = scratch + (size_t)n * BORDER_SEG * 8 * cout;
   hipLaunchKernelGGL(border_sums_kernel, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
   hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, border, db, S, n * BORDER_SEG, cout);
+  if (bn_bwd_sums) {
+    if (!w || !mean || !istd) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: the BatchNorm backward sums need w, mean, istd");
+    hipLaunchKernelGGL(fold_bn_bwd_sums_kernel, dim3((unsigned)cin), dim3(256), 0, s, w, dw, S, mean, istd, bn_bwd_sums, cin, cout);
+  }
   const long long total4 = 9LL * cin * cout / 4;
   hipLaunchKernelGGL(fold_fix_kernel, dim3((unsigned)std::min<long long>((total4 + 255) / 256, 2048)), dim3(256), 0, s, dw, scale, shift, S, cin, cout / 4, total4);
   UNET_CHECK_LAUNCH(ctx, "wgrad_bn_fold_fix");

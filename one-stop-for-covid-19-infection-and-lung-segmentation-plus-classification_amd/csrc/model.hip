@@ -188,14 +188,16 @@ int32_t unet_conv3x3_bnfold_fwd(unet_ctx* ctx, const float* x, const float* bnp,
   const float* tab = ws + (size_t)9 * cin * cout;
   return k_conv3x3_wino_fwd(ctx, x, u, tab, tab, MASK_BIAS_TAB, y, n, h, wd, cin, cout, act, 0.0f, 0, s);
 }
-int32_t unet_conv3x3_bnfold_bwd_weights(unet_ctx* ctx, const float* x, const float* bnp, const float* dy, float* dw, float* db, void* gws, size_t gws_bytes, float* ws,
-                                        int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
+int32_t unet_conv3x3_bnfold_bwd_weights(unet_ctx* ctx, const float* x, const float* bnp, const float* dy, const float* w, float* dw, float* db, double* bn_bwd_sums, void* gws,
+                                        size_t gws_bytes, float* ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
   if (!ctx || !x || !bnp || !dy || !dw || !db || !ws || n < 1 || h < 1 || wd < 1 || cin < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bnfold_bwd_weights: bad args");
   if (!wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bnfold_bwd_weights: cout=%d (needs a divisor of 256)", cout);
   hipStream_t s = as_stream(stream);
   int32_t r = conv3x3_wgrad_dispatch(ctx, x, dy, dw, db, gws, gws_bytes, n, h, wd, cin, cout, algo, s);
   if (r) return r;
-  return k_wgrad_bn_fold_fix(ctx, dy, n, h, wd, cin, cout, bnp, bnp + cin, dw, db, ws + bn_fold_scratch_floats(cin, cout) + (size_t)16 * cin * cout, s);
+  if (bn_bwd_sums && !w) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bnfold_bwd_weights: bn_bwd_sums needs the kernel w");
+  return k_wgrad_bn_fold_fix(ctx, dy, n, h, wd, cin, cout, bnp, bnp + cin, dw, db, ws + bn_fold_scratch_floats(cin, cout) + (size_t)16 * cin * cout, s,
+                             bn_bwd_sums ? w : nullptr, bn_bwd_sums ? bnp + 2 * cin : nullptr, bn_bwd_sums ? bnp + 3 * cin : nullptr, bn_bwd_sums);
 }
 
 size_t unet_conv3x3_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
@@ -728,7 +730,9 @@ void build_programs(unet_model* m) {
       if (!xraw.empty()) {
         const size_t go = m->fold_g_off.at(name), bo = m->bnp_off.at(in);
         ADD_OP(BW, "wgrad_bn_fold_fix:" + name, 2.0 * 9 * cin * cout, 8.0 * 9 * cin * cout, {
-          return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s);
+          // ... and the BatchNorm's backward sums (sum dz, sum dz * xhat) come out of W, the raw dw and S: no pass over dz / x (bn_bwd below: stats_done)
+          return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
+                                     m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in));
         });
       }
       if (want_dx) {
@@ -779,7 +783,7 @@ void build_programs(unet_model* m) {
       int cprev = (k == 6) ? 512 : dec[k - 7];
       conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
       conv_bwd("c" + ks + "a", "bn" + ks, 2 * c, c, true, false, m->fold_off.count("c" + ks + "a") ? "cat" + ks : "");
-      bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, false);
+      bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, m->fold_off.count("c" + ks + "a") != 0);
       const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
       const std::string un = "u" + ks;
       ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, eb * (nel(ib) + nel(ug)), {

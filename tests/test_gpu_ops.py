@@ -349,8 +349,21 @@ def test_conv3x3_bnfold_matches_bn_apply_then_conv(ops, shape):
     pre.backward(T64(dy))
     gb = int(ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co)); gws = ops.z(max(gb // 4, 4))
     dw = ops.z(3, 3, ci, co); db = ops.z(co)
-    ops.ck(ops.lib.unet_conv3x3_bnfold_bwd_weights(ops.h, ops.d(x).data_ptr(), bnp.data_ptr(), ops.d(dy).data_ptr(), dw.data_ptr(), db.data_ptr(), gws.data_ptr(), gb, ws.data_ptr(),
-                                                   n, h, w, ci, co, 0, ops.s), "fold wgrad")
+    bsums = ops.z(2 * ci, dtype=torch.float64)
+    ops.ck(ops.lib.unet_conv3x3_bnfold_bwd_weights(ops.h, ops.d(x).data_ptr(), bnp.data_ptr(), ops.d(dy).data_ptr(), ops.d(k).data_ptr(), dw.data_ptr(), db.data_ptr(), bsums.data_ptr(),
+                                                   gws.data_ptr(), gb, ws.data_ptr(), n, h, w, ci, co, 0, ops.s), "fold wgrad")
+    # the BatchNorm's backward sums without a pass over dz: (sum dz, sum dz * xhat) with dz = d loss / d z from the oracle (bnp mean = 0, invstd = 0 -> xhat = 0 here,
+    # so give the op a real mean / invstd through a second bnp)
+    dz = torch.autograd.grad(O.conv3x3_bias_relu(zt.requires_grad_(True), kt.detach(), bt.detach(), False), zt, T64(dy))[0].numpy()
+    assert relerr(bsums.cpu().numpy()[:ci], dz.sum((0, 1, 2))) < 5e-5
+    mean = x.astype(np.float64).mean((0, 1, 2)); istd = 1.0 / np.sqrt(x.astype(np.float64).var((0, 1, 2)) + 1e-3)
+    bnp2 = ops.d(np.concatenate([scale, shift, mean.astype(np.float32), istd.astype(np.float32)]))
+    bsums2 = ops.z(2 * ci, dtype=torch.float64)
+    ops.ck(ops.lib.unet_conv3x3_bnfold_bwd_weights(ops.h, ops.d(x).data_ptr(), bnp2.data_ptr(), ops.d(dy).data_ptr(), ops.d(k).data_ptr(), dw.data_ptr(), db.data_ptr(), bsums2.data_ptr(),
+                                                   gws.data_ptr(), gb, ws.data_ptr(), n, h, w, ci, co, 0, ops.s), "fold wgrad + bn sums")
+    xhat = (x.astype(np.float64) - mean.astype(np.float32)) * istd.astype(np.float32)
+    want2 = (dz * xhat).sum((0, 1, 2))
+    assert np.abs(bsums2.cpu().numpy()[ci:] - want2).max() < 1e-4 * max(np.abs(want2).max(), np.abs(dz).sum((0, 1, 2)).max() * 1e-2)
     assert relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
     assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < 5e-5
     gmax = np.abs(kt.grad.numpy()).max()                     # per tap, against the gradient's scale: on a one-column image the side taps are exactly 0
