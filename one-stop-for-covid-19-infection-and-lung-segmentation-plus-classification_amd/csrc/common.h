@@ -145,6 +145,10 @@ enum { MASK_NONE = 0, MASK_RELU = 1, MASK_ELU = 2, MASK_ELU_DROP = 3 };
 // internal to the F(2x2,3x3) forward kernels: `mask` is not a mask but the border-class bias table of a conv whose input BatchNorm was
 // folded into its weights (k_bn_fold_prepare): [16][Cout], class = 4 * (row == 0 | (row == H-1) << 1) + (col == 0 | (col == W-1) << 1)
 enum { MASK_BIAS_TAB = 4 };
+// internal to the same kernels, data-gradient launches: the BatchNorm backward of the conv's (folded) input BatchNorm applied in the epilogue --
+// `mask` = the BatchNorm's input x (same shape as the output), `bias` = coefficients [3][Cout]: out = K0 * dz + K1 * x + K2 (k_bn_bwd_coef)
+enum { MASK_BN_BWD = 5 };
+int32_t k_bn_bwd_coef(unet_ctx*, const float* bnp, const double* sums, double count, float* coef, int c, hipStream_t s);
 __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep_scale component */, float rate) {
   if (mode == MASK_RELU) return m > 0.0f ? 1.0f : 0.0f;
   if (mode == MASK_ELU) return m > 0.0f ? 1.0f : m + 1.0f;

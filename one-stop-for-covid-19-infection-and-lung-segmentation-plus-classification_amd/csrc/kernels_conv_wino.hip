@@ -468,16 +468,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
       xb[(half * 16 + r) * 64 + lane] = send;
     }
   }
+  const int e = l31 & 3, q4 = l31 & ~3;
+  const bool odd1 = e & 1, odd2 = e & 2;
+  const int co = nbase + wc * 32 + q4;
+  // the per-element epilogue input (ReLU mask of a data gradient / x of a folded BatchNorm backward) is requested BEFORE the exchange barrier: its HBM
+  // latency overlaps the exchange and the transposes instead of ending every workgroup (the accumulators are dead, registers are free)
+  float4 mpre[4][2];
+  const bool want_m = !GEN && (mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD);
+  if (want_m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int mt = e + 8 * g + 4 * hi;
+        const int px = x0 + 2 * (mt % WT) + half, py = y0 + 2 * (wm * RPW + mt / WT) + kh;
+        mpre[g][half] = (py < H && px < W && co < Cout) ? *reinterpret_cast<const float4*>(mask + (((long long)n * H + py) * W + px) * Cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
   __syncthreads();
 #pragma unroll
   for (int half = 0; half < 2; ++half)
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[half][r] += pb[(half * 16 + r) * 64 + lane];
 
-  const int e = l31 & 3, q4 = l31 & ~3;
-  const bool odd1 = e & 1, odd2 = e & 2;
-  const int co = nbase + wc * 32 + q4;
   const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 kb1 = bb, kb2 = bb;                                 // MASK_BN_BWD: bb = K0, these K1, K2
+  if (mask_mode == MASK_BN_BWD && co < Cout) { kb1 = *reinterpret_cast<const float4*>(bias + Cout + co); kb2 = *reinterpret_cast<const float4*>(bias + 2 * Cout + co); }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -504,9 +520,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
       float4 o4 = make_float4(v0 + bs.x, v1 + bs.y, v2 + bs.z, v3 + bs.w);
       const long long o = (((long long)n * H + py) * W + px) * Cout + co;
       if (!GEN) {
+        if (mask_mode == MASK_BN_BWD) {                       // the folded BatchNorm's backward: dx = K0 * dz + K1 * x + K2
+          const float4 m = mpre[g][half];
+          o4.x = fmaf(bb.x, v0, fmaf(kb1.x, m.x, kb2.x)); o4.y = fmaf(bb.y, v1, fmaf(kb1.y, m.y, kb2.y));
+          o4.z = fmaf(bb.z, v2, fmaf(kb1.z, m.z, kb2.z)); o4.w = fmaf(bb.w, v3, fmaf(kb1.w, m.w, kb2.w));
+        }
         if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
         if (mask_mode == MASK_RELU) {
-          const float4 m = *reinterpret_cast<const float4*>(mask + o);
+          const float4 m = mpre[g][half];
           o4.x = m.x > 0.f ? o4.x : 0.f; o4.y = m.y > 0.f ? o4.y : 0.f; o4.z = m.z > 0.f ? o4.z : 0.f; o4.w = m.w > 0.f ? o4.w : 0.f;
         }
       } else {
@@ -654,8 +675,20 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
     xb[r * 64 + lane] = (m0 + m1) + m2;
     xb[(16 + r) * 64 + lane] = (m1 - m2) - m3;
   }
-  __syncthreads();
   const int orow = kq & 1, half = kq >> 1;
+  // the per-element epilogue input (ReLU mask / x of a folded BatchNorm backward) is requested before the exchange barrier (see conv_wino2d_kernel)
+  float4 mpre[4];
+  const bool want_m = !GEN && (mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD);
+  if (want_m) {
+    const int co_ = nbase + (l31 & ~3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int mt = (l31 & 3) + 8 * g + 4 * hi;
+      const int px = x0 + 2 * (mt % WT) + half, py = y0 + 2 * (mt / WT) + orow;
+      mpre[g] = (py < H && px < W && co_ < Cout) ? *reinterpret_cast<const float4*>(mask + (((long long)n * H + py) * W + px) * Cout + co_) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
   f32x16 mine;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -667,6 +700,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
   const bool odd1 = e & 1, odd2 = e & 2;
   const int co = nbase + q4;
   const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 kb1 = bb, kb2 = bb;                                 // MASK_BN_BWD: bb = K0, these K1, K2
+  if (mask_mode == MASK_BN_BWD && co < Cout) { kb1 = *reinterpret_cast<const float4*>(bias + Cout + co); kb2 = *reinterpret_cast<const float4*>(bias + 2 * Cout + co); }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float v0 = mine[4 * g + 0], v1 = mine[4 * g + 1], v2 = mine[4 * g + 2], v3 = mine[4 * g + 3];
@@ -691,9 +726,14 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
     float4 o4 = make_float4(v0 + bs.x, v1 + bs.y, v2 + bs.z, v3 + bs.w);
     const long long o = (((long long)n * H + py) * W + px) * Cout + co;
     if (!GEN) {
+      if (mask_mode == MASK_BN_BWD) {                         // the folded BatchNorm's backward: dx = K0 * dz + K1 * x + K2
+        const float4 m = mpre[g];
+        o4.x = fmaf(bb.x, v0, fmaf(kb1.x, m.x, kb2.x)); o4.y = fmaf(bb.y, v1, fmaf(kb1.y, m.y, kb2.y));
+        o4.z = fmaf(bb.z, v2, fmaf(kb1.z, m.z, kb2.z)); o4.w = fmaf(bb.w, v3, fmaf(kb1.w, m.w, kb2.w));
+      }
       if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
       if (mask_mode == MASK_RELU) {
-        const float4 m = *reinterpret_cast<const float4*>(mask + o);
+        const float4 m = mpre[g];
         o4.x = m.x > 0.f ? o4.x : 0.f; o4.y = m.y > 0.f ? o4.y : 0.f; o4.z = m.z > 0.f ? o4.z : 0.f; o4.w = m.w > 0.f ? o4.w : 0.f;
       }
     } else {
@@ -840,6 +880,14 @@ __global__ __launch_bounds__(576) void bn_fold_table_kernel(const float* __restr
     table[(long long)cls * cout + o] = b0 + v;
   }
 }
+// coefficients of the BatchNorm backward as one affine map of (dz, x): dx = sc (dz - k1 - xhat k2) = K0 dz + K1 x + K2, k1 = sum dz / count, k2 = sum dz xhat / count
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ bnp, const double* __restrict__ sums, double inv_count, float* __restrict__ coef, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sc = bnp[c], mean = bnp[2 * C + c], istd = bnp[3 * C + c];
+  const double k1 = sums[c] * inv_count, k2 = sums[C + c] * inv_count;
+  coef[c] = (float)sc; coef[C + c] = (float)(-sc * istd * k2); coef[2 * C + c] = (float)(sc * (mean * istd * k2 - k1));
+}
 }  // namespace
 
 static bool use_2d(int h, int cout) { return wino_2d_mode() && h >= 2 && cout % 32 == 0; }
@@ -849,6 +897,13 @@ int wino_tile_cols(int wd) {
   return u32 > 1.1 * u64 ? 32 : 64;
 }
 bool wino_uses_2d(int h, int cout) { return use_2d(h, cout); }
+
+int32_t k_bn_bwd_coef(unet_ctx* ctx, const float* bnp, const double* sums, double count, float* coef, int c, hipStream_t s) {
+  if (!bnp || !sums || !coef || c < 1 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_coef: bad args");
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((unsigned)((c + 127) / 128)), dim3(128), 0, s, bnp, sums, 1.0 / count, coef, c);
+  UNET_CHECK_LAUNCH(ctx, "bn_bwd_coef");
+  return UNET_OK;
+}
 
 size_t bn_fold_scratch_floats(int cin, int cout) { return (size_t)9 * cin * cout + 16 * (size_t)cout + (size_t)((cin + 31) / 32) * 9 * cout; }
 // scratch = [w_scaled 9*cin*cout][table 16*cout][tap partials]: bn_fold_scratch_floats(cin, cout)
@@ -910,7 +965,7 @@ int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const 
     if (cout % 64 == 0) return launch_wino2d<32, 1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
     return launch_wino2d<32, 2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   }
-  if (mask_mode == MASK_BIAS_TAB) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3 winograd: the folded-BatchNorm bias table needs the F(2x2,3x3) kernels (h=%d cout=%d)", h, cout);
+  if (mask_mode == MASK_BIAS_TAB || mask_mode == MASK_BN_BWD) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3 winograd: the folded-BatchNorm epilogues need the F(2x2,3x3) kernels (h=%d cout=%d)", h, cout);
   // One image row per wave (64 accumulator registers) -> 3 workgroups per CU: occupancy pays more than sharing the weight operand
   // between two rows did (the <64,4,2,2> / <32,8,4,1> tiles measured 1-8 % slower on every U-Net layer).
   if (cout % 64 == 0) return launch_wino<64, 2, 2, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);

@@ -70,9 +70,11 @@ static bool bn_concat_analytic() {
 }
 
 // decoder BatchNorm folded into the conv behind it (no normalised copy of the concat); 0 = materialise it with bn_apply as before
-static bool bn_fold_enabled() {
-  static const int on = [] { const char* e = getenv("UNET_BN_FOLD"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
-  return on != 0;
+// 0 = materialise the normalised concat (bn_apply) and run the BatchNorm backward as two passes; 1 = forward + weight gradient + backward sums folded;
+// 2 (default) = also the BatchNorm backward applied in the data-gradient epilogue
+static int bn_fold_enabled() {
+  static const int on = [] { const char* e = getenv("UNET_BN_FOLD"); return e ? atoi(e) : 2; }();   // A/B switch for measurements
+  return on;
 }
 
 static bool use_wino(int algo, int wd, int cin, int cout, const float* uws) {
@@ -336,7 +338,7 @@ struct unet_model {
                                                       // filled by ONE batched launch at the start of a program
   // U-Net fp32: convs whose input BatchNorm is folded into them: conv name -> scratch of (scaled weights, bias table) / of the
   // weight-gradient correction; folded_bn maps the BatchNorm's activation name to (its input buffer, its channel count): never written by the programs
-  std::map<std::string, size_t> fold_off, fold_g_off;
+  std::map<std::string, size_t> fold_off, fold_g_off, fold_c_off;     // fold_c_off: + the BatchNorm backward runs in the conv's data-gradient epilogue (coefficients [3][cin])
   std::map<std::string, std::pair<std::string, int>> folded_bn;
   std::vector<Op> prog[3];
   std::vector<unet_sync_point> sync[3];
@@ -467,7 +469,12 @@ void plan_workspace(unet_model* m) {
     }
   }
   m->ws_floats_infer = cv.cur;
-  for (auto& kv : m->fold_off) m->fold_g_off[kv.first] = cv.take(wgrad_bn_fold_scratch_floats(N, m->act.at(kv.first).c));
+  for (auto& kv : m->fold_off) {
+    const Buf ob = m->act.at(kv.first); const int cin = 2 * ob.c, cout = ob.c;
+    m->fold_g_off[kv.first] = cv.take(wgrad_bn_fold_scratch_floats(N, cout));
+    // the data gradient (cout -> cin channels) on the F(2x2,3x3) kernels too: the BatchNorm backward moves into its epilogue
+    if (bn_fold_enabled() >= 2 && use_wino(m->algo, ob.w, cout, cin, reinterpret_cast<const float*>(m)) && wino_uses_2d(ob.h, cin)) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
+  }
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
   // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
@@ -735,6 +742,22 @@ void build_programs(unet_model* m) {
                                      m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in));
         });
       }
+      if (!xraw.empty() && m->fold_c_off.count(name)) {
+        // BatchNorm backward inside the data gradient: the sums are already there (from the weight gradient), so param grads -> [cross-rank sum] -> coefficients ->
+        // dgrad whose epilogue writes dx = K0 dz + K1 x + K2 straight into the gradient of the raw concat; dz itself is never stored
+        const std::string bnn = in;
+        const size_t so = m->bn_bsum_off.at(bnn), bo = m->bnp_off.at(bnn), co = m->fold_c_off.at(name);
+        ADD_OP(BW, "bn_bwd_param_grads:" + bnn, 0, 0, {
+          return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(bnn + "/gamma"), m->G(bnn + "/beta"), cin, s);
+        });
+        SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)cin});
+        ADD_OP(BW, "conv3x3_dgrad_bn_bwd:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + 2 * cin) + 4.0 * 9.0 * cin * cout, {
+          int32_t r = k_bn_bwd_coef(ctx, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, px * gcount, m->wsf(co), cin, s);
+          if (r) return r;
+          return k_conv3x3_wino_fwd(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->wsf(co), m->A(xraw), MASK_BN_BWD, m->D(xraw), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0, s);
+        });
+        return;
+      }
       if (want_dx) {
         ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? cin : 0)) + 4.0 * 9.0 * cin * cout, {
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mask_in ? CBF(m->Av(in)) : nullptr, mask_in ? MASK_RELU : MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h,
@@ -783,7 +806,7 @@ void build_programs(unet_model* m) {
       int cprev = (k == 6) ? 512 : dec[k - 7];
       conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
       conv_bwd("c" + ks + "a", "bn" + ks, 2 * c, c, true, false, m->fold_off.count("c" + ks + "a") ? "cat" + ks : "");
-      bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, m->fold_off.count("c" + ks + "a") != 0);
+      if (!m->fold_c_off.count("c" + ks + "a")) bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, m->fold_off.count("c" + ks + "a") != 0);
       const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
       const std::string un = "u" + ks;
       ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, eb * (nel(ib) + nel(ug)), {
@@ -1523,6 +1546,7 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
   if (it == mp.end()) return UNET_E_ARG;
   const Buf& b = it->second;
   const auto fb = m->folded_bn.find(name);
+  if (grad && fb != m->folded_bn.end() && m->fold_c_off.count("c" + std::string(name).substr(2) + "a")) return UNET_E_STATE;   // dz is consumed in the data-gradient epilogue, never stored
   if (!grad && fb != m->folded_bn.end()) {
     // the programs never write this tensor (its BatchNorm is folded into the next conv): a tap materialises it from the layer's input and the
     // scale / shift of the last forward, on the null stream, and waits for it

@@ -76,11 +76,12 @@ def test_live_oracle_all_grads_and_taps(hw, n):
     eng.set_weights(wts)
     ld = eng.forward_backward(x, y).cpu().numpy()
     assert abs(ld[0] - r["loss"]) < 1e-5 and abs(ld[1] - r["dice"]) < 1e-5
-    if w_ >= 32:
-        # the wide case runs the folded decoder BatchNorms (no bn_apply pass, scaled weights + border-class bias, corrected weight gradient):
-        # everything below -- c9a's output, its kernel gradient, the taps of bn9 (materialised on demand) -- is checked THROUGH that path
-        fwd = [o[0] for o in eng.op_profile(n, 0)]; bwd = [o[0] for o in eng.op_profile(n, 1)]
-        assert "bn_fold_prepare:c9a" in fwd and "bn_apply:bn9" not in fwd and "wgrad_bn_fold_fix:c9a" in bwd, fwd
+    # both cases run the folded decoder BatchNorms (no bn_apply pass, scaled weights + border-class bias, corrected weight gradient, BatchNorm backward
+    # in the data-gradient epilogue): everything below -- c9a's output, its kernel gradient, bn9's gamma / beta gradients, the gradient reaching u9 and the
+    # encoder, the taps of bn9 (materialised on demand) -- is checked THROUGH that path
+    fwd = [o[0] for o in eng.op_profile(n, 0)]; bwd = [o[0] for o in eng.op_profile(n, 1)]
+    assert "bn_fold_prepare:c9a" in fwd and "bn_apply:bn9" not in fwd and "wgrad_bn_fold_fix:c9a" in bwd and "conv3x3_dgrad_bn_bwd:c9a" in bwd, (fwd, bwd)
+    assert "bn_bwd_apply:bn9" not in bwd and "bn_bwd_stats:bn9" not in bwd
     for name in ("c1a", "c1b", "bn1", "p1", "c3b", "bn4", "p4", "c5b", "u6", "bn6", "c6a", "u9", "bn9", "c9b"):
         assert relerr(eng.tap(n, name), r["acts"][name]) < 2e-5, name
     # A ReLU whose pre-activation rounds to the other side of 0 in fp32 is a discontinuity, not an error: ONE such
@@ -92,6 +93,11 @@ def test_live_oracle_all_grads_and_taps(hw, n):
     assert flips <= 8, flips
     # gradients wrt activations (ours are already ReLU-masked where the producer is a ReLU conv)
     for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c5b", True), ("p4", False), ("bn4", False), ("c4b", True), ("c1a", True)):
+        if name == "bn9":
+            # folded: the gradient w.r.t. bn9's output lives only in the data-gradient epilogue of c9a (which writes the gradient of the raw concat: "u9" below)
+            with pytest.raises(Exception):
+                eng.tap(n, name, grad=True)
+            continue
         want = r["act_grads"][name] * ((eng.tap(n, name) > 0) if masked else 1.0)
         assert relerr(eng.tap(n, name, grad=True), want) < tol_a, (name, flips)
     g = eng.get_grads()
