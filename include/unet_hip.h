@@ -180,6 +180,22 @@ int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx*, const float* y, int32_t l
                                             int32_t lddx, const float* gamma, const float* beta, double* sums,
                                             int32_t n, int32_t h, int32_t wd, int32_t c, float rate,
                                             uint64_t seed, void* stream);
+/* The same encoder tail WITHOUT a pass for the statistics (fp32): the BatchNorm backward sums of the gradient g = g_skip + route(dy_pooled)
+ * come from the pooled tensors alone -- the routed part touches only the arg-max elements, whose BatchNorm output is the pooled activation
+ * itself (unet_maxpool2x2_dropout_bwd_sums: sum dy ks, sum dy ks (p/ks - beta)/gamma over 1/4 of the pixels) -- plus a closed-form term for
+ * g_skip, which is the skip half of the DECODER BatchNorm's backward output: orthogonal to 1 exactly and to its own xhat up to
+ * eps/(var+eps), and the decoder's xhat of a skip channel is gamma_e * invstd_d times the encoder's (unet_bn_bwd_skip_term adds
+ * frac * gamma_d S2_d eps invstd_d^2 / gamma_e to sums[c + j]; the dec_* pointers at the decoder layer's skip channels, S2_d its
+ * cross-rank-reduced sum dz*xhat, frac = this rank's share 1/world).  gamma == 0 is not supported (as in the fused form above).
+ * unet_bn_maxpool_bwd_apply then does pool backward + skip add + BatchNorm backward + ReLU mask of the BN input x in ONE pass:
+ * dx[.., c] = 1[x>0] scale (g - k1 - xhat k2); y = BN(x) is recomputed for the arg-max exactly as the forward stored it. */
+int32_t unet_maxpool2x2_dropout_bwd_sums(unet_ctx*, const float* pooled, const float* dy_pooled, const float* gamma, const float* beta, double* sums,
+                                         int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream);
+int32_t unet_bn_bwd_skip_term(unet_ctx*, double* sums, const double* dec_sum_dyxhat, const float* dec_invstd, const float* dec_gamma,
+                              const float* gamma, int32_t c, double frac, void* stream);
+int32_t unet_bn_maxpool_bwd_apply(unet_ctx*, const float* x, int32_t ldx, const float* bnp, const double* sums, double count, const float* g_skip,
+                                  int32_t ldg, const float* dy_pooled, float* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c,
+                                  float rate, uint64_t seed, void* stream);
 
 /* Replaces: Conv2D(1,(1,1),activation='sigmoid') T1:913 fused with the reductions of
  * bce_dice_loss / dice_coeff T1:784-799.  p = sigmoid(b + x.w).  If y_true != NULL,

@@ -333,6 +333,90 @@ __global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const T* __restri
   }
 }
 
+// Encoder backward tail without a pass for the statistics (fp32 U-Net).  The gradient reaching the encoder BatchNorm output y is
+// g = g_skip + route(dyp): g_skip comes out of the DECODER BatchNorm's backward (the skip half of its dx), dyp through max-pool + dropout.
+//   * sum g_skip = 0 and sum g_skip * xhat = gamma_d S2_d eps istd_d^2 / gamma_e analytically (bn_bwd_skip_term_kernel: a BatchNorm backward output is
+//     orthogonal to 1 and, up to eps / (var + eps), to its own xhat, and the decoder's xhat of a skip channel is gamma_e istd_d times the encoder's);
+//   * the pooled path only touches the arg-max elements, whose y is the pooled activation p itself: sum over the POOLED tensors (1/4 of the pixels)
+//     of dyp * ks and dyp * ks * (p / ks - beta) / gamma (pool_bwd_sums_kernel).
+// With the sums known, ONE pass does pool backward + skip add + BatchNorm backward + ReLU mask: pool_bn_bwd_apply_kernel.
+template <typename T>
+__global__ __launch_bounds__(TPB) void pool_bwd_sums_kernel(const T* __restrict__ pooled, const T* __restrict__ dyp, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, double* sums, long long total, int C, float rate, uint64_t seed) {
+  const int lpp = C >> 2, tid = threadIdx.x, q = tid % lpp;                        // lpp divides TPB: a thread keeps its channel quad
+  const float4 g4 = ld4(gamma + q * 4), b4 = ld4(beta + q * 4);
+  const float4 ig = make_float4(g4.x != 0.f ? 1.f / g4.x : 0.f, g4.y != 0.f ? 1.f / g4.y : 0.f, g4.z != 0.f ? 1.f / g4.z : 0.f, g4.w != 0.f ? 1.f / g4.w : 0.f);
+  const float unkeep = 1.0f - rate;                                                // p = max * keep_scale: the kept maxima are p * (1 - rate)
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = s1;
+  for (long long i = (long long)blockIdx.x * TPB + tid; i < total; i += (long long)gridDim.x * TPB) {
+    float4 g = ld4(dyp + i * 4);
+    const float4 pv = ld4(pooled + i * 4);
+    if (rate > 0.0f) { const float4 k = keep_scale(i, rate, seed); g.x *= k.x; g.y *= k.y; g.z *= k.z; g.w *= k.w; }
+    s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+    s2.x += g.x * (pv.x * unkeep - b4.x) * ig.x; s2.y += g.y * (pv.y * unkeep - b4.y) * ig.y;
+    s2.z += g.z * (pv.z * unkeep - b4.z) * ig.z; s2.w += g.w * (pv.w * unkeep - b4.w) * ig.w;
+  }
+  __shared__ float4 sh1[TPB], sh2[TPB];
+  sh1[tid] = s1; sh2[tid] = s2;
+  __syncthreads();
+  if (tid < lpp) {
+    for (int k = 1; k < TPB / lpp; ++k) {
+      float4 u = sh1[tid + k * lpp], w2 = sh2[tid + k * lpp];
+      s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w; s2.x += w2.x; s2.y += w2.y; s2.z += w2.z; s2.w += w2.w;
+    }
+    double* d1 = sums + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies
+    atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y); atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
+    atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y); atomicAdd(d2 + 2, (double)s2.z); atomicAdd(d2 + 3, (double)s2.w);
+  }
+}
+// sums[C + j] += frac * gamma_d[j] * S2_d[j] * eps * istd_d[j]^2 / gamma_e[j]   (pointers of the decoder layer already offset to its skip half)
+__global__ void bn_bwd_skip_term_kernel(double* __restrict__ sums, const double* __restrict__ dec_s2, const float* __restrict__ dec_istd, const float* __restrict__ dec_gamma,
+                                        const float* __restrict__ gamma, int C, double frac, float eps) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C || gamma[j] == 0.f) return;
+  const double is = dec_istd[j];
+  sums[C + j] += frac * (double)dec_gamma[j] * dec_s2[j] * (double)eps * is * is / (double)gamma[j];
+}
+// one thread = one pooled pixel x 4 channels: y = BN(x) recomputed exactly as the forward stored it (arg-max), total gradient, BatchNorm backward, ReLU mask
+template <typename T>
+__global__ __launch_bounds__(TPB) void pool_bn_bwd_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ bnp, const double* __restrict__ sums, double inv_count,
+                                                                const T* __restrict__ gskip, int ldg, const T* __restrict__ dyp, T* __restrict__ dx, int lddx, int N, int H,
+                                                                int W, int C, float rate, uint64_t seed) {
+  const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo * lpp;
+  const int tid = threadIdx.x, q = tid % lpp;                        // lpp divides TPB: a thread keeps its channel quad
+  const float4 sc = ld4(bnp + q * 4), sh = ld4(bnp + C + q * 4), mean = ld4(bnp + 2 * C + q * 4), istd = ld4(bnp + 3 * C + q * 4);
+  const double* s1 = sums + q * 4; const double* s2 = sums + C + q * 4;
+  const float4 k1 = make_float4((float)(s1[0] * inv_count), (float)(s1[1] * inv_count), (float)(s1[2] * inv_count), (float)(s1[3] * inv_count));
+  const float4 k2 = make_float4((float)(s2[0] * inv_count), (float)(s2[1] * inv_count), (float)(s2[2] * inv_count), (float)(s2[3] * inv_count));
+  for (long long i = (long long)blockIdx.x * TPB + tid; i < total; i += (long long)gridDim.x * TPB) {
+    const unsigned pu = (unsigned)i / (unsigned)lpp, tu = pu / (unsigned)Wo;             // 32-bit index math (launcher checks total < 2^31)
+    const int jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
+    const long long p = pu, n = tu / (unsigned)Ho;
+    const long long pix = (n * H + 2 * io) * W + 2 * jo;
+    const long long offs[4] = {0, 1, (long long)W, (long long)W + 1};
+    float4 xv[4], yv[4], gs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xv[k] = ld4(x + (pix + offs[k]) * ldx + q * 4); gs[k] = ld4(gskip + (pix + offs[k]) * ldg + q * 4); }
+    float4 g = ld4(dyp + p * C + q * 4);
+    if (rate > 0.0f) { const float4 k = keep_scale(i, rate, seed); g.x *= k.x; g.y *= k.y; g.z *= k.z; g.w *= k.w; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yv[k] = make_float4(fmaf(xv[k].x, sc.x, sh.x), fmaf(xv[k].y, sc.y, sh.y), fmaf(xv[k].z, sc.z, sh.z), fmaf(xv[k].w, sc.w, sh.w));
+    const int kx = argmax4(yv[0].x, yv[1].x, yv[2].x, yv[3].x), ky = argmax4(yv[0].y, yv[1].y, yv[2].y, yv[3].y);
+    const int kz = argmax4(yv[0].z, yv[1].z, yv[2].z, yv[3].z), kw = argmax4(yv[0].w, yv[1].w, yv[2].w, yv[3].w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float tx = gs[k].x + (kx == k ? g.x : 0.f), ty = gs[k].y + (ky == k ? g.y : 0.f), tz = gs[k].z + (kz == k ? g.z : 0.f), tw = gs[k].w + (kw == k ? g.w : 0.f);
+      float4 r;
+      r.x = xv[k].x > 0.f ? sc.x * (tx - k1.x - (xv[k].x - mean.x) * istd.x * k2.x) : 0.f;
+      r.y = xv[k].y > 0.f ? sc.y * (ty - k1.y - (xv[k].y - mean.y) * istd.y * k2.y) : 0.f;
+      r.z = xv[k].z > 0.f ? sc.z * (tz - k1.z - (xv[k].z - mean.z) * istd.z * k2.z) : 0.f;
+      r.w = xv[k].w > 0.f ? sc.w * (tw - k1.w - (xv[k].w - mean.w) * istd.w * k2.w) : 0.f;
+      st4(dx + (pix + offs[k]) * lddx + q * 4, r);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // 1x1 conv + sigmoid head fused with the loss reductions; and its backward.
 // lpp = cin/4 lanes per pixel (power of two <= 64), xor-shuffle dot product.
@@ -748,6 +832,36 @@ extern "C++" template <typename T> static int32_t maxpool_bwd_bnstats_impl(unet_
   hipLaunchKernelGGL(pool_bwd_bnstats_kernel<T>, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, ctx->bn_slots, n, h, wd, c, rate, seed);
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd + bn stats"); return UNET_OK;
+}
+
+int32_t unet_maxpool2x2_dropout_bwd_sums(unet_ctx* ctx, const float* pooled, const float* dy_pooled, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h,
+                                         int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) {
+  if (!ctx || !pooled || !dy_pooled || !gamma || !beta || !sums || (c & 3) || c < 4 || TPB % (c / 4) || (h & 1) || (wd & 1) || rate < 0 || rate >= 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd sums: bad args (c/4 must divide 256)");
+  const long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
+  int grid = (int)std::min<long long>(cdiv64(total, TPB * 4), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(pool_bwd_sums_kernel<float>, dim3(grid), dim3(TPB), 0, as_stream(stream), pooled, dy_pooled, gamma, beta, ctx->bn_slots, total, c, rate, seed);
+  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
+  UNET_CHECK_LAUNCH(ctx, "maxpool bwd sums"); return UNET_OK;
+}
+
+int32_t unet_bn_bwd_skip_term(unet_ctx* ctx, double* sums, const double* dec_sum_dyxhat, const float* dec_invstd, const float* dec_gamma, const float* gamma, int32_t c, double frac,
+                              void* stream) {
+  if (!ctx || !sums || !dec_sum_dyxhat || !dec_invstd || !dec_gamma || !gamma || c < 1) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_skip_term: bad args");
+  hipLaunchKernelGGL(bn_bwd_skip_term_kernel, dim3((c + 127) / 128), dim3(128), 0, as_stream(stream), sums, dec_sum_dyxhat, dec_invstd, dec_gamma, gamma, c, frac, 1e-3f);
+  UNET_CHECK_LAUNCH(ctx, "bn_bwd_skip_term"); return UNET_OK;
+}
+
+int32_t unet_bn_maxpool_bwd_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, const double* sums, double count, const float* g_skip, int32_t ldg,
+                                  const float* dy_pooled, float* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) {
+  if (!ctx || !x || !bnp || !sums || !g_skip || !dy_pooled || !dx || (c & 3) || c < 4 || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldx | ldg | lddx) & 3) || count < 1 || rate < 0 || rate >= 1)
+    UNET_FAIL(ctx, UNET_E_ARG, "bn + maxpool bwd apply: bad args (c/4 must divide 256)");
+  const long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
+  if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
+  hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, sums, 1.0 / count, g_skip, ldg, dy_pooled, dx, lddx, n, h,
+                     wd, c, rate, seed);
+  UNET_CHECK_LAUNCH(ctx, "bn + maxpool bwd apply"); return UNET_OK;
 }
 
 extern "C++" template <typename T> static int32_t head_fwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* bias, float* p, const float* y_true,

@@ -92,7 +92,7 @@ def test_live_oracle_all_grads_and_taps(hw, n):
     tol_a, tol_g = (2e-4, 3e-4) if flips == 0 else (2e-2, 2e-2)
     assert flips <= 8, flips
     # gradients wrt activations (ours are already ReLU-masked where the producer is a ReLU conv)
-    for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c5b", True), ("p4", False), ("bn4", False), ("c4b", True), ("c1a", True)):
+    for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c5b", True), ("p4", False), ("c4b", True), ("c1a", True)):       # (bn4's total gradient is only formed inside the fused encoder-tail pass: c4b checks its result)
         if name == "bn9":
             # folded: the gradient w.r.t. bn9's output lives only in the data-gradient epilogue of c9a (which writes the gradient of the raw concat: "u9" below)
             with pytest.raises(Exception):

@@ -318,6 +318,52 @@ def test_bn_stats_concat_analytic_skip_half(ops, shape):
     assert ops.lib.unet_bn_stats_concat(ops.h, cat.data_ptr(), ld, es.data_ptr(), 0.0, ops.d(ge).data_ptr(), ops.d(be).data_ptr(), got.data_ptr(), pixels, cu, cs, ops.s) != 0
 
 
+@pytest.mark.parametrize("rate,seed", [(0.0, 0), (0.25, 99)])
+@pytest.mark.parametrize("shape", [(2, 12, 16, 32), (1, 8, 8, 128), (3, 6, 10, 64)])
+def test_encoder_tail_backward_without_a_statistics_pass(ops, shape, rate, seed):
+    """T1:861-863 backward: (sum g, sum g xhat) of g = g_skip + route(dy_pooled) from the pooled tensors plus the closed-form term for g_skip (a genuine
+    decoder BatchNorm backward output, small |gamma| so that eps/(var+eps) is far from 0), and the one-pass apply, against pool_bwd_bnstats + bn_bwd_apply"""
+    from gpu_util import relerr
+    n, h, w, c = shape
+    rng = np.random.default_rng(c + h)
+    pixels, ld = n * h * w, 2 * c
+    xe = np.maximum(rng.standard_normal((n, h, w, c)) * rng.uniform(0.5, 2.0, c) + 0.3, 0).astype(np.float32)                # post-ReLU conv output
+    ge = (rng.uniform(0.05, 0.5, c) * rng.choice([-1, 1], c)).astype(np.float32); be = (rng.standard_normal(c) * 0.3).astype(np.float32)
+    gd = rng.uniform(0.5, 1.5, ld).astype(np.float32); bd = (rng.standard_normal(ld) * 0.2).astype(np.float32)
+    up = rng.standard_normal((n, h, w, c)).astype(np.float32); dz = rng.standard_normal((n, h, w, ld)).astype(np.float32)
+    dyp = rng.standard_normal((n, h // 2, w // 2, c)).astype(np.float32)
+    xd = ops.d(xe); es = ops.z(2 * c, dtype=torch.float64); bnpe = ops.z(4 * c)
+    ops.ck(ops.lib.unet_bn_stats(ops.h, xd.data_ptr(), c, es.data_ptr(), pixels, c, ops.s), "enc stats")
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, es.data_ptr(), float(pixels), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), ops.z(c).data_ptr(), ops.z(c).data_ptr(), bnpe.data_ptr(), c, ops.s), "enc fin")
+    cat = ops.z(n, h, w, ld); cat[..., :c] = ops.d(up); pooled = ops.z(n, h // 2, w // 2, c)
+    ysl = cat.data_ptr() + 4 * c
+    ops.ck(ops.lib.unet_bn_apply_maxpool_dropout_fwd(ops.h, xd.data_ptr(), c, bnpe.data_ptr(), ysl, ld, pooled.data_ptr(), n, h, w, c, rate, seed, ops.s), "enc fwd")
+    # decoder BatchNorm over the concat, forward statistics and a full backward: its dx skip half is g_skip
+    ds = ops.z(2 * ld, dtype=torch.float64); bnpd = ops.z(4 * ld); dbs = ops.z(2 * ld, dtype=torch.float64); dcat = ops.z(n, h, w, ld)
+    ops.ck(ops.lib.unet_bn_stats_concat(ops.h, cat.data_ptr(), ld, es.data_ptr(), float(pixels), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), ds.data_ptr(), pixels, c, c, ops.s), "dec stats")
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, ds.data_ptr(), float(pixels), ops.d(gd).data_ptr(), ops.d(bd).data_ptr(), ops.z(ld).data_ptr(), ops.z(ld).data_ptr(), bnpd.data_ptr(), ld, ops.s), "dec fin")
+    dzd = ops.d(dz)
+    ops.ck(ops.lib.unet_bn_bwd_stats(ops.h, dzd.data_ptr(), ld, cat.data_ptr(), ld, bnpd.data_ptr(), dbs.data_ptr(), pixels, ld, ops.s), "dec bwd stats")
+    ops.ck(ops.lib.unet_bn_bwd_apply(ops.h, dzd.data_ptr(), ld, cat.data_ptr(), ld, bnpd.data_ptr(), dbs.data_ptr(), float(pixels), 0, 0.0, 0, dcat.data_ptr(), ld, pixels, ld, ops.s), "dec bwd apply")
+    # reference: routed gradient accumulated into the slice + measured sums, then the BatchNorm backward with the ReLU mask
+    da = dcat.clone(); sa = ops.z(2 * c, dtype=torch.float64); want = ops.z(n, h, w, c)
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd_bnstats(ops.h, ysl, ld, ops.d(dyp).data_ptr(), da.data_ptr() + 4 * c, ld, ops.d(ge).data_ptr(), ops.d(be).data_ptr(), sa.data_ptr(), n, h, w, c,
+                                                      rate, seed, ops.s), "ref pool bwd + stats")
+    ops.ck(ops.lib.unet_bn_bwd_apply(ops.h, da.data_ptr() + 4 * c, ld, xd.data_ptr(), c, bnpe.data_ptr(), sa.data_ptr(), float(pixels), 1, 0.0, 0, want.data_ptr(), c, pixels, c, ops.s), "ref bn bwd")
+    # no statistics pass
+    sb = ops.z(2 * c, dtype=torch.float64); got = ops.z(n, h, w, c)
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd_sums(ops.h, pooled.data_ptr(), ops.d(dyp).data_ptr(), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), sb.data_ptr(), n, h, w, c, rate, seed, ops.s), "pooled sums")
+    no_skip = sb.cpu().numpy().copy()
+    ops.ck(ops.lib.unet_bn_bwd_skip_term(ops.h, sb.data_ptr(), dbs.data_ptr() + 8 * (ld + c), bnpd.data_ptr() + 4 * (3 * ld + c), ops.d(gd).data_ptr() + 4 * c, ops.d(ge).data_ptr(), c, 1.0, ops.s), "skip term")
+    san, sbn = sa.cpu().numpy(), sb.cpu().numpy()
+    scale = np.abs(san).max()
+    assert np.abs(sbn - san).max() < 2e-5 * scale, (np.abs(sbn - san).max(), scale)
+    assert np.abs(no_skip[c:] - san[c:]).max() > 20 * np.abs(sbn[c:] - san[c:]).max()          # the closed-form term is not a rounding detail here
+    ops.ck(ops.lib.unet_bn_maxpool_bwd_apply(ops.h, xd.data_ptr(), c, bnpe.data_ptr(), sb.data_ptr(), float(pixels), dcat.data_ptr() + 4 * c, ld, ops.d(dyp).data_ptr(), got.data_ptr(), c,
+                                             n, h, w, c, rate, seed, ops.s), "fused apply")
+    assert relerr(got.cpu().numpy(), want.cpu().numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 64, 64, 32), (1, 9, 70, 128, 64), (3, 2, 33, 32, 32), (2, 12, 40, 512, 256), (1, 64, 64, 16, 128), (2, 5, 1, 32, 64)])
 def test_conv3x3_bnfold_matches_bn_apply_then_conv(ops, shape):
     """decoder BN -> Conv (T1:888-889): the BatchNorm folded into the conv (scaled weights + a bias per border class, weight gradient corrected
