@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   // the per-element epilogue input (ReLU mask of a data gradient / x of a folded BatchNorm backward) is requested BEFORE the exchange barrier: its HBM
   // latency overlaps the exchange and the transposes instead of ending every workgroup (the accumulators are dead, registers are free)
   float4 mpre[4][2];
-  const bool want_m = !GEN && (mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD);
+  const bool want_m = mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
   if (want_m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
         if (mask_mode == MASK_NONE) {
           if (rate > 0.0f) { const float4 ks = keep_scale(o >> 2, rate, seed); o4.x *= ks.x; o4.y *= ks.y; o4.z *= ks.z; o4.w *= ks.w; }
         } else {
-          const float4 m = *reinterpret_cast<const float4*>(mask + o);
+          const float4 m = mpre[g][half];
           float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
           if (mask_mode == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
           o4.x *= mask_factor(m.x, mask_mode, ks.x, rate); o4.y *= mask_factor(m.y, mask_mode, ks.y, rate);
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
   const int orow = kq & 1, half = kq >> 1;
   // the per-element epilogue input (ReLU mask / x of a folded BatchNorm backward) is requested before the exchange barrier (see conv_wino2d_kernel)
   float4 mpre[4];
-  const bool want_m = !GEN && (mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD);
+  const bool want_m = mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
   if (want_m) {
     const int co_ = nbase + (l31 & ~3);
 #pragma unroll
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
       if (mask_mode == MASK_NONE) {
         if (rate > 0.0f) { const float4 ks = keep_scale(o >> 2, rate, seed); o4.x *= ks.x; o4.y *= ks.y; o4.z *= ks.z; o4.w *= ks.w; }
       } else {
-        const float4 m = *reinterpret_cast<const float4*>(mask + o);
+        const float4 m = mpre[g];
         float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
         if (mask_mode == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
         o4.x *= mask_factor(m.x, mask_mode, ks.x, rate); o4.y *= mask_factor(m.y, mask_mode, ks.y, rate);
