@@ -143,7 +143,9 @@ def main():
     eng.set_profiling(False)
     if rank == 0:
         ops = eng.op_profile(B, 0) + eng.op_profile(B, 1)
-        dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_dgrad:")]
+        # (conv3x3_dgrad_bn_bwd: the data gradient of a decoder block's first conv with the folded BatchNorm's backward in its epilogue -- the same
+        #  kernel, same FLOPs; the op's time includes its 5 us coefficient launch)
+        dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_dgrad:") or o[0].startswith("conv3x3_dgrad_bn_bwd:")]
         dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel
         fl = sum(o[1] for o in dom); ms = sum(o[3] / max(o[4], 1) for o in dom); launches = len(dom)
         # executed MFMA work: the Winograd F(2,3)-along-x launches do 12 instead of 18 multiplies per pair of outputs
@@ -152,7 +154,7 @@ def main():
         for o in dom:
             kind, lname = o[0].split(":")
             _, _, ci, co = shapes[lname + "/kernel"]
-            if kind == "conv3x3_dgrad":
+            if kind.startswith("conv3x3_dgrad"):
                 ci, co = co, ci
             ptr, ld, nn, hh, ww, cc = _tap_dims(eng, B, lname)
             ratio = 1.0 if args.dtype == "bf16" else eng.lib.unet_conv3x3_exec_ratio(args.algo, hh, ww, ci, co)
