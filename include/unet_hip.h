@@ -276,6 +276,11 @@ int32_t unet_maxpool2x2_dropout_bwd_bf16(unet_ctx*, const unet_bf16* x, int32_t 
 int32_t unet_bn_apply_maxpool_dropout_fwd_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy,
                                                unet_bf16* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
                                                void* stream);
+int32_t unet_maxpool2x2_dropout_bwd_sums_bf16(unet_ctx*, const unet_bf16* pooled, const unet_bf16* dy_pooled, const float* gamma, const float* beta,
+                                              double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream);
+int32_t unet_bn_maxpool_bwd_apply_bf16(unet_ctx*, const unet_bf16* x, int32_t ldx, const float* bnp, const double* sums, double count,
+                                       const unet_bf16* g_skip, int32_t ldg, const unet_bf16* dy_pooled, unet_bf16* dx, int32_t lddx, int32_t n,
+                                       int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream);
 int32_t unet_maxpool2x2_dropout_bwd_bnstats_bf16(unet_ctx*, const unet_bf16* y, int32_t ldy, const unet_bf16* dy, unet_bf16* dx, int32_t lddx,
                                                  const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd,
                                                  int32_t c, float rate, uint64_t seed, void* stream);

@@ -86,6 +86,8 @@ _PROTOS = {
     "unet_bn_apply_maxpool_dropout_fwd_bf16": (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd_bnstats": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd_sums": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_maxpool2x2_dropout_bwd_sums_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),
+    "unet_bn_maxpool_bwd_apply_bf16": (i32, [vp, vp, i32, vp, vp, f64, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, u64, vp]),
     "unet_bn_bwd_skip_term": (i32, [vp, vp, vp, vp, vp, vp, i32, f64, vp]),
     "unet_bn_maxpool_bwd_apply": (i32, [vp, vp, i32, vp, vp, f64, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, u64, vp]),
     "unet_maxpool2x2_dropout_bwd_bnstats_bf16": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp]),

@@ -834,14 +834,14 @@ extern "C++" template <typename T> static int32_t maxpool_bwd_bnstats_impl(unet_
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd + bn stats"); return UNET_OK;
 }
 
-int32_t unet_maxpool2x2_dropout_bwd_sums(unet_ctx* ctx, const float* pooled, const float* dy_pooled, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h,
-                                         int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) {
+extern "C++" template <typename T> static int32_t maxpool_bwd_sums_impl(unet_ctx* ctx, const T* pooled, const T* dy_pooled, const float* gamma, const float* beta, double* sums, int32_t n,
+                                                                        int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) {
   if (!ctx || !pooled || !dy_pooled || !gamma || !beta || !sums || (c & 3) || c < 4 || TPB % (c / 4) || (h & 1) || (wd & 1) || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "maxpool bwd sums: bad args (c/4 must divide 256)");
   const long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   int grid = (int)std::min<long long>(cdiv64(total, TPB * 4), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(pool_bwd_sums_kernel<float>, dim3(grid), dim3(TPB), 0, as_stream(stream), pooled, dy_pooled, gamma, beta, ctx->bn_slots, total, c, rate, seed);
+  hipLaunchKernelGGL(pool_bwd_sums_kernel<T>, dim3(grid), dim3(TPB), 0, as_stream(stream), pooled, dy_pooled, gamma, beta, ctx->bn_slots, total, c, rate, seed);
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd sums"); return UNET_OK;
 }
@@ -853,13 +853,14 @@ int32_t unet_bn_bwd_skip_term(unet_ctx* ctx, double* sums, const double* dec_sum
   UNET_CHECK_LAUNCH(ctx, "bn_bwd_skip_term"); return UNET_OK;
 }
 
-int32_t unet_bn_maxpool_bwd_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, const double* sums, double count, const float* g_skip, int32_t ldg,
-                                  const float* dy_pooled, float* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) {
+extern "C++" template <typename T> static int32_t bn_maxpool_bwd_apply_impl(unet_ctx* ctx, const T* x, int32_t ldx, const float* bnp, const double* sums, double count, const T* g_skip,
+                                                                            int32_t ldg, const T* dy_pooled, T* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate,
+                                                                            uint64_t seed, void* stream) {
   if (!ctx || !x || !bnp || !sums || !g_skip || !dy_pooled || !dx || (c & 3) || c < 4 || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldx | ldg | lddx) & 3) || count < 1 || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn + maxpool bwd apply: bad args (c/4 must divide 256)");
   const long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
-  hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, sums, 1.0 / count, g_skip, ldg, dy_pooled, dx, lddx, n, h,
+  hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, sums, 1.0 / count, g_skip, ldg, dy_pooled, dx, lddx, n, h,
                      wd, c, rate, seed);
   UNET_CHECK_LAUNCH(ctx, "bn + maxpool bwd apply"); return UNET_OK;
 }
@@ -960,6 +961,10 @@ int32_t unet_maxpool2x2_dropout_bwd(unet_ctx* ctx, const float* x, int32_t ldx, 
 int32_t unet_maxpool2x2_dropout_bwd_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const unet_bf16* dy, unet_bf16* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, int32_t accumulate, void* stream) { return maxpool_bwd_impl(ctx, x, ldx, dy, dx, lddx, n, h, wd, c, rate, seed, accumulate, stream); }
 int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, float* y, int32_t ldy, float* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_apply_maxpool_impl(ctx, x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed, stream); }
 int32_t unet_bn_apply_maxpool_dropout_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy, unet_bf16* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_apply_maxpool_impl(ctx, x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed, stream); }
+int32_t unet_maxpool2x2_dropout_bwd_sums(unet_ctx* ctx, const float* pooled, const float* dy_pooled, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_sums_impl(ctx, pooled, dy_pooled, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
+int32_t unet_maxpool2x2_dropout_bwd_sums_bf16(unet_ctx* ctx, const unet_bf16* pooled, const unet_bf16* dy_pooled, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_sums_impl(ctx, pooled, dy_pooled, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
+int32_t unet_bn_maxpool_bwd_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, const double* sums, double count, const float* g_skip, int32_t ldg, const float* dy_pooled, float* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_maxpool_bwd_apply_impl(ctx, x, ldx, bnp, sums, count, g_skip, ldg, dy_pooled, dx, lddx, n, h, wd, c, rate, seed, stream); }
+int32_t unet_bn_maxpool_bwd_apply_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const float* bnp, const double* sums, double count, const unet_bf16* g_skip, int32_t ldg, const unet_bf16* dy_pooled, unet_bf16* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_maxpool_bwd_apply_impl(ctx, x, ldx, bnp, sums, count, g_skip, ldg, dy_pooled, dx, lddx, n, h, wd, c, rate, seed, stream); }
 int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32_t ldy, const float* dy, float* dx, int32_t lddx, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_bnstats_impl(ctx, y, ldy, dy, dx, lddx, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
 int32_t unet_maxpool2x2_dropout_bwd_bnstats_bf16(unet_ctx* ctx, const unet_bf16* y, int32_t ldy, const unet_bf16* dy, unet_bf16* dx, int32_t lddx, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_bnstats_impl(ctx, y, ldy, dy, dx, lddx, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
 int32_t unet_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* p, const float* y_true, double* loss_sums, int64_t pixels, int32_t cin, void* stream) { return head_fwd_impl(ctx, x, w, bias, p, y_true, loss_sums, pixels, cin, stream); }

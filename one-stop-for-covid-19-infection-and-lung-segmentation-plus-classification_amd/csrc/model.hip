@@ -835,15 +835,17 @@ void build_programs(unet_model* m) {
       const Buf xb = m->act.at("bn" + ks), gb = m->grad.at("bn" + ks);
       const std::string bnn = "bn" + ks, pn = "p" + ks;
       const size_t so = m->bn_bsum_off.at(bnn);
-      if (!dt && enc_bn_fused()) {
+      if (enc_bn_fused()) {
         // no pass for the statistics: sums from the pooled tensors + the closed-form skip term, then pool backward + skip add + BatchNorm backward + ReLU mask in ONE pass
         const std::string dn = "bn" + std::to_string(10 - k), cb = "c" + ks + "b";
         const size_t sod = m->bn_bsum_off.at(dn), bod = m->bnp_off.at(dn), bo = m->bnp_off.at(bnn);
         const Buf cbuf = m->act.at(cb), cg = m->grad.at(cb);
         const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
         ADD_OP(BW, "pool_bwd_sums:" + pn, 0, eb * 0.5 * nel(xb), {
-          int32_t r = unet_maxpool2x2_dropout_bwd_sums(ctx, m->A(pn), m->D(pn), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c,
-                                                       m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
+          int32_t r = dt ? unet_maxpool2x2_dropout_bwd_sums_bf16(ctx, CBF(m->Av(pn)), CBF(m->Dv(pn)), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h,
+                                                                 xb.w, xb.c, m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s)
+                         : unet_maxpool2x2_dropout_bwd_sums(ctx, m->A(pn), m->D(pn), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c,
+                                                            m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
           if (r) return r;
           r = unet_bn_bwd_skip_term(ctx, m->wsd(m->off_bn_bsums) + so, m->wsd(m->off_bn_bsums) + sod + 3 * (size_t)c, m->wsf(bod) + 7 * (size_t)c, m->P(dn + "/gamma") + c,
                                     m->P(bnn + "/gamma"), c, 1.0 / gcount, s);
@@ -852,6 +854,8 @@ void build_programs(unet_model* m) {
         });
         SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
         ADD_OP(BW, "bn_pool_bwd_apply:" + bnn, 0, eb * 3.25 * nel(xb), {
+          if (dt) return unet_bn_maxpool_bwd_apply_bf16(ctx, CBF(m->Av(cb)), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, CBF(m->Dv(bnn)), gb.ld, CBF(m->Dv(pn)),
+                                                        WBF(m->Dv(cb)), cg.ld, xb.n, xb.h, xb.w, xb.c, m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
           return unet_bn_maxpool_bwd_apply(ctx, m->A(cb), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, m->D(bnn), gb.ld, m->D(pn), m->D(cb), cg.ld,
                                            xb.n, xb.h, xb.w, xb.c, m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
         });
