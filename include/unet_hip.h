@@ -188,7 +188,8 @@ int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx*, const float* y, int32_t l
  * frac * gamma_d S2_d eps invstd_d^2 / gamma_e to sums[c + j]; the dec_* pointers at the decoder layer's skip channels, S2_d its
  * cross-rank-reduced sum dz*xhat, frac = this rank's share 1/world).  gamma == 0 is not supported (as in the fused form above).
  * unet_bn_maxpool_bwd_apply then does pool backward + skip add + BatchNorm backward + ReLU mask of the BN input x in ONE pass:
- * dx[.., c] = 1[x>0] scale (g - k1 - xhat k2); y = BN(x) is recomputed for the arg-max exactly as the forward stored it. */
+ * dx[.., c] = 1[x>0] scale (g - k1 - xhat k2); y = BN(x) is recomputed for the arg-max exactly as the forward stored it.
+ * g_skip may be NULL (no skip connection: the classifier's Conv -> BN -> MaxPool tails, T2:752-754 -- then the pooled sums are the whole statistics). */
 int32_t unet_maxpool2x2_dropout_bwd_sums(unet_ctx*, const float* pooled, const float* dy_pooled, const float* gamma, const float* beta, double* sums,
                                          int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream);
 int32_t unet_bn_bwd_skip_term(unet_ctx*, double* sums, const double* dec_sum_dyxhat, const float* dec_invstd, const float* dec_gamma,

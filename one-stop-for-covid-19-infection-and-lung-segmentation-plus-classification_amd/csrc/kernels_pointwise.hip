@@ -397,7 +397,7 @@ __global__ __launch_bounds__(TPB) void pool_bn_bwd_apply_kernel(const T* __restr
     const long long offs[4] = {0, 1, (long long)W, (long long)W + 1};
     float4 xv[4], yv[4], gs[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { xv[k] = ld4(x + (pix + offs[k]) * ldx + q * 4); gs[k] = ld4(gskip + (pix + offs[k]) * ldg + q * 4); }
+    for (int k = 0; k < 4; ++k) { xv[k] = ld4(x + (pix + offs[k]) * ldx + q * 4); gs[k] = gskip ? ld4(gskip + (pix + offs[k]) * ldg + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f); }
     float4 g = ld4(dyp + p * C + q * 4);
     if (rate > 0.0f) { const float4 k = keep_scale(i, rate, seed); g.x *= k.x; g.y *= k.y; g.z *= k.z; g.w *= k.w; }
 #pragma unroll
@@ -856,7 +856,7 @@ int32_t unet_bn_bwd_skip_term(unet_ctx* ctx, double* sums, const double* dec_sum
 extern "C++" template <typename T> static int32_t bn_maxpool_bwd_apply_impl(unet_ctx* ctx, const T* x, int32_t ldx, const float* bnp, const double* sums, double count, const T* g_skip,
                                                                             int32_t ldg, const T* dy_pooled, T* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate,
                                                                             uint64_t seed, void* stream) {
-  if (!ctx || !x || !bnp || !sums || !g_skip || !dy_pooled || !dx || (c & 3) || c < 4 || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldx | ldg | lddx) & 3) || count < 1 || rate < 0 || rate >= 1)
+  if (!ctx || !x || !bnp || !sums || !dy_pooled || !dx || (c & 3) || c < 4 || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldx | lddx) & 3) || (g_skip && (ldg & 3)) || count < 1 || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn + maxpool bwd apply: bad args (c/4 must divide 256)");
   const long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);

@@ -1433,11 +1433,32 @@ void build_programs_cls(unet_model* m) {
     const int c = CLS_C[k - 1], cin = k == 1 ? m->in_ch : CLS_C[k - 2];
     const std::string ks = std::to_string(k), ca = "c" + ks + "a", cb = "c" + ks + "b", ba = "bn" + ks + "a", bb = "bn" + ks + "b", pk = "p" + ks;
     const Buf xb = m->act.at(bb);
+    if (enc_bn_fused()) {
+      // Conv -> BN -> MaxPool tail (T2:752-754): the BatchNorm's backward sums come from the pooled tensors alone (only arg-max elements carry gradient and their
+      // BatchNorm output is the pooled activation), then pool backward + BatchNorm backward + ReLU mask in one pass
+      const Buf cbuf = m->act.at(cb), cg = m->grad.at(cb);
+      const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
+      const size_t so = m->bn_bsum_off.at(bb), bo = m->bnp_off.at(bb);
+      ADD_OP(BW, "pool_bwd_sums:" + pk, 0, eb * 0.5 * nel(xb), {
+        int32_t r = dt ? unet_maxpool2x2_dropout_bwd_sums_bf16(ctx, CBF(m->Av(pk)), CBF(m->Dv(pk)), m->P(bb + "/gamma"), m->P(bb + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, s)
+                       : unet_maxpool2x2_dropout_bwd_sums(ctx, m->A(pk), m->D(pk), m->P(bb + "/gamma"), m->P(bb + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, s);
+        if (r) return r;
+        return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(bb + "/gamma"), m->G(bb + "/beta"), c, s);
+      });
+      SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
+      ADD_OP(BW, "bn_pool_bwd_apply:" + bb, 0, eb * 2.25 * nel(xb), {
+        if (dt) return unet_bn_maxpool_bwd_apply_bf16(ctx, CBF(m->Av(cb)), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, nullptr, 0, CBF(m->Dv(pk)), WBF(m->Dv(cb)), cg.ld,
+                                                      xb.n, xb.h, xb.w, xb.c, 0.0f, 0, s);
+        return unet_bn_maxpool_bwd_apply(ctx, m->A(cb), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, nullptr, 0, m->D(pk), m->D(cb), cg.ld, xb.n, xb.h, xb.w, xb.c,
+                                         0.0f, 0, s);
+      });
+    } else {
     ADD_OP(BW, "pool_bwd:" + pk, 0, eb * 2.25 * nel(xb), {
       if (dt) return unet_maxpool2x2_dropout_bwd_bf16(ctx, CBF(m->Av(bb)), xb.ld, CBF(m->Dv(pk)), WBF(m->Dv(bb)), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 0, s);
       return unet_maxpool2x2_dropout_bwd(ctx, m->A(bb), xb.ld, m->D(pk), m->D(bb), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, 0, s);
     });
     bn_bwd(bb, cb, c);
+    }
     conv_bwd(cb, ba, c, c, true);
     bn_bwd(ba, ca, c);
     conv_bwd(ca, k == 1 ? "" : "p" + std::to_string(k - 1), cin, c, k > 1);
