@@ -173,6 +173,8 @@ size_t wgrad_bn_fold_scratch_floats(int n, int cout);
 bool wgrad_bn_fold_supported(int cout);
 int32_t k_wgrad_bn_fold_fix(unet_ctx*, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db, float* scratch,
                             hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
+int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx*, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
+                                 float* scratch, hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
 int wino_tile_cols(int wd);                                          // 64 or 32 columns per row tile of the 2-D kernel                                 // F(2x2,3x3) instead of F(2,3)-along-x for this output shape
 int32_t k_conv3x3_wino_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
                              int cin, int cout, hipStream_t s);      // kernels_conv_mfma.hip (shares the split-K machinery)

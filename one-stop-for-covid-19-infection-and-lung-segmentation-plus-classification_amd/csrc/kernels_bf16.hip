@@ -211,8 +211,31 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
       if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
       else o = (((long long)n * H + py) * W + px_) * ldy + mb;
       float v[16];
+      if (MODE == 0 && mask_mode == MASK_BN_BWD) {
+        // data gradient of a conv whose input BatchNorm is folded: dx = K0 dz + K1 x + K2, x read where a ReLU layer reads its mask
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mask + o), m1 = *reinterpret_cast<const uint4*>(mask + o + 8);
+        const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = acc[r][nb][i] + bv[i];
+        for (int q = 0; q < 4; ++q) {
+          const float4 k1 = *reinterpret_cast<const float4*>(bias + M + mb + q * 4), k2 = *reinterpret_cast<const float4*>(bias + 2 * M + mb + q * 4);
+          v[q * 4] = fmaf(bv[q * 4], acc[r][nb][q * 4], fmaf(k1.x, bf16_lo(mw[2 * q]), k2.x));
+          v[q * 4 + 1] = fmaf(bv[q * 4 + 1], acc[r][nb][q * 4 + 1], fmaf(k1.y, bf16_hi(mw[2 * q]), k2.y));
+          v[q * 4 + 2] = fmaf(bv[q * 4 + 2], acc[r][nb][q * 4 + 2], fmaf(k1.z, bf16_lo(mw[2 * q + 1]), k2.z));
+          v[q * 4 + 3] = fmaf(bv[q * 4 + 3], acc[r][nb][q * 4 + 3], fmaf(k1.w, bf16_hi(mw[2 * q + 1]), k2.w));
+        }
+      } else if (MODE == 0 && mask_mode == MASK_BIAS_TAB && (py == 0 || py == H - 1 || px_ == 0 || px_ == W - 1)) {
+        // forward of such a conv: border pixels see fewer taps of the BatchNorm shift -- the bias vector of their border class (`mask` = float table [16][M])
+        const int cls = (((py == 0) | ((py == H - 1) << 1)) << 2) | ((px_ == 0) | ((px_ == W - 1) << 1));
+        const float* tb = reinterpret_cast<const float*>(mask) + (long long)cls * M + mb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4*>(tb + q * 4);
+          v[q * 4] = acc[r][nb][q * 4] + b4.x; v[q * 4 + 1] = acc[r][nb][q * 4 + 1] + b4.y; v[q * 4 + 2] = acc[r][nb][q * 4 + 2] + b4.z; v[q * 4 + 3] = acc[r][nb][q * 4 + 3] + b4.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = acc[r][nb][i] + bv[i];
+      }
       if (MODE == 0 || MODE == 2) {
         if (!GEN) {
           if (act == ACT_RELU) {
@@ -272,7 +295,7 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
   const long long total = (long long)tiles_x * tiles_y * n * groups;
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
-  const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU);
+  const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP);
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_bf16");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);

@@ -978,21 +978,22 @@ namespace {
 // out[n * SEG + seg][8][C]: sums of dy over (segment seg of) row 0, row H-1, column 0, column W-1 and the corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
 // of image n.  grid (8 * SEG, N)
 constexpr int BORDER_SEG = 4;
-__global__ __launch_bounds__(256) void border_sums_kernel(const float* __restrict__ dy, float* __restrict__ out, int H, int W, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void border_sums_kernel(const T* __restrict__ dy, float* __restrict__ out, int H, int W, int C) {
   __shared__ float s_p[256];
   const int kind = blockIdx.x & 7, seg = blockIdx.x >> 3, n = blockIdx.y;
   const int co = threadIdx.x % C, sl = threadIdx.x / C, nsl = 256 / C;
-  const float* img = dy + (long long)n * H * W * C;
+  const T* img = dy + (long long)n * H * W * C;
   float acc = 0.f;
   if (kind < 2) {
-    const float* r = img + (long long)(kind ? H - 1 : 0) * W * C;
+    const T* r = img + (long long)(kind ? H - 1 : 0) * W * C;
     const int per = (W + BORDER_SEG - 1) / BORDER_SEG, j1 = min(W, (seg + 1) * per);
-    for (int j = seg * per + sl; j < j1; j += nsl) acc += r[(long long)j * C + co];
+    for (int j = seg * per + sl; j < j1; j += nsl) acc += ld1(r + (long long)j * C + co);
   } else if (kind < 4) {
-    const float* q = img + (long long)(kind == 3 ? W - 1 : 0) * C;
+    const T* q = img + (long long)(kind == 3 ? W - 1 : 0) * C;
     const int per = (H + BORDER_SEG - 1) / BORDER_SEG, i1 = min(H, (seg + 1) * per);
-    for (int i = seg * per + sl; i < i1; i += nsl) acc += q[(long long)i * W * C + co];
-  } else if (sl == 0 && seg == 0) { const int i = (kind & 2) ? H - 1 : 0, j = (kind & 1) ? W - 1 : 0; acc = img[((long long)i * W + j) * C + co]; }
+    for (int i = seg * per + sl; i < i1; i += nsl) acc += ld1(q + (long long)i * W * C + co);
+  } else if (sl == 0 && seg == 0) { const int i = (kind & 2) ? H - 1 : 0, j = (kind & 1) ? W - 1 : 0; acc = ld1(img + ((long long)i * W + j) * C + co); }
   s_p[threadIdx.x] = acc;
   __syncthreads();
   if (sl == 0) { for (int k = 1; k < nsl; ++k) acc += s_p[k * C + co]; out[(((long long)n * BORDER_SEG + seg) * 8 + kind) * C + co] = acc; }
@@ -1058,11 +1059,12 @@ __global__ void fold_fix_kernel(float* __restrict__ dw, const float* __restrict_
 bool wgrad_bn_fold_supported(int cout) { return cout >= 4 && cout <= 256 && 256 % cout == 0; }
 size_t wgrad_bn_fold_scratch_floats(int n, int cout) { return (size_t)(n > 0 ? n : 0) * BORDER_SEG * 8 * cout + 9 * (size_t)cout; }
 // w / mean / istd / bn_bwd_sums (all or none): also accumulate the folded BatchNorm's backward sums (sum dz, sum dz * xhat) -- from W, the raw dw and S
-int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
+template <typename T>
+static int32_t wgrad_bn_fold_fix_impl(unet_ctx* ctx, const T* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
+                                      float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
   if (!dy || !scale || !shift || !dw || !db || !scratch || !wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: bad args (cout=%d)", cout);
   float* border = scratch; float* S = scratch + (size_t)n * BORDER_SEG * 8 * cout;
-  hipLaunchKernelGGL(border_sums_kernel, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
+  hipLaunchKernelGGL(border_sums_kernel<T>, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
   hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, border, db, S, n * BORDER_SEG, cout);
   if (bn_bwd_sums) {
     if (!w || !mean || !istd) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: the BatchNorm backward sums need w, mean, istd");
@@ -1072,6 +1074,14 @@ int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd
   hipLaunchKernelGGL(fold_fix_kernel, dim3((unsigned)std::min<long long>((total4 + 255) / 256, 2048)), dim3(256), 0, s, dw, scale, shift, S, cin, cout / 4, total4);
   UNET_CHECK_LAUNCH(ctx, "wgrad_bn_fold_fix");
   return UNET_OK;
+}
+int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
+                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
+  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums);
+}
+int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx* ctx, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
+                                 float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
+  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums);
 }
 
 int32_t k_conv3x3_wino_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,

@@ -464,11 +464,13 @@ void plan_workspace(unet_model* m) {
   // per-layer scratch of the prepared weights: 16 Winograd taps (fp32) or the 9-tap bf16 image
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
   // decoder BatchNorm folded into the conv that consumes it: whenever that conv runs on the F(2x2,3x3) kernels (the only ones with the border-class bias)
-  if (!m->dt && bn_fold_enabled()) {
+  if (bn_fold_enabled()) {
     for (int k = 6; k <= 9; ++k) {
       const std::string ks = std::to_string(k), cn = "c" + ks + "a";
       const Buf ob = m->act.at(cn); const int cin = 2 * ob.c, cout = ob.c;
-      if (!use_wino(m->algo, ob.w, cin, cout, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, cout) || !wgrad_bn_fold_supported(cout)) continue;
+      if (!wgrad_bn_fold_supported(cout)) continue;
+      if (m->dt) { if (!bf16_conv3x3_supported(cin, cout) || !bf16_conv3x3_supported(cout, cin)) continue; }      // bf16 storage: the direct MFMA kernel has both epilogues
+      else if (!use_wino(m->algo, ob.w, cin, cout, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, cout)) continue;
       m->fold_off[cn] = cv.take(bn_fold_scratch_floats(cin, cout));
       m->folded_bn["bn" + ks] = {"cat" + ks, cin};
     }
@@ -478,7 +480,7 @@ void plan_workspace(unet_model* m) {
     const Buf ob = m->act.at(kv.first); const int cin = 2 * ob.c, cout = ob.c;
     m->fold_g_off[kv.first] = cv.take(wgrad_bn_fold_scratch_floats(N, cout));
     // the data gradient (cout -> cin channels) on the F(2x2,3x3) kernels too: the BatchNorm backward moves into its epilogue
-    if (bn_fold_enabled() >= 2 && use_wino(m->algo, ob.w, cout, cin, reinterpret_cast<const float*>(m)) && wino_uses_2d(ob.h, cin)) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
+    if (bn_fold_enabled() >= 2 && (m->dt || (use_wino(m->algo, ob.w, cout, cin, reinterpret_cast<const float*>(m)) && wino_uses_2d(ob.h, cin)))) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
   }
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
   // --- training extras: gradient twins ---
@@ -559,6 +561,7 @@ void build_programs(unet_model* m) {
     unet_wimg_prep_list L; L.n = 0; int ci[UNET_WINO_PREP_MAX], co[UNET_WINO_PREP_MAX];
     for (auto& it : prep_items) {
       if (L.n >= UNET_WINO_PREP_MAX) break;
+      if (!flip && m->fold_off.count(it.name)) continue;          // image built from the scaled weights after the BatchNorm's finalize
       L.item[L.n] = unet_wimg_prep{m->P(it.name + "/kernel"), static_cast<unet_bf16*>(static_cast<void*>(m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)))), 0, 0, 0, 0, 0, 0, flip, 0};
       ci[L.n] = flip ? it.cout : it.cin; co[L.n] = flip ? it.cin : it.cout; ++L.n;
     }
@@ -674,11 +677,13 @@ void build_programs(unet_model* m) {
         const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn), uo = m->wprep_f.at(cn);
         ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * cin * cout * 2, 4.0 * 9 * cin * cout * 4, {
           int32_t r = k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + cin, cin, cout, m->wsf(fo), s);
-          if (r) return r;
+          if (r || dt) return r;                                // bf16 storage: the conv below builds its weight image from the scaled fp32 weights
           return k_wino_weights(ctx, m->wsf(fo), m->wsf(uo), cin, cout, 0, ob.h, s);
         });
         ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout, {
           const float* tab = m->wsf(fo) + (size_t)9 * cin * cout;
+          if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(xn)), m->wsf(fo), tab, reinterpret_cast<const unet_bf16*>(tab), MASK_BIAS_TAB, WBF(m->Av(cn)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU,
+                                            0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s, nullptr);
           return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(uo), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0, s);
         });
       } else
@@ -732,7 +737,7 @@ void build_programs(unet_model* m) {
       ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
         if (dt) {
           if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
-          return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(in)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w,
+          return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(xsrc)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w,
                                       cin, cout, s);
         }
         const float* xin = xsrc.empty() ? m->x : m->A(xsrc);
@@ -743,6 +748,8 @@ void build_programs(unet_model* m) {
         const size_t go = m->fold_g_off.at(name), bo = m->bnp_off.at(in);
         ADD_OP(BW, "wgrad_bn_fold_fix:" + name, 2.0 * 9 * cin * cout, 8.0 * 9 * cin * cout, {
           // ... and the BatchNorm's backward sums (sum dz, sum dz * xhat) come out of W, the raw dw and S: no pass over dz / x (bn_bwd below: stats_done)
+          if (dt) return k_wgrad_bn_fold_fix_bf16(ctx, CBF(m->Dv(name)), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
+                                                  m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in));
           return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
                                      m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in));
         });
@@ -759,6 +766,8 @@ void build_programs(unet_model* m) {
         ADD_OP(BW, "conv3x3_dgrad_bn_bwd:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + 2 * cin) + 4.0 * 9.0 * cin * cout, {
           int32_t r = k_bn_bwd_coef(ctx, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, px * gcount, m->wsf(co), cin, s);
           if (r) return r;
+          if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), m->wsf(co), CBF(m->Av(xraw)), MASK_BN_BWD, WBF(m->Dv(xraw)), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0,
+                                            WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s, CBF(static_cast<void*>(m->wsf(m->wprep_b.at(name)))));
           return k_conv3x3_wino_fwd(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->wsf(co), m->A(xraw), MASK_BN_BWD, m->D(xraw), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0, s);
         });
         return;
@@ -1603,7 +1612,9 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
     // the programs never write this tensor (its BatchNorm is folded into the next conv): a tap materialises it from the layer's input and the
     // scale / shift of the last forward, on the null stream, and waits for it
     const Buf& xb = m->act.at(fb->second.first);
-    int32_t r = unet_bn_apply(m->ctx, m->A(fb->second.first), xb.ld, m->wsf(m->bnp_off.at(name)), const_cast<float*>(m->A(name)), b.ld, (int64_t)b.n * b.h * b.w, fb->second.second, nullptr);
+    int32_t r = m->dt ? unet_bn_apply_bf16(m->ctx, static_cast<const unet_bf16*>(m->Av(fb->second.first)), xb.ld, m->wsf(m->bnp_off.at(name)), static_cast<unet_bf16*>(m->Av(name)), b.ld,
+                                           (int64_t)b.n * b.h * b.w, fb->second.second, nullptr)
+                      : unet_bn_apply(m->ctx, m->A(fb->second.first), xb.ld, m->wsf(m->bnp_off.at(name)), const_cast<float*>(m->A(name)), b.ld, (int64_t)b.n * b.h * b.w, fb->second.second, nullptr);
     if (r) return r;
     if (hipStreamSynchronize(nullptr) != hipSuccess) return UNET_E_HIP;
   }

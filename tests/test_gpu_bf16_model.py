@@ -74,7 +74,11 @@ def test_bf16_fwd_bwd_matches_storage_emulating_oracle(hw, n):
     for name in ("c1a", "c1b", "bn1", "p1", "c2a", "c3b", "bn4", "p4", "c5a", "c5b", "u6", "bn6", "c6a", "u9", "bn9", "c9a", "c9b"):
         assert relerr(eng.tap(n, name), r["acts"][name]) < TOL_T, name
     assert np.abs(eng._p_train.cpu().numpy().reshape(r["p"].shape) - r["p"]).max() < 2e-2
-    for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c6a", True), ("c5b", True), ("c5a", True), ("p4", False),
+    bwd = [o[0] for o in eng.op_profile(n, 1)]
+    assert "conv3x3_dgrad_bn_bwd:c9a" in bwd and "bn_bwd_apply:bn9" not in bwd          # the folded decoder BatchNorm is the path under test
+    with pytest.raises(Exception):
+        eng.tap(n, "bn9", grad=True)                                                      # ... whose output gradient is never stored
+    for name, masked in (("c9b", True), ("c9a", True), ("u9", False), ("c6a", True), ("c5b", True), ("c5a", True), ("p4", False),
                          ("c4b", True), ("c2a", True), ("c1a", True)):      # (bn4's total gradient only exists inside the fused encoder-tail pass; c4b is its result)
         want = r["act_grads"][name] * ((r["acts"][name] > 0) if masked else 1.0)
         got = eng.tap(n, name, grad=True)
