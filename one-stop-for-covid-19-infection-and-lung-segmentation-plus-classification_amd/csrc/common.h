@@ -148,6 +148,8 @@ enum { MASK_BIAS_TAB = 4 };
 // internal to the same kernels, data-gradient launches: the BatchNorm backward of the conv's (folded) input BatchNorm applied in the epilogue --
 // `mask` = the BatchNorm's input x (same shape as the output), `bias` = coefficients [3][Cout]: out = K0 * dz + K1 * x + K2 (k_bn_bwd_coef)
 enum { MASK_BN_BWD = 5 };
+// ... followed by the derivative of what produced x (U-Net++ conv_block: x = dropout(elu(conv)), keep mask recomputed from rate / seed): out = mask_factor(x) * (K0 dz + K1 x + K2)
+enum { MASK_BN_BWD_ELU = 6, MASK_BN_BWD_ELU_DROP = 7 };
 int32_t k_bn_bwd_coef(unet_ctx*, const float* bnp, const double* sums, double count, float* coef, int c, hipStream_t s);
 __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep_scale component */, float rate) {
   if (mode == MASK_RELU) return m > 0.0f ? 1.0f : 0.0f;

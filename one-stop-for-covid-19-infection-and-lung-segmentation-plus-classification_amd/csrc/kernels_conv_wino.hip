@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
   // the per-element epilogue input (ReLU mask of a data gradient / x of a folded BatchNorm backward) is requested BEFORE the exchange barrier: its HBM
   // latency overlaps the exchange and the transposes instead of ending every workgroup (the accumulators are dead, registers are free)
   float4 mpre[4][2];
-  const bool want_m = mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
+  const bool want_m = mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB;
   if (want_m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
 
   const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 kb1 = bb, kb2 = bb;                                 // MASK_BN_BWD: bb = K0, these K1, K2
-  if (mask_mode == MASK_BN_BWD && co < Cout) { kb1 = *reinterpret_cast<const float4*>(bias + Cout + co); kb2 = *reinterpret_cast<const float4*>(bias + 2 * Cout + co); }
+  if (mask_mode >= MASK_BN_BWD && co < Cout) { kb1 = *reinterpret_cast<const float4*>(bias + Cout + co); kb2 = *reinterpret_cast<const float4*>(bias + 2 * Cout + co); }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -532,8 +532,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
         }
       } else {
         o4.x = apply_act(o4.x, act); o4.y = apply_act(o4.y, act); o4.z = apply_act(o4.z, act); o4.w = apply_act(o4.w, act);
-        if (mask_mode == MASK_NONE) {
+        if (mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) {
           if (rate > 0.0f) { const float4 ks = keep_scale(o >> 2, rate, seed); o4.x *= ks.x; o4.y *= ks.y; o4.z *= ks.z; o4.w *= ks.w; }
+        } else if (mask_mode >= MASK_BN_BWD) {                // folded BatchNorm backward, then the ELU (+ dropout) derivative of x's producer
+          const float4 m = mpre[g][half];
+          const int mm = mask_mode == MASK_BN_BWD_ELU_DROP ? MASK_ELU_DROP : MASK_ELU;
+          float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (mm == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
+          o4.x = fmaf(bb.x, v0, fmaf(kb1.x, m.x, kb2.x)) * mask_factor(m.x, mm, ks.x, rate); o4.y = fmaf(bb.y, v1, fmaf(kb1.y, m.y, kb2.y)) * mask_factor(m.y, mm, ks.y, rate);
+          o4.z = fmaf(bb.z, v2, fmaf(kb1.z, m.z, kb2.z)) * mask_factor(m.z, mm, ks.z, rate); o4.w = fmaf(bb.w, v3, fmaf(kb1.w, m.w, kb2.w)) * mask_factor(m.w, mm, ks.w, rate);
         } else {
           const float4 m = mpre[g][half];
           float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
   const int orow = kq & 1, half = kq >> 1;
   // the per-element epilogue input (ReLU mask / x of a folded BatchNorm backward) is requested before the exchange barrier (see conv_wino2d_kernel)
   float4 mpre[4];
-  const bool want_m = mask_mode == MASK_RELU || mask_mode == MASK_BN_BWD || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
+  const bool want_m = mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB;
   if (want_m) {
     const int co_ = nbase + (l31 & ~3);
 #pragma unroll
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
   const int co = nbase + q4;
   const float4 bb = (bias && co < Cout) ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 kb1 = bb, kb2 = bb;                                 // MASK_BN_BWD: bb = K0, these K1, K2
-  if (mask_mode == MASK_BN_BWD && co < Cout) { kb1 = *reinterpret_cast<const float4*>(bias + Cout + co); kb2 = *reinterpret_cast<const float4*>(bias + 2 * Cout + co); }
+  if (mask_mode >= MASK_BN_BWD && co < Cout) { kb1 = *reinterpret_cast<const float4*>(bias + Cout + co); kb2 = *reinterpret_cast<const float4*>(bias + 2 * Cout + co); }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float v0 = mine[4 * g + 0], v1 = mine[4 * g + 1], v2 = mine[4 * g + 2], v3 = mine[4 * g + 3];
@@ -738,8 +745,15 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
       }
     } else {
       o4.x = apply_act(o4.x, act); o4.y = apply_act(o4.y, act); o4.z = apply_act(o4.z, act); o4.w = apply_act(o4.w, act);
-      if (mask_mode == MASK_NONE) {
+      if (mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) {
         if (rate > 0.0f) { const float4 ks = keep_scale(o >> 2, rate, seed); o4.x *= ks.x; o4.y *= ks.y; o4.z *= ks.z; o4.w *= ks.w; }
+      } else if (mask_mode >= MASK_BN_BWD) {                  // folded BatchNorm backward, then the ELU (+ dropout) derivative of x's producer
+        const float4 m = mpre[g];
+        const int mm = mask_mode == MASK_BN_BWD_ELU_DROP ? MASK_ELU_DROP : MASK_ELU;
+        float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (mm == MASK_ELU_DROP) ks = keep_scale(o >> 2, rate, seed);
+        o4.x = fmaf(bb.x, v0, fmaf(kb1.x, m.x, kb2.x)) * mask_factor(m.x, mm, ks.x, rate); o4.y = fmaf(bb.y, v1, fmaf(kb1.y, m.y, kb2.y)) * mask_factor(m.y, mm, ks.y, rate);
+        o4.z = fmaf(bb.z, v2, fmaf(kb1.z, m.z, kb2.z)) * mask_factor(m.z, mm, ks.z, rate); o4.w = fmaf(bb.w, v3, fmaf(kb1.w, m.w, kb2.w)) * mask_factor(m.w, mm, ks.w, rate);
       } else {
         const float4 m = mpre[g];
         float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -760,7 +774,7 @@ int32_t launch_wino2d4(unet_ctx* ctx, const float* x, const float* u, const floa
   const int tiles_x = (wd + 2 * WT - 1) / (2 * WT), tiles_y = (h + TH - 1) / TH;
   const dim3 grid((unsigned)(8 * ((tiles_x * tiles_y * n + 7) / 8) * ((cout + TN - 1) / TN)));
   const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * (CKV + 4)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));
-  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP;
   UNET_BIG_LDS(ctx, (conv_wino2d4_kernel<WTT, false, CKV>), lds, "conv_wino2d4");
   UNET_BIG_LDS(ctx, (conv_wino2d4_kernel<WTT, true, CKV>), lds, "conv_wino2d4");
   if (gen) hipLaunchKernelGGL((conv_wino2d4_kernel<WTT, true, CKV>), grid, dim3(256), lds, s, x, u, bias, mask, y, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
@@ -781,7 +795,7 @@ int32_t launch_wino2d(unet_ctx* ctx, const float* x, const float* u, const float
   static const int breg_env = [] { const char* e = getenv("UNET_WINO_BREG"); return e ? atoi(e) : -1; }();
   const int breg = breg_env >= 0 ? breg_env : (WC == 2 ? 1 : 0);
   const size_t lds = std::max((size_t)((TH + 2) * 4 * WT * CKP + (breg ? 0 : 16 * CK * TN)) * sizeof(float), (size_t)4 * 32 * 64 * sizeof(float));   // >= the epilogue exchange
-  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP;
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP;
   {
     const size_t big = (size_t)((TH + 2) * 4 * WT * CKP + 16 * CK * TN) * sizeof(float);
     UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, false, false, 8>), big, "conv_wino2d"); UNET_BIG_LDS(ctx, (conv_wino2d_kernel<WTT, WM, WC, true, false, 8>), big, "conv_wino2d");
@@ -965,7 +979,7 @@ int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const 
     if (cout % 64 == 0) return launch_wino2d<32, 1, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
     return launch_wino2d<32, 2, 1>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   }
-  if (mask_mode == MASK_BIAS_TAB || mask_mode == MASK_BN_BWD) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3 winograd: the folded-BatchNorm epilogues need the F(2x2,3x3) kernels (h=%d cout=%d)", h, cout);
+  if (mask_mode >= MASK_BIAS_TAB) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3 winograd: the folded-BatchNorm epilogues need the F(2x2,3x3) kernels (h=%d cout=%d)", h, cout);
   // One image row per wave (64 accumulator registers) -> 3 workgroups per CU: occupancy pays more than sharing the weight operand
   // between two rows did (the <64,4,2,2> / <32,8,4,1> tiles measured 1-8 % slower on every U-Net layer).
   if (cout % 64 == 0) return launch_wino<64, 2, 2, 2>(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);

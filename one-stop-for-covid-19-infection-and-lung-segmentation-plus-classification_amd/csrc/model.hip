@@ -958,7 +958,18 @@ void plan_workspace_pp(unet_model* m) {
   }
   for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)16 * l.cin * l.cout);
   m->off_wt = cv.take(wt0);
+  // conv_block = [Conv -> Dropout -> BN] x 2 (UPP:860-868): the first BatchNorm feeds only the second conv -> folded into it, fp32 on the
+  // F(2x2,3x3) kernels
+  if (!m->dt && bn_fold_enabled() >= 2) {
+    for (auto& nd : pp_nodes()) {
+      const std::string nm = nd.name; const Buf ob = m->act.at(nm + "b"); const int c = nd.c;
+      if (!wgrad_bn_fold_supported(c) || !use_wino(m->algo, ob.w, c, c, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, c)) continue;
+      m->fold_off[nm + "b"] = cv.take(bn_fold_scratch_floats(c, c));
+      m->folded_bn[nm + "abn"] = {nm + "a", c};
+    }
+  }
   m->ws_floats_infer = cv.cur;
+  for (auto& kv : m->fold_off) { const int c = m->act.at(kv.first).c; m->fold_g_off[kv.first] = cv.take(wgrad_bn_fold_scratch_floats(N, c)); m->fold_c_off[kv.first] = cv.take((size_t)3 * c); }
   // ---- training: one dense gradient twin per activation buffer (aliases share it)
   std::map<size_t, std::string> seen;
   for (auto& kv : m->act) {
@@ -1039,7 +1050,9 @@ void build_programs_pp(unet_model* m) {
           return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
         });
       }
-      if (pool.empty()) {
+      if (pool.empty() && m->folded_bn.count(name)) {
+        // folded into the conv behind it: no normalised tensor
+      } else if (pool.empty()) {
         ADD_OP(F, "bn_apply:" + name, 0, 2 * eb * pixels * c, {
           if (dt) return unet_bn_apply_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(out)), ob.ld, pixels, c, s);
           return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(out), ob.ld, pixels, c, s);
@@ -1080,6 +1093,22 @@ void build_programs_pp(unet_model* m) {
         }
         conv(it + "a", cat, cb.c, c, PP_BLOCK_DROP);
         bn(it + "abn", it + "a", it + "abn", c, "");
+        if (m->fold_off.count(it + "b")) {
+          const std::string cn = it + "b", xn = it + "a", bnn = it + "abn";
+          const Buf ob = m->act.at(cn);
+          const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn);
+          const uint64_t sd = seed_of(cn);
+          ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * c * c * 2, 4.0 * 9 * c * c * 4, {
+            return k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + c, c, c, m->wsf(fo), s);
+          });
+          ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * c * c * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * 2 * c + 4.0 * 9.0 * c * c, {
+            const float r = (tr && m->drop_rate > 0.0f) ? PP_BLOCK_DROP : 0.0f;
+            const float* tab = m->wsf(fo) + (size_t)9 * c * c;
+            int32_t e = k_wino_weights(ctx, m->wsf(fo), m->wsf(m->off_wt), c, c, 0, ob.h, s);
+            if (e) return e;
+            return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(m->off_wt), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, c, c, ACT_ELU, r, m->drop_seed + sd, s);
+          });
+        } else
         conv(it + "b", it + "abn", c, c, PP_BLOCK_DROP);
         bn(it + "bbn", it + "b", it, c, "");
       }
@@ -1193,8 +1222,37 @@ void build_programs_pp(unet_model* m) {
       const Buf sb = m->act.at(src), cb = m->act.at(cat);
       const int c = nd->c, csrc = pp_width(src);
       bn_bwd(it + "bbn", it, it + "b", c, MASK_ELU_DROP, PP_BLOCK_DROP, seed_of(it + "b"));
+      if (m->fold_off.count(it + "b")) {
+        // folded BatchNorm (abn -> conv b): weight gradient on the raw x, corrected; the BatchNorm's backward sums from W . dW_raw and S; its backward apply and the
+        // ELU / dropout derivative of conv a in the data-gradient epilogue, which writes conv a's pre-activation gradient directly
+        const std::string cn = it + "b", xn = it + "a", bnn = it + "abn";
+        const Buf ob = m->act.at(cn);
+        const double px = (double)ob.n * ob.h * ob.w;
+        const size_t go = m->fold_g_off.at(cn), co = m->fold_c_off.at(cn), bo = m->bnp_off.at(bnn), so = m->bn_bsum_off.at(bnn);
+        const uint64_t sda = seed_of(xn);
+        ADD_OP(BW, "conv3x3_wgrad:" + cn, 2.0 * 9 * c * c * px, eb * px * 2 * c + 4.0 * 9.0 * c * c, {
+          return conv3x3_wgrad_dispatch(ctx, m->A(xn), m->D(cn), m->G(cn + "/kernel"), m->G(cn + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, c, c, algo, s);
+        });
+        ADD_OP(BW, "wgrad_bn_fold_fix:" + cn, 2.0 * 9 * c * c, 8.0 * 9 * c * c, {
+          int32_t r = k_wgrad_bn_fold_fix(ctx, m->D(cn), ob.n, ob.h, ob.w, c, c, m->wsf(bo), m->wsf(bo) + c, m->G(cn + "/kernel"), m->G(cn + "/bias"), m->wsf(go), s, m->P(cn + "/kernel"),
+                                          m->wsf(bo) + 2 * c, m->wsf(bo) + 3 * c, m->wsd(m->off_bn_bsums) + so);
+          if (r) return r;
+          return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(bnn + "/gamma"), m->G(bnn + "/beta"), c, s);
+        });
+        SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
+        ADD_OP(BW, "conv3x3_dgrad_bn_bwd:" + cn, 2.0 * 9 * c * c * px, eb * px * 3 * c + 4.0 * 9.0 * c * c, {
+          const bool drop = m->drop_rate > 0.0f;
+          int32_t r = k_bn_bwd_coef(ctx, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, px * gcount, m->wsf(co), c, s);
+          if (r) return r;
+          r = k_wino_weights(ctx, m->P(cn + "/kernel"), m->wsf(m->off_wt), c, c, 1, ob.h, s);
+          if (r) return r;
+          return k_conv3x3_wino_fwd(ctx, m->D(cn), m->wsf(m->off_wt), m->wsf(co), m->A(xn), drop ? MASK_BN_BWD_ELU_DROP : MASK_BN_BWD_ELU, m->D(xn), ob.n, ob.h, ob.w, c, c, ACT_NONE,
+                                    drop ? PP_BLOCK_DROP : 0.0f, m->drop_seed + sda, s);
+        });
+      } else {
       conv_bwd(it + "b", it + "abn", c, c, true, MASK_NONE, 0.0f, 0);
       bn_bwd(it + "abn", it + "abn", it + "a", c, MASK_ELU_DROP, PP_BLOCK_DROP, seed_of(it + "a"));
+      }
       conv_bwd(it + "a", cat, cb.c, c, true, MASK_NONE, 0.0f, 0);
       const Buf ug = m->grad.at(un);
       ADD_OP(BW, "convT_wgrad:" + un, 2.0 * 4 * csrc * c * nel(sb) / sb.c, eb * (nel(sb) + 4.0 * nel(sb) / sb.c * c), {
@@ -1607,7 +1665,11 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
   if (it == mp.end()) return UNET_E_ARG;
   const Buf& b = it->second;
   const auto fb = m->folded_bn.find(name);
-  if (grad && fb != m->folded_bn.end() && m->fold_c_off.count("c" + std::string(name).substr(2) + "a")) return UNET_E_STATE;   // dz is consumed in the data-gradient epilogue, never stored
+  if (grad && fb != m->folded_bn.end()) {                  // dz is consumed in the data-gradient epilogue, never stored
+    const std::string nm = name;
+    const std::string conv = nm.rfind("bn", 0) == 0 ? "c" + nm.substr(2) + "a" : nm.substr(0, nm.size() - 3) + "b";      // U-Net: bnK -> cKa; U-Net++: <node>abn -> <node>b
+    if (m->fold_c_off.count(conv)) return UNET_E_STATE;
+  }
   if (!grad && fb != m->folded_bn.end()) {
     // the programs never write this tensor (its BatchNorm is folded into the next conv): a tap materialises it from the layer's input and the
     // scale / shift of the last forward, on the null stream, and waits for it

@@ -44,6 +44,11 @@ def test_fwd_bwd_all_grads(hw, n, algo):
     eng.set_weights(wts)
     ld = eng.forward_backward(x, y).cpu().numpy()
     assert abs(ld[0] - r["loss"]) < 1e-5 and abs(ld[1] - r["dice"]) < 1e-5
+    if algo == 0:
+        # auto algorithm: the first BatchNorm of every conv_block is folded into the block's second conv -- x1_2b's output, its kernel
+        # gradient, x1_2abn's gamma / beta and everything upstream are checked through that path ("x1_2abn" below is materialised by the tap)
+        bwd = [o[0] for o in eng.op_profile(n, 1)]
+        assert "conv3x3_dgrad_bn_bwd:x1_2b" in bwd and "bn_bwd_apply:x1_2abn" not in bwd and "bn_bwd_apply:x1_2bbn" in bwd, bwd
     for name in ("c1a", "c1b", "bn1", "p1", "c4b", "bn4", "u1_2", "x1_2a", "x1_2abn", "x1_2b", "x1_2bbn", "x2_3bbn", "x1_3a", "x1_4bbn"):
         assert relerr(eng.tap(n, name), r["acts"][name]) < 2e-5, name
     g = eng.get_grads()
