@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
       if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
       else o = (((long long)n * H + py) * W + px_) * ldy + mb;
       float v[16];
-      if (MODE == 0 && mask_mode == MASK_BN_BWD) {
+      if (MODE == 0 && mask_mode >= MASK_BN_BWD) {
         // data gradient of a conv whose input BatchNorm is folded: dx = K0 dz + K1 x + K2, x read where a ReLU layer reads its mask
         const uint4 m0 = *reinterpret_cast<const uint4*>(mask + o), m1 = *reinterpret_cast<const uint4*>(mask + o + 8);
         const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
@@ -254,7 +254,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
         } else {
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = apply_act(v[i], act);
-          if (mask_mode == MASK_NONE) {
+          if (mask_mode >= MASK_BN_BWD) {                      // (v already holds K0 dz + K1 x + K2) then the ELU (+ dropout) derivative of x's producer
+            const int mm = mask_mode == MASK_BN_BWD_ELU_DROP ? MASK_ELU_DROP : MASK_ELU;
+            const uint4 m0 = *reinterpret_cast<const uint4*>(mask + o), m1 = *reinterpret_cast<const uint4*>(mask + o + 8);
+            const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
+              if (mm == MASK_ELU_DROP) ks4 = keep_scale((o >> 2) + q, rate, seed);
+              v[q * 4] *= mask_factor(bf16_lo(mw[2 * q]), mm, ks4.x, rate); v[q * 4 + 1] *= mask_factor(bf16_hi(mw[2 * q]), mm, ks4.y, rate);
+              v[q * 4 + 2] *= mask_factor(bf16_lo(mw[2 * q + 1]), mm, ks4.z, rate); v[q * 4 + 3] *= mask_factor(bf16_hi(mw[2 * q + 1]), mm, ks4.w, rate);
+            }
+          } else if (mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) {
             if (rate > 0.0f) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
@@ -295,7 +306,7 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
   const long long total = (long long)tiles_x * tiles_y * n * groups;
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
-  const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP);
+  const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP);
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_bf16");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);

@@ -960,10 +960,12 @@ void plan_workspace_pp(unet_model* m) {
   m->off_wt = cv.take(wt0);
   // conv_block = [Conv -> Dropout -> BN] x 2 (UPP:860-868): the first BatchNorm feeds only the second conv -> folded into it, fp32 on the
   // F(2x2,3x3) kernels
-  if (!m->dt && bn_fold_enabled() >= 2) {
+  if (bn_fold_enabled() >= 2) {
     for (auto& nd : pp_nodes()) {
       const std::string nm = nd.name; const Buf ob = m->act.at(nm + "b"); const int c = nd.c;
-      if (!wgrad_bn_fold_supported(c) || !use_wino(m->algo, ob.w, c, c, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, c)) continue;
+      if (!wgrad_bn_fold_supported(c)) continue;
+      if (m->dt) { if (!bf16_conv3x3_supported(c, c)) continue; }       // bf16 storage: the direct MFMA kernel has the same epilogues
+      else if (!use_wino(m->algo, ob.w, c, c, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, c)) continue;
       m->fold_off[nm + "b"] = cv.take(bn_fold_scratch_floats(c, c));
       m->folded_bn[nm + "abn"] = {nm + "a", c};
     }
@@ -1104,6 +1106,8 @@ void build_programs_pp(unet_model* m) {
           ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * c * c * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * 2 * c + 4.0 * 9.0 * c * c, {
             const float r = (tr && m->drop_rate > 0.0f) ? PP_BLOCK_DROP : 0.0f;
             const float* tab = m->wsf(fo) + (size_t)9 * c * c;
+            if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(xn)), m->wsf(fo), tab, reinterpret_cast<const unet_bf16*>(tab), MASK_BIAS_TAB, WBF(m->Av(cn)), ob.n, ob.h, ob.w, c, c, ACT_ELU, r,
+                                              m->drop_seed + sd, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
             int32_t e = k_wino_weights(ctx, m->wsf(fo), m->wsf(m->off_wt), c, c, 0, ob.h, s);
             if (e) return e;
             return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(m->off_wt), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, c, c, ACT_ELU, r, m->drop_seed + sd, s);
@@ -1231,11 +1235,14 @@ void build_programs_pp(unet_model* m) {
         const size_t go = m->fold_g_off.at(cn), co = m->fold_c_off.at(cn), bo = m->bnp_off.at(bnn), so = m->bn_bsum_off.at(bnn);
         const uint64_t sda = seed_of(xn);
         ADD_OP(BW, "conv3x3_wgrad:" + cn, 2.0 * 9 * c * c * px, eb * px * 2 * c + 4.0 * 9.0 * c * c, {
+          if (dt) return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(xn)), CBF(m->Dv(cn)), m->G(cn + "/kernel"), m->G(cn + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, c, c, s);
           return conv3x3_wgrad_dispatch(ctx, m->A(xn), m->D(cn), m->G(cn + "/kernel"), m->G(cn + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, c, c, algo, s);
         });
         ADD_OP(BW, "wgrad_bn_fold_fix:" + cn, 2.0 * 9 * c * c, 8.0 * 9 * c * c, {
-          int32_t r = k_wgrad_bn_fold_fix(ctx, m->D(cn), ob.n, ob.h, ob.w, c, c, m->wsf(bo), m->wsf(bo) + c, m->G(cn + "/kernel"), m->G(cn + "/bias"), m->wsf(go), s, m->P(cn + "/kernel"),
-                                          m->wsf(bo) + 2 * c, m->wsf(bo) + 3 * c, m->wsd(m->off_bn_bsums) + so);
+          int32_t r = dt ? k_wgrad_bn_fold_fix_bf16(ctx, CBF(m->Dv(cn)), ob.n, ob.h, ob.w, c, c, m->wsf(bo), m->wsf(bo) + c, m->G(cn + "/kernel"), m->G(cn + "/bias"), m->wsf(go), s,
+                                                    m->P(cn + "/kernel"), m->wsf(bo) + 2 * c, m->wsf(bo) + 3 * c, m->wsd(m->off_bn_bsums) + so)
+                         : k_wgrad_bn_fold_fix(ctx, m->D(cn), ob.n, ob.h, ob.w, c, c, m->wsf(bo), m->wsf(bo) + c, m->G(cn + "/kernel"), m->G(cn + "/bias"), m->wsf(go), s, m->P(cn + "/kernel"),
+                                               m->wsf(bo) + 2 * c, m->wsf(bo) + 3 * c, m->wsd(m->off_bn_bsums) + so);
           if (r) return r;
           return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(bnn + "/gamma"), m->G(bnn + "/beta"), c, s);
         });
@@ -1244,6 +1251,8 @@ void build_programs_pp(unet_model* m) {
           const bool drop = m->drop_rate > 0.0f;
           int32_t r = k_bn_bwd_coef(ctx, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, px * gcount, m->wsf(co), c, s);
           if (r) return r;
+          if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(cn)), m->P(cn + "/kernel"), m->wsf(co), CBF(m->Av(xn)), drop ? MASK_BN_BWD_ELU_DROP : MASK_BN_BWD_ELU, WBF(m->Dv(xn)), ob.n, ob.h, ob.w, c, c,
+                                            ACT_NONE, drop ? PP_BLOCK_DROP : 0.0f, m->drop_seed + sda, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
           r = k_wino_weights(ctx, m->P(cn + "/kernel"), m->wsf(m->off_wt), c, c, 1, ob.h, s);
           if (r) return r;
           return k_conv3x3_wino_fwd(ctx, m->D(cn), m->wsf(m->off_wt), m->wsf(co), m->A(xn), drop ? MASK_BN_BWD_ELU_DROP : MASK_BN_BWD_ELU, m->D(xn), ob.n, ob.h, ob.w, c, c, ACT_NONE,
