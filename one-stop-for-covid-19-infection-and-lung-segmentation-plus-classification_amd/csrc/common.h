@@ -150,6 +150,8 @@ enum { MASK_BIAS_TAB = 4 };
 enum { MASK_BN_BWD = 5 };
 // ... followed by the derivative of what produced x (U-Net++ conv_block: x = dropout(elu(conv)), keep mask recomputed from rate / seed): out = mask_factor(x) * (K0 dz + K1 x + K2)
 enum { MASK_BN_BWD_ELU = 6, MASK_BN_BWD_ELU_DROP = 7 };
+// ... or by the ReLU mask of x's producer (classifier: Conv(relu) -> BN -> Conv, T2:748-751): out = x > 0 ? K0 dz + K1 x + K2 : 0
+enum { MASK_BN_BWD_RELU = 8 };
 int32_t k_bn_bwd_coef(unet_ctx*, const float* bnp, const double* sums, double count, float* coef, int c, hipStream_t s);
 __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep_scale component */, float rate) {
   if (mode == MASK_RELU) return m > 0.0f ? 1.0f : 0.0f;

@@ -222,6 +222,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
           v[q * 4 + 1] = fmaf(bv[q * 4 + 1], acc[r][nb][q * 4 + 1], fmaf(k1.y, bf16_hi(mw[2 * q]), k2.y));
           v[q * 4 + 2] = fmaf(bv[q * 4 + 2], acc[r][nb][q * 4 + 2], fmaf(k1.z, bf16_lo(mw[2 * q + 1]), k2.z));
           v[q * 4 + 3] = fmaf(bv[q * 4 + 3], acc[r][nb][q * 4 + 3], fmaf(k1.w, bf16_hi(mw[2 * q + 1]), k2.w));
+          if (mask_mode == MASK_BN_BWD_RELU) {                // x = relu(conv): the gradient stops where it was clipped
+            v[q * 4] = bf16_lo(mw[2 * q]) > 0.f ? v[q * 4] : 0.f; v[q * 4 + 1] = bf16_hi(mw[2 * q]) > 0.f ? v[q * 4 + 1] : 0.f;
+            v[q * 4 + 2] = bf16_lo(mw[2 * q + 1]) > 0.f ? v[q * 4 + 2] : 0.f; v[q * 4 + 3] = bf16_hi(mw[2 * q + 1]) > 0.f ? v[q * 4 + 3] : 0.f;
+          }
         }
       } else if (MODE == 0 && mask_mode == MASK_BIAS_TAB && (py == 0 || py == H - 1 || px_ == 0 || px_ == W - 1)) {
         // forward of such a conv: border pixels see fewer taps of the BatchNorm shift -- the bias vector of their border class (`mask` = float table [16][M])

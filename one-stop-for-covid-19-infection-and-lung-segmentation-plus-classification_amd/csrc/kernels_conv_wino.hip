@@ -520,10 +520,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2d_kernel(const float* __rest
       float4 o4 = make_float4(v0 + bs.x, v1 + bs.y, v2 + bs.z, v3 + bs.w);
       const long long o = (((long long)n * H + py) * W + px) * Cout + co;
       if (!GEN) {
-        if (mask_mode == MASK_BN_BWD) {                       // the folded BatchNorm's backward: dx = K0 * dz + K1 * x + K2
+        if (mask_mode == MASK_BN_BWD || mask_mode == MASK_BN_BWD_RELU) {      // the folded BatchNorm's backward: dx = K0 * dz + K1 * x + K2 (x = relu(.): masked)
           const float4 m = mpre[g][half];
           o4.x = fmaf(bb.x, v0, fmaf(kb1.x, m.x, kb2.x)); o4.y = fmaf(bb.y, v1, fmaf(kb1.y, m.y, kb2.y));
           o4.z = fmaf(bb.z, v2, fmaf(kb1.z, m.z, kb2.z)); o4.w = fmaf(bb.w, v3, fmaf(kb1.w, m.w, kb2.w));
+          if (mask_mode == MASK_BN_BWD_RELU) { o4.x = m.x > 0.f ? o4.x : 0.f; o4.y = m.y > 0.f ? o4.y : 0.f; o4.z = m.z > 0.f ? o4.z : 0.f; o4.w = m.w > 0.f ? o4.w : 0.f; }
         }
         if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
         if (mask_mode == MASK_RELU) {
@@ -733,10 +734,11 @@ __global__ __launch_bounds__(256, 3) void conv_wino2d4_kernel(const float* __res
     float4 o4 = make_float4(v0 + bs.x, v1 + bs.y, v2 + bs.z, v3 + bs.w);
     const long long o = (((long long)n * H + py) * W + px) * Cout + co;
     if (!GEN) {
-      if (mask_mode == MASK_BN_BWD) {                         // the folded BatchNorm's backward: dx = K0 * dz + K1 * x + K2
+      if (mask_mode == MASK_BN_BWD || mask_mode == MASK_BN_BWD_RELU) {        // the folded BatchNorm's backward: dx = K0 * dz + K1 * x + K2 (x = relu(.): masked)
         const float4 m = mpre[g];
         o4.x = fmaf(bb.x, v0, fmaf(kb1.x, m.x, kb2.x)); o4.y = fmaf(bb.y, v1, fmaf(kb1.y, m.y, kb2.y));
         o4.z = fmaf(bb.z, v2, fmaf(kb1.z, m.z, kb2.z)); o4.w = fmaf(bb.w, v3, fmaf(kb1.w, m.w, kb2.w));
+        if (mask_mode == MASK_BN_BWD_RELU) { o4.x = m.x > 0.f ? o4.x : 0.f; o4.y = m.y > 0.f ? o4.y : 0.f; o4.z = m.z > 0.f ? o4.z : 0.f; o4.w = m.w > 0.f ? o4.w : 0.f; }
       }
       if (act == ACT_RELU) { o4.x = fmaxf(o4.x, 0.f); o4.y = fmaxf(o4.y, 0.f); o4.z = fmaxf(o4.z, 0.f); o4.w = fmaxf(o4.w, 0.f); }
       if (mask_mode == MASK_RELU) {

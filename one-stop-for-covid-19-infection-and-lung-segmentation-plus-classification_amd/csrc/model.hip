@@ -1346,7 +1346,24 @@ void plan_workspace_cls(unet_model* m) {
   m->off_dense_ws = cv.take((m->dense_ws_bytes + 3) / 4);
   for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)16 * l.cin * l.cout);
   m->off_wt = cv.take(wt0);
+  // Conv(relu) -> BN -> Conv (T2:748-751): the first BatchNorm of a block feeds only the block's second conv -> folded into it.  fp32: where that conv
+  // runs on the F(2x2,3x3) kernels (the 32- and 64-channel blocks)
+  if (bn_fold_enabled() >= 2) {
+    for (int k = 1; k <= 3; ++k) {
+      const int c = CLS_C[k - 1]; const std::string cn = "c" + std::to_string(k) + "b";
+      const Buf ob = m->act.at(cn);
+      if (!wgrad_bn_fold_supported(c)) continue;
+      // (bf16 storage has the epilogues too -- UNET_CLS_FOLD_BF16=1 -- but measured 1 % slower here: these layers are short-K, the per-step weight image of
+      //  the scaled weights and the x read in the data-gradient epilogue cost what the two saved passes gain)
+      static const int bf16_too = [] { const char* e = getenv("UNET_CLS_FOLD_BF16"); return e ? atoi(e) : 0; }();
+      if (m->dt) { if (!bf16_too || !bf16_conv3x3_supported(c, c)) continue; }
+      else if (!use_wino(m->algo, ob.w, c, c, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, c)) continue;
+      m->fold_off[cn] = cv.take(bn_fold_scratch_floats(c, c));
+      m->folded_bn["bn" + std::to_string(k) + "a"] = {"c" + std::to_string(k) + "a", c};
+    }
+  }
   m->ws_floats_infer = cv.cur;
+  for (auto& kv : m->fold_off) { const int c = m->act.at(kv.first).c; m->fold_g_off[kv.first] = cv.take(wgrad_bn_fold_scratch_floats(N, c)); m->fold_c_off[kv.first] = cv.take((size_t)3 * c); }
   for (auto& kv : m->act) {
     const Buf& b = kv.second;
     if (kv.first == "h1") { Buf g = b; g.off = cv.take((size_t)N * CLS_HIDDEN); m->grad[kv.first] = g; }
@@ -1410,7 +1427,9 @@ void build_programs_cls(unet_model* m) {
           return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
         });
       }
-      if (pool.empty()) {
+      if (pool.empty() && m->folded_bn.count(name)) {
+        // folded into the conv behind it: no normalised tensor
+      } else if (pool.empty()) {
         ADD_OP(F, "bn_apply:" + name, 0, 2 * eb * pixels * c, {
           if (dt) return unet_bn_apply_bf16(ctx, CBF(m->Av(in)), ib.ld, m->wsf(bo), WBF(m->Av(name)), ob.ld, pixels, c, s);
           return unet_bn_apply(ctx, m->A(in), ib.ld, m->wsf(bo), m->Aw(name), ob.ld, pixels, c, s);
@@ -1427,6 +1446,22 @@ void build_programs_cls(unet_model* m) {
       const int c = CLS_C[k - 1]; const std::string ks = std::to_string(k);
       conv("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cprev, c);
       bn("bn" + ks + "a", "c" + ks + "a", c, "");
+      if (m->fold_off.count("c" + ks + "b")) {
+        const std::string cn = "c" + ks + "b", xn = "c" + ks + "a", bnn = "bn" + ks + "a";
+        const Buf ob = m->act.at(cn);
+        const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn);
+        ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * c * c * 2, 4.0 * 9 * c * c * 4, {
+          return k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + c, c, c, m->wsf(fo), s);
+        });
+        ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * c * c * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * 2 * c + 4.0 * 9.0 * c * c, {
+          const float* tab = m->wsf(fo) + (size_t)9 * c * c;
+          if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(xn)), m->wsf(fo), tab, reinterpret_cast<const unet_bf16*>(tab), MASK_BIAS_TAB, WBF(m->Av(cn)), ob.n, ob.h, ob.w, c, c, ACT_RELU, 0.0f, 0,
+                                            WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
+          int32_t e = k_wino_weights(ctx, m->wsf(fo), m->wsf(m->off_wt), c, c, 0, ob.h, s);
+          if (e) return e;
+          return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(m->off_wt), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, c, c, ACT_RELU, 0.0f, 0, s);
+        });
+      } else
       conv("c" + ks + "b", "bn" + ks + "a", c, c);
       bn("bn" + ks + "b", "c" + ks + "b", c, "p" + ks);
       cprev = c;
@@ -1535,8 +1570,38 @@ void build_programs_cls(unet_model* m) {
     });
     bn_bwd(bb, cb, c);
     }
+    if (m->fold_off.count(cb)) {
+      // folded BatchNorm (bn_ka -> conv kb): weight gradient on the raw x, corrected; backward sums from W . dW_raw and S; backward apply + ReLU mask of conv ka in the
+      // data-gradient epilogue, which writes conv ka's output gradient directly
+      const Buf ob = m->act.at(cb);
+      const double px = (double)ob.n * ob.h * ob.w;
+      const size_t go = m->fold_g_off.at(cb), co = m->fold_c_off.at(cb), bo = m->bnp_off.at(ba), so = m->bn_bsum_off.at(ba);
+      ADD_OP(BW, "conv3x3_wgrad:" + cb, 2.0 * 9 * c * c * px, eb * px * 2 * c + 4.0 * 9.0 * c * c, {
+        if (dt) return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(ca)), CBF(m->Dv(cb)), m->G(cb + "/kernel"), m->G(cb + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, c, c, s);
+        return conv3x3_wgrad_dispatch(ctx, m->A(ca), m->D(cb), m->G(cb + "/kernel"), m->G(cb + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, c, c, algo, s);
+      });
+      ADD_OP(BW, "wgrad_bn_fold_fix:" + cb, 2.0 * 9 * c * c, 8.0 * 9 * c * c, {
+        int32_t r = dt ? k_wgrad_bn_fold_fix_bf16(ctx, CBF(m->Dv(cb)), ob.n, ob.h, ob.w, c, c, m->wsf(bo), m->wsf(bo) + c, m->G(cb + "/kernel"), m->G(cb + "/bias"), m->wsf(go), s,
+                                                  m->P(cb + "/kernel"), m->wsf(bo) + 2 * c, m->wsf(bo) + 3 * c, m->wsd(m->off_bn_bsums) + so)
+                       : k_wgrad_bn_fold_fix(ctx, m->D(cb), ob.n, ob.h, ob.w, c, c, m->wsf(bo), m->wsf(bo) + c, m->G(cb + "/kernel"), m->G(cb + "/bias"), m->wsf(go), s, m->P(cb + "/kernel"),
+                                             m->wsf(bo) + 2 * c, m->wsf(bo) + 3 * c, m->wsd(m->off_bn_bsums) + so);
+        if (r) return r;
+        return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(ba + "/gamma"), m->G(ba + "/beta"), c, s);
+      });
+      SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
+      ADD_OP(BW, "conv3x3_dgrad_bn_bwd:" + cb, 2.0 * 9 * c * c * px, eb * px * 3 * c + 4.0 * 9.0 * c * c, {
+        int32_t r = k_bn_bwd_coef(ctx, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, px * gcount, m->wsf(co), c, s);
+        if (r) return r;
+        if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(cb)), m->P(cb + "/kernel"), m->wsf(co), CBF(m->Av(ca)), MASK_BN_BWD_RELU, WBF(m->Dv(ca)), ob.n, ob.h, ob.w, c, c, ACT_NONE, 0.0f, 0,
+                                          WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
+        r = k_wino_weights(ctx, m->P(cb + "/kernel"), m->wsf(m->off_wt), c, c, 1, ob.h, s);
+        if (r) return r;
+        return k_conv3x3_wino_fwd(ctx, m->D(cb), m->wsf(m->off_wt), m->wsf(co), m->A(ca), MASK_BN_BWD_RELU, m->D(ca), ob.n, ob.h, ob.w, c, c, ACT_NONE, 0.0f, 0, s);
+      });
+    } else {
     conv_bwd(cb, ba, c, c, true);
     bn_bwd(ba, ca, c);
+    }
     conv_bwd(ca, k == 1 ? "" : "p" + std::to_string(k - 1), cin, c, k > 1);
   }
   { const TInfo a = m->tinfo.at("c1a/kernel"), b = m->tinfo.at("bn3b/beta"); SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off}); }
@@ -1676,7 +1741,8 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
   const auto fb = m->folded_bn.find(name);
   if (grad && fb != m->folded_bn.end()) {                  // dz is consumed in the data-gradient epilogue, never stored
     const std::string nm = name;
-    const std::string conv = nm.rfind("bn", 0) == 0 ? "c" + nm.substr(2) + "a" : nm.substr(0, nm.size() - 3) + "b";      // U-Net: bnK -> cKa; U-Net++: <node>abn -> <node>b
+    std::string conv = nm.rfind("bn", 0) == 0 ? "c" + nm.substr(2) + "a" : nm.substr(0, nm.size() - 3) + "b";      // U-Net: bnK -> cKa; U-Net++: <node>abn -> <node>b
+    if (m->arch == UNET_ARCH_CLASSIFIER) conv = "c" + nm.substr(2, 1) + "b";                                             // classifier: bnKa -> cKb
     if (m->fold_c_off.count(conv)) return UNET_E_STATE;
   }
   if (!grad && fb != m->folded_bn.end()) {
