@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- CT images/sec of one full U-Net training step (fwd + loss + bwd + Keras-Adam,
 gradient all-reduce when >1 GPU) at 512x512x1, batch 16 per GPU, fp32, synthetic data resident
-in HBM (BASELINE.json configs[1]).  One process per GPU; for N>1 launch with torch.distributed.run.
+in HBM (BASELINE.json configs[1]).  One process per GPU: under torch.distributed.run the ranks read RANK / LOCAL_RANK /
+WORLD_SIZE; a bare `python bench.py --gpus N` (N > 1) re-launches itself under torch.distributed.run on 127.0.0.1.
+`--config 2` = BASELINE.json configs[2] (task-3 lung U-Net, same graph, batch 8 per GPU = global 64 on 8 GPUs).
 
 Prints ONE JSON line (rank 0).  Besides the driver contract it carries
   roofline     : the dominant kernel (fp32 MFMA 3x3 convolution, forward + data-gradient launches):
@@ -63,7 +65,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)     # the chip needs ~1 s of load to settle its clocks
     ap.add_argument("--warmup", type=int, default=15)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16 (configs[1]) or 8 (--config 2)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2], help="BASELINE.json configs index: 1 = infection U-Net 512x512x1 bs16 per GPU (headline); "
+                    "2 = lung U-Net (task 3, same graph T3:850-913) 512x512x1 at batch 8 per GPU = global 64 on 8 GPUs")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (MFMA), 1 direct kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,6 +78,18 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="bf16 = activations / activation gradients stored as bf16 (U-Net graph only); "
                     "NOT the headline metric, which BASELINE.json fixes at fp32")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8 if args.config == 2 else 16
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     import numpy as np
     import torch
@@ -85,16 +101,15 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # test hooks (single-GPU dry run of the multi-process path): UNET_BENCH_BACKEND=gloo UNET_BENCH_ONE_DEVICE=1
     backend = os.environ.get("UNET_BENCH_BACKEND", "nccl")
     if os.environ.get("UNET_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
     pg = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or os.environ.get("UNET_BENCH_FORCE_PG"):          # UNET_BENCH_FORCE_PG=1: run the process-group code at world 1 (RCCL path smoke on a 1-GPU box)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -115,6 +130,27 @@ def main():
                   arch=args.arch, dtype=args.dtype)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
+    # ---- untimed setup 1 (rank 0, N=1): the CPU baseline first, so the GPU work of this command is one contiguous block at its end
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(S, arch=args.arch)
+
+    # ---- untimed setup 2, the roofline leg: per-op hipEvent timing (profiling mode serialises the ops and brackets each with events on the
+    # launch stream) of PROF_STEPS steps; every rank runs them (they contain the collectives), rank 0 reports.  Running it BEFORE the
+    # warm-up also means the chip has seen ~0.5 s of load when the W warm-up steps start (its clocks need ~1 s to settle)
+    PROF_STEPS = 8
+    roof = None
+    for _ in range(2):
+        eng.train_batch(x, y)                # first-touch: plans, workspace, weight images
+    eng.set_profiling(True, B)
+    for _ in range(PROF_STEPS):
+        eng.train_batch(x, y)
+    torch.cuda.synchronize()
+    eng.set_profiling(False)
+    ops = eng.op_profile(B, 0) + eng.op_profile(B, 1)
+    eng.set_weights(W.init_weights(0, 1, args.arch, (S, S))); eng.reset_optimizer()
+
+    # ---- the measurement the contract defines: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize
     for _ in range(args.warmup):
         eng.train_batch(x, y)
     torch.cuda.synchronize()
@@ -134,88 +170,94 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     loss_dice = last.cpu().numpy().tolist()
 
-    # ---- roofline leg: per-op hipEvent timing of two more steps (profiling mode serialises ops)
-    roof = None
-    eng.set_profiling(True, B)               # every rank runs these steps (they contain collectives); rank 0 reports
-    for _ in range(2):
-        eng.train_batch(x, y)
-    torch.cuda.synchronize()
-    eng.set_profiling(False)
     if rank == 0:
-        ops = eng.op_profile(B, 0) + eng.op_profile(B, 1)
         # (conv3x3_dgrad_bn_bwd: the data gradient of a decoder block's first conv with the folded BatchNorm's backward in its epilogue -- the same
         #  kernel, same FLOPs; the op's time includes its 5 us coefficient launch)
         dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_dgrad:") or o[0].startswith("conv3x3_dgrad_bn_bwd:")]
         dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel
         fl = sum(o[1] for o in dom); ms = sum(o[3] / max(o[4], 1) for o in dom); launches = len(dom)
-        # executed MFMA work: the Winograd F(2,3)-along-x launches do 12 instead of 18 multiplies per pair of outputs
         shapes = W.weight_shapes(1, args.arch, (S, S))
-        fl_exec, n_wino = 0.0, 0
-        for o in dom:
-            kind, lname = o[0].split(":")
+
+        def exec_ratio(opname):
+            """executed / algorithmic multiplies of a conv3x3 op: 4/9 F(2x2,3x3), 2/3 F(2,3) along x, 1 direct (unet_conv3x3_exec_ratio)"""
+            kind, lname = opname.split(":")
+            if not kind.startswith("conv3x3") or args.dtype == "bf16" or lname + "/kernel" not in shapes:
+                return 1.0
             _, _, ci, co = shapes[lname + "/kernel"]
             if kind.startswith("conv3x3_dgrad"):
                 ci, co = co, ci
-            ptr, ld, nn, hh, ww, cc = _tap_dims(eng, B, lname)
-            ratio = 1.0 if args.dtype == "bf16" else eng.lib.unet_conv3x3_exec_ratio(args.algo, hh, ww, ci, co)
-            fl_exec += o[1] * ratio; n_wino += int(ratio < 1.0)
+            _, _, _, hh, ww, _ = _tap_dims(eng, B, lname)
+            if kind.startswith("conv3x3_wgrad"):
+                return float(eng.lib.unet_conv3x3_wgrad_exec_ratio(args.algo, hh, ww, ci, co))
+            return float(eng.lib.unet_conv3x3_exec_ratio(args.algo, hh, ww, ci, co))
+
+        fl_exec = sum(o[1] * exec_ratio(o[0]) for o in dom); n_wino = sum(int(exec_ratio(o[0]) < 1.0) for o in dom)
         groups = {}
         for name, flops, by, tms, calls in ops:
             k = name.split(":")[0]
             g = groups.setdefault(k, [0.0, 0.0, 0.0]); g[0] += tms / max(calls, 1); g[1] += flops; g[2] += by
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE; collected offline at
-        # this exact workload, calibration inside the file) -- only quoted for the configuration it was measured on
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if args.dtype == "fp32" else "r01_pmc_traffic_bf16.json")
-        if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet":
-            traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
+        effective = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0               # algorithmic (direct-convolution) FLOPs / time
+        executed = fl_exec / (ms * 1e-3) / 1e12 if ms > 0 else 0.0           # multiplies the matrix cores really perform / time
+        # whole-step floor on the EXECUTED work: every op at max(its algorithmic bytes / HBM peak, its executed FLOPs / fp32 MFMA peak)
+        peak_fl = (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12
+        floor_ms = sum(max(o[2] / (HBM_PEAK_GBS * 1e9), o[1] * exec_ratio(o[0]) / peak_fl) for o in ops) * 1e3
+        # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE): collected OFFLINE at this exact workload
+        # (tools/collect_profiles.sh, calibration inside the file), not in this run -- only quoted for the configuration it was measured on
+        traffic, tname = None, None
+        for tname in (("r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.dtype == "fp32" else ("r02_pmc_traffic_bf16.json", "r01_pmc_traffic_bf16.json")):
+            tfile = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet":
+                traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
+                break
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
-        roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
-                                           f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)", "achieved": round(achieved, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "executed_tflops": round(fl_exec / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
-                "executed_frac": round(fl_exec / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ms > 0 else 0.0,
-                "note": "achieved = ALGORITHMIC (direct-convolution) FLOPs / time; executed_* counts the multiplies the matrix cores really do",
+        roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino2d4_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
+                                           f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)",
+                "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+                "effective_tflops": round(effective, 2),
+                "note": "achieved / frac = multiplies the matrix cores EXECUTE (Winograd: 4/9 or 2/3 of the direct count) / time, <= peak by construction; "
+                        "effective_tflops = ALGORITHMIC (direct-convolution, SURVEY 8d) FLOPs of the same launches / the same time",
                 "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)", "algorithmic_bytes_per_launch": round(alg_bytes),
+                "traffic_unit": f"HBM bytes per launch, rocprofv3 PMC collected offline on this workload (profiles/{tname}); not measured in this run",
+                "algorithmic_bytes_per_launch": round(alg_bytes),
                 "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3),
+                "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3), "avg_launch_gflop_executed": round(fl_exec / max(launches, 1) / 1e9, 3),
+                "step_floor_ms": round(floor_ms, 3), "step_frac": round(floor_ms / (dt / args.steps * 1e3), 4),
+                "step_note": "step_floor_ms = sum over the step's ops of max(algorithmic bytes / 8 TB/s, executed FLOPs / MFMA peak); step_frac = floor / measured ms_per_step",
+                "profiled_steps": PROF_STEPS,
                 "op_ms_per_step": {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
         if args.dtype == "bf16":
             # bf16 storage: the same launches priced against HBM (they move half the bytes and the bf16 MFMA rate is 16x the fp32 one)
             gbs = sum(o[2] for o in dom) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             step_bytes = sum(o[2] for o in ops)
             roof.update({"bound": "hbm", "kernel": "conv3x3 fwd + data-gradient launches: conv_bf16_kernel<0,...> (v_mfma_f32_32x32x16_bf16, direct)",
-                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic_bf16.json)",
-                         "mfma_tflops": round(achieved, 1), "mfma_frac_of_bf16_peak": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "mfma_tflops": round(effective, 1), "mfma_frac_of_bf16_peak": round(effective / BF16_MFMA_PEAK_TFLOPS, 4),
                          "note": "achieved = algorithmic bytes (activations at 2 B/element, weights 4 B) of these launches / their time; mfma_* = their algorithmic FLOP rate",
                          "step_algorithmic_bytes": round(step_bytes), "step_hbm_frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)})
-            for k in ("executed_tflops", "executed_frac"):
-                roof.pop(k, None)
+            roof.pop("effective_tflops", None)
 
     if rank == 0:
         total_imgs = B * world * args.steps
         out = {
-            "metric": ("CT images/sec (fwd+bwd) U-Net 512x512x1 bs16" if args.arch == "unet" else
+            "metric": (f"CT images/sec (fwd+bwd) U-Net 512x512x1 bs{B}" if args.arch == "unet" else
                        f"CT images/sec (fwd+bwd) {'U-Net++' if args.arch == 'unetpp' else 'slice classifier'} {S}x{S}x1 bs{B}"), "value": round(total_imgs / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16 storage, f32 accumulate/params", "data": "synthetic",
-            "config": {"workload": (f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
+            "config": {"workload": (f"U-Net lung seg (task3 graph T3:850-913), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam" if args.arch == "unet" and args.config == 2 else
+                                    f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
                                     if args.arch == "unet" else
                                     f"U-Net++ infection seg (task1_unet_plus_plus.py:858-950), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
                                     if args.arch == "unetpp" else
                                     f"slice classifier (task2_covid19_classifcation.py:747-776), {S}x{S}x1, batch {B}/GPU, fp32, fwd+BCE+bwd+Keras-Adam")
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
-                                   + {"unet": "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
+                                   + {"unet": "configs[2]" if args.config == 2 else "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
                        "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: winograd F(2x2,3x3) / F(2,3) on mfma_f32_32x32x2, direct mfma otherwise", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd"}[args.algo],
                        "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, arch=args.arch)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -67,6 +67,8 @@ size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout);
 int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout);
 /* executed / algorithmic multiplies of that launch: 1 (direct), 2/3 (Winograd F(2,3) along x), 4/9 (F(2x2,3x3)) */
 double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
+/* ... and of the weight-gradient launch (unet_conv3x3_bwd_weights with the workspace it asks for): 1, 2/3 or 4/9 */
+double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
                          int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
                          int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, float* w_ws, void* stream);

@@ -40,6 +40,7 @@ _PROTOS = {
     "unet_conv3x3_w_ws_floats": (sz, [i32, i32]),
     "unet_conv3x3_pick_algo": (i32, [i32, i32, i32, i32]),
     "unet_conv3x3_exec_ratio": (f64, [i32, i32, i32, i32, i32]),
+    "unet_conv3x3_wgrad_exec_ratio": (f64, [i32, i32, i32, i32, i32]),
     "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, i32, vp, vp]),
     "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, i32, f32, u64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),

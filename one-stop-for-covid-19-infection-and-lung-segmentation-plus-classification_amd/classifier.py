@@ -153,6 +153,10 @@ class ClassifierModel:
     def save_weights(self, path):
         W.save_weights(path, self.backend.get_weights(), self.in_ch, "classifier", self._hw)
 
+    def save(self, path):
+        """model.save(path): what ModelCheckpoint(filepath_loss, ...) writes (T2:820) -- `model_weights/` + `model_config`."""
+        W.save_weights(path, self.backend.get_weights(), self.in_ch, "classifier", self._hw, full_model=True)
+
     def load_weights(self, path):
         self.backend.set_weights(W.load_weights(path, self.in_ch, "classifier", self._hw))
 
@@ -216,7 +220,7 @@ class ClassifierModel:
                 if checkpoint_loss and ev[0] < best_loss:
                     if self.verbose:
                         print(f"\nEpoch {ep + 1:05d}: val_loss improved from {best_loss:.5f} to {ev[0]:.5f}, saving model to {checkpoint_loss}")
-                    best_loss = ev[0]; self.save_weights(checkpoint_loss)
+                    best_loss = ev[0]; self.save(checkpoint_loss)
             if self.verbose:
                 print(line)
         return hist

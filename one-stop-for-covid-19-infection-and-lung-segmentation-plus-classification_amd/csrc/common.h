@@ -211,6 +211,7 @@ bool mfma_conv3x3_supported(int cin, int cout);
 int32_t k_conv3x3_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                            float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 bool mfma_wgrad_supported(int ca, int cb);
+double wino_wgrad_exec_ratio(int h);
 bool mfma_convT_supported(int cin, int cout);
 int32_t k_convT_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd,
                          int cin, int cout, hipStream_t s);

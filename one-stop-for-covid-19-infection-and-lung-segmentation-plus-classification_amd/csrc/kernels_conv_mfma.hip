@@ -1084,10 +1084,17 @@ int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx* ctx, const unet_bf16* dy, int n, int 
   return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums);
 }
 
+static int wgrad_wino_form() {
+  static const int form = [] { const char* e = getenv("UNET_WINO_WGRAD_2D"); return e ? atoi(e) : 1; }();      // A/B switch: 0 = F(2,3) along x
+  return form;
+}
+// executed / algorithmic multiplies of the Winograd-domain weight gradient of this shape: 4/9 (F(2x2,3x3)) or 2/3 (F(2,3) along x)
+double wino_wgrad_exec_ratio(int h) { return (wgrad_wino_form() && h >= 2) ? 4.0 / 9.0 : 2.0 / 3.0; }
+
 int32_t k_conv3x3_wino_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
                              int wd, int cin, int cout, hipStream_t s) {
   if (!mfma_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad winograd: cin=%d cout=%d unsupported", cin, cout);
-  static const int form = [] { const char* e = getenv("UNET_WINO_WGRAD_2D"); return e ? atoi(e) : 1; }();      // A/B switch: 0 = F(2,3) along x
+  const int form = wgrad_wino_form();
   if (form && h >= 2) return run_wgrad<3>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   return run_wgrad<2>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
 }

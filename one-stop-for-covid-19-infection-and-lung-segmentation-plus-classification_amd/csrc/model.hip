@@ -123,10 +123,14 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
   return k_conv3x3_naive_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
 }
 
+static int wgrad_wino_enabled() {
+  static const int wino = [] { const char* e = getenv("UNET_WINO_WGRAD"); return e ? atoi(e) : 1; }();      // A/B switch for measurements
+  return wino;
+}
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
                                       size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
   if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout)) {
-    static const int wino = [] { const char* e = getenv("UNET_WINO_WGRAD"); return e ? atoi(e) : 1; }();      // A/B switch for measurements
+    const int wino = wgrad_wino_enabled();
     if (algo == UNET_ALGO_WINOGRAD || (algo == UNET_ALGO_AUTO && wino)) return k_conv3x3_wino_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   }
@@ -159,6 +163,14 @@ double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin,
   static float dummy;
   if (!use_wino(algo, wd, cin, cout, &dummy)) return 1.0;
   return wino_uses_2d(h, cout) ? 4.0 / 9.0 : 2.0 / 3.0;
+}
+
+/* the same for the weight-gradient launch (given the workspace unet_conv3x3_bwd_weights_ws_bytes asks for) */
+double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
+  (void)wd;
+  if (algo == UNET_ALGO_NAIVE || !mfma_wgrad_supported(cin, cout)) return 1.0;
+  if (algo == UNET_ALGO_WINOGRAD || (algo == UNET_ALGO_AUTO && wgrad_wino_enabled())) return wino_wgrad_exec_ratio(h);
+  return 1.0;
 }
 
 size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return (size_t)16 * (cin > 0 ? cin : 0) * (cout > 0 ? cout : 0); }

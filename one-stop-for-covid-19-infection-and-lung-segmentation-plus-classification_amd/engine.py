@@ -30,7 +30,7 @@ class HipUNet:
 
     def __init__(self, h: int, w: int, in_ch: int = 1, device: int | None = None, conv_algo: int = _lib.ALGO_AUTO,
                  process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR,
-                 arch: str = "unet", dtype: str = "fp32"):
+                 arch: str = "unet", dtype: str = "fp32", force_dp: bool = False):
         torch = _torch()
         self.lib = _lib.load()
         # dtype "bf16": activations / activation gradients stored as bf16 in the workspace (BASELINE.json configs[3], [4]); image,
@@ -50,17 +50,23 @@ class HipUNet:
         self.class_weights = (1.0, 1.0)
         self.pg = process_group
         self.pg_grad = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
+        # force_dp: walk the data-parallel program (sync points, side stream, second communicator) even at world size 1 -- every SUM all-reduce is
+        # then the identity, so the step must equal the plain one bit for bit: how the RCCL code path is exercised on a 1-GPU box
+        self._dp = False
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
-            if self.world > 1:
+            self.rank = dist.get_rank(process_group)
+            self._dp = self.world > 1 or bool(force_dp)
+            if self._dp:
                 # gradient buckets get their OWN communicator: collectives of one process group are serialised on one
                 # internal stream, so a bucket all-reduce would otherwise delay the small inline (BN / Dice) reductions
                 self.pg_grad = dist.new_group(ranks=dist.get_process_group_ranks(process_group), backend=dist.get_backend(process_group))
         self.sync_bn = sync_bn
         self.dropout_rate, self.seed, self.lr = float(dropout_rate), int(seed), float(lr)
         self.step = 0
+        self._drop_calls = 0                   # dropout stream position: advances with every training forward, NOT reset by compile() / reset_optimizer()
         self._plans = {}
         self._ws = None
         # flat buffers sized from a probe plan
@@ -79,7 +85,7 @@ class HipUNet:
             assert cnt.value == int(np.prod(shape)), (name, cnt.value, shape)
             self._tinfo[name] = (bool(st.value), off.value, cnt.value, shape)
         self.lib.unet_model_destroy(probe)
-        self._comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self._comm_stream = torch.cuda.Stream(device=self.dev) if self._dp else None
 
     # ------------------------------------------------------------------ plans / buffers
     def _create_plan(self, n):
@@ -171,7 +177,7 @@ class HipUNet:
         lib, m = self.lib, plan["m"]
         nops = lib.unet_model_num_ops(m, prog)
         run_range = lambda b, e: self.ctx.check(lib.unet_model_run(m, prog, b, e, self._stream()), "model_run")
-        if self.world == 1:
+        if not self._dp:
             run_range(0, nops)
             return
         torch = _torch()
@@ -208,7 +214,10 @@ class HipUNet:
             self._p_train = torch.empty(self._out_elems(n), dtype=torch.float32, device=self.dev)
         assert yd.numel() == self._out_elems(n), (tuple(yd.shape), self._out_elems(n))
         rate = self.dropout_rate if training_dropout else 0.0
-        self.ctx.check(self.lib.unet_model_set_dropout(plan["m"], rate, self.seed * 1000003 + self.step), "set_dropout")
+        # one Philox key per (seed, rank, training forward): ranks draw different masks for their shards, and a re-compiled model (k-fold runner:
+        # one compile() per fold, CV4:1062) continues the stream instead of replaying it
+        self.ctx.check(self.lib.unet_model_set_dropout(plan["m"], rate, (self.seed * 1000003 + self.rank * 2654435761 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF), "set_dropout")
+        self._drop_calls += 1
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr(), self._p_train.data_ptr()), "set_io")
         self._keep = (xd, yd)
         self._run(plan, _lib.PROG_FWD_TRAIN)
@@ -251,7 +260,7 @@ class HipUNet:
         out = torch.zeros((len(thresholds), 3), dtype=torch.float64, device=self.dev)
         self.ctx.check(self.lib.unet_seg_metrics_sweep(self.ctx.handle, p.data_ptr(), yd.data_ptr(), th.data_ptr(), len(thresholds),
                                                        out.data_ptr(), p.numel(), self._stream()), "metrics_sweep")
-        if self.world > 1:
+        if self._dp:
             self._all_reduce(out)
         return out
 

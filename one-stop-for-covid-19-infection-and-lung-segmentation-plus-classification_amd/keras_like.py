@@ -76,10 +76,16 @@ class UNetModel:
         self.backend.set_weights(w)
 
     def save_weights(self, path):
-        W.save_weights(path, self.backend.get_weights(), self.in_ch, self.arch)
+        """model.save_weights(path) T1:1079: Keras HDF5 weight file (weights.save_weights)."""
+        W.save_weights(path, self.backend.get_weights(), self.in_ch, self.arch, (self.h, self.w))
+
+    def save(self, path):
+        """model.save(path) -- what ModelCheckpoint(save_weights_only=False) calls (T1:1046-1047): `model_weights/` + `model_config`;
+        optimizer state is not written."""
+        W.save_weights(path, self.backend.get_weights(), self.in_ch, self.arch, (self.h, self.w), full_model=True)
 
     def load_weights(self, path):
-        self.backend.set_weights(W.load_weights(path, self.in_ch, self.arch))
+        self.backend.set_weights(W.load_weights(path, self.in_ch, self.arch, (self.h, self.w)))
 
     def to_json(self):
         return W.to_json(self.h, self.w, self.in_ch, self.arch)
@@ -113,11 +119,11 @@ class UNetModel:
                 if checkpoint_dice and ev["dice_coeff"] > best_dice:
                     if self.verbose:
                         print(f"\nEpoch {ep + 1:05d}: val_dice_coeff improved from {best_dice:.5f} to {ev['dice_coeff']:.5f}, saving model to {checkpoint_dice}")
-                    best_dice = ev["dice_coeff"]; self.save_weights(checkpoint_dice)
+                    best_dice = ev["dice_coeff"]; self.save(checkpoint_dice)
                 if checkpoint_loss and ev["loss"] < best_loss:
                     if self.verbose:
                         print(f"\nEpoch {ep + 1:05d}: val_loss improved from {best_loss:.5f} to {ev['loss']:.5f}, saving model to {checkpoint_loss}")
-                    best_loss = ev["loss"]; self.save_weights(checkpoint_loss)
+                    best_loss = ev["loss"]; self.save(checkpoint_loss)
             if self.verbose:
                 print(line)
         return hist

@@ -3,9 +3,9 @@
 Mirrors what the reference gets from Keras for the model built at
 task1_preprocessing_plus_unet_with_comments.py:853-916:  model.get_weights() order,
 ``save_weights`` / ``load_weights`` (T1:1073, 1079) and ``to_json`` (T1:1091-1093).
-h5py is not available in this image, so the on-disk container is ``.npz`` keyed by the Keras
-layer/weight names (``conv2d_3/kernel:0`` ...) -- file names ending in .h5/.hdf5 are accepted
-and written as npz so the reference's filenames keep working.
+The on-disk container is the Keras HDF5 weight layout (written / read by hdf5_min.py: h5py is not
+in this image); ``.npz`` archives keyed by the Keras weight names are the alternative for paths
+ending in ``.npz``.
 """
 from __future__ import annotations
 
@@ -161,19 +161,87 @@ def init_weights(seed: int = 0, in_ch: int = 1, arch: str = "unet", hw=None):
     return w
 
 
-def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet", hw=None):
+_KERAS_WEIGHT_ORDER = {"kernel": 0, "bias": 1, "gamma": 0, "beta": 1, "mean": 2, "var": 3}
+
+
+def _layer_weight_lists(weights, in_ch, arch, hw):
+    """[(keras layer name, [(keras weight name, array)])] in model.layers order, weight-less layers included (keras_graph)."""
+    from . import keras_graph as KG
     kn = keras_names(in_ch, arch, hw)
-    with open(path, "wb") as f:          # keep the caller's filename (.hdf5/.h5) -- content is npz
-        np.savez(f, **{kn[k]: np.asarray(v) for k, v in weights.items()})
+    per = {}
+    for k, v in weights.items():
+        per.setdefault(k.split("/")[0], []).append((kn[k], np.asarray(v, np.float32), _KERAS_WEIGHT_ORDER[k.split("/")[1]]))
+    out = []
+    for l in KG.keras_layers(in_ch, arch, hw or ((224, 224) if arch != "classifier" else CLS_HW)):
+        ws = sorted(per.get(l["engine"], []), key=lambda t: t[2]) if l["engine"] else []
+        out.append((l["name"], [(n, a) for n, a, _ in ws]))
+    return out
+
+
+def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet", hw=None, full_model: bool = False):
+    """model.save_weights(path) (T1:1079) / the file ModelCheckpoint writes (T1:1046-1047, `full_model=True`): a Keras HDF5 weight file --
+    root (or `model_weights/`) attributes `layer_names`, `backend`, `keras_version`; one group per layer with `weight_names` and the
+    datasets `<layer>/<layer>/kernel:0` ... (hdf5_min.py).  A path ending in `.npz` writes a NumPy archive keyed by the same Keras
+    weight names instead."""
+    if str(path).endswith(".npz"):
+        kn = keras_names(in_ch, arch, hw)
+        with open(path, "wb") as f:
+            np.savez(f, **{kn[k]: np.asarray(v) for k, v in weights.items()})
+        return
+    from . import hdf5_min as H5
+    cfg = None
+    if full_model:
+        from . import keras_graph as KG
+        h, w = hw or ((224, 224) if arch != "classifier" else CLS_HW)
+        cfg = KG.to_json(h, w, in_ch, arch)
+    H5.save_keras_weights(path, _layer_weight_lists(weights, in_ch, arch, hw), full_model=full_model, model_config=cfg)
 
 
 def load_weights(path: str, in_ch: int = 1, arch: str = "unet", hw=None):
+    """model.load_weights(path) (T1:1073): a Keras HDF5 file in either layout (weights at the root, or a full-model file with
+    `model_weights/`), detected by its signature; layers are matched by their Keras names, or -- like Keras' topological loading -- in
+    `layer_names` order when the names carry another session's counters (`conv2d_20` ...).  `.npz` archives (keyed by the Keras
+    weight names) are read too.  Shapes are checked against the graph."""
     kn = keras_names(in_ch, arch, hw)
-    z = np.load(path)
     sh = weight_shapes(in_ch, arch, hw)
+    with open(path, "rb") as f:
+        head = f.read(8)
+    if head[:4] == b"PK\x03\x04":
+        z = np.load(path)
+        flat = {k: z[k] for k in z.files}
+    else:
+        from . import hdf5_min as H5
+        if head != H5.SIGNATURE:
+            raise ValueError(f"{path}: neither an HDF5 file (Keras weights) nor an .npz archive")
+        layers, _ = H5.load_keras_weights(path)
+        want_layers = []
+        for k in sh:
+            ln = kn[k].split("/")[0]
+            if ln not in want_layers:
+                want_layers.append(ln)
+        flat = {}
+        if all(ln in layers for ln in want_layers):
+            for ln in want_layers:
+                flat.update(layers[ln])
+        else:
+            have = [(ln, ws) for ln, ws in layers.items() if ws]
+            if len(have) != len(want_layers):
+                raise ValueError(f"{path}: {len(have)} layers with weights, the {arch} graph has {len(want_layers)}")
+            from . import keras_graph as KG
+            order = [l["name"] for l in KG.keras_layers(in_ch, arch, hw or ((224, 224) if arch != "classifier" else CLS_HW)) if l["name"] in want_layers]
+            for mine, (theirs, ws) in zip(order, have):
+                names = [v for k, v in kn.items() if v.split("/")[0] == mine]
+                if len(names) != len(ws):
+                    raise ValueError(f"{path}: layer {theirs} has {len(ws)} weights, {mine} needs {len(names)}")
+                # Keras weight order inside a layer: kernel, bias / gamma, beta, moving_mean, moving_variance
+                rank = {"kernel:0": 0, "bias:0": 1, "gamma:0": 0, "beta:0": 1, "moving_mean:0": 2, "moving_variance:0": 3}
+                for nm, a in zip(sorted(names, key=lambda n: rank[n.split("/")[1]]), ws.values()):
+                    flat[nm] = a
     out = OrderedDict()
     for k, shape in sh.items():
-        a = z[kn[k]]
+        if kn[k] not in flat:
+            raise ValueError(f"{path}: weight {kn[k]} is missing")
+        a = np.asarray(flat[kn[k]])
         if tuple(a.shape) != tuple(shape):
             raise ValueError(f"{path}: {kn[k]} has shape {a.shape}, expected {shape}")
         out[k] = a.astype(np.float32)
@@ -181,8 +249,6 @@ def load_weights(path: str, in_ch: int = 1, arch: str = "unet", hw=None):
 
 
 def to_json(h: int, w: int, in_ch: int = 1, arch: str = "unet") -> str:
-    hw = (h, w)
-    """Architecture description (the reference dumps model.to_json(), T1:1091-1093)."""
-    layers = [{"name": n, "kind": k, "cin": ci, "cout": co} for n, k, ci, co in layer_table(in_ch, arch, hw)]
-    return json.dumps({"class_name": "Model", "arch": arch, "backend": "unet_hip/gfx950", "input_shape": [h, w, in_ch],
-                       "data_format": "channels_last", "layers": layers, "keras_names": keras_names(in_ch, arch, hw)})
+    """model.to_json() (T1:1091-1093): the Keras 2.3 architecture JSON of the graph (keras_graph.py)."""
+    from . import keras_graph as KG
+    return KG.to_json(h, w, in_ch, arch)

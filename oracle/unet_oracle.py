@@ -206,40 +206,72 @@ def store_bf16(t):
     return _StoreBF16.apply(t)
 
 
-def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, store=None):
+def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False):
     """Whole graph T1:853-916.  weights: dict name->array/tensor.  x: [N,H,W,Cin].
     keep_masks: None (dropout off / inference) or dict 'p1'..'p4' -> {0,1} arrays of the
     pooled shapes.  store: None, or store_bf16 to emulate bf16 storage of every activation the engine materialises
     (conv / BN / pool / ConvT outputs and the concat buffers; the probabilities stay full precision).
+    ckpt: recompute each block in backward (torch.utils.checkpoint) instead of keeping its intermediates: same
+    arithmetic, a third of the memory -- what lets the fp64 golden of the 512x512 batch-16 step fit in this
+    container (tests/golden/make_fullsize_goldens.py); no activations are returned then.
     Returns (p, acts, bn_batch_stats)."""
     st = store if store is not None else (lambda t: t)
     W = {k: _t(v, dtype) for k, v in weights.items()}
     a = OrderedDict()
     stats = OrderedDict()
-    h = _t(x, dtype)
-    skips = {}
-    for k in (1, 2, 3, 4):                                                   # T1:859-881
-        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"])); a[f"c{k}a"] = h
-        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"])); a[f"c{k}b"] = h
+    keep = want_acts and not ckpt
+
+    def run(fn, *args):
+        if ckpt:
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(fn, *args, use_reentrant=False)
+        return fn(*args)
+
+    def enc(k, h):                                                           # T1:859-881
+        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]))
+        if keep: a[f"c{k}a"] = h
+        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]))
+        if keep: a[f"c{k}b"] = h
         h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
-        h = st(h); a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
-        skips[k] = h
+        h = st(h); stats[f"bn{k}"] = (mu.detach(), va.detach(), h.shape[0] * h.shape[1] * h.shape[2])
+        if keep: a[f"bn{k}"] = h
+        skip = h
         h = st(maxpool2x2(h))
         if training and keep_masks is not None:
             h = st(dropout(h, _t(keep_masks[f"p{k}"], dtype)))
-        a[f"p{k}"] = h
-    h = st(conv3x3_bias_relu(h, W["c5a/kernel"], W["c5a/bias"])); a["c5a"] = h    # T1:883-884
-    h = st(conv3x3_bias_relu(h, W["c5b/kernel"], W["c5b/bias"])); a["c5b"] = h
-    for k, sk in zip((6, 7, 8, 9), (4, 3, 2, 1)):                            # T1:886-911
-        u = st(convT2x2s2_bias(h, W[f"u{k}/kernel"], W[f"u{k}/bias"])); a[f"u{k}"] = u
-        h = st(torch.cat([u, skips[sk]], dim=3))                             # [up, skip]
+        if keep: a[f"p{k}"] = h
+        return skip, h
+
+    def mid(h):                                                              # T1:883-884
+        h = st(conv3x3_bias_relu(h, W["c5a/kernel"], W["c5a/bias"]))
+        if keep: a["c5a"] = h
+        h = st(conv3x3_bias_relu(h, W["c5b/kernel"], W["c5b/bias"]))
+        if keep: a["c5b"] = h
+        return h
+
+    def dec(k, h, skip):                                                     # T1:886-911
+        u = st(convT2x2s2_bias(h, W[f"u{k}/kernel"], W[f"u{k}/bias"]))
+        if keep: a[f"u{k}"] = u
+        h = st(torch.cat([u, skip], dim=3))                                  # [up, skip]
         h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
-        h = st(h); a[f"bn{k}"] = h; stats[f"bn{k}"] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
-        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"])); a[f"c{k}a"] = h
-        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"])); a[f"c{k}b"] = h
+        h = st(h); stats[f"bn{k}"] = (mu.detach(), va.detach(), h.shape[0] * h.shape[1] * h.shape[2])
+        if keep: a[f"bn{k}"] = h
+        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]))
+        if keep: a[f"c{k}a"] = h
+        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]))
+        if keep: a[f"c{k}b"] = h
+        return h
+
+    h = _t(x, dtype)
+    skips = {}
+    for k in (1, 2, 3, 4):
+        skips[k], h = run(lambda t, k=k: enc(k, t), h)
+    h = run(mid, h)
+    for k, sk in zip((6, 7, 8, 9), (4, 3, 2, 1)):
+        h = run(lambda t, s, k=k: dec(k, t, s), h, skips[sk])
     p = conv1x1_sigmoid(h, W["out/kernel"], W["out/bias"])                   # T1:913
-    a["out"] = p
-    return (p, a, stats) if want_acts else (p, None, stats)
+    if keep: a["out"] = p
+    return (p, a, stats) if keep else (p, None, stats)
 
 
 # ---------------------------------------------------------------------------------------
@@ -290,13 +322,13 @@ def sm_scores(tp, spr, sgt, smooth=SM_SMOOTH):
 # ---------------------------------------------------------------------------------------
 # Training step (fwd -> loss -> autograd bwd -> Keras-form Adam) and evaluation
 # ---------------------------------------------------------------------------------------
-def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, store=None):
+def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False):
     """One training-mode fwd + bwd.  Returns dict(loss, dice, grads{name}, bn_stats, p[, acts, act_grads])."""
     names = trainable_names(np.asarray(x).shape[-1])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=True, store=store)
+    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=want_acts, store=store, ckpt=ckpt)
     t = _t(y, dtype)
     loss = bce_dice_loss(t, p)
     dice = dice_coeff(t, p)
@@ -451,50 +483,67 @@ def pp_init_weights(seed: int = 0, in_ch: int = 1, dtype=np.float32):
     return w
 
 
-def pp_forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False):
+def pp_forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, ckpt=False):
     """U-Net++ graph.  keep_masks: None or dict conv-name -> {0,1} array of that conv's output shape (the
-    Dropout that follows it); returns (p, acts, bn_batch_stats)."""
+    Dropout that follows it); ckpt: recompute each encoder block / node in backward (see forward()); returns
+    (p, acts, bn_batch_stats)."""
     W = {k: _t(v, dtype) for k, v in weights.items()}
     a, stats, T = OrderedDict(), OrderedDict(), {}
+    keep = want_acts and not ckpt
+
+    def run(fn, *args):
+        if ckpt:
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(fn, *args, use_reentrant=False)
+        return fn(*args)
 
     def conv(name, h, rate):
         z = conv3x3_bias_relu(h, W[name + "/kernel"], W[name + "/bias"], relu=False)
         y = F.elu(z)
         if training and keep_masks is not None and rate > 0:
             y = dropout(y, _t(keep_masks[name], dtype), rate)
-        a[name] = y
+        if keep: a[name] = y
         return y
 
     def bn(name, h):
         y, mu, va = batchnorm(h, W[name + "/gamma"], W[name + "/beta"], W[name + "/mean"], W[name + "/var"], training)
-        a[name] = y; stats[name] = (mu, va, h.shape[0] * h.shape[1] * h.shape[2])
+        stats[name] = (mu.detach(), va.detach(), h.shape[0] * h.shape[1] * h.shape[2])
+        if keep: a[name] = y
         return y
+
+    def enc(k, h):
+        h = conv(f"c{k}a", h, PP_ENC_DROP)
+        h = conv(f"c{k}b", h, 0.0)
+        return bn(f"bn{k}", h)
+
+    def node(nm, c, tsrc, *tskips):
+        u = convT2x2s2_bias(tsrc, W[f"u{nm[1:]}/kernel"], W[f"u{nm[1:]}/bias"])
+        if keep: a[f"u{nm[1:]}"] = u
+        hh = torch.cat([u] + list(tskips), dim=3)
+        hh = bn(nm + "abn", conv(nm + "a", hh, PP_BLOCK_DROP))
+        return bn(nm + "bbn", conv(nm + "b", hh, PP_BLOCK_DROP))
 
     h = _t(x, dtype)
     todo = {1: [], 2: ["x1_2"], 3: ["x2_2", "x1_3"], 4: ["x3_2", "x2_3", "x1_4"]}
     nodes = {n[0]: n for n in PP_NODES}
     for k in (1, 2, 3, 4):
-        h = conv(f"c{k}a", h, PP_ENC_DROP)
-        h = conv(f"c{k}b", h, 0.0)
-        T[f"c{k}"] = bn(f"bn{k}", h)
+        T[f"c{k}"] = run(lambda t, k=k: enc(k, t), h)
         for nm in todo[k]:
             _, c, src, skips = nodes[nm]
-            u = convT2x2s2_bias(T[src], W[f"u{nm[1:]}/kernel"], W[f"u{nm[1:]}/bias"]); a[f"u{nm[1:]}"] = u
-            hh = torch.cat([u] + [T[s] for s in skips], dim=3)
-            hh = bn(nm + "abn", conv(nm + "a", hh, PP_BLOCK_DROP))
-            T[nm] = bn(nm + "bbn", conv(nm + "b", hh, PP_BLOCK_DROP))
-        h = maxpool2x2(T[f"c{k}"]); a[f"p{k}"] = h
+            T[nm] = run(lambda ts, *sk, nm=nm, c=c: node(nm, c, ts, *sk), T[src], *[T[s] for s in skips])
+        h = maxpool2x2(T[f"c{k}"])
+        if keep: a[f"p{k}"] = h
     p = conv1x1_sigmoid(T["x1_4"], W["out/kernel"], W["out/bias"])
-    a["out"] = p
-    return (p, a, stats) if want_acts else (p, None, stats)
+    if keep: a["out"] = p
+    return (p, a, stats) if keep else (p, None, stats)
 
 
-def pp_loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False):
+def pp_loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, ckpt=False):
     names = pp_trainable_names(np.asarray(x).shape[-1])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = pp_forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=True)
+    p, acts, stats = pp_forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=want_acts, ckpt=ckpt)
     t = _t(y, dtype)
     loss = bce_dice_loss(t, p); dice = dice_coeff(t, p)
     if want_acts:
@@ -575,27 +624,41 @@ def cls_init_weights(seed: int = 0, in_ch: int = 1, hw=(224, 224), dtype=np.floa
     return w
 
 
-def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32, want_acts=False):
-    """keep_mask: None or {0,1} array [n, 32] of the Dropout(0.4) after Dense(32).  Returns (p [n], acts, bn stats)."""
+def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32, want_acts=False, ckpt=False):
+    """keep_mask: None or {0,1} array [n, 32] of the Dropout(0.4) after Dense(32).  ckpt: recompute each conv block in
+    backward (see forward()).  Returns (p [n], acts, bn stats)."""
     W = {k: _t(v, dtype) for k, v in weights.items()}
     a, stats = OrderedDict(), OrderedDict()
-    h = _t(x, dtype)
-    for k in (1, 2, 3):
+    keep = want_acts and not ckpt
+
+    def block(k, h):
         for ab in "ab":
-            h = conv3x3_bias_relu(h, W[f"c{k}{ab}/kernel"], W[f"c{k}{ab}/bias"]); a[f"c{k}{ab}"] = h
+            h = conv3x3_bias_relu(h, W[f"c{k}{ab}/kernel"], W[f"c{k}{ab}/bias"])
+            if keep: a[f"c{k}{ab}"] = h
             nm = f"bn{k}{ab}"
             src = h
             h, mu, va = batchnorm(h, W[nm + "/gamma"], W[nm + "/beta"], W[nm + "/mean"], W[nm + "/var"], training)
-            a[nm] = h; stats[nm] = (mu, va, src.shape[0] * src.shape[1] * src.shape[2])
-        h = maxpool2x2(h); a[f"p{k}"] = h
+            stats[nm] = (mu.detach(), va.detach(), src.shape[0] * src.shape[1] * src.shape[2])
+            if keep: a[nm] = h
+        h = maxpool2x2(h)
+        if keep: a[f"p{k}"] = h
+        return h
+
+    h = _t(x, dtype)
+    for k in (1, 2, 3):
+        if ckpt:
+            from torch.utils.checkpoint import checkpoint
+            h = checkpoint(lambda t, k=k: block(k, t), h, use_reentrant=False)
+        else:
+            h = block(k, h)
     flat = h.reshape(h.shape[0], -1)                                  # channels_last Flatten: (i*W + j)*C + c
     h1 = torch.relu(flat @ W["fc1/kernel"] + W["fc1/bias"])
     if training and keep_mask is not None:
         h1 = dropout(h1, _t(keep_mask, dtype), CLS_DROP)
-    a["h1"] = h1
+    if keep: a["h1"] = h1
     p = torch.sigmoid(h1 @ W["fc2/kernel"] + W["fc2/bias"]).reshape(-1)
-    a["out"] = p
-    return (p, a, stats) if want_acts else (p, None, stats)
+    if keep: a["out"] = p
+    return (p, a, stats) if keep else (p, None, stats)
 
 
 def cls_f1(y_true, y_pred):
@@ -615,13 +678,13 @@ def cls_loss(y_true, y_pred, class_weights=(1.0, 1.0)):
     return (l * w).mean()
 
 
-def cls_loss_and_grads(weights, x, y, keep_mask=None, class_weights=(1.0, 1.0), dtype=torch.float32, want_acts=False):
+def cls_loss_and_grads(weights, x, y, keep_mask=None, class_weights=(1.0, 1.0), dtype=torch.float32, want_acts=False, ckpt=False):
     xs = np.asarray(x)
     names = cls_trainable_names(xs.shape[-1], xs.shape[1:3])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = cls_forward(W, x, training=True, keep_mask=keep_mask, dtype=dtype, want_acts=True)
+    p, acts, stats = cls_forward(W, x, training=True, keep_mask=keep_mask, dtype=dtype, want_acts=want_acts, ckpt=ckpt)
     t = _t(np.asarray(y, np.float64).reshape(-1), dtype)
     loss = cls_loss(t, p, class_weights); f1 = cls_f1(t, p)
     if want_acts:

@@ -1,0 +1,53 @@
+"""Known answers for ONE training-mode forward + backward at the sizes BASELINE.json states:
+
+    unet_512_bs16    configs[1]  U-Net (T1:853-916) 512x512x1, batch 16
+    unetpp_256_bs32  configs[3]  U-Net++ (UPP:858-950) 256x256x1, batch 32
+    cls_224_bs256    configs[4]  slice classifier (T2:747-776) 224x224x1, batch 256
+
+computed by the CPU oracle in FLOAT64 (dropout off, training-mode BatchNorm; each block recomputed in backward so the step
+fits in this container's 62 GB: `ckpt=True`, same arithmetic).  Stored per case: loss, dice_coeff / f1, the norm and the sum
+of EVERY parameter gradient, seven gradients in full, every 1009th probability (classifier: all), the batch statistics of
+every BatchNorm, and checksums of the seeded inputs.  tests/test_gpu_fullsize.py runs the same step on the HIP engine.
+
+    python tests/golden/make_fullsize_goldens.py [case ...]       (about 8 + 3 + 3 minutes on 8 cores, 40 GB peak)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+from oracle import unet_oracle as O          # noqa: E402
+import fullsize_cases as FC                  # noqa: E402
+
+P_STRIDE = 1009
+
+
+def main():
+    for name in (sys.argv[1:] or list(FC.CASES)):
+        arch, w, x, y = FC.build(name)
+        t0 = time.time()
+        fn = {"unet": O.loss_and_grads, "unetpp": O.pp_loss_and_grads, "classifier": O.cls_loss_and_grads}[arch]
+        r = fn(w, x, y, dtype=torch.float64, ckpt=True)
+        ws, xs, ys = FC.checksums(w, x, y)
+        arrs = dict(loss=np.float64(r["loss"]), metric=np.float64(r["f1"] if arch == "classifier" else r["dice"]),
+                    w_checksum=np.float64(ws), x_sum=np.float64(xs), y_sum=np.float64(ys),
+                    p_sample=(r["p"].reshape(-1) if arch == "classifier" else r["p"].reshape(-1)[::P_STRIDE]).astype(np.float32),
+                    p_mean=np.float64(r["p"].mean()))
+        for k, g in r["grads"].items():
+            arrs["gnorm/" + k] = np.float64(np.linalg.norm(g)); arrs["gsum/" + k] = np.float64(g.sum())
+        for k in FC.FULL_GRADS[arch]:
+            arrs["grad/" + k] = r["grads"][k].astype(np.float32)
+        for k, (mu, va, n) in r["bn_stats"].items():
+            arrs["bn_mean/" + k] = mu.astype(np.float32); arrs["bn_var/" + k] = va.astype(np.float32)
+        out = os.path.join(HERE, f"fullsize_{name}.npz")
+        np.savez_compressed(out, **arrs)
+        print(f"{name}: {time.time() - t0:.0f} s, loss {r['loss']:.9f}, metric {float(arrs['metric']):.9f}, wrote {out} ({os.path.getsize(out)} bytes)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

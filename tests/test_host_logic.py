@@ -64,13 +64,26 @@ def test_weight_file_roundtrip_and_keras_names(tmp_path):
     w = W.init_weights(3)
     f = str(tmp_path / "unet_0.8954_cosine_annealer.h5")          # reference file name T1:1079
     W.save_weights(f, w)
-    z = np.load(f)
-    assert "conv2d_1/kernel:0" in z.files and "batch_normalization_8/moving_variance:0" in z.files and len(z.files) == len(w) == 78
+    from covidseg_amd import hdf5_min as H5
+    assert H5.is_hdf5(f)                                           # a Keras HDF5 weight file, not an .npz under another name
+    layers, _ = H5.load_keras_weights(f)
+    assert len(layers) == 44 and list(layers)[:3] == ["input_1", "conv2d_1", "conv2d_2"] and list(layers)[-1] == "conv2d_19"
+    assert list(layers["conv2d_1"]) == ["conv2d_1/kernel:0", "conv2d_1/bias:0"] and not layers["dropout_2"]
+    assert list(layers["batch_normalization_8"]) == [f"batch_normalization_8/{p}:0" for p in ("gamma", "beta", "moving_mean", "moving_variance")]
+    assert sum(len(v) for v in layers.values()) == len(w) == 78
     w2 = W.load_weights(f)
     assert all(np.array_equal(w[k], w2[k]) for k in w)
+    g = str(tmp_path / "w.npz")                                    # explicit .npz: archive keyed by the Keras weight names
+    W.save_weights(g, w)
+    z = np.load(g)
+    assert "conv2d_1/kernel:0" in z.files and "batch_normalization_8/moving_variance:0" in z.files and len(z.files) == 78
+    assert all(np.array_equal(w[k], v) for k, v in W.load_weights(g).items())
     import json
-    js = json.loads(W.to_json(224, 224))
-    assert js["input_shape"] == [224, 224, 1] and len(js["layers"]) == 31
+    js = json.loads(W.to_json(224, 224))                           # model.to_json() T1:1091: Keras 2.3 functional-model schema
+    assert js["class_name"] == "Model" and js["keras_version"] == "2.3.1" and len(js["config"]["layers"]) == 44
+    l1 = js["config"]["layers"][1]
+    assert l1["name"] == "conv2d_1" and l1["class_name"] == "Conv2D" and l1["config"]["filters"] == 32 and l1["inbound_nodes"] == [[["input_1", 0, 0, {}]]]
+    assert js["config"]["layers"][0]["config"]["batch_input_shape"] == [None, 224, 224, 1] and js["config"]["output_layers"] == [["conv2d_19", 0, 0]]
 
 
 def test_init_statistics():
