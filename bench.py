@@ -127,7 +127,7 @@ def main():
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
-                  arch=args.arch, dtype=args.dtype)
+                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")))
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     # ---- untimed setup 1 (rank 0, N=1): the CPU baseline first, so the GPU work of this command is one contiguous block at its end
@@ -180,7 +180,7 @@ def main():
 
         def exec_ratio(opname):
             """executed / algorithmic multiplies of a conv3x3 op: 4/9 F(2x2,3x3), 2/3 F(2,3) along x, 1 direct (unet_conv3x3_exec_ratio)"""
-            kind, lname = opname.split(":")
+            kind, _, lname = opname.partition(":")
             if not kind.startswith("conv3x3") or args.dtype == "bf16" or lname + "/kernel" not in shapes:
                 return 1.0
             _, _, ci, co = shapes[lname + "/kernel"]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 6
+#define UNET_ABI_VERSION 7
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -344,6 +344,14 @@ int32_t unet_pre_clahe_u8(unet_ctx*, const uint8_t* src, uint8_t* dst, int32_t n
 enum { UNET_RESIZE_LINEAR = 1, UNET_RESIZE_AREA = 3 };
 int32_t unet_pre_resize_u8(unet_ctx*, const uint8_t* src, int32_t n, int32_t sh, int32_t sw, const int32_t* rects, uint8_t* dst, int32_t dh,
                            int32_t dw, int32_t dst_ld, int32_t dst_x0, int32_t interp, void* stream);
+/* The contour search of `cropper` (T1:219-233, T3:221-235) on the HOST: `cv2.findContours(img, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)`, then
+ * `cv2.contourArea(c)` and `cv2.boundingRect(c)` of every contour, for n uint8 slices (non-zero = foreground) in HOST memory [n][h][w].  Border following
+ * (Suzuki-Abe, what OpenCV implements; restated: parity unpinned) is a serial walk, so it runs on CPU threads (`threads` <= 0: all cores, one slice per
+ * thread at a time).  Per slice i: counts[i] = number of contours; the first min(counts[i], max_contours) areas / rects (x, y, w, h) are written in cv2's
+ * output order (hierarchy pre-order, siblings newest first).  The caller does the reference's `np.argsort(areas)` and picks the two largest.
+ * ctx may be NULL (no device is touched). */
+int32_t unet_pre_contours_u8(unet_ctx*, const uint8_t* host_imgs, int32_t n, int32_t h, int32_t w, int32_t max_contours, double* areas, int32_t* rects,
+                             int32_t* counts, int32_t threads);
 
 /* ------------------------------------------------------------------------------------
  * Model level.  Replaces the Keras Model built at T1:853-916 and driven by

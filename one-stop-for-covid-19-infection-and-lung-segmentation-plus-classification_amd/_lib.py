@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA, ALGO_WINOGRAD = 0, 1, 2, 3
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
@@ -120,6 +120,7 @@ _PROTOS = {
     "unet_pre_clahe_ws_bytes": (sz, [i32, i32, i32]),
     "unet_pre_clahe_u8": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, i32, vp, sz, vp]),
     "unet_pre_resize_u8": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "unet_pre_contours_u8": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32]),        # host buffers (ABI v7)
     "unet_model_create": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     "unet_model_dtype": (i32, [vp]),
     "unet_model_tap_elem_bytes": (i32, [vp, C.c_char_p, i32]),

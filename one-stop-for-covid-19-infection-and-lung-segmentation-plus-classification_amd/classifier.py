@@ -12,6 +12,7 @@ import math
 import numpy as np
 
 from . import weights as W
+from .keras_like import dp_info, dp_shard
 
 
 # ----------------------------------------------------------------------------------------- sklearn / plot-metric restatements
@@ -191,13 +192,15 @@ class ClassifierModel:
         n = len(x)
         best_loss = np.inf
         rng = np.random.RandomState(shuffle_seed)
+        world, rank = dp_info(self.backend)
         for ep in range(epochs):
             order = rng.permutation(n) if shuffle else np.arange(n)
             self.backend.set_class_weights(*cw)
             outs, sizes = [], []
             for i in range(0, n, batch_size):
                 idx = order[i:i + batch_size]
-                outs.append(self.backend.train_batch(x[idx], y[idx], dropout)); sizes.append(len(idx))
+                sel, kw = dp_shard(idx, world, rank)                  # data parallel: keras_like.dp_shard
+                outs.append(self.backend.train_batch(x[sel], y[sel], dropout, **kw)); sizes.append(len(idx))
             vals = np.stack([_host(o) for o in outs])
             hist.history["loss"].append(float(np.average(vals[:, 0], weights=sizes))); hist.history["f1"].append(float(vals[:, 1].mean()))
             line = f"Epoch {ep + 1}/{epochs} - loss: {hist.history['loss'][-1]:.4f} - f1: {hist.history['f1'][-1]:.4f}"
@@ -213,16 +216,20 @@ class ClassifierModel:
                         print('\rroc-auc_train: %s - roc-auc_val: %s' % (str(round(roc_train, 4)), str(round(roc_val, 4))), end=100 * ' ' + '\n')
                     if self.best_val_auc < roc_val:
                         self.best_val_auc = roc_val
-                        if best_auc_path:
+                        if best_auc_path and rank == 0:
                             self.save_weights(best_auc_path)
                         if self.verbose:
                             print("Saving best validation AUC weights")
                 if checkpoint_loss and ev[0] < best_loss:
                     if self.verbose:
                         print(f"\nEpoch {ep + 1:05d}: val_loss improved from {best_loss:.5f} to {ev[0]:.5f}, saving model to {checkpoint_loss}")
-                    best_loss = ev[0]; self.save(checkpoint_loss)
+                    best_loss = ev[0]
+                    if rank == 0:
+                        self.save(checkpoint_loss)
             if self.verbose:
                 print(line)
+        if world > 1:
+            self.backend.barrier()
         return hist
 
     def evaluate(self, x, y, batch_size=32):
@@ -230,17 +237,20 @@ class ClassifierModel:
         y = np.asarray(y, np.float32).reshape(-1)
         self.backend.set_class_weights(1.0, 1.0)
         vals, sizes = [], []
+        world, rank = dp_info(self.backend)
         for i in range(0, len(x), batch_size):
-            _, ld = self.backend.predict_batch(x[i:i + batch_size], y[i:i + batch_size])
-            vals.append(ld); sizes.append(len(x[i:i + batch_size]))
+            sel, kw = dp_shard(np.arange(i, min(i + batch_size, len(x))), world, rank)
+            _, ld = self.backend.predict_batch(x[sel], y[sel], **kw)
+            vals.append(ld); sizes.append(min(i + batch_size, len(x)) - i)
         v = np.stack([_host(a) for a in vals])
         return [float(np.average(v[:, 0], weights=sizes)), float(v[:, 1].mean())]
 
     def predict(self, x, batch_size=32):
         """model.predict(x_valid) T2:910 -> [n, 1]."""
         outs = []
+        kw = {"replicated": True} if dp_info(self.backend)[0] > 1 else {}
         for i in range(0, len(x), batch_size):
-            p, _ = self.backend.predict_batch(x[i:i + batch_size])
+            p, _ = self.backend.predict_batch(x[i:i + batch_size], **kw)
             outs.append(p)
         return np.concatenate([(_o.detach().cpu().numpy() if hasattr(_o, "detach") else np.asarray(_o)) for _o in outs], 0).reshape(-1, 1)
 

@@ -88,21 +88,24 @@ class HipUNet:
         self._comm_stream = torch.cuda.Stream(device=self.dev) if self._dp else None
 
     # ------------------------------------------------------------------ plans / buffers
-    def _create_plan(self, n):
+    def _create_plan(self, n, replicated=False):
         m = _lib.vp()
         self.ctx.check(self.lib.unet_model_create(self.ctx.handle, self._arch_id, self.in_ch, n, self.h, self.w,
-                                                  self.world if self.sync_bn else 1, self.algo, self._dtype_id, C.byref(m)), "model_create")
+                                                  self.world if (self.sync_bn and not replicated) else 1, self.algo, self._dtype_id, C.byref(m)), "model_create")
         return m
 
-    def _plan(self, n: int):
+    def _plan(self, n: int, replicated: bool = False):
+        """The op programs for a local batch of n.  replicated: a step that every rank runs on the SAME full batch with no cross-rank
+        reduction (world size 1 baked in) -- how the host code handles a batch that does not divide by the world size."""
         torch = _torch()
-        if n not in self._plans:
-            m = self._create_plan(n)
+        key = (n, True) if (replicated and self._dp) else n
+        if key not in self._plans:
+            m = self._create_plan(n, replicated)
             need = self.lib.unet_model_workspace_bytes(m, 1)
-            self._plans[n] = {"m": m, "bytes": need, "bound_ws": None}
+            self._plans[key] = {"m": m, "bytes": need, "bound_ws": None}
             if self.arch == "classifier":
                 self.ctx.check(self.lib.unet_model_set_class_weights(m, *self.class_weights), "set_class_weights")
-        p = self._plans[n]
+        p = self._plans[key]
         if self._ws is None or self._ws.numel() < p["bytes"]:
             self._ws = torch.empty(p["bytes"], dtype=torch.uint8, device=self.dev)
         if p["bound_ws"] != self._ws.data_ptr():
@@ -173,11 +176,11 @@ class HipUNet:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
-    def _run(self, plan, prog):
+    def _run(self, plan, prog, replicated=False):
         lib, m = self.lib, plan["m"]
         nops = lib.unet_model_num_ops(m, prog)
         run_range = lambda b, e: self.ctx.check(lib.unet_model_run(m, prog, b, e, self._stream()), "model_run")
-        if not self._dp:
+        if not self._dp or replicated:
             run_range(0, nops)
             return
         torch = _torch()
@@ -203,71 +206,79 @@ class HipUNet:
         off = ptr - self._ws.data_ptr()
         return self._ws[off:off + 8].view(torch.float32)
 
-    def forward_backward(self, x, y, training_dropout=True):
+    def forward_backward(self, x, y, training_dropout=True, replicated=False):
         """fwd (training mode) + loss + bwd on one batch; gradients land in self.grads.
-        Returns a device tensor [loss, dice_coeff] (no host sync)."""
+        Returns a device tensor [loss, dice_coeff] (no host sync).  Under data parallelism x, y are THIS rank's shard of the global batch
+        (equal shard sizes on all ranks); replicated=True: x, y are the whole batch, identical on every rank, no reductions."""
         torch = _torch()
         xd, yd = self._to_dev(x), self._to_dev(y)
         n = xd.shape[0]
-        plan = self._plan(n)
+        plan = self._plan(n, replicated)
         if not hasattr(self, "_p_train") or self._p_train.numel() != self._out_elems(n):
             self._p_train = torch.empty(self._out_elems(n), dtype=torch.float32, device=self.dev)
         assert yd.numel() == self._out_elems(n), (tuple(yd.shape), self._out_elems(n))
         rate = self.dropout_rate if training_dropout else 0.0
         # one Philox key per (seed, rank, training forward): ranks draw different masks for their shards, and a re-compiled model (k-fold runner:
         # one compile() per fold, CV4:1062) continues the stream instead of replaying it
-        self.ctx.check(self.lib.unet_model_set_dropout(plan["m"], rate, (self.seed * 1000003 + self.rank * 2654435761 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF), "set_dropout")
+        self.ctx.check(self.lib.unet_model_set_dropout(plan["m"], rate, (self.seed * 1000003 + (0 if replicated else self.rank) * 2654435761 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF), "set_dropout")
         self._drop_calls += 1
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr(), self._p_train.data_ptr()), "set_io")
         self._keep = (xd, yd)
-        self._run(plan, _lib.PROG_FWD_TRAIN)
-        self._run(plan, _lib.PROG_BWD)
+        self._run(plan, _lib.PROG_FWD_TRAIN, replicated)
+        self._run(plan, _lib.PROG_BWD, replicated)
         return self._loss_tensor(plan)
 
-    def adam_step(self):
+    def adam_step(self, replicated=False):
         self.step += 1
         t = self.step
         lr_t = self.lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         self.ctx.check(self.lib.unet_adam_keras(self.ctx.handle, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                                                 self.adam_v.data_ptr(), self.n_params, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS,
-                                                1.0 if (self.world == 1 or self.sync_bn) else 1.0 / self.world, self._stream()), "adam")
+                                                1.0 if (self.world == 1 or self.sync_bn or replicated) else 1.0 / self.world, self._stream()), "adam")
 
-    def train_batch(self, x, y, training_dropout=True):
+    def train_batch(self, x, y, training_dropout=True, replicated=False):
         """One optimizer step (model.fit inner loop, T1:1059).  Returns device tensor [loss, dice]."""
-        out = self.forward_backward(x, y, training_dropout) + 0.0      # a copy made by a kernel (clone() takes the D2D-copy path: ~20 us bubble)
-        self.adam_step()
+        out = self.forward_backward(x, y, training_dropout, replicated) + 0.0      # a copy made by a kernel (clone() takes the D2D-copy path: ~20 us bubble)
+        self.adam_step(replicated)
         return out
 
-    def predict_batch(self, x, y=None):
+    def predict_batch(self, x, y=None, replicated=False):
         """Inference forward (moving BN stats, no dropout).  Returns (p [n,h,w,1] device tensor,
-        [loss, dice] device tensor or None)."""
+        [loss, dice] device tensor or None).  Under data parallelism (and not `replicated`) x, y are this rank's shard: p is the shard's,
+        [loss, dice] the global batch's."""
         torch = _torch()
         xd = self._to_dev(x)
         n = xd.shape[0]
-        plan = self._plan(n)
+        plan = self._plan(n, replicated)
         p = torch.empty((n, 1) if self.arch == "classifier" else (n, self.h, self.w, 1), dtype=torch.float32, device=self.dev)
         yd = self._to_dev(y) if y is not None else None
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr() if yd is not None else None, p.data_ptr()), "set_io")
         self._keep = (xd, yd)
-        self._run(plan, _lib.PROG_FWD_INFER)
+        self._run(plan, _lib.PROG_FWD_INFER, replicated)
         return p, (self._loss_tensor(plan) + 0.0 if yd is not None else None)
 
-    def threshold_sums(self, p, y, thresholds):
-        """[T,3] float64 (sum gt*pr, sum pr, sum gt) with pr = p > t  (sm.metrics, T1:1206-1207)."""
+    def threshold_sums(self, p, y, thresholds, replicated=False):
+        """[T,3] float64 (sum gt*pr, sum pr, sum gt) with pr = p > t  (sm.metrics, T1:1206-1207); summed over the ranks' shards under data parallelism."""
         torch = _torch()
         yd = self._to_dev(y)
         th = torch.tensor(np.asarray(thresholds, np.float32), device=self.dev)
         out = torch.zeros((len(thresholds), 3), dtype=torch.float64, device=self.dev)
         self.ctx.check(self.lib.unet_seg_metrics_sweep(self.ctx.handle, p.data_ptr(), yd.data_ptr(), th.data_ptr(), len(thresholds),
                                                        out.data_ptr(), p.numel(), self._stream()), "metrics_sweep")
-        if self._dp:
+        if self._dp and not replicated:
             self._all_reduce(out)
         return out
 
-    def tap(self, n, name, grad=False):
+    def barrier(self):
+        if self._dp:
+            import torch.distributed as dist
+            _torch().cuda.synchronize(self.dev)
+            dist.barrier(group=self.pg)
+
+    def tap(self, n, name, grad=False, replicated=False):
         """Copy of an intermediate activation / gradient of the last run (tests)."""
         torch = _torch()
-        plan = self._plan(n)
+        plan = self._plan(n, replicated)
         ptr, ld, nn, hh, ww, cc = _lib.vp(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         self.ctx.check(self.lib.unet_model_tap(plan["m"], name.encode(), int(grad), C.byref(ptr), C.byref(ld), C.byref(nn), C.byref(hh),
                                                C.byref(ww), C.byref(cc)), f"tap({name})")

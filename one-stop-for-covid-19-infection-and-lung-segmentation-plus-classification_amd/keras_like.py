@@ -32,6 +32,26 @@ def _host(v):
     return np.asarray(v, np.float64)
 
 
+def dp_info(backend):
+    """(world, rank) of a data-parallel backend (engine.HipUNet built with a process group), else (1, 0)."""
+    return (int(backend.world), int(backend.rank)) if getattr(backend, "_dp", False) else (1, 0)
+
+
+def dp_shard(idx, world, rank):
+    """How one global mini-batch is run on `world` ranks so that the step equals the single-process step on the whole batch
+    (the engine reduces BatchNorm sums, Dice sums and gradients over the ranks, engine.py): a batch whose size divides by the world size
+    is cut into equal contiguous shards, rank r takes the r-th -> (shard, {}); any other size (the short last batch of an epoch,
+    T1:1059: 1130 = 35 x 32 + 10) is run by every rank in full with no reduction -> (idx, {"replicated": True}): identical replicas
+    apply the identical update."""
+    if world == 1:
+        return idx, {}
+    m = len(idx)
+    if m % world == 0:
+        q = m // world
+        return idx[rank * q:(rank + 1) * q], {}
+    return idx, {"replicated": True}
+
+
 class History:
     def __init__(self):
         self.history = {"loss": [], "dice_coeff": [], "val_loss": [], "val_dice_coeff": []}
@@ -101,12 +121,14 @@ class UNetModel:
         n = len(x)
         best_dice, best_loss = -np.inf, np.inf
         rng = np.random.RandomState(shuffle_seed)
+        world, rank = dp_info(self.backend)       # data parallel (T3:989-1009 on N GPUs): every rank walks the same shuffled batches, each takes its shard
         for ep in range(epochs):
             order = rng.permutation(n) if shuffle else np.arange(n)
             outs, sizes = [], []
             for i in range(0, n, batch_size):
                 idx = order[i:i + batch_size]
-                outs.append(self.backend.train_batch(x[idx], y[idx], dropout))
+                sel, kw = dp_shard(idx, world, rank)
+                outs.append(self.backend.train_batch(x[sel], y[sel], dropout, **kw))          # [loss, dice_coeff] of the WHOLE batch on every rank
                 sizes.append(len(idx))
             vals = np.stack([_host(o) for o in outs])                     # one host sync per epoch
             hist.history["loss"].append(float(np.average(vals[:, 0], weights=sizes)))
@@ -119,13 +141,19 @@ class UNetModel:
                 if checkpoint_dice and ev["dice_coeff"] > best_dice:
                     if self.verbose:
                         print(f"\nEpoch {ep + 1:05d}: val_dice_coeff improved from {best_dice:.5f} to {ev['dice_coeff']:.5f}, saving model to {checkpoint_dice}")
-                    best_dice = ev["dice_coeff"]; self.save(checkpoint_dice)
+                    best_dice = ev["dice_coeff"]
+                    if rank == 0:
+                        self.save(checkpoint_dice)                   # replicas are identical: rank 0 writes the file
                 if checkpoint_loss and ev["loss"] < best_loss:
                     if self.verbose:
                         print(f"\nEpoch {ep + 1:05d}: val_loss improved from {best_loss:.5f} to {ev['loss']:.5f}, saving model to {checkpoint_loss}")
-                    best_loss = ev["loss"]; self.save(checkpoint_loss)
+                    best_loss = ev["loss"]
+                    if rank == 0:
+                        self.save(checkpoint_loss)
             if self.verbose:
                 print(line)
+        if world > 1:
+            self.backend.barrier()                                    # the checkpoint files exist before any rank goes on to load_weights (T1:1073)
         return hist
 
     def evaluate(self, x, y, batch_size=32, thresholds=None, verbose=0):
@@ -133,12 +161,14 @@ class UNetModel:
         the per-batch values.  With `thresholds`, ONE forward pass per batch feeds all thresholds
         (the reference re-compiles and re-runs evaluate per threshold, T1:1205-1211)."""
         losses, dices, sizes, per_batch = [], [], [], []
+        world, rank = dp_info(self.backend)
         for i in range(0, len(x), batch_size):
-            xb, yb = x[i:i + batch_size], y[i:i + batch_size]
-            p, ld = self.backend.predict_batch(xb, yb)
-            losses.append(ld); sizes.append(len(xb))
+            sel, kw = dp_shard(np.arange(i, min(i + batch_size, len(x))), world, rank)
+            xb, yb = x[sel], y[sel]
+            p, ld = self.backend.predict_batch(xb, yb, **kw)          # loss / dice_coeff and the threshold sums are the whole batch's on every rank
+            losses.append(ld); sizes.append(min(i + batch_size, len(x)) - i)
             if thresholds is not None and len(thresholds):
-                per_batch.append(self.backend.threshold_sums(p, yb, thresholds))
+                per_batch.append(self.backend.threshold_sums(p, yb, thresholds, **kw))
         vals = np.stack([_host(v) for v in losses])
         out = {"loss": float(np.average(vals[:, 0], weights=sizes)), "dice_coeff": float(vals[:, 1].mean())}
         if per_batch:
@@ -154,16 +184,18 @@ class UNetModel:
         rev = {v.split("/")[0]: k.split("/")[0] for k, v in W.keras_names(self.in_ch, self.arch).items()}
         name = rev.get(layer_name, layer_name)
         outs = []
+        kw = {"replicated": True} if dp_info(self.backend)[0] > 1 else {}
         for i in range(0, len(x), batch_size):
             xb = x[i:i + batch_size]
-            self.backend.predict_batch(xb)
-            outs.append(self.backend.tap(len(xb), name))
+            self.backend.predict_batch(xb, **kw)
+            outs.append(self.backend.tap(len(xb), name, **kw))
         return np.concatenate(outs, 0)
 
     def predict(self, x, batch_size=32):
         """model.predict T1:1137."""
         outs = []
+        kw = {"replicated": True} if dp_info(self.backend)[0] > 1 else {}          # every rank predicts everything (no gather needed)
         for i in range(0, len(x), batch_size):
-            p, _ = self.backend.predict_batch(x[i:i + batch_size])
+            p, _ = self.backend.predict_batch(x[i:i + batch_size], **kw)
             outs.append(p)
         return np.concatenate([(_o.detach().cpu().numpy() if hasattr(_o, "detach") else np.asarray(_o)) for _o in outs], 0)

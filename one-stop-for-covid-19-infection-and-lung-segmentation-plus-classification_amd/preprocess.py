@@ -7,9 +7,12 @@
     cv2.resize(img[b:b+d, a:a+c], (125,250), INTER_AREA) x2 + np.concatenate   T1:354-358, 364-368 -> crop_resize_fuse
     cv2.resize(cts[i], (new_dim,new_dim), INTER_LINEAR)      T1:486-488   -> resize
 
-They call the C ABI (`unet_pre_*`, csrc/kernels_pre.hip); like the rest of the product there is no CPU fallback.  The contour search that
-produces the lung rectangles (cv2.findContours / contourArea / boundingRect inside `cropper`, T1:219-233: serial border following) stays on
-the host side of a user's pipeline; its output -- two (x, y, w, h) rectangles per slice -- is what crop_resize_fuse takes.
+    cropper(test_img, demo)                                  T1:211-273   -> cropper (same name, arguments and return triple), lung_rects
+
+They call the C ABI (`unet_pre_*`, csrc/kernels_pre.hip); like the rest of the product there is no CPU fallback.  The contour search of
+`cropper` (cv2.findContours / contourArea / boundingRect, T1:219-233) is serial border following: it runs in native host code of the same
+library (csrc/host_contours.hip, `unet_pre_contours_u8`, threaded over slices); its output -- two (x, y, w, h) rectangles per slice -- feeds
+crop_resize_fuse on the GPU.
 """
 from __future__ import annotations
 
@@ -150,3 +153,51 @@ def prepare_infections(raw_masks, rects1=None, rects2=None, new_dim=None):
         u8 = resize(u8, (int(new_dim), int(new_dim)), INTER_LINEAR)
     a = u8_to_unit(u8)
     return a[..., None] if a.ndim == 3 else a[None, ..., None]
+
+
+def contours(img_u8, max_contours=4096, threads=0):
+    """Per uint8 slice: (areas float64 [k], rects int32 [k, 4]) of EVERY contour cv2.findContours(img, RETR_TREE, CHAIN_APPROX_SIMPLE) returns, in cv2's order
+    (`[cv2.contourArea(c) for c in contours]`, `cv2.boundingRect(c)`; T1:219-220, 232-233).  Host code of the library; needs no GPU."""
+    import ctypes as C
+    lib = _lib.load()
+    a, single = _as_batch(img_u8)
+    a = np.ascontiguousarray(a, np.uint8)
+    n, h, w = a.shape
+    while True:
+        areas = np.zeros((n, max_contours), np.float64); rects = np.zeros((n, max_contours, 4), np.int32); counts = np.zeros(n, np.int32)
+        rc = lib.unet_pre_contours_u8(None, a.ctypes.data, n, h, w, max_contours, areas.ctypes.data, rects.ctypes.data, counts.ctypes.data, int(threads))
+        if rc != 0:
+            raise _lib.UNetHipError(f"unet_pre_contours_u8 failed with status {rc}")
+        if counts.max(initial=0) <= max_contours:
+            break
+        max_contours = int(counts.max())                     # a very noisy slice: ask again with room for all of its contours
+    out = [(areas[i, :counts[i]].copy(), rects[i, :counts[i]].copy()) for i in range(n)]
+    return out[0] if single else out
+
+
+def lung_rects(img_u8, threads=0):
+    """The rectangle part of `cropper` (T1:219-233) for slice(s): `x = np.argsort(areas)`; the largest (`x[x.size - 1]`) and second largest
+    (`x[x.size - 2]`) contour; `cv2.boundingRect` of each.  -> (rects1, rects2) int32 [N, 4] (or two 4-lists for one slice): `all_points1`,
+    `all_points2` of T1:340-345, the arguments crop_resize_fuse takes.  A slice without any contour raises (the reference indexes an empty
+    argsort there; T1:333 skips uniform masks before calling)."""
+    a, single = _as_batch(img_u8)
+    r1, r2 = np.zeros((len(a), 4), np.int32), np.zeros((len(a), 4), np.int32)
+    for i, (areas, rects) in enumerate(contours(a, threads=threads)):
+        x = np.argsort(areas)
+        if x.size == 0:
+            raise IndexError(f"cropper: slice {i} has no contour")
+        r1[i], r2[i] = rects[x[x.size - 1]], rects[x[x.size - 2]]          # (one contour: numpy's x[-1] twice, as in the reference)
+    return (r1[0].tolist(), r2[0].tolist()) if single else (r1, r2)
+
+
+def cropper(test_img, demo=0):
+    """cropper(test_img, demo) T1:211-273: a [0, 1] lung mask -> (fused uint8 [250, 250], points_lung1 [x, y, w, h], points_lung2 [p, q, r, s]).
+    `np.uint8(test_img * 255)` and the crops + INTER_AREA resizes + fuse run on the GPU, the contour search in the library's host code; `demo` plots nothing."""
+    torch = _torch(); lib, ctx = _ctx()
+    a = np.asarray(test_img)
+    x = torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    u8 = torch.empty(x.shape, dtype=torch.uint8, device="cuda")
+    ctx.check(lib.unet_pre_unit_to_u8(ctx.handle, x.data_ptr(), u8.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream), "pre_unit_to_u8")
+    u8 = u8.cpu().numpy()
+    r1, r2 = lung_rects(u8)
+    return crop_resize_fuse(u8, np.asarray([r1], np.int32), np.asarray([r2], np.int32)), r1, r2

@@ -18,6 +18,7 @@ import os
 
 import numpy as np
 
+from . import dp_launch
 from .data import kfold_indices, synthetic_classification, synthetic_ct, train_test_split
 from .keras_like import UNetModel
 
@@ -97,15 +98,23 @@ def _segmentation_runner(tag, ckpt_dice, ckpt_loss, fine_range, data=None, input
 
 
 def holdout_runner_unet_infection_segmentation(**kw):
-    """Task 1 hold-out U-Net (app.py 'three').  Checkpoint names T1:1044-1045; fine sweep .52-.60 T1:1250."""
+    """Task 1 hold-out U-Net (app.py 'three').  Checkpoint names T1:1044-1045; fine sweep .52-.60 T1:1250.
+    UNET_GPUS=N in the environment: data parallel on N GPUs (dp_launch.py)."""
+    r = dp_launch.maybe_launch("holdout_runner_unet_infection_segmentation", kw)
+    if r is not None:
+        return r
     return _segmentation_runner("infection", "unet_covid_weights_dice_coeff.hdf5", "unet_covid_weights_val_loss.hdf5",
                                 np.arange(0.52, 0.60, 0.001), **kw)
 
 
 def runner_lung_segmentation(**kw):
     """Task 3 lung U-Net (app.py 'six').  Same graph/recipe (T3:850-1009); fine sweep .43-.53 T3:1206;
-    the checkpoint file names are the same "unet_covid_weights_*" literals, T3:991-992."""
+    the checkpoint file names are the same "unet_covid_weights_*" literals, T3:991-992.  UNET_GPUS=N in the environment: data parallel on
+    N GPUs, the global batch (32, or UNET_BATCH=64 for BASELINE.json configs[2]) sharded over the ranks (dp_launch.py)."""
     kw.setdefault("seed", 1)
+    r = dp_launch.maybe_launch("runner_lung_segmentation", kw)
+    if r is not None:
+        return r
     return _segmentation_runner("lung", "unet_covid_weights_dice_coeff.hdf5", "unet_covid_weights_val_loss.hdf5",
                                 np.arange(0.43, 0.53, 0.001), **kw)
 
@@ -144,9 +153,14 @@ def _kfold_runner(k, data=None, input_size=None, epochs=None, batch_size=None, n
         histories.append(model.fit(x_train, y_train, batch_size=batch_size, epochs=epochs, validation_data=(x_valid, y_valid),
                                    checkpoint_dice=paths[fold_number - 1], dropout=dropout, shuffle_seed=seed + fold_number).history)
     print(f"Time of {k}-fold cross validation: ", time.perf_counter() - start)                               # CV4:1099
+    from .keras_like import dp_info
+    world, rank = dp_info(model.backend)
     if overwrite_fold_files:
         for p in paths:
-            model.save_weights(p)                                                                            # CV4:1105-1108
+            if rank == 0:
+                model.save_weights(p)                                                                        # CV4:1105-1108
+        if world > 1:
+            model.backend.barrier()
     out = {"histories": histories, "paths": paths, "folds": folds, "model": model, "scores": []}
     dots = "." * 118
     for split_number, (train_index, test_index) in enumerate(folds, 1):                                      # CV4:1183-1195
@@ -183,11 +197,17 @@ def _kfold_runner(k, data=None, input_size=None, epochs=None, batch_size=None, n
 
 def three_fold_runner_unet_infection_segmentation(**kw):
     """Task 1, 3-fold cross-validation U-Net (app.py 'one'; task1_crossval_3folds_unet.py:6)."""
+    r = dp_launch.maybe_launch("three_fold_runner_unet_infection_segmentation", kw)
+    if r is not None:
+        return r
     return _kfold_runner(3, **kw)
 
 
 def four_fold_runner_unet_infection_segmentation(**kw):
     """Task 1, 4-fold cross-validation U-Net (app.py 'two'; task1_crossval_4folds_unet.py:6)."""
+    r = dp_launch.maybe_launch("four_fold_runner_unet_infection_segmentation", kw)
+    if r is not None:
+        return r
     return _kfold_runner(4, **kw)
 
 
@@ -195,6 +215,9 @@ def holdout_runner_unetplusplus_infection_segmentation(**kw):
     """Task 1 hold-out U-Net++ (app.py 'four'; task1_unet_plus_plus.py:6): nested-skip graph UPP:858-950, same recipe
     (Adam 5e-4, bce_dice_loss, batch 32, 80 epochs UPP:1054-1074), fine sweep .40-.50 (UPP:1274)."""
     kw.setdefault("seed", 2)
+    r = dp_launch.maybe_launch("holdout_runner_unetplusplus_infection_segmentation", kw)
+    if r is not None:
+        return r
     return _segmentation_runner("infection_unetpp", "unet_covid_weights_dice_coeff.hdf5", "unet_covid_weights_val_loss.hdf5",
                                 np.arange(0.40, 0.50, 0.001), arch="unetpp", **kw)
 
@@ -207,6 +230,11 @@ def runner_classification(data=None, input_size=None, epochs=None, batch_size=No
     RocCallback + ModelCheckpoint(val_loss) T2:814-820; best-AUC weights reloaded T2:851; evaluate T2:884; confusion-matrix
     reports at thresholds 0.50 and 0.81 T2:916-967.  `data=(cts [N,S,S,1], y_label [N])` or env UNET_DATA_NPZ, else synthetic."""
     from .classifier import ClassifierModel, compute_class_weight_balanced, confusion_report, stratified_shuffle_split
+    _kw = dict(data=data, input_size=input_size, epochs=epochs, batch_size=batch_size, n_samples=n_samples, seed=seed, backend=backend, dropout=dropout,
+               init_weights=init_weights, workdir=workdir, verbose=verbose, honour_array_class_weight=honour_array_class_weight, **backend_kw)
+    r = dp_launch.maybe_launch("runner_classification", {k: v for k, v in _kw.items() if v is not None})      # UNET_GPUS=N: data parallel (dp_launch.py)
+    if r is not None:
+        return r
     size = input_size or _env_int("UNET_SIZE", 224)
     epochs = epochs if epochs is not None else _env_int("UNET_EPOCHS", 25)
     batch_size = batch_size or _env_int("UNET_BATCH", 32)
@@ -241,8 +269,10 @@ def runner_classification(data=None, input_size=None, epochs=None, batch_size=No
                         shuffle_seed=seed)                                                                   # T2:833-835
     if os.path.exists(fa):
         model.load_weights(fa)                                                                               # T2:851
-    with open(os.path.join(workdir, "best_val_auc_weights.json"), "w") as f:                                 # T2:867-869
-        f.write(model.to_json())
+    from .keras_like import dp_info
+    if dp_info(model.backend)[1] == 0:
+        with open(os.path.join(workdir, "best_val_auc_weights.json"), "w") as f:                             # T2:867-869
+            f.write(model.to_json())
     print("Best saved AUCROC on validation set :", model.best_val_auc)                                       # T2:878
     score = model.evaluate(x_valid, y_valid, batch_size=32)                                                  # T2:884
     print("test loss:", score[0], "\ntest f1 score:", score[1])                                              # T2:885

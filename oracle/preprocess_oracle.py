@@ -213,3 +213,162 @@ def crop_resize_fuse(img_u8, rect1, rect2, interpolation=INTER_AREA):
     i1 = resize_u8(img_u8[b:b + d, a:a + c], (125, 250), interpolation)
     i2 = resize_u8(img_u8[f:f + h, e:e + g], (125, 250), interpolation)
     return np.concatenate((i1, i2), axis=1)
+
+
+# =======================================================================================================================
+# cropper: cv2.findContours(img, RETR_TREE, CHAIN_APPROX_SIMPLE) -> contourArea -> two largest -> boundingRect   (T1:211-233, T3:213-236)
+#
+# PARITY UNPINNED (cv2 absent, see the module docstring).  Restated from the published algorithm OpenCV implements -- Suzuki & Abe,
+# "Topological structural analysis of digitized binary images by border following", CVGIP 30 (1985), Algorithm 1 -- with the
+# conventions of opencv/modules/imgproc/src/contours.cpp as remembered:
+#   * non-zero pixels are foreground; the image is embedded in a 1-pixel zero frame (OpenCV >= 3.2 copies with copyMakeBorder, so
+#     components touching the image edge keep their border pixels; coordinates are reported without the frame);
+#   * raster scan; at a 0 -> 1 transition with an UNVISITED pixel an outer border starts, at a (positive label) -> 0 transition a hole
+#     border starts from the last foreground pixel; 8-connected following: first neighbour searched clockwise from the background side
+#     (direction codes 0 = +x, counter-clockwise in image coordinates: 1 = (+1,-1), 2 = (0,-1) ...), next neighbour counter-clockwise
+#     from the one after the previous point; a pixel whose right neighbour was examined and found empty is marked with the negative label;
+#   * CHAIN_APPROX_SIMPLE keeps a point only where the step direction changes;
+#   * hierarchy (Suzuki's LNBD table): the parent of a new border follows from the last border met on the row; cv2 returns the tree
+#     flattened in pre-order with siblings in REVERSE order of discovery (cvInsertNodeIntoTree pushes a new contour at the head of its
+#     parent's child list) -- the order only matters to np.argsort's tie-breaking in `cropper`;
+#   * contourArea = |shoelace| / 2 over the (integer) points in double; boundingRect = (min x, min y, max x - min x + 1, max y - min y + 1).
+# =======================================================================================================================
+_DX = (1, 1, 0, -1, -1, -1, 0, 1)
+_DY = (0, -1, -1, -1, 0, 1, 1, 1)
+
+
+def _follow_border(f, x, y, is_hole, nbd):
+    """icvFetchContourEx: follow one border of label image f (framed, int32) from (x, y); marks f; returns the CHAIN_APPROX_SIMPLE points, the full chain's
+    shoelace sum (2 x signed area) and the bounding box (framed coordinates)."""
+    pts = []
+    s_end = s = 0 if is_hole else 4
+    while True:
+        s = (s - 1) & 7
+        if f[y + _DY[s], x + _DX[s]] != 0:
+            break
+        if s == s_end:
+            break
+    minx = maxx = x; miny = maxy = y
+    if f[y + _DY[s], x + _DX[s]] == 0:                     # single-pixel component
+        f[y, x] = -nbd
+        return [(x, y)], 0, (x, y, x, y)
+    x1, y1 = x + _DX[s], y + _DY[s]                         # first neighbour (i1)
+    x3, y3 = x, y
+    prev_s = s ^ 4
+    shoelace = 0
+    while True:
+        s_end = s
+        while True:
+            s += 1
+            x4, y4 = x3 + _DX[s & 7], y3 + _DY[s & 7]
+            if f[y4, x4] != 0:
+                break
+        s &= 7
+        if ((s - 1) & 0xFFFFFFFF) < s_end:                  # the right neighbour was examined and is empty
+            f[y3, x3] = -nbd
+        elif f[y3, x3] == 1:
+            f[y3, x3] = nbd
+        if s != prev_s:
+            pts.append((x3, y3)); prev_s = s
+        shoelace += x3 * y4 - y3 * x4
+        minx = min(minx, x4); maxx = max(maxx, x4); miny = min(miny, y4); maxy = max(maxy, y4)
+        if x4 == x and y4 == y and x3 == x1 and y3 == y1:
+            break
+        x3, y3 = x4, y4
+        s = (s + 4) & 7
+    return pts, shoelace, (minx, miny, maxx, maxy)
+
+
+def find_contours(img):
+    """cv2.findContours(img, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE) for a 2-D uint8 image.
+    -> list of dicts in cv2's output order: points int32 [k, 2] (x, y), area (cv2.contourArea), rect (cv2.boundingRect), is_hole, parent (index into the
+    same list or -1)."""
+    img = np.asarray(img)
+    h, w = img.shape
+    f = np.zeros((h + 2, w + 2), np.int32)
+    f[1:-1, 1:-1] = (img != 0)
+    found = []                                              # discovery order: [pts, shoelace, bbox, is_hole, parent label]
+    info = {1: (True, 1)}                                   # label -> (is_hole, parent label); the frame (label 1) counts as a hole border
+    nbd = 1
+    for y in range(1, h + 1):
+        row = f[y]
+        lnbd = 1
+        x = 1
+        while x <= w + 1:
+            nz = np.flatnonzero(row[x:w + 2] != row[x - 1:w + 1])
+            if nz.size == 0:
+                break
+            x += int(nz[0])
+            p, prev = int(row[x]), int(row[x - 1])
+            start = None
+            if prev == 0 and p == 1:
+                start = (x, False)
+            elif p == 0 and prev >= 1:
+                if prev > 1:
+                    lnbd = prev
+                start = (x - 1, True)
+            if start is not None:
+                sx, is_hole = start
+                nbd += 1
+                b_hole, b_parent = info[lnbd]
+                parent = (b_parent if b_hole == is_hole else lnbd)          # Suzuki's table 1
+                info[nbd] = (is_hole, parent)
+                pts, sh, bb = _follow_border(f, sx, y, is_hole, nbd)
+                found.append((pts, sh, bb, is_hole, parent, nbd))
+            v = int(row[x])                                 # (after marking)
+            if v not in (0, 1):
+                lnbd = abs(v)
+            x += 1
+    # flatten: pre-order, siblings in reverse order of discovery
+    children = {}
+    for i, c in enumerate(found):
+        children.setdefault(c[4], []).append(i)
+    order = []
+
+    def visit(label):
+        for i in reversed(children.get(label, [])):
+            order.append(i); visit(found[i][5])
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
+    visit(1)
+    pos = {found[i][5]: k for k, i in enumerate(order)}
+    out = []
+    for i in order:
+        pts, sh, (x0, y0, x1, y1), is_hole, parent, label = found[i]
+        out.append({"points": np.array(pts, np.int32).reshape(-1, 2) - 1, "area": abs(float(sh)) * 0.5, "rect": (x0 - 1, y0 - 1, x1 - x0 + 1, y1 - y0 + 1),
+                    "is_hole": is_hole, "parent": pos.get(parent, -1)})
+    return out
+
+
+def contour_area(points):
+    """cv2.contourArea(contour): |sum(x_prev * y - y_prev * x)| / 2 in double over the closed polygon."""
+    p = np.asarray(points, np.float64).reshape(-1, 2)
+    if len(p) == 0:
+        return 0.0
+    q = np.roll(p, 1, axis=0)
+    return abs(float((q[:, 0] * p[:, 1] - q[:, 1] * p[:, 0]).sum())) * 0.5
+
+
+def bounding_rect(points):
+    p = np.asarray(points).reshape(-1, 2)
+    x0, y0 = p.min(0); x1, y1 = p.max(0)
+    return int(x0), int(y0), int(x1 - x0 + 1), int(y1 - y0 + 1)
+
+
+def lung_rects(img_u8):
+    """The rectangle part of `cropper` (T1:219-233): contours -> areas -> np.argsort -> the largest and the second largest -> boundingRect each.
+    -> (points_lung1 [x, y, w, h], points_lung2 [p, q, r, s])."""
+    cs = find_contours(img_u8)
+    areas = [c["area"] for c in cs]
+    x = np.argsort(areas)
+    if x.size == 0:
+        raise IndexError("cropper: no contour in the image (the reference indexes x[x.size - 1] of an empty argsort)")
+    c1, c2 = cs[int(x[x.size - 1])], cs[int(x[x.size - 2])]              # (one contour: x[-1] twice, as numpy's negative index does in the reference)
+    return list(c1["rect"]), list(c2["rect"])
+
+
+def cropper(test_img, demo=0):
+    """cropper(test_img, demo) T1:211-273: test_img in [0, 1] (a lung mask) -> (fused uint8 [250, 250], points_lung1, points_lung2)."""
+    u8 = to_u8(test_img)
+    r1, r2 = lung_rects(u8)
+    return crop_resize_fuse(u8, r1, r2, INTER_AREA), r1, r2

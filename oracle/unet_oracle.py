@@ -136,10 +136,15 @@ def _t(a, dtype):
     return a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a), dtype=dtype)
 
 
-def conv3x3_bias_relu(x, kernel, bias, relu=True):
-    """Conv2D(C,(3,3),'relu','same') T1:859: cross-correlation, zero pad 1, +bias, ReLU."""
+def conv3x3_bias_relu(x, kernel, bias, relu=True, relu_mask=None):
+    """Conv2D(C,(3,3),'relu','same') T1:859: cross-correlation, zero pad 1, +bias, ReLU.
+    relu_mask ({0,1} array of the output shape): use z * mask instead of max(z, 0) -- the same function wherever sign(z) agrees with
+    the mask; the GPU tests pass the ENGINE's own sign pattern so that a pre-activation which rounds to the other side of 0 in fp32
+    (a discontinuity of the gradient, not an arithmetic error) does not enter the gradient comparison."""
     y = F.conv2d(x.permute(0, 3, 1, 2), kernel.permute(3, 2, 0, 1), bias, padding=1)
     y = y.permute(0, 2, 3, 1)
+    if relu and relu_mask is not None:
+        return y * relu_mask
     return torch.relu(y) if relu else y
 
 
@@ -206,11 +211,12 @@ def store_bf16(t):
     return _StoreBF16.apply(t)
 
 
-def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False):
+def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False, relu_masks=None):
     """Whole graph T1:853-916.  weights: dict name->array/tensor.  x: [N,H,W,Cin].
     keep_masks: None (dropout off / inference) or dict 'p1'..'p4' -> {0,1} arrays of the
     pooled shapes.  store: None, or store_bf16 to emulate bf16 storage of every activation the engine materialises
     (conv / BN / pool / ConvT outputs and the concat buffers; the probabilities stay full precision).
+    relu_masks: None or dict conv name ('c1a' ... 'c9b') -> {0,1} array: the ReLU sign pattern to use (see conv3x3_bias_relu).
     ckpt: recompute each block in backward (torch.utils.checkpoint) instead of keeping its intermediates: same
     arithmetic, a third of the memory -- what lets the fp64 golden of the 512x512 batch-16 step fit in this
     container (tests/golden/make_fullsize_goldens.py); no activations are returned then.
@@ -220,6 +226,7 @@ def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, wa
     a = OrderedDict()
     stats = OrderedDict()
     keep = want_acts and not ckpt
+    rm = (lambda n: _t(relu_masks[n], dtype)) if relu_masks is not None else (lambda n: None)
 
     def run(fn, *args):
         if ckpt:
@@ -228,9 +235,9 @@ def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, wa
         return fn(*args)
 
     def enc(k, h):                                                           # T1:859-881
-        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]))
+        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"], relu_mask=rm(f"c{k}a")))
         if keep: a[f"c{k}a"] = h
-        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]))
+        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"], relu_mask=rm(f"c{k}b")))
         if keep: a[f"c{k}b"] = h
         h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
         h = st(h); stats[f"bn{k}"] = (mu.detach(), va.detach(), h.shape[0] * h.shape[1] * h.shape[2])
@@ -243,9 +250,9 @@ def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, wa
         return skip, h
 
     def mid(h):                                                              # T1:883-884
-        h = st(conv3x3_bias_relu(h, W["c5a/kernel"], W["c5a/bias"]))
+        h = st(conv3x3_bias_relu(h, W["c5a/kernel"], W["c5a/bias"], relu_mask=rm("c5a")))
         if keep: a["c5a"] = h
-        h = st(conv3x3_bias_relu(h, W["c5b/kernel"], W["c5b/bias"]))
+        h = st(conv3x3_bias_relu(h, W["c5b/kernel"], W["c5b/bias"], relu_mask=rm("c5b")))
         if keep: a["c5b"] = h
         return h
 
@@ -256,9 +263,9 @@ def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, wa
         h, mu, va = batchnorm(h, W[f"bn{k}/gamma"], W[f"bn{k}/beta"], W[f"bn{k}/mean"], W[f"bn{k}/var"], training)
         h = st(h); stats[f"bn{k}"] = (mu.detach(), va.detach(), h.shape[0] * h.shape[1] * h.shape[2])
         if keep: a[f"bn{k}"] = h
-        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"]))
+        h = st(conv3x3_bias_relu(h, W[f"c{k}a/kernel"], W[f"c{k}a/bias"], relu_mask=rm(f"c{k}a")))
         if keep: a[f"c{k}a"] = h
-        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"]))
+        h = st(conv3x3_bias_relu(h, W[f"c{k}b/kernel"], W[f"c{k}b/bias"], relu_mask=rm(f"c{k}b")))
         if keep: a[f"c{k}b"] = h
         return h
 
@@ -322,13 +329,13 @@ def sm_scores(tp, spr, sgt, smooth=SM_SMOOTH):
 # ---------------------------------------------------------------------------------------
 # Training step (fwd -> loss -> autograd bwd -> Keras-form Adam) and evaluation
 # ---------------------------------------------------------------------------------------
-def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False):
+def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False, relu_masks=None):
     """One training-mode fwd + bwd.  Returns dict(loss, dice, grads{name}, bn_stats, p[, acts, act_grads])."""
     names = trainable_names(np.asarray(x).shape[-1])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=want_acts, store=store, ckpt=ckpt)
+    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=want_acts, store=store, ckpt=ckpt, relu_masks=relu_masks)
     t = _t(y, dtype)
     loss = bce_dice_loss(t, p)
     dice = dice_coeff(t, p)
@@ -624,7 +631,7 @@ def cls_init_weights(seed: int = 0, in_ch: int = 1, hw=(224, 224), dtype=np.floa
     return w
 
 
-def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32, want_acts=False, ckpt=False):
+def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32, want_acts=False, ckpt=False, relu_masks=None):
     """keep_mask: None or {0,1} array [n, 32] of the Dropout(0.4) after Dense(32).  ckpt: recompute each conv block in
     backward (see forward()).  Returns (p [n], acts, bn stats)."""
     W = {k: _t(v, dtype) for k, v in weights.items()}
@@ -633,7 +640,7 @@ def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32,
 
     def block(k, h):
         for ab in "ab":
-            h = conv3x3_bias_relu(h, W[f"c{k}{ab}/kernel"], W[f"c{k}{ab}/bias"])
+            h = conv3x3_bias_relu(h, W[f"c{k}{ab}/kernel"], W[f"c{k}{ab}/bias"], relu_mask=(_t(relu_masks[f"c{k}{ab}"], dtype) if relu_masks is not None else None))
             if keep: a[f"c{k}{ab}"] = h
             nm = f"bn{k}{ab}"
             src = h
@@ -678,13 +685,13 @@ def cls_loss(y_true, y_pred, class_weights=(1.0, 1.0)):
     return (l * w).mean()
 
 
-def cls_loss_and_grads(weights, x, y, keep_mask=None, class_weights=(1.0, 1.0), dtype=torch.float32, want_acts=False, ckpt=False):
+def cls_loss_and_grads(weights, x, y, keep_mask=None, class_weights=(1.0, 1.0), dtype=torch.float32, want_acts=False, ckpt=False, relu_masks=None):
     xs = np.asarray(x)
     names = cls_trainable_names(xs.shape[-1], xs.shape[1:3])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = cls_forward(W, x, training=True, keep_mask=keep_mask, dtype=dtype, want_acts=want_acts, ckpt=ckpt)
+    p, acts, stats = cls_forward(W, x, training=True, keep_mask=keep_mask, dtype=dtype, want_acts=want_acts, ckpt=ckpt, relu_masks=relu_masks)
     t = _t(np.asarray(y, np.float64).reshape(-1), dtype)
     loss = cls_loss(t, p, class_weights); f1 = cls_f1(t, p)
     if want_acts:

@@ -9,7 +9,7 @@ fits in this container's 62 GB: `ckpt=True`, same arithmetic).  Stored per case:
 of EVERY parameter gradient, seven gradients in full, every 1009th probability (classifier: all), the batch statistics of
 every BatchNorm, and checksums of the seeded inputs.  tests/test_gpu_fullsize.py runs the same step on the HIP engine.
 
-    python tests/golden/make_fullsize_goldens.py [case ...]       (about 8 + 3 + 3 minutes on 8 cores, 40 GB peak)
+    python tests/golden/make_fullsize_goldens.py [case ...]       (about 6 + 5 + 3 minutes on 8 cores, 40 GB peak)
 """
 import os
 import sys
@@ -44,6 +44,15 @@ def main():
             arrs["grad/" + k] = r["grads"][k].astype(np.float32)
         for k, (mu, va, n) in r["bn_stats"].items():
             arrs["bn_mean/" + k] = mu.astype(np.float32); arrs["bn_var/" + k] = va.astype(np.float32)
+        # calibration: how far the SAME step in fp32 on the CPU (torch / oneDNN -- the stand-in for the reference's fp32 Keras run) lands from
+        # the fp64 answer.  At these pixel counts ~1e-6 of the ReLU pre-activations round to the other side of 0 in fp32; each flip is a
+        # discontinuity of the gradient and the first layers' weight gradients move by ~sqrt(flip fraction).  The GPU test bounds the engine's
+        # error by max(3e-4, 4 x this) per tensor.
+        r32 = fn(w, x, y, dtype=torch.float32, ckpt=True)
+        for k, g in r["grads"].items():
+            e = float(np.linalg.norm(r32["grads"][k].astype(np.float64) - g) / (np.linalg.norm(g) + 1e-30))
+            arrs["fp32ref_relerr/" + k] = np.float64(e)
+        arrs["fp32ref_loss_err"] = np.float64(abs(r32["loss"] - r["loss"]))
         out = os.path.join(HERE, f"fullsize_{name}.npz")
         np.savez_compressed(out, **arrs)
         print(f"{name}: {time.time() - t0:.0f} s, loss {r['loss']:.9f}, metric {float(arrs['metric']):.9f}, wrote {out} ({os.path.getsize(out)} bytes)", flush=True)

@@ -110,7 +110,7 @@ def count_flips(eng, n, acts, names, thr=1e-5):
 
 
 @pytest.mark.parametrize("algo", [0, 1])
-@pytest.mark.parametrize("hw,n", [((32, 32), 4), ((24, 40), 5)])
+@pytest.mark.parametrize("hw,n", [((32, 32), 4), ((24, 40), 5), ((96, 128), 24)])
 def test_model_fwd_bwd_all_grads(hw, n, algo):
     h, w_ = hw
     rng = np.random.default_rng(h + n)
@@ -126,8 +126,15 @@ def test_model_fwd_bwd_all_grads(hw, n, algo):
     for name in convs + ["bn1a", "bn2b", "p1", "p3"]:
         assert relerr(eng.tap(n, name), r["acts"][name]) < 2e-5, name
     assert relerr(eng.tap(n, "h1").reshape(n, 32), r["acts"]["h1"]) < 2e-5
+    # ReLU pre-activations the fp32 engine and the fp64 oracle put on different sides of 0 are discontinuities of the gradient, not arithmetic
+    # errors: the gradient reference is the oracle evaluated on the ENGINE's sign pattern (z * mask; identical wherever the signs agree), so the
+    # tight tolerance holds with or without flips (the 96 x 128 x 24 case has them)
     flips = count_flips(eng, n, r["acts"], convs)
-    tol = 3e-4 if flips == 0 else 2e-2
+    assert flips <= 1e-5 * sum(r["acts"][c].size for c in convs) + 8, flips
+    if flips:
+        r = O.cls_loss_and_grads(wts, x, y, class_weights=cw, dtype=torch.float64, relu_masks={c: (eng.tap(n, c) > 0).astype(np.float64) for c in convs})
+        assert abs(ld[0] - r["loss"]) < 1e-5
+    tol = 3e-4
     g = eng.get_grads()
     assert set(g) == set(r["grads"])
     for k in g:

@@ -99,3 +99,69 @@ def test_two_ranks_bf16_storage_match_full_batch(tmp_path):
         assert a @ v / (na * nv + 1e-300) > 0.9 and 0.8 < na / (nv + 1e-300) < 1.25, k
     ref_losses = np.array([eng.train_batch(x, y).cpu().numpy() for _ in range(2)])
     assert np.abs(got["losses"] - ref_losses).max() < 5e-3            # batch-global loss / Dice on every rank
+
+
+def _nccl_world1_worker(rank, port, wfile, x, y, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from covidseg_amd.engine import HipUNet
+    wts = dict(np.load(wfile))
+    eng = HipUNet(x.shape[1], x.shape[2], 1, device=0, process_group=dist.group.WORLD, dropout_rate=0.0, force_dp=True)
+    assert eng._dp and eng._comm_stream is not None and eng.pg_grad is not eng.pg          # the production multi-GPU objects exist
+    eng.set_weights(wts)
+    losses = [eng.train_batch(x, y).cpu().numpy() for _ in range(3)]
+    p, ld = eng.predict_batch(x, y)
+    sums = eng.threshold_sums(p, y, [0.3, 0.5]).cpu().numpy()
+    np.savez(out, losses=np.array(losses), ld=ld.cpu().numpy(), sums=sums, **{"w/" + k: v for k, v in eng.get_weights().items()})
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_rccl_code_path_at_world_size_one_is_bitwise_the_plain_step(tmp_path):
+    """The production multi-GPU path -- backend "nccl" (= RCCL), device-side all-reduces of the inline fp64 sums, the gradient buckets on the
+    side stream through the second communicator, the event chain back into Adam -- executed on the one GPU of this box: with a single rank
+    every SUM all-reduce is the identity, so three optimizer steps must reproduce the plain engine BIT FOR BIT."""
+    import torch.multiprocessing as mp
+    from covidseg_amd import weights as W
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.engine import HipUNet
+    x, y = synthetic_ct(4, 64, seed=8)
+    wts = W.init_weights(6, 1, "unet", (64, 64))
+    wfile = str(tmp_path / "w.npz"); np.savez(wfile, **wts)
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_nccl_world1_worker, args=(_free_port(), wfile, x, y, out), nprocs=1, join=True)
+    got = np.load(out)
+    eng = HipUNet(64, 64, 1, dropout_rate=0.0); eng.set_weights(wts)
+    ref = np.array([eng.train_batch(x, y).cpu().numpy() for _ in range(3)])
+    assert np.array_equal(got["losses"], ref)
+    p, ld = eng.predict_batch(x, y)
+    assert np.array_equal(got["ld"], ld.cpu().numpy()) and np.array_equal(got["sums"], eng.threshold_sums(p, y, [0.3, 0.5]).cpu().numpy())
+    for k, v in eng.get_weights().items():
+        assert np.array_equal(got["w/" + k], v), k
+
+
+@pytest.mark.parametrize("runner,batch", [("runner_lung_segmentation", 8), ("holdout_runner_unet_infection_segmentation", 6)])
+def test_runner_on_two_ranks_equals_the_single_process_runner(tmp_path, monkeypatch, runner, batch):
+    """BASELINE.json configs[2] in miniature: runner_lung_segmentation() (T3:989-1009) data parallel -- UNET_GPUS=2 makes the runner launch
+    itself as two ranks (dp_launch.py; here both on this box's one GPU with the gloo group staged through the host), every global batch is
+    sharded over the ranks (batch 6 on 16 training samples also leaves a 4-sample tail: 2 + 2; the 7 validation samples end in a replicated
+    odd batch) -- and must print the single-process run's history, scores and threshold tables."""
+    from covidseg_amd import runners
+    from covidseg_amd import weights as W
+    from covidseg_amd.data import synthetic_ct
+    x, y = synthetic_ct(23, 32, seed=2)
+    wts = W.init_weights(9, 1, "unet", (32, 32))
+    d1, d2 = tmp_path / "single", tmp_path / "dp"; d1.mkdir(); d2.mkdir()
+    kw = dict(data=(x, y), epochs=2, batch_size=batch, dropout=False, init_weights=wts, verbose=0)
+    single = getattr(runners, runner)(workdir=str(d1), **kw)
+    monkeypatch.setenv("UNET_GPUS", "2"); monkeypatch.setenv("UNET_DP_BACKEND", "gloo"); monkeypatch.setenv("UNET_DP_ONE_DEVICE", "1")
+    dp = getattr(runners, runner)(workdir=str(d2), **kw)
+    assert dp["world_size"] == 2
+    for k, v in single["history"].items():
+        assert np.abs(np.array(dp["history"][k]) - np.array(v)).max() < 2e-4, (k, dp["history"][k], v)
+    assert np.abs(np.array(dp["score"]) - np.array(single["score"])).max() < 2e-4
+    for k in ("dices", "ious", "new_dices", "new_ious", "precisions", "recalls"):
+        assert np.abs(np.array(dp[k]) - np.array(single[k])).max() < 1e-3, k                       # the BASELINE bar
+    from covidseg_amd import hdf5_min as H5
+    assert H5.is_hdf5(str(d2 / "unet_covid_weights_dice_coeff.hdf5"))                               # rank 0 wrote the reference's checkpoint files

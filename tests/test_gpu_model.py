@@ -59,7 +59,7 @@ def test_golden_fixture_fwd_bwd(algo):
     assert relerr(wa["out/kernel"], z["w_after/out/kernel"]) < 1e-3 and relerr(wa["bn1/mean"], z["w_after/bn1/mean"]) < 1e-4
 
 
-@pytest.mark.parametrize("hw,n", [((64, 48), 2), ((16, 16), 5)])
+@pytest.mark.parametrize("hw,n", [((64, 48), 2), ((16, 16), 5), ((128, 160), 3)])
 def test_live_oracle_all_grads_and_taps(hw, n):
     h, w_ = hw
     rng = np.random.default_rng(h)
@@ -84,13 +84,18 @@ def test_live_oracle_all_grads_and_taps(hw, n):
     assert "bn_bwd_apply:bn9" not in bwd and "bn_bwd_stats:bn9" not in bwd
     for name in ("c1a", "c1b", "bn1", "p1", "c3b", "bn4", "p4", "c5b", "u6", "bn6", "c6a", "u9", "bn9", "c9b"):
         assert relerr(eng.tap(n, name), r["acts"][name]) < 2e-5, name
-    # A ReLU whose pre-activation rounds to the other side of 0 in fp32 is a discontinuity, not an error: ONE such
-    # element changes every upstream gradient by ~1e-3 relative (the fp32 CPU oracle shows the same, see
-    # tools/debug_parity.py).  So: count mask flips vs the fp64 oracle; tight tolerance when there are none.
+    # A ReLU whose pre-activation rounds to the other side of 0 in fp32 is a discontinuity of the gradient, not an arithmetic error: ONE such
+    # element changes every upstream gradient by ~1e-3 relative at these sizes (the fp32 CPU oracle shows the same, tools/debug_parity.py).
+    # So the gradient reference is the oracle evaluated on the ENGINE's sign pattern (z * mask instead of max(z, 0): the same function wherever
+    # the signs agree -- as the dropout test below feeds the engine's keep masks): the tight tolerance holds with or without flips.
     convs = [f"c{k}{ab}" for k in range(1, 10) for ab in "ab"]
-    flips = sum(int(((eng.tap(n, name) > 0) != (r["acts"][name] > 0)).sum()) for name in convs)
-    tol_a, tol_g = (2e-4, 3e-4) if flips == 0 else (2e-2, 2e-2)
-    assert flips <= 8, flips
+    emasks = {name: (eng.tap(n, name) > 0) for name in convs}
+    flips = sum(int((emasks[name] != (r["acts"][name] > 0)).sum()) for name in convs)
+    assert flips <= 1e-5 * sum(m.size for m in emasks.values()) + 8, flips
+    if flips:
+        r = O.loss_and_grads(wts, x, y, dtype=torch.float64, want_acts=True, relu_masks={k: m.astype(np.float64) for k, m in emasks.items()})
+        assert abs(ld[0] - r["loss"]) < 1e-5
+    tol_a, tol_g = 2e-4, 3e-4
     # gradients wrt activations (ours are already ReLU-masked where the producer is a ReLU conv)
     for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c5b", True), ("p4", False), ("c4b", True), ("c1a", True)):       # (bn4's total gradient is only formed inside the fused encoder-tail pass: c4b checks its result)
         if name == "bn9":

@@ -117,3 +117,16 @@ def test_full_cts_and_infection_chain_with_rectangles():
         assert np.array_equal(got[i, ..., 0], P.u8_to_unit(e))
         e = P.resize_u8(P.crop_resize_fuse(P.minmax_to_u8(msk[i]), r1[i], r2[i]), (224, 224), P.INTER_LINEAR)
         assert np.array_equal(gotm[i, ..., 0], P.u8_to_unit(e))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 4])
+def test_cropper_end_to_end_matches_the_oracle(seed):
+    """cropper(test_img, demo) T1:211-273 on a lung-like mask: uint8 cast on the GPU, contour search in the library's host code (tests/test_contours.py
+    checks it bit-exact on its own), both crops INTER_AREA-resized to 125 x 250 and fused on the GPU -- against the oracle's cropper, byte for byte."""
+    from test_contours import lung_mask
+    m = lung_mask(256, seed)
+    from covidseg_amd import preprocess as PP
+    fused, r1, r2 = PP.cropper(m, demo=0)
+    wf, w1, w2 = P.cropper(m, demo=0)
+    assert r1 == w1 and r2 == w2 and isinstance(r1, list) and len(r1) == 4
+    assert fused.shape == (250, 250) and fused.dtype == np.uint8 and np.array_equal(fused, wf)
