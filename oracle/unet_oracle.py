@@ -292,7 +292,12 @@ def dice_coeff(y_true, y_pred):
 
 def binary_crossentropy_mean(y_true, y_pred):
     """keras binary_crossentropy on probabilities, then Keras' mean over everything.
-    clip -> logit -> max(z,0) - z*t + log(1+exp(-|z|))  (same algebra as T1:819-825)."""
+    clip -> logit -> max(z,0) - z*t + log(1+exp(-|z|))  (same algebra as T1:819-825).
+    VERSION NOTE (parity unpinned, see the header): this is the form of standalone Keras 2.3 on TF 1.x (`K.binary_crossentropy` with
+    from_logits=False clips to [eps, 1 - eps] with eps = 1e-7 and converts back to logits) and of the reference's own weighted_bce_loss.
+    tf.keras / TF 2.2 -- the other stack the reference's notebooks could have run on -- back-tracks a `Sigmoid` op to its logits and applies
+    sigmoid_cross_entropy_with_logits WITHOUT the clip.  The two differ by <= 1e-7 per element except where |logit| > 16.1 (p within 1e-7 of 0 or 1),
+    where the clipped form saturates at 16.1 * |t - p|; far below the 1e-3 Dice bar and invisible to the tests, but a property of this restatement."""
     p = torch.clamp(y_pred, BCE_EPS, 1.0 - BCE_EPS)
     z = torch.log(p / (1.0 - p))
     l = torch.clamp(z, min=0) - z * y_true + torch.log1p(torch.exp(-torch.abs(z)))

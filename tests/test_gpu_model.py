@@ -189,6 +189,29 @@ def test_runner_end_to_end_small(tmp_path, capsys):
         assert (np.abs(a - b) < tol).all(), (key, np.abs(a - b).max())
 
 
+def test_lung_runner_on_the_engine_matches_the_oracle_backend(tmp_path, capsys):
+    """runner_lung_segmentation() (app.py 'six', T3:6; BASELINE.json configs[2]'s entry point) on the HIP engine against the same runner on the
+    CPU-oracle backend: task 3's own split / recipe / checkpoint names and its fine threshold range 0.43 ... 0.53 (T3:1206)."""
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.runners import runner_lung_segmentation
+    from oracle_backend import OracleBackend
+    x, y = synthetic_ct(10, 64, seed=4)
+    y = np.clip(y * 3, 0, 1).astype(np.float32)                     # lungs are big: most thresholds see thousands of pixels
+    out = runner_lung_segmentation(data=(x, y), epochs=2, batch_size=4, dropout=False, workdir=str(tmp_path), verbose=0, dropout_rate=0.0)
+    txt = capsys.readouterr().out
+    assert "(7, 64, 64, 1) (3, 64, 64, 1)" in txt and "We just checked for 100 steps between 0.43 and 0.53" in txt      # T3:1227
+    os.makedirs(tmp_path / "r", exist_ok=True)
+    ref = runner_lung_segmentation(data=(x, y), epochs=2, batch_size=4, dropout=False, workdir=str(tmp_path / "r"), verbose=0, backend=OracleBackend(64, 64))
+    assert np.allclose(out["new_range"], np.arange(0.43, 0.53, 0.001)) and len(out["new_dices"]) == 100
+    for k in ("loss", "dice_coeff", "val_loss", "val_dice_coeff"):
+        assert np.abs(np.array(out["history"][k]) - np.array(ref["history"][k])).max() < 3e-4, k
+    assert np.abs(np.array(out["score"]) - np.array(ref["score"])).max() < 3e-4
+    for key in ("dices", "ious", "new_dices", "new_ious", "precisions", "recalls"):
+        a, b = np.array(out[key]), np.array(ref[key])
+        tol = np.where(b > 0.01, 1e-3, 5e-3)                        # (see test_runner_end_to_end_small)
+        assert (np.abs(a - b) < tol).all(), (key, np.abs(a - b).max())
+
+
 def test_full_size_512_properties():
     """BASELINE config 2 size (512x512, batch 2 here to bound memory/time): size-independent properties --
     probabilities in (0,1), loss finite, dice_coeff identity from sums, gradient of a zero-loss-gradient

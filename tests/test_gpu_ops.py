@@ -518,6 +518,37 @@ def test_winograd_matches_direct_mfma_at_full_size(ops, shape):
         assert relerr(c, a) < 1e-5, nm
 
 
+@pytest.mark.parametrize("shape", [(2, 512, 512, 32, 32), (1, 512, 512, 64, 32), (2, 256, 256, 64, 64)])
+def test_full_size_layers_against_the_fp64_oracle(ops, shape):
+    """The 512 x 512 layers of the headline workload (c1b / c9b, c9a, c2b shapes: the XCD tile maps, split-K and grids of the real plan) against the
+    ORACLE -- torch-CPU float64 conv3x3 + bias + ReLU with autograd for both gradients (10-40 GFLOP, seconds on the box's cores) -- not only
+    against the other GPU algorithm: forward, data gradient (ReLU-masked by the producer's output) and weight / bias gradient, <= 2e-5 as at
+    the small shapes."""
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(ci + co + h)
+    x = np.maximum(rng.standard_normal((n, h, w, ci)), 0).astype(np.float32)          # an activation: ReLU output of the layer before
+    k = (rng.standard_normal((3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32); b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True); kt = torch.tensor(k, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    z = O.conv3x3_bias_relu(xt, kt, bt, relu=False)
+    z.backward(torch.tensor(dy, dtype=torch.float64))
+    want_y = torch.relu(z).detach().numpy()
+    want_dx = xt.grad.numpy() * (x > 0)                                               # MASK_RELU: the derivative of the producer's ReLU fused into the data gradient
+    xd, kd, bd, dyd = ops.d(x), ops.d(k), ops.d(b), ops.d(dy)
+    ws = torch.empty(int(ops.lib.unet_conv3x3_w_ws_floats(ci, co)), device="cuda")
+    nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co); wgs = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    y = torch.empty(n, h, w, co, device="cuda"); dx = torch.empty(n, h, w, ci, device="cuda"); dw = torch.empty(3, 3, ci, co, device="cuda"); db = torch.empty(co, device="cuda")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, xd.data_ptr(), kd.data_ptr(), bd.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, ws.data_ptr(), ops.s), "fwd")
+    assert ops.lib.unet_conv3x3_exec_ratio(0, h, w, ci, co) < 0.5                     # the F(2x2,3x3) kernels are the path under test
+    assert relerr(y.cpu().numpy(), want_y) < 2e-5
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, dyd.data_ptr(), kd.data_ptr(), xd.data_ptr(), 1, 0.0, 0, dx.data_ptr(), ws.data_ptr(), n, h, w, ci, co, 0, ops.s), "dgrad")
+    assert relerr(dx.cpu().numpy(), want_dx) < 2e-5
+    ops.ck(ops.lib.unet_conv3x3_bwd_weights(ops.h, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), wgs.data_ptr(), nb, n, h, w, ci, co, 0, ops.s), "wgrad")
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < 2e-5 and relerr(db.cpu().numpy(), bt.grad.numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_wgrad_random_shapes_all_algorithms_agree(ops, seed):
     """odd heights / widths / channel counts (tile overhang, single-row chunks, odd last row pair): the 2-D Winograd, direct MFMA and
