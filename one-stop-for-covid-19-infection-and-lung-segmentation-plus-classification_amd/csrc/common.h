@@ -189,6 +189,13 @@ struct unet_wino_prep { const float* w; float* u; int cin, cout, flip, two_d; };
 struct unet_wino_prep_list { unet_wino_prep item[UNET_WINO_PREP_MAX]; int n; };          // passed by value as a kernel argument (1.3 KiB)
 int32_t k_wino_weights_multi(unet_ctx*, unet_wino_prep_list* L, const int* h, hipStream_t s);
 // fp32 conv3x3 on the bf16 matrix cores through the exact 3-term bf16 split (kernels_conv_x3.hip); K = contraction channels, M = output channels of a launch
+// ... and through the block-scaled 2-term fp16 split (kernels_conv_h2.hip): three fp16 MFMA products per multiply; asked before x3
+bool h2_conv3x3_selected(int K, int M);
+size_t h2_wimg_bytes(int K, int M);
+int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s);
+int32_t k_h2_weights_multi(unet_ctx*, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s);
+int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
+                         int act, float rate, uint64_t seed, hipStream_t s);
 bool x3_conv3x3_selected(int K, int M);
 size_t x3_wimg_bytes(int K, int M);
 int32_t k_x3_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s);

@@ -1,0 +1,431 @@
+// fp32 3x3 convolution (forward + data gradient) on the 16-bit matrix cores with fp32 accuracy: the "h2" kernels.
+//
+// gfx950's fp32 MFMA runs at the vector rate (157 TFLOP/s, no TF32); v_mfma_f32_32x32x16_f16 runs 16x faster.  An fp32 number that sits in the
+// comfortable part of the fp16 range is, to 22 significant bits, the sum of TWO fp16 numbers: x ~ h + m, h = RN_f16(x), m = RN_f16(x - h)
+// (11 + 11 bits; x - h is exact in fp32), so
+//     x * w = xh wh + xh wm + xm wh + O(2^-22 |x w|)
+// -- three fp16 MFMAs with fp32 accumulation per multiply, 3/16 of the fp32-MFMA time, half of the bf16 three-term split of kernels_conv_x3.hip.
+// What fp16 lacks is RANGE (activation gradients are ~1e-8), so both operands are block-scaled by exact powers of two:
+//   * weights: one exponent per layer, from the layer's max |w| (h2_wmax_kernel), folded into the weight image; max |w| 2^e lands in [2^11, 2^12);
+//   * activations / gradients: one exponent per workgroup, tracked along the K loop.  While a 16-channel chunk of the input patch is staged, the workgroup
+//     takes its max |x| (registers -> wave shuffle -> 4 LDS words, no extra barrier); if the chunk would come within 2x of the fp16 maximum under the
+//     running exponent, the exponent is lowered to put that maximum at [2^11, 2^12) and the fp32 accumulators are multiplied by the (exact)
+//     power-of-two ratio.  So nothing can overflow, and every element keeps >= 22 bits down to 2^-14 of the largest element the workgroup has seen
+//     (absolute precision 2^-36 of that maximum below).  The epilogue multiplies by 2^-(e_x + e_w).
+// Measured on the box (tools/probe/split3_probe.hip, K = 16 ... 4608, against float64): relative L2 error 7.1e-8 / 2.2e-7 / 8.5e-7 for the three fp16
+// products vs 7.1e-8 / 3.2e-7 / 1.3e-6 for v_mfma_f32_32x32x2_f32: the same accuracy class as the fp32 matrix path it replaces.
+//
+// Kernel structure = the implicit GEMM of kernels_bf16.hip / kernels_conv_x3.hip: A = weights (32 output channels x 16 k), B = 32 pixels of an image row,
+// a lane ends with 16 consecutive output channels of one pixel.  Per 16-channel chunk: (TH + 2) x 34 pixel patch as two fp16 planes + the weight slab
+// (two planes) in LDS, single-buffered; the next chunk travels global -> registers under the current chunk's MFMAs and is scaled, split and stored
+// between two barriers while the CU's other workgroup(s) keep the matrix pipes busy (58 KB and ~200 registers per workgroup: two per CU).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unet_f32x16 f32x16;
+constexpr int H2_HEADER = 256;                              // bytes in front of a weight image: [0] = 2^-e_w (float)
+
+__host__ __device__ inline int cperm(int m) { return ((m >> 2) & 1) * 16 + (m & 3) + 4 * (m >> 3); }       // lane -> 16 consecutive channels (kernels_bf16.hip)
+
+// two values -> packed fp16 pairs h and m with a ~ h + m
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m) {
+  const f16x2 hh = __builtin_convertvector((unet_f32x2){a, b}, f16x2);
+  const f16x2 mm = __builtin_convertvector((unet_f32x2){a - (float)hh[0], b - (float)hh[1]}, f16x2);
+  h = __builtin_bit_cast(unsigned, hh); m = __builtin_bit_cast(unsigned, mm);
+}
+// exponent e (as the float 2^e) that puts a block maximum with biased exponent field `eb` into [2^11, 2^12); eb < 11: the block is numerically zero
+__device__ __forceinline__ int scale_exp_for(int eb) { return 138 - eb; }
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }          // -126 <= e <= 127
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weights: max |w| of a layer (one workgroup per layer), then the split image
+//   img = [header 256 B][((((((g*nchunks + chunk)*9 + tap)*NB + nb)*2 + plane)*2 + half)*32 + m][8 fp16]
+//   k = chunk*16 + half*8 + j,  mm = (g*NB + nb)*32 + cperm(m),  W(tap,k,mm) = w[(flip ? 8-tap : tap)*tap_stride + k*sk + mm*sm] * 2^e_w
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void h2_wmax_kernel(unet_wimg_prep_list L) {
+  const unet_wimg_prep& p = L.item[blockIdx.x];
+  const long long n4 = 9LL * p.tap_stride / 4;               // tap_stride = cin * cout (a multiple of 4)
+  float mx = 0.f;
+  for (long long i = threadIdx.x; i < n4; i += 1024) {
+    const float4 v = reinterpret_cast<const float4*>(p.w)[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  __shared__ float red[16];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+    const int eb = (int)((__float_as_uint(mx) >> 23) & 0xFF);
+    int e = eb >= 11 ? scale_exp_for(eb) : 0;
+    e = min(max(e, -100), 100);
+    float* hdr = reinterpret_cast<float*>(reinterpret_cast<char*>(p.img));
+    hdr[0] = pow2f(-e); hdr[1] = pow2f(e);
+  }
+}
+__global__ __launch_bounds__(256) void h2_wimg_multi_kernel(unet_wimg_prep_list L) {          // blockIdx.y = layer
+  const unet_wimg_prep& p = L.item[blockIdx.y];
+  const int NB = p.nb, nchunks = p.nchunks, M = p.m;
+  const float sc = reinterpret_cast<const float*>(p.img)[1];
+  unet_bf16* const img = p.img + H2_HEADER / 2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < p.total8; e += (long long)gridDim.x * 256) {          // e indexes (g, chunk, tap, nb, half, m)
+    long long r = e;
+    const int m = (int)(r & 31); r >>= 5;
+    const int half = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r % NB); r /= NB;
+    const int tap = (int)(r % 9); r /= 9;
+    const int chunk = (int)(r % nchunks); const int g = (int)(r / nchunks);
+    const long long k0 = (long long)chunk * 16 + half * 8;
+    const long long mm = ((long long)g * NB + nb) * 32 + cperm(m);
+    const float* src = p.w + (long long)(p.flip ? 8 - tap : tap) * p.tap_stride + k0 * p.sk + mm * p.sm;
+    unsigned hh[4], ml[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = mm < M ? src[(2 * j) * p.sk] * sc : 0.0f, b = mm < M ? src[(2 * j + 1) * p.sk] * sc : 0.0f;
+      split2(a, b, hh[j], ml[j]);
+    }
+    const long long base = (((((long long)g * nchunks + chunk) * 9 + tap) * NB + nb) * 2 * 2 + half) * 32 + m;        // plane 0; plane 1 is 2 * 32 rows further
+    *reinterpret_cast<uint4*>(img + (base + 0 * 64) * 8) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    *reinterpret_cast<uint4*>(img + (base + 1 * 64) * 8) = make_uint4(ml[0], ml[1], ml[2], ml[3]);
+  }
+}
+
+__device__ __forceinline__ f16x8 lds_frag(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+
+template <int NB, int RW, bool GEN, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
+                                                           const float* __restrict__ mask, float* __restrict__ y, int N, int H, int W, int K, int M, int act,
+                                                           int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
+                                                           int total_blocks) {
+  constexpr int TH = 4 * RW;                             // tile rows: RW per wave
+  constexpr int PR = TH + 2, PWD = 34, NPIX = PR * PWD;
+  constexpr int PLANE = NPIX * 32;                       // bytes of one fp16 plane of the 16-channel pixel patch
+  constexpr int IN_BYTES = 2 * PLANE, W_BYTES = 9 * NB * 2 * 2 * 32 * 16;
+  constexpr int PPIECES = NPIX * 4, WPIECES = W_BYTES / 16;          // 16-B fp32 pieces of the patch (pixel, channel quad); 16-B pieces of the weight slab
+  constexpr int PL = (PPIECES + 255) / 256, WL = (WPIECES + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [IN_BYTES] [W_BYTES] [4 floats: per-wave max |x| of the chunk being staged]
+  char* const s_in = smem; char* const s_w = smem + IN_BYTES;
+  float* const s_amax = reinterpret_cast<float*>(smem + IN_BYTES + W_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware block map (workgroup b runs on XCD b % 8): an XCD gets a contiguous range of work items -- the channel groups of one spatial tile,
+  // then the neighbouring tiles -- so a patch is fetched into ONE L2
+  const int per = gridDim.x >> 3;
+  const int wi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (wi >= total_blocks) return;
+  const int g = wi % groups; int t = wi / groups;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y; const int n = t / tiles_y;
+  const int x0 = tx * 32, y0 = ty * TH;
+  const int nchunks = K / 16;
+  const unet_bf16* const wimg = wimg_hdr + H2_HEADER / 2;
+  const float w_unscale = *reinterpret_cast<const float*>(wimg_hdr);          // 2^-e_w of the layer
+
+  f32x16 acc[RW][NB];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x + (long long)n * H * W * K, (long long)H * W * K * 4);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(wimg), 0, (int)((long long)groups * nchunks * W_BYTES), 0x00020000);
+  int poff[PL];
+#pragma unroll
+  for (int k = 0; k < PL; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx & 3, pix = idx >> 2;
+    const int r = pix / PWD, c = pix - r * PWD;
+    const int gy = y0 + r - 1, gx = x0 + c - 1;
+    const bool ok = idx < PPIECES && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    poff[k] = ok ? ((gy * W + gx) * K + q * 4) * 4 : UNET_OOB;          // halo and overhang pieces read 0 (out-of-range buffer offset)
+  }
+  unet_u32x4 preg[PL], wreg[WL];
+  auto issue_loads = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k) preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, poff[k], chunk * 64, 0);
+    const int wsoff = (g * nchunks + chunk) * W_BYTES;
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const int idx = tid + k * 256;
+      wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, idx < WPIECES ? idx * 16 : UNET_OOB, wsoff, 0);
+    }
+  };
+  // max |x| of the pieces this wave holds -> s_amax[wave]
+  auto post_amax = [&]() __attribute__((always_inline)) {
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(__uint_as_float(preg[k][j])));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) s_amax[wave] = mx;
+  };
+  int e_run = 120;                                           // running exponent of the activation operand: staged values are x * 2^e_run
+  // after the barrier that follows post_amax: lower the running exponent if this chunk needs it (rescaling the accumulators), then scale, split and store
+  auto store_lds = [&]() __attribute__((always_inline)) {
+    const float mx = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+    const int eb = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(mx) >> 23) & 0xFF));
+    if (eb >= 11 && eb - 127 + e_run >= 15) {                // the chunk's maximum would land at >= 2^15 (fp16 overflows at 2^16): re-centre at [2^11, 2^12)
+      const int e_new = scale_exp_for(eb);
+      const int d = max(e_new - e_run, -126);
+      const float f = pow2f(d);
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+      e_run = e_new;
+    }
+    const float sc = pow2f(e_run);
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < PPIECES) {
+        unsigned h0, m0, h1, m1;
+        split2(__uint_as_float(preg[k][0]) * sc, __uint_as_float(preg[k][1]) * sc, h0, m0);
+        split2(__uint_as_float(preg[k][2]) * sc, __uint_as_float(preg[k][3]) * sc, h1, m1);
+        char* p = s_in + idx * 8;                                       // plane-local layout [pixel][16 channels] fp16: piece (pixel, quad) -> 8 bytes
+        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0, m1);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < WPIECES) *reinterpret_cast<unet_u32x4*>(s_w + idx * 16) = wreg[k];
+    }
+  };
+
+  issue_loads(0);
+  post_amax();
+  __syncthreads();
+  store_lds();
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) issue_loads(chunk + 1);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      f16x8 px[2][RW + 2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int rr = 0; rr < RW + 2; ++rr) px[p][rr] = lds_frag(s_in + p * PLANE + (((wave * RW + rr) * PWD + l31 + kx) * 32 + hi * 16));
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        f16x8 wf[NB][2];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) wf[nb][p] = lds_frag(s_w + (((((ky * 3 + kx) * NB + nb) * 2 + p) * 2 + hi) * 512 + l31 * 16));
+        // three products per (row, block), small terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+          constexpr int PW[3] = {0, 1, 0}, PX[3] = {1, 0, 0};            // (weight plane, pixel plane): wh xm, wm xh, wh xh
+#pragma unroll
+          for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nb][PW[pr]], px[PX[pr]][r + ky], acc[r][nb], 0, 0, 0);
+        }
+      }
+    }
+    if (chunk + 1 < nchunks) {
+      post_amax();
+      __syncthreads();                                     // every wave is done reading this chunk's planes; the four partial maxima are visible
+      store_lds();
+      __syncthreads();
+    }
+  }
+  const float unscale = pow2f(max(-e_run, -126)) * w_unscale;            // 2^-(e_x + e_w)
+
+  // ---- epilogue: lane (l31, hi) holds, for pixel column l31 of each of its RW rows, channels mb + 0..15
+  const int px_ = x0 + l31;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int mb = (g * NB + nb) * 32 + hi * 16;
+    if (mb >= M) continue;                                 // zero-padded rows of a tile that overhangs M
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + mb + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int py = y0 + wave * RW + r;
+      if (py >= H || px_ >= W) continue;
+      const long long o = (((long long)n * H + py) * W + px_) * M + mb;
+      float v[16], mv[16], a[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] = acc[r][nb][i] * unscale;
+      const bool want_m = mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB;
+      if (want_m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 m4 = *reinterpret_cast<const float4*>(mask + o + q * 4);
+          mv[q * 4] = m4.x; mv[q * 4 + 1] = m4.y; mv[q * 4 + 2] = m4.z; mv[q * 4 + 3] = m4.w;
+        }
+      }
+      if (mask_mode >= MASK_BN_BWD) {
+        // data gradient of a conv whose input BatchNorm is folded: dx = K0 dz + K1 x + K2, x read where a ReLU layer reads its mask
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 k1 = *reinterpret_cast<const float4*>(bias + M + mb + q * 4), k2 = *reinterpret_cast<const float4*>(bias + 2 * M + mb + q * 4);
+          v[q * 4] = fmaf(bv[q * 4], a[q * 4], fmaf(k1.x, mv[q * 4], k2.x));
+          v[q * 4 + 1] = fmaf(bv[q * 4 + 1], a[q * 4 + 1], fmaf(k1.y, mv[q * 4 + 1], k2.y));
+          v[q * 4 + 2] = fmaf(bv[q * 4 + 2], a[q * 4 + 2], fmaf(k1.z, mv[q * 4 + 2], k2.z));
+          v[q * 4 + 3] = fmaf(bv[q * 4 + 3], a[q * 4 + 3], fmaf(k1.w, mv[q * 4 + 3], k2.w));
+        }
+        if (mask_mode == MASK_BN_BWD_RELU) {               // x = relu(conv): the gradient stops where it was clipped
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = mv[i] > 0.f ? v[i] : 0.f;
+        }
+      } else if (mask_mode == MASK_BIAS_TAB && (py == 0 || py == H - 1 || px_ == 0 || px_ == W - 1)) {
+        // forward of such a conv: border pixels see fewer taps of the BatchNorm shift -- the bias vector of their border class (`mask` = table [16][M])
+        const int cls = (((py == 0) | ((py == H - 1) << 1)) << 2) | ((px_ == 0) | ((px_ == W - 1) << 1));
+        const float* tb = mask + (long long)cls * M + mb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4*>(tb + q * 4);
+          v[q * 4] = a[q * 4] + b4.x; v[q * 4 + 1] = a[q * 4 + 1] + b4.y; v[q * 4 + 2] = a[q * 4 + 2] + b4.z; v[q * 4 + 3] = a[q * 4 + 3] + b4.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = a[i] + bv[i];
+      }
+      if (!GEN) {
+        if (act == ACT_RELU) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (mask_mode == MASK_RELU) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = mv[i] > 0.f ? v[i] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = apply_act(v[i], act);
+        if (mask_mode >= MASK_BN_BWD) {                    // (v already holds K0 dz + K1 x + K2) then the ELU (+ dropout) derivative of x's producer
+          if (mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP) {
+            const int mm = mask_mode == MASK_BN_BWD_ELU_DROP ? MASK_ELU_DROP : MASK_ELU;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
+              if (mm == MASK_ELU_DROP) ks4 = keep_scale((o >> 2) + q, rate, seed);
+              v[q * 4] *= mask_factor(mv[q * 4], mm, ks4.x, rate); v[q * 4 + 1] *= mask_factor(mv[q * 4 + 1], mm, ks4.y, rate);
+              v[q * 4 + 2] *= mask_factor(mv[q * 4 + 2], mm, ks4.z, rate); v[q * 4 + 3] *= mask_factor(mv[q * 4 + 3], mm, ks4.w, rate);
+            }
+          }
+        } else if (mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) {
+          if (rate > 0.0f) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 ks4 = keep_scale((o >> 2) + q, rate, seed);
+              v[q * 4] *= ks4.x; v[q * 4 + 1] *= ks4.y; v[q * 4 + 2] *= ks4.z; v[q * 4 + 3] *= ks4.w;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 ks4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (mask_mode == MASK_ELU_DROP) ks4 = keep_scale((o >> 2) + q, rate, seed);
+            v[q * 4] *= mask_factor(mv[q * 4], mask_mode, ks4.x, rate); v[q * 4 + 1] *= mask_factor(mv[q * 4 + 1], mask_mode, ks4.y, rate);
+            v[q * 4 + 2] *= mask_factor(mv[q * 4 + 2], mask_mode, ks4.z, rate); v[q * 4 + 3] *= mask_factor(mv[q * 4 + 3], mask_mode, ks4.w, rate);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(y + o + q * 4) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+    }
+  }
+}
+
+template <int NB, int RW, int WPS>
+int32_t launch_h2(unet_ctx* ctx, const float* x, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K,
+                  int M, int act, float rate, unsigned long long seed, hipStream_t s) {
+  constexpr int TH = 4 * RW;
+  constexpr int NPIX = (TH + 2) * 34;
+  constexpr size_t smem = (size_t)2 * NPIX * 32 + (size_t)9 * NB * 2 * 2 * 32 * 16 + 16;
+  if (!mask) mask_mode = MASK_NONE;
+  const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
+  const long long total = (long long)tiles_x * tiles_y * n * groups;
+  if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv h2: too many tiles");
+  const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
+  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP;
+  auto go = [&](auto kern) -> int32_t {
+    if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, wimg, bias, mask, y, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);
+    return UNET_OK;
+  };
+  int32_t r;
+  if (gen) r = go(conv_h2_kernel<NB, RW, true, WPS>); else r = go(conv_h2_kernel<NB, RW, false, WPS>);
+  if (r) return r;
+  UNET_CHECK_LAUNCH(ctx, "conv_h2");
+  return UNET_OK;
+}
+
+int h2_mode() {
+  static const int on = [] { const char* e = getenv("UNET_H2"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = the x3 / fp32-MFMA Winograd kernels
+  return on;
+}
+
+}  // namespace
+
+static int h2_nb(int M) { return (M % 64) == 0 ? 2 : 1; }      // n-blocks of 32 output channels per workgroup
+
+// a launch with K contraction channels and M output channels runs on the h2 kernels (both the weight preparation and the launch ask this)
+bool h2_conv3x3_selected(int K, int M) { return h2_mode() != 0 && K >= 16 && (K % 16) == 0 && M >= 32 && (M % 32) == 0; }
+
+// bytes of the split weight image: 256-B header + 36 * K * M (fits the 16 * cin * cout floats every caller reserves for transformed weights)
+size_t h2_wimg_bytes(int K, int M) { return (size_t)H2_HEADER + (size_t)36 * K * M; }
+
+int32_t k_h2_weights_multi(unet_ctx* ctx, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s) {
+  if (count < 1) return UNET_OK;
+  if (count > UNET_WINO_PREP_MAX) UNET_FAIL(ctx, UNET_E_ARG, "h2_weights_multi: too many layers");
+  unet_wimg_prep_list L; L.n = count;
+  long long most = 1;
+  for (int k = 0; k < count; ++k) {
+    unet_wimg_prep* p = &L.item[k];
+    const int K = flip[k] ? cout[k] : cin[k], M = flip[k] ? cin[k] : cout[k];
+    const int nb = h2_nb(M), groups = (M + 32 * nb - 1) / (32 * nb), nchunks = K / 16;
+    p->w = w[k]; p->img = static_cast<unet_bf16*>(img[k]); p->tap_stride = (long long)cin[k] * cout[k]; p->flip = flip[k];
+    p->sk = flip[k] ? 1 : cout[k]; p->sm = flip[k] ? cout[k] : 1;
+    p->nb = nb; p->nchunks = nchunks; p->m = M;
+    p->total8 = (long long)groups * nchunks * 9 * nb * 2 * 32;
+    most = std::max(most, p->total8);
+  }
+  hipLaunchKernelGGL(h2_wmax_kernel, dim3((unsigned)count), dim3(1024), 0, s, L);
+  hipLaunchKernelGGL(h2_wimg_multi_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 256), (unsigned)count), dim3(256), 0, s, L);
+  UNET_CHECK_LAUNCH(ctx, "h2_weights_multi");
+  return UNET_OK;
+}
+
+int32_t k_h2_weights(unet_ctx* ctx, const float* w, void* img, int cin, int cout, int flip, hipStream_t s) {
+  const float* ws[1] = {w}; void* is[1] = {img};
+  return k_h2_weights_multi(ctx, ws, is, &cin, &cout, &flip, 1, s);
+}
+
+// x [n,h,wd,K] dense NHWC fp32, wimg from k_h2_weights (K contraction channels, M output channels), y [n,h,wd,M] fp32
+int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K,
+                         int M, int act, float rate, uint64_t seed, hipStream_t s) {
+  if (K < 16 || (K % 16) || M < 32 || (M % 32)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: K=%d (multiple of 16) M=%d (multiple of 32)", K, M);
+  if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
+  static const int tile = [] { const char* e = getenv("UNET_H2_TILE"); return e ? atoi(e) : 0; }();          // measurements: 1 = 8-row tiles everywhere, 2 = 16-row tiles for 64-wide groups
+  if (h2_nb(M) == 1) return launch_h2<1, 2, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
+  if (tile == 2 && h > 8) return launch_h2<2, 4, 1>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
+  return launch_h2<2, 2, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
+}

@@ -944,11 +944,13 @@ int32_t k_wino_weights_multi(unet_ctx* ctx, unet_wino_prep_list* L, const int* h
     const float* xw[UNET_WINO_PREP_MAX]; void* xi[UNET_WINO_PREP_MAX]; int xci[UNET_WINO_PREP_MAX], xco[UNET_WINO_PREP_MAX], xf[UNET_WINO_PREP_MAX], nx = 0, keep = 0;
     for (int k = 0; k < L->n; ++k) {
       const unet_wino_prep p = L->item[k];
-      if (x3_conv3x3_selected(p.flip ? p.cout : p.cin, p.flip ? p.cin : p.cout)) { xw[nx] = p.w; xi[nx] = p.u; xci[nx] = p.cin; xco[nx] = p.cout; xf[nx] = p.flip; ++nx; }
+      if (h2_conv3x3_selected(p.flip ? p.cout : p.cin, p.flip ? p.cin : p.cout) || x3_conv3x3_selected(p.flip ? p.cout : p.cin, p.flip ? p.cin : p.cout)) { xw[nx] = p.w; xi[nx] = p.u; xci[nx] = p.cin; xco[nx] = p.cout; xf[nx] = p.flip; ++nx; }
       else { L->item[keep] = p; hk[keep] = h[k]; ++keep; }
     }
     if (nx) {
-      int32_t r = k_x3_weights_multi(ctx, xw, xi, xci, xco, xf, nx, s);
+      // (one predicate for the whole list: h2 and x3 take the same shapes, h2 is asked first)
+      int32_t r = h2_conv3x3_selected(xf[0] ? xco[0] : xci[0], xf[0] ? xci[0] : xco[0]) ? k_h2_weights_multi(ctx, xw, xi, xci, xco, xf, nx, s)
+                                                                                        : k_x3_weights_multi(ctx, xw, xi, xci, xco, xf, nx, s);
       if (r) return r;
     }
     L->n = keep; h = hk;
@@ -967,6 +969,7 @@ int32_t k_wino_weights_multi(unet_ctx* ctx, unet_wino_prep_list* L, const int* h
 
 // transformed weights for k_conv3x3_wino_fwd on an image of `h` rows (the 2-D form is picked per shape, both sides must agree)
 int32_t k_wino_weights(unet_ctx* ctx, const float* w, float* u, int cin, int cout, int flip, int h, hipStream_t s) {
+  if (h2_conv3x3_selected(flip ? cout : cin, flip ? cin : cout)) return k_h2_weights(ctx, w, u, cin, cout, flip, s);
   if (x3_conv3x3_selected(flip ? cout : cin, flip ? cin : cout)) return k_x3_weights(ctx, w, u, cin, cout, flip, s);
   const long long total = (long long)cin * cout;
   hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, w, u, cin, cout, flip,
@@ -980,6 +983,7 @@ int32_t k_conv3x3_wino_fwd(unet_ctx* ctx, const float* x, const float* u, const 
                            int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   if (!wino_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: cin=%d cout=%d unsupported", cin, cout);
   if ((long long)h * wd * std::max(cin, cout) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 winograd: one image must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
+  if (h2_conv3x3_selected(cin, cout)) return k_conv3x3_h2_fwd(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);      // u = the split fp16 weight image
   if (x3_conv3x3_selected(cin, cout)) return k_conv3x3_x3_fwd(ctx, x, u, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);      // u = the split weight image
   if (use_2d(h, cout)) {
     // UNET_WINO_4WAY: 0 never, 1 (default) the four-way accumulator split for 32-wide cout groups (c1b 0.54 -> 0.52 ms, c9a 0.89 -> 0.86;

@@ -163,6 +163,7 @@ double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin,
   static float dummy;
   if (!use_wino(algo, wd, cin, cout, &dummy)) return 1.0;
   // x3 kernels: six bf16 MFMA products per multiply on a pipe 2500 / 157.3 times faster than the fp32 MFMA -> this fraction of the fp32-MFMA time
+  if (h2_conv3x3_selected(cin, cout)) return 3.0 * 157.3 / 2500.0;          // h2 kernels: three fp16 MFMA products per multiply
   if (x3_conv3x3_selected(cin, cout)) return 6.0 * 157.3 / 2500.0;
   return wino_uses_2d(h, cout) ? 4.0 / 9.0 : 2.0 / 3.0;
 }

