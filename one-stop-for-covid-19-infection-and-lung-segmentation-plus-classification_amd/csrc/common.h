@@ -196,6 +196,9 @@ int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, in
 int32_t k_h2_weights_multi(unet_ctx*, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s);
 int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
                          int act, float rate, uint64_t seed, hipStream_t s);
+bool h2_wgrad_selected(int cin, int cout);
+size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
+int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);
 bool x3_conv3x3_selected(int K, int M);
 size_t x3_wimg_bytes(int K, int M);
 int32_t k_x3_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s);

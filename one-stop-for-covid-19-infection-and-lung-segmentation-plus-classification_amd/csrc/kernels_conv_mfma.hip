@@ -967,7 +967,8 @@ int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // large enough for the direct AND the Winograd form
   if (!mfma_wgrad_supported(cin, cout)) return 0;
   const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout), q = plan_wgrad(12, n, h, wd, cin, cout, cout), r = plan_wgrad(16, n, h, wd, cin, cout, cout, true);
-  return std::max(std::max(p.part_floats + p.bias_floats + p.part2_floats, q.part_floats + q.bias_floats + q.part2_floats), r.part_floats + r.bias_floats + r.part2_floats) * sizeof(float);
+  return std::max(std::max(std::max(p.part_floats + p.bias_floats + p.part2_floats, q.part_floats + q.bias_floats + q.part2_floats), r.part_floats + r.bias_floats + r.part2_floats) * sizeof(float),
+                  h2_wgrad_ws_bytes(n, h, wd, cin, cout));
 }
 
 // ---- weight gradient of a conv whose input BatchNorm was folded into it (common.h: k_bn_fold_prepare) --------------------------------------

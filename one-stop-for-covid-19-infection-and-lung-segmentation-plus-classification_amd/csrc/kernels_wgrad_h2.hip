@@ -1,0 +1,343 @@
+// fp32 weight gradient of conv3x3 on the 16-bit matrix cores with fp32 accuracy: the "h2" form (see kernels_conv_h2.hip for the arithmetic).
+//   dW[tap][ci][co] = sum_p X[p + tap][ci] * dY[p][co],   db[co] = sum_p dY[p][co]
+// GEMM per tap with K = pixels: A = X (32 input channels x 16 pixels), B = dY (16 pixels x 32 output channels); both operands are ACTIVATIONS here, so
+// both are block-scaled while they are staged: the workgroup tracks one running exponent per operand (max |x|, max |dy| of every staged row block:
+// registers -> wave shuffle -> LDS words, no extra barrier; when a block needs a lower exponent the accumulators are multiplied by the exact
+// power-of-two ratio), splits x 2^e into two fp16 planes and accumulates xh dym + xm dyh + xh dyh in fp32.  The partial slabs leave multiplied
+// by 2^-(e_x + e_dy).  Everything else is the structure of wgrad_bf16_kernel (kernels_bf16.hip): split-K over (image, 32-column strip, row chunk),
+// rows staged as they come from HBM ([plane][32-channel sub-plane][row][pixel][32 ch] fp16) and read back with the gfx950 LDS transpose read
+// ds_read_b64_tr_b16 (8 consecutive pixels of one channel per lane), 4 waves = WA x WB channel tiles x WR row phases, 9 taps = 144 accumulator
+// registers per wave, fixed-order slab reduction (k_wgrad_reduce: deterministic).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unet_f32x16 f32x16;
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m) {
+  const f16x2 hh = __builtin_convertvector((unet_f32x2){a, b}, f16x2);
+  const f16x2 mm = __builtin_convertvector((unet_f32x2){a - (float)hh[0], b - (float)hh[1]}, f16x2);
+  h = __builtin_bit_cast(unsigned, hh); m = __builtin_bit_cast(unsigned, mm);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }          // -126 <= e <= 127
+
+__device__ __forceinline__ f16x8 lds_tr_frag(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(f16x8, v);
+}
+
+constexpr int APX = 34;                                       // X pixels per staged row (32 + halo)
+
+// R = dY rows per step.  R = 2 (default): 9 + 4 staged pieces beside the 144 accumulators fit 256 registers -> two workgroups per CU cover each other's
+// staging phases; R = 4: twice the MFMAs per barrier pair but one workgroup per CU (512-register budget): measured 25 % slower (UNET_WGRAD_H2_ROWS=4)
+template <int WA, int WB, int WR, int R>
+__global__ __launch_bounds__(256, R == 4 ? 1 : 2) void wgrad_h2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
+                                                          int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
+                                                          int npairs, long long pstride, int units, int upb) {
+  static_assert(WA * WB * WR == 4 && WR <= R, "4 waves");
+  constexpr int TAPS = 9, AROWS = R + 2;
+  constexpr int ASUB = AROWS * APX * 64, BSUB = R * 32 * 64;      // bytes of one 32-channel sub-plane of one fp16 plane
+  constexpr int STAGE1 = WA * ASUB + WB * BSUB;                   // one fp16 plane of everything that is staged per step
+  constexpr int RED = WR > 1 ? 2 * TAPS * 16 * 64 * 4 : 0;        // two accumulator images for the row-phase reduction
+  constexpr int STAGE = 2 * STAGE1;
+  __shared__ __attribute__((aligned(16))) char smem[STAGE > RED ? STAGE : RED];
+  __shared__ float s_bs[4][64];
+  __shared__ float s_amax[2][4];
+  char* const s_a = smem; char* const s_b = smem + WA * ASUB;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave % WR, wb = (wave / WR) % WB, wa = wave / (WR * WB);
+  // XCD-aware block map: all channel-tile pairs of one pixel split run on the same XCD back to back
+  const int sq = blockIdx.x >> 3;
+  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);
+  if (split >= nsplit) return;
+  const int ta = pair / tiles_b, tb = pair % tiles_b;
+  const int a0 = ta * 32 * WA, b0 = tb * 32 * WB;
+  const int chunk = split % chunks_per_strip; const int ublk = split / chunks_per_strip;
+  const int ya = chunk * rows_per_chunk;
+  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bsum = 0.0f;
+  int e_a = 120, e_b = 120;                                      // running exponents: staged values are x * 2^e_a, dy * 2^e_b
+
+  // transpose-read addressing: 16-lane group g4 reads [4 pixels][16 channels]; lane i -> pixel i>>2, channel quad i&3
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int tr_px = (g4 >> 1) * 8 + (i16 >> 2), tr_ch = ((g4 & 1) * 16 + (i16 & 3) * 4) * 2;
+  const char* const pa = s_a + wa * ASUB + tr_ch;
+  const char* const pb = s_b + wb * BSUB + tr_ch;
+
+  const int u1 = (ublk + 1) * upb < units ? (ublk + 1) * upb : units;
+  for (int unit = ublk * upb; unit < u1; ++unit) {
+    const int cs = unit % strips, n = unit / strips;
+    const int x0 = cs * 32;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + (long long)n * H * W * CA, (long long)H * W * CA * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + (long long)n * H * W * CB, (long long)H * W * CB * 4);
+    // staging plan.  A thread always fetches channel quad q = tid & 7 of pixel column pc = tid >> 3 (0..31) of a staged row, so one byte offset per
+    // operand (and per 32-channel sub-plane: its validity differs) is all it keeps; rows and sub-planes are wave-uniform immediates.  The X rows have
+    // 34 pixels: columns 0..31 (image column x0 - 1 + pc) go with the main pieces, columns 32 / 33 with one extra piece of the first 16 * WA * AROWS threads.
+    const int q8 = tid & 7, pc = tid >> 3;
+    int abase_t[WA], bbase_t[WB];
+#pragma unroll
+    for (int sub = 0; sub < WA; ++sub) {
+      const int gx = x0 - 1 + pc, ch = a0 + sub * 32 + q8 * 4;
+      abase_t[sub] = (gx >= 0 && gx < W && ch < CA) ? (gx * CA + ch) * 4 : UNET_OOB;
+    }
+#pragma unroll
+    for (int sub = 0; sub < WB; ++sub) {
+      const int gx = x0 + pc, ch = b0 + sub * 32 + q8 * 4;
+      bbase_t[sub] = (gx < W && ch < CB) ? (gx * CB + ch) * 4 : UNET_OOB;
+    }
+    // halo piece: thread t < 16 * WA * AROWS -> column 32 + ((t >> 3) & 1), (sub, row) = t >> 4
+    constexpr int HALO_T = 16 * WA * AROWS;
+    const int h_rs = tid >> 4, h_row = h_rs % AROWS, h_sub = h_rs / AROWS, h_px = 32 + ((tid >> 3) & 1);
+    int hbase_t;
+    {
+      const int gx = x0 - 1 + h_px, ch = a0 + h_sub * 32 + q8 * 4;
+      hbase_t = (tid < HALO_T && gx < W && ch < CA) ? (gx * CA + ch) * 4 : UNET_OOB;
+    }
+    constexpr int NA = WA * AROWS, NB_ = WB * R;                 // main pieces per thread
+    unet_u32x4 areg[NA + 1], breg[NB_];
+    auto issue_loads = [&](int ys) __attribute__((always_inline)) {        // ys = first dY row of the step
+      const int ysa = ys - 1;                                            // image row of staged X row 0 (the halo row above)
+#pragma unroll
+      for (int sub = 0; sub < WA; ++sub)
+#pragma unroll
+        for (int row = 0; row < AROWS; ++row) {
+          const int gy = ysa + row;                                      // wave-uniform
+          const bool ok = gy >= 0 && gy < H;
+          areg[sub * AROWS + row] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? abase_t[sub] : UNET_OOB, ok ? gy * W * CA * 4 : 0, 0);
+        }
+      {
+        const int gy = ysa + h_row;
+        areg[NA] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (gy >= 0 && gy < H) ? hbase_t + gy * W * CA * 4 : UNET_OOB, 0, 0);
+      }
+#pragma unroll
+      for (int sub = 0; sub < WB; ++sub)
+#pragma unroll
+        for (int row = 0; row < R; ++row) {
+          const int gy = ys + row;
+          const bool ok = gy < yb;                                       // rows past the chunk contribute 0
+          breg[sub * R + row] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, ok ? bbase_t[sub] : UNET_OOB, ok ? gy * W * CB * 4 : 0, 0);
+        }
+    };
+    auto post_amax = [&]() __attribute__((always_inline)) {
+      float ma = 0.f, mb = 0.f;
+#pragma unroll
+      for (int k = 0; k < NA + 1; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ma = fmaxf(ma, fabsf(__uint_as_float(areg[k][j])));
+#pragma unroll
+      for (int k = 0; k < NB_; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mb = fmaxf(mb, fabsf(__uint_as_float(breg[k][j])));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+      if (lane == 0) { s_amax[0][wave] = ma; s_amax[1][wave] = mb; }
+    };
+    auto store_lds = [&]() __attribute__((always_inline)) {
+      const float ma = fmaxf(fmaxf(s_amax[0][0], s_amax[0][1]), fmaxf(s_amax[0][2], s_amax[0][3]));
+      const float mb = fmaxf(fmaxf(s_amax[1][0], s_amax[1][1]), fmaxf(s_amax[1][2], s_amax[1][3]));
+      const int eba = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(ma) >> 23) & 0xFF));
+      const int ebb = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(mb) >> 23) & 0xFF));
+      int d = 0;
+      if (eba >= 11 && eba - 127 + e_a >= 15) { d += 138 - eba - e_a; e_a = 138 - eba; }      // re-centre the block maximum at [2^11, 2^12)
+      if (ebb >= 11 && ebb - 127 + e_b >= 15) {
+        const int db_ = 138 - ebb - e_b;
+        bsum *= pow2f(max(db_, -126));
+        d += db_; e_b = 138 - ebb;
+      }
+      if (d != 0) {
+        const float f = pow2f(max(d, -126));
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+      }
+      const float sa = pow2f(e_a), sb = pow2f(e_b);
+      auto put = [&](char* dst, const unet_u32x4& v, float sc) __attribute__((always_inline)) {
+        unsigned h0, m0, h1, m1;
+        split2(__uint_as_float(v[0]) * sc, __uint_as_float(v[1]) * sc, h0, m0);
+        split2(__uint_as_float(v[2]) * sc, __uint_as_float(v[3]) * sc, h1, m1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + STAGE1) = make_uint2(m0, m1);
+      };
+      // LDS layout of a plane: X [sub][row][34 px][64 B], then dY [sub][row][32 px][64 B]; image column x0 - 1 + p sits at pixel slot p
+#pragma unroll
+      for (int sub = 0; sub < WA; ++sub)
+#pragma unroll
+        for (int row = 0; row < AROWS; ++row) put(s_a + ((sub * AROWS + row) * APX + pc) * 64 + q8 * 8, areg[sub * AROWS + row], sa);
+      if (tid < HALO_T) put(s_a + ((h_sub * AROWS + h_row) * APX + h_px) * 64 + q8 * 8, areg[NA], sa);
+#pragma unroll
+      for (int sub = 0; sub < WB; ++sub)
+#pragma unroll
+        for (int row = 0; row < R; ++row) put(s_b + ((sub * R + row) * 32 + pc) * 64 + q8 * 8, breg[sub * R + row], sb);
+    };
+
+    issue_loads(ya);
+    post_amax();
+    __syncthreads();
+    store_lds();
+    __syncthreads();
+    for (int ys = ya; ys < yb; ys += R) {
+      const bool more = ys + R < yb;
+      if (more) issue_loads(ys + R);
+#pragma unroll
+      for (int r = wr; r < R; r += WR) {
+#pragma unroll
+        for (int kst = 0; kst < 2; ++kst) {
+          const char* bp = pb + (r * 32 + kst * 16 + tr_px) * 64;
+          const f16x8 bh = lds_tr_frag(bp, bp + 4 * 64), bm = lds_tr_frag(bp + STAGE1, bp + STAGE1 + 4 * 64);
+          if (wa == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += (float)bh[j] + (float)bm[j];
+          }
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            // the three taps of a kernel row together: 3 products x 3 taps, consecutive MFMAs on different accumulators (a dependent 32x32x16 MFMA right
+            // behind its producer stalls the matrix pipe)
+            f16x8 ah[3], am[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const char* ap = pa + ((r + ky) * APX + kst * 16 + tr_px + kx) * 64;
+              ah[kx] = lds_tr_frag(ap, ap + 4 * 64); am[kx] = lds_tr_frag(ap + STAGE1, ap + STAGE1 + 4 * 64);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kx], bm, acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[kx], bh, acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kx], bh, acc[ky * 3 + kx], 0, 0, 0);
+          }
+        }
+      }
+      if (more) post_amax();
+      __syncthreads();
+      if (more) { store_lds(); __syncthreads(); }
+    }
+  }
+  const float un_b = pow2f(max(-e_b, -126));
+  const float un = pow2f(max(-e_a, -126)) * un_b;                 // 2^-(e_x + e_dy)
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] *= un;
+  bsum *= un_b;
+
+  // ---- row phases of one channel tile are summed inside the workgroup (fixed order, through LDS): one slab per split
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (WR > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    const int grp = wave / WR;
+    s_bs[wave][lane] = bsum;
+#pragma unroll
+    for (int stride = WR / 2; stride >= 1; stride >>= 1) {
+      float* img = red + (size_t)(grp * stride + (wr % stride)) * (TAPS * 16 * 64);
+      if (wr >= stride && wr < 2 * stride) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) img[(t * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (wr < stride) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += img[(t * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (wr == 0) { bsum = s_bs[wave][lane]; for (int k = 1; k < WR; ++k) bsum += s_bs[wave + k][lane]; }
+  }
+  if (wr != 0) return;
+  float* P = part + (long long)split * pstride;
+  const int ar = a0 + wa * 32, bc = b0 + wb * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = acc[t][r];
+    }
+  if (wa == 0 && ta == 0 && lane < 32 && bc < CB) P[(long long)TAPS * CA * CB + bc] = bsum;
+}
+
+struct WgPlanH2 { int WA, WB, WR, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs, units, upb; size_t floats; };
+
+int wgrad_h2_rows() {
+  static const int r = [] { const char* e = getenv("UNET_WGRAD_H2_ROWS"); return e && atoi(e) == 4 ? 4 : 2; }();          // measured: 2 rows, two workgroups per CU
+  return r;
+}
+
+WgPlanH2 plan_wgrad_h2(int n, int h, int w, int ca, int cb) {
+  WgPlanH2 p;
+  const int R = wgrad_h2_rows();
+  p.WA = (ca % 64) == 0 ? 2 : 1; p.WB = (cb % 64) == 0 ? 2 : 1;
+  p.WR = 4 / (p.WA * p.WB); if (p.WR > R) { p.WB = 2; p.WR = 4 / (p.WA * p.WB); }      // (a 64-wide dY tile may overhang cb: masked)
+  p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
+  const long long pairs = (long long)p.tiles_a * p.tiles_b, per = 9LL * ca * cb;
+  const long long units = (long long)n * p.strips;
+  static const long long target_env = [] { const char* e = getenv("UNET_WGRAD_H2_BLOCKS"); return e ? atoll(e) : 0LL; }();
+  const long long target = target_env ? target_env : (R == 4 ? 256LL : 512LL);          // one resident round: 256 CUs x 1 (R = 4) or 2 (R = 2) workgroups
+  long long want = std::max<long long>(1, target / pairs);
+  const long long cap = std::max<long long>(1, (64LL << 20) / per);
+  want = std::min(want, cap);
+  p.units = (int)units; p.upb = (int)std::max<long long>(1, units / want);
+  const long long ublocks = (units + p.upb - 1) / p.upb;
+  long long cps = std::max<long long>(1, want / ublocks);
+  cps = std::min<long long>(cps, std::max<long long>(1, h / 8));
+  int rpc = (int)((h + cps - 1) / cps); rpc = (rpc + R - 1) / R * R;                // whole steps
+  p.rows_per_chunk = rpc; p.chunks_per_strip = (h + rpc - 1) / rpc;
+  p.nsplit = (int)(ublocks * p.chunks_per_strip); p.nslabs = p.nsplit;
+  p.floats = (size_t)p.nslabs * (per + cb) + wgrad_reduce_scratch_floats(9, ca, cb, cb, p.nslabs);
+  return p;
+}
+
+int h2_wgrad_mode() {
+  static const int on = [] { const char* e = getenv("UNET_H2_WGRAD"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = the fp32-MFMA Winograd weight gradient
+  return on;
+}
+
+}  // namespace
+
+// (32 x 32-channel layers would run a 64-wide dY tile half empty: they stay on the fp32 Winograd weight gradient)
+bool h2_wgrad_selected(int cin, int cout) { return h2_wgrad_mode() != 0 && cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0 && (cin >= 64 || cout >= 64); }
+size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_wgrad_selected(cin, cout) ? plan_wgrad_h2(n, h, wd, cin, cout).floats * sizeof(float) : 0; }
+
+int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
+                           hipStream_t s) {
+  if (cin < 16 || (cin % 16) || cout < 16 || (cout % 16)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2: cin=%d cout=%d unsupported (multiples of 16)", cin, cout);
+  if ((long long)h * wd * std::max(cin, cout) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  const WgPlanH2 p = plan_wgrad_h2(n, h, wd, cin, cout);
+  if (!ws || ws_bytes < p.floats * sizeof(float)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad h2: workspace %zu < %zu bytes", ws_bytes, p.floats * sizeof(float));
+  float* part = static_cast<float*>(ws);
+  const long long S = 9LL * cin * cout + cout;
+  const int npairs = p.tiles_a * p.tiles_b;
+  const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
+#define UNET_WG(WA_, WB_, WR_) if (wgrad_h2_rows() == 4) hipLaunchKernelGGL((wgrad_h2_kernel<WA_, WB_, WR_, 4>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, \
+                                                  p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb); \
+                               else hipLaunchKernelGGL((wgrad_h2_kernel<WA_, WB_, WR_, 2>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, \
+                                                  p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb)
+  if (p.WA == 2 && p.WB == 2) UNET_WG(2, 2, 1);
+  else if (p.WA == 2) UNET_WG(2, 1, 2);
+  else UNET_WG(1, 2, 2);
+#undef UNET_WG
+  UNET_CHECK_LAUNCH(ctx, "wgrad_h2");
+  return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
+}

@@ -131,6 +131,8 @@ static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float
                                       size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
   if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout)) {
     const int wino = wgrad_wino_enabled();
+    if (algo == UNET_ALGO_AUTO && h2_wgrad_selected(cin, cout) && ws_bytes >= h2_wgrad_ws_bytes(n, h, wd, cin, cout))
+      return k_conv3x3_h2_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);      // three fp16 MFMA products of the block-scaled two-term split
     if (algo == UNET_ALGO_WINOGRAD || (algo == UNET_ALGO_AUTO && wino)) return k_conv3x3_wino_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   }
@@ -172,6 +174,7 @@ double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin,
 double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
   (void)wd;
   if (algo == UNET_ALGO_NAIVE || !mfma_wgrad_supported(cin, cout)) return 1.0;
+  if (algo == UNET_ALGO_AUTO && h2_wgrad_selected(cin, cout)) return 3.0 * 157.3 / 2500.0;
   if (algo == UNET_ALGO_WINOGRAD || (algo == UNET_ALGO_AUTO && wgrad_wino_enabled())) return wino_wgrad_exec_ratio(h);
   return 1.0;
 }
