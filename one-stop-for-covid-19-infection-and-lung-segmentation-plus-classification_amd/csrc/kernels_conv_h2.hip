@@ -49,27 +49,29 @@ __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned
 //   img = [header 256 B][((((((g*nchunks + chunk)*9 + tap)*NB + nb)*2 + plane)*2 + half)*32 + m][8 fp16]
 //   k = chunk*16 + half*8 + j,  mm = (g*NB + nb)*32 + cperm(m),  W(tap,k,mm) = w[(flip ? 8-tap : tap)*tap_stride + k*sk + mm*sm] * 2^e_w
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void h2_wmax_kernel(unet_wimg_prep_list L) {
-  const unet_wimg_prep& p = L.item[blockIdx.x];
+// header words of an image: [0] = 2^-e_w, [1] = 2^e_w (floats, written by h2_wscale_kernel), [2] = bit pattern of max |w| (atomicMax target)
+__global__ __launch_bounds__(64) void h2_wzero_kernel(unet_wimg_prep_list L) {
+  if (threadIdx.x < (unsigned)L.n) reinterpret_cast<unsigned*>(L.item[threadIdx.x].img)[2] = 0u;
+}
+__global__ __launch_bounds__(256) void h2_wmax_kernel(unet_wimg_prep_list L) {          // grid (blocks, layers)
+  const unet_wimg_prep& p = L.item[blockIdx.y];
   const long long n4 = 9LL * p.tap_stride / 4;               // tap_stride = cin * cout (a multiple of 4)
   float mx = 0.f;
-  for (long long i = threadIdx.x; i < n4; i += 1024) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(p.w)[i];
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
-  __shared__ float red[16];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
-    const int eb = (int)((__float_as_uint(mx) >> 23) & 0xFF);
-    int e = eb >= 11 ? scale_exp_for(eb) : 0;
-    e = min(max(e, -100), 100);
-    float* hdr = reinterpret_cast<float*>(reinterpret_cast<char*>(p.img));
-    hdr[0] = pow2f(-e); hdr[1] = pow2f(e);
-  }
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.img) + 2, __float_as_uint(mx));          // non-negative floats order like their bit patterns
+}
+__global__ __launch_bounds__(64) void h2_wscale_kernel(unet_wimg_prep_list L) {
+  if (threadIdx.x >= (unsigned)L.n) return;
+  float* hdr = reinterpret_cast<float*>(L.item[threadIdx.x].img);
+  const int eb = (int)((reinterpret_cast<unsigned*>(hdr)[2] >> 23) & 0xFF);
+  int e = eb >= 11 ? scale_exp_for(eb) : 0;
+  e = min(max(e, -100), 100);
+  hdr[0] = pow2f(-e); hdr[1] = pow2f(e);
 }
 __global__ __launch_bounds__(256) void h2_wimg_multi_kernel(unet_wimg_prep_list L) {          // blockIdx.y = layer
   const unet_wimg_prep& p = L.item[blockIdx.y];
@@ -407,7 +409,10 @@ int32_t k_h2_weights_multi(unet_ctx* ctx, const float* const* w, void* const* im
     p->total8 = (long long)groups * nchunks * 9 * nb * 2 * 32;
     most = std::max(most, p->total8);
   }
-  hipLaunchKernelGGL(h2_wmax_kernel, dim3((unsigned)count), dim3(1024), 0, s, L);
+  static_assert(UNET_WINO_PREP_MAX <= 64, "one lane per layer");
+  hipLaunchKernelGGL(h2_wzero_kernel, dim3(1), dim3(64), 0, s, L);
+  hipLaunchKernelGGL(h2_wmax_kernel, dim3(48, (unsigned)count), dim3(256), 0, s, L);
+  hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(64), 0, s, L);
   hipLaunchKernelGGL(h2_wimg_multi_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 256), (unsigned)count), dim3(256), 0, s, L);
   UNET_CHECK_LAUNCH(ctx, "h2_weights_multi");
   return UNET_OK;

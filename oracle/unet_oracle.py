@@ -173,9 +173,28 @@ def bn_moving_update(mean, var, mu, va, n):
     return new_mean, new_var
 
 
-def maxpool2x2(x):
-    """MaxPooling2D((2,2)) T1:862: stride 2, 'valid'; ties -> first in row-major (di,dj)."""
+def maxpool2x2(x, sel=None):
+    """MaxPooling2D((2,2)) T1:862: stride 2, 'valid'; ties -> first in row-major (di,dj).
+    sel ({0,1} array of x's shape with exactly one 1 per 2 x 2 window): take THAT element of every window instead of the maximum -- the same
+    function wherever it is the maximum; the GPU tests pass the engine's own choices (pool_selection) so that a window whose two largest
+    entries differ by less than the fp32 round-off (the gradient is routed to the other element: a discontinuity, not an arithmetic error) does
+    not enter the gradient comparison."""
+    if sel is not None:
+        n, h, w, c = x.shape
+        return (x * sel)[:, :h // 2 * 2, :w // 2 * 2].reshape(n, h // 2, 2, w // 2, 2, c).sum(dim=(2, 4))
     return F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+
+
+def pool_selection(x):
+    """{0,1} float64 array marking, per 2 x 2 window of x [N,H,W,C] (numpy), the element MaxPooling2D picks (first maximum in row-major order)."""
+    x = np.asarray(x)
+    n, h, w, c = x.shape
+    h2, w2 = h // 2, w // 2
+    win = x[:, :h2 * 2, :w2 * 2].reshape(n, h2, 2, w2, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(n, h2, w2, c, 4)
+    one = np.eye(4)[win.argmax(-1)]                                      # first maximum on ties
+    sel = np.zeros((n, h, w, c))
+    sel[:, :h2 * 2, :w2 * 2] = one.reshape(n, h2, w2, c, 2, 2).transpose(0, 1, 4, 2, 5, 3).reshape(n, h2 * 2, w2 * 2, c)
+    return sel
 
 
 def dropout(x, keep_mask, rate=DROPOUT_RATE):
@@ -211,12 +230,13 @@ def store_bf16(t):
     return _StoreBF16.apply(t)
 
 
-def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False, relu_masks=None):
+def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False, relu_masks=None, pool_sel=None):
     """Whole graph T1:853-916.  weights: dict name->array/tensor.  x: [N,H,W,Cin].
     keep_masks: None (dropout off / inference) or dict 'p1'..'p4' -> {0,1} arrays of the
     pooled shapes.  store: None, or store_bf16 to emulate bf16 storage of every activation the engine materialises
     (conv / BN / pool / ConvT outputs and the concat buffers; the probabilities stay full precision).
-    relu_masks: None or dict conv name ('c1a' ... 'c9b') -> {0,1} array: the ReLU sign pattern to use (see conv3x3_bias_relu).
+    relu_masks: None or dict conv name ('c1a' ... 'c9b') -> {0,1} array: the ReLU sign pattern to use (see conv3x3_bias_relu);
+    pool_sel: None or dict 'p1'..'p4' -> {0,1} array: the element every 2 x 2 pooling window takes (see maxpool2x2).
     ckpt: recompute each block in backward (torch.utils.checkpoint) instead of keeping its intermediates: same
     arithmetic, a third of the memory -- what lets the fp64 golden of the 512x512 batch-16 step fit in this
     container (tests/golden/make_fullsize_goldens.py); no activations are returned then.
@@ -243,7 +263,7 @@ def forward(weights, x, training=False, keep_masks=None, dtype=torch.float32, wa
         h = st(h); stats[f"bn{k}"] = (mu.detach(), va.detach(), h.shape[0] * h.shape[1] * h.shape[2])
         if keep: a[f"bn{k}"] = h
         skip = h
-        h = st(maxpool2x2(h))
+        h = st(maxpool2x2(h, _t(pool_sel[f"p{k}"], dtype) if pool_sel is not None else None))
         if training and keep_masks is not None:
             h = st(dropout(h, _t(keep_masks[f"p{k}"], dtype)))
         if keep: a[f"p{k}"] = h
@@ -334,13 +354,13 @@ def sm_scores(tp, spr, sgt, smooth=SM_SMOOTH):
 # ---------------------------------------------------------------------------------------
 # Training step (fwd -> loss -> autograd bwd -> Keras-form Adam) and evaluation
 # ---------------------------------------------------------------------------------------
-def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False, relu_masks=None):
+def loss_and_grads(weights, x, y, keep_masks=None, dtype=torch.float32, want_acts=False, store=None, ckpt=False, relu_masks=None, pool_sel=None):
     """One training-mode fwd + bwd.  Returns dict(loss, dice, grads{name}, bn_stats, p[, acts, act_grads])."""
     names = trainable_names(np.asarray(x).shape[-1])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=want_acts, store=store, ckpt=ckpt, relu_masks=relu_masks)
+    p, acts, stats = forward(W, x, training=True, keep_masks=keep_masks, dtype=dtype, want_acts=want_acts, store=store, ckpt=ckpt, relu_masks=relu_masks, pool_sel=pool_sel)
     t = _t(y, dtype)
     loss = bce_dice_loss(t, p)
     dice = dice_coeff(t, p)
@@ -636,7 +656,7 @@ def cls_init_weights(seed: int = 0, in_ch: int = 1, hw=(224, 224), dtype=np.floa
     return w
 
 
-def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32, want_acts=False, ckpt=False, relu_masks=None):
+def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32, want_acts=False, ckpt=False, relu_masks=None, pool_sel=None):
     """keep_mask: None or {0,1} array [n, 32] of the Dropout(0.4) after Dense(32).  ckpt: recompute each conv block in
     backward (see forward()).  Returns (p [n], acts, bn stats)."""
     W = {k: _t(v, dtype) for k, v in weights.items()}
@@ -652,7 +672,7 @@ def cls_forward(weights, x, training=False, keep_mask=None, dtype=torch.float32,
             h, mu, va = batchnorm(h, W[nm + "/gamma"], W[nm + "/beta"], W[nm + "/mean"], W[nm + "/var"], training)
             stats[nm] = (mu.detach(), va.detach(), src.shape[0] * src.shape[1] * src.shape[2])
             if keep: a[nm] = h
-        h = maxpool2x2(h)
+        h = maxpool2x2(h, _t(pool_sel[f"p{k}"], dtype) if pool_sel is not None else None)
         if keep: a[f"p{k}"] = h
         return h
 
@@ -690,13 +710,13 @@ def cls_loss(y_true, y_pred, class_weights=(1.0, 1.0)):
     return (l * w).mean()
 
 
-def cls_loss_and_grads(weights, x, y, keep_mask=None, class_weights=(1.0, 1.0), dtype=torch.float32, want_acts=False, ckpt=False, relu_masks=None):
+def cls_loss_and_grads(weights, x, y, keep_mask=None, class_weights=(1.0, 1.0), dtype=torch.float32, want_acts=False, ckpt=False, relu_masks=None, pool_sel=None):
     xs = np.asarray(x)
     names = cls_trainable_names(xs.shape[-1], xs.shape[1:3])
     W = {k: _t(v, dtype).clone() for k, v in weights.items()}
     for k in names:
         W[k].requires_grad_(True)
-    p, acts, stats = cls_forward(W, x, training=True, keep_mask=keep_mask, dtype=dtype, want_acts=want_acts, ckpt=ckpt, relu_masks=relu_masks)
+    p, acts, stats = cls_forward(W, x, training=True, keep_mask=keep_mask, dtype=dtype, want_acts=want_acts, ckpt=ckpt, relu_masks=relu_masks, pool_sel=pool_sel)
     t = _t(np.asarray(y, np.float64).reshape(-1), dtype)
     loss = cls_loss(t, p, class_weights); f1 = cls_f1(t, p)
     if want_acts:

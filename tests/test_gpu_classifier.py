@@ -132,11 +132,12 @@ def test_model_fwd_bwd_all_grads(hw, n, algo):
     flips = count_flips(eng, n, r["acts"], convs)
     assert flips <= 1e-5 * sum(r["acts"][c].size for c in convs) + 8, flips
     if flips:
-        r = O.cls_loss_and_grads(wts, x, y, class_weights=cw, dtype=torch.float64, relu_masks={c: (eng.tap(n, c) > 0).astype(np.float64) for c in convs})
+        # ... and on the engine's max-pool choices: a 2 x 2 window whose two largest entries differ by less than the fp32 round-off routes its gradient
+        # to the other element -- the same kind of discontinuity (ONE such window in p3 moves every upstream gradient of this case by 3e-4)
+        r = O.cls_loss_and_grads(wts, x, y, class_weights=cw, dtype=torch.float64, relu_masks={c: (eng.tap(n, c) > 0).astype(np.float64) for c in convs},
+                                 pool_sel={f"p{k}": O.pool_selection(eng.tap(n, f"bn{k}b")) for k in (1, 2, 3)})
         assert abs(ld[0] - r["loss"]) < 1e-5
-    # (what the sign pattern does not neutralise: a 2 x 2 max-pool window whose two largest entries differ by less than the fp32 round-off routes its
-    #  gradient to the other element -- the same kind of discontinuity, seen at the 3e-4 level in the first layer of the 96 x 128 x 24 case only)
-    tol = 3e-4 if not flips else 6e-4
+    tol = 3e-4
     g = eng.get_grads()
     assert set(g) == set(r["grads"])
     for k in g:
