@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   auto issue_loads = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < PL; ++k) preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, poff[k], chunk * 64, 0);
+  };
+  // the weight slab of a chunk: 27-36 KB that every workgroup of the channel group reads -- L2 hits (~250 cycles).  It is requested AFTER the chunk's MFMAs
+  // (behind the barrier), so its staging registers share the MFMA operand registers, and lands while the patch is scaled and split
+  auto issue_w_loads = [&](int chunk) __attribute__((always_inline)) {
     const int wsoff = (g * nchunks + chunk) * W_BYTES;
 #pragma unroll
     for (int k = 0; k < WL; ++k) {
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   };
 
   issue_loads(0);
+  issue_w_loads(0);
   post_amax();
   __syncthreads();
   store_lds();
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     if (chunk + 1 < nchunks) {
       post_amax();
       __syncthreads();                                     // every wave is done reading this chunk's planes; the four partial maxima are visible
+      issue_w_loads(chunk + 1);
       store_lds();
       __syncthreads();
     }
@@ -431,6 +437,6 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
   static const int tile = [] { const char* e = getenv("UNET_H2_TILE"); return e ? atoi(e) : 0; }();          // measurements: 1 = 8-row tiles everywhere, 2 = 16-row tiles for 64-wide groups
   if (h2_nb(M) == 1) return launch_h2<1, 2, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
-  if (tile == 2 && h > 8) return launch_h2<2, 4, 1>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
+  if (tile == 2 && h > 8) return launch_h2<2, 4, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
   return launch_h2<2, 2, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
 }
