@@ -210,21 +210,40 @@ def main():
                 traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
                 break
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
-        roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino2d4_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
-                                           f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)",
-                "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-                "effective_tflops": round(effective, 2),
-                "note": "achieved / frac = multiplies the matrix cores EXECUTE (Winograd: 4/9 or 2/3 of the direct count) / time, <= peak by construction; "
-                        "effective_tflops = ALGORITHMIC (direct-convolution, SURVEY 8d) FLOPs of the same launches / the same time",
-                "traffic": traffic,
-                "traffic_unit": f"HBM bytes per launch, rocprofv3 PMC collected offline on this workload (profiles/{tname}); not measured in this run",
-                "algorithmic_bytes_per_launch": round(alg_bytes),
-                "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3), "avg_launch_gflop_executed": round(fl_exec / max(launches, 1) / 1e9, 3),
-                "step_floor_ms": round(floor_ms, 3), "step_frac": round(floor_ms / (dt / args.steps * 1e3), 4),
-                "step_note": "step_floor_ms = sum over the step's ops of max(algorithmic bytes / 8 TB/s, executed FLOPs / MFMA peak); step_frac = floor / measured ms_per_step",
-                "profiled_steps": PROF_STEPS,
-                "op_ms_per_step": {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}}
+        H2R, X3R = 3.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS, 6.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
+        ratios = [exec_ratio(o[0]) for o in dom]
+        n_h2 = sum(int(abs(r - H2R) < 1e-9) for r in ratios); n_x3 = sum(int(abs(r - X3R) < 1e-9) for r in ratios)
+        gbs = sum(o[2] for o in dom) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        if n_h2 + n_x3 == launches and launches:
+            # every launch of the dominant family runs on the 16-bit matrix pipe (h2: three fp16 products per multiply, x3: six bf16 products): price
+            # the products it EXECUTES against that pipe's dense peak
+            per = [3.0 if abs(r - H2R) < 1e-9 else 6.0 for r in ratios]
+            prod = sum(o[1] * k for o, k in zip(dom, per)) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_h2_kernel (fp32 in / out, block-scaled two-term fp16 split, 3 v_mfma_f32_32x32x16_f16 products "
+                                               f"per multiply, {n_h2} launches)" + (f" / conv_x3_kernel (three-term bf16 split, 6 products, {n_x3} launches)" if n_x3 else ""),
+                    "achieved": round(prod, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(prod / BF16_MFMA_PEAK_TFLOPS, 4),
+                    "effective_tflops": round(effective, 2),
+                    "note": "achieved / frac = 16-bit MFMA FLOPs the matrix cores EXECUTE (3 or 6 products per fp32 multiply) / time vs the 2.5 PFLOP/s dense fp16 / bf16 peak; "
+                            "effective_tflops = ALGORITHMIC fp32 FLOPs (SURVEY 8d) of the same launches / the same time (the fp32 MFMA peak is 157.3)",
+                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        else:
+            roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino2d4_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
+                                               f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)",
+                    "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "effective_tflops": round(effective, 2),
+                    "note": "achieved / frac = multiplies the matrix cores EXECUTE (Winograd: 4/9 or 2/3 of the direct count; 16-bit split launches at their fp32-MFMA-time equivalent) / time, "
+                            "<= peak by construction; effective_tflops = ALGORITHMIC (direct-convolution, SURVEY 8d) FLOPs of the same launches / the same time",
+                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        roof.update({"traffic": traffic,
+                     "traffic_unit": f"HBM bytes per launch, rocprofv3 PMC collected offline on this workload (profiles/{tname}); not measured in this run",
+                     "algorithmic_bytes_per_launch": round(alg_bytes),
+                     "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
+                     "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3),
+                     "step_floor_ms": round(floor_ms, 3), "step_frac": round(floor_ms / (dt / args.steps * 1e3), 4),
+                     "step_note": "step_floor_ms = sum over the step's ops of max(algorithmic bytes / 8 TB/s, executed matrix FLOPs / that pipe's peak); step_frac = floor / measured ms_per_step",
+                     "step_hbm_gbs": round(sum(o[2] for o in ops) / (dt / args.steps) / 1e9, 1), "step_hbm_frac": round(sum(o[2] for o in ops) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "profiled_steps": PROF_STEPS,
+                     "op_ms_per_step": {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}})
         if args.dtype == "bf16":
             # bf16 storage: the same launches priced against HBM (they move half the bytes and the bf16 MFMA rate is 16x the fp32 one)
             gbs = sum(o[2] for o in dom) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -252,7 +271,7 @@ def main():
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
                                    + {"unet": "configs[2]" if args.config == 2 else "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
-                       "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: winograd F(2x2,3x3) / F(2,3) on mfma_f32_32x32x2, direct mfma otherwise", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd"}[args.algo],
+                       "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: fp32 conv3x3 as three fp16 MFMA products of a block-scaled two-term split (h2; fp32-class accuracy), winograd F(2x2,3x3) on mfma_f32_32x32x2 for the 32x32-channel weight gradients, ConvT on mfma_f32_32x32x2", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd"}[args.algo],
                        "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }

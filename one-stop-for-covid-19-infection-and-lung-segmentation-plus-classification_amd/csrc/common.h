@@ -19,6 +19,8 @@ struct unet_ctx {
   int num_cu = 256;
   int profiling = 0;
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS x UNET_BN_SLOT_DOUBLES, all zero between launches
+  void* convt_img = nullptr;        // device scratch for the split fp16 weight image of a ConvT launch (kernels_conv_h2.hip); launches on one stream only
+  size_t convt_img_bytes = 0;
   std::set<const void*> big_lds_kernels;   // kernels already opted in to > 64 KiB of dynamic LDS on this context's device
   std::string err;
 };
@@ -196,6 +198,9 @@ int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, in
 int32_t k_h2_weights_multi(unet_ctx*, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s);
 int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
                          int act, float rate, uint64_t seed, hipStream_t s);
+bool h2_convT_selected(const unet_ctx* ctx, int cin, int cout);
+int32_t k_convT_h2_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s);
+int32_t k_convT_h2_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s);
 bool h2_wgrad_selected(int cin, int cout);
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);

@@ -65,6 +65,16 @@ __global__ __launch_bounds__(256) void h2_wmax_kernel(unet_wimg_prep_list L) {  
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.img) + 2, __float_as_uint(mx));          // non-negative floats order like their bit patterns
 }
+__global__ __launch_bounds__(256) void h2_wmax1_kernel(const float* __restrict__ w, long long n4, unsigned* __restrict__ hdr) {          // one tensor of n4 float4
+  float mx = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(w)[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(hdr + 2, __float_as_uint(mx));
+}
 __global__ __launch_bounds__(64) void h2_wscale_kernel(unet_wimg_prep_list L) {
   if (threadIdx.x >= (unsigned)L.n) return;
   float* hdr = reinterpret_cast<float*>(L.item[threadIdx.x].img);
@@ -100,18 +110,53 @@ __global__ __launch_bounds__(256) void h2_wimg_multi_kernel(unet_wimg_prep_list 
   }
 }
 
+// generic form (T taps, KS k-steps per chunk): img = [header][(((((((g*nchunks + chunk)*KS + ks)*T + tap)*NB + nb)*2 + plane)*2 + half)*32 + m][8 fp16],
+// k = (chunk*KS + ks)*16 + half*8 + j; W(tap, k, mm) = w[tap*tap_stride + k*sk + mm*sm] * 2^e_w.  One layer per launch (the ConvT kernels)
+__global__ __launch_bounds__(256) void h2_wimg_generic_kernel(const float* __restrict__ w, unet_bf16* __restrict__ img_hdr, int T, int KS, int NB, int nchunks, long long tap_stride,
+                                                             long long sk, long long sm, long long total, int M) {
+  const float sc = reinterpret_cast<const float*>(img_hdr)[1];
+  unet_bf16* const img = img_hdr + H2_HEADER / 2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {          // e indexes (g, chunk, ks, tap, nb, half, m)
+    long long r = e;
+    const int m = (int)(r & 31); r >>= 5;
+    const int half = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r % NB); r /= NB;
+    const int tap = (int)(r % T); r /= T;
+    const int ks = (int)(r % KS); r /= KS;
+    const int chunk = (int)(r % nchunks); const int g = (int)(r / nchunks);
+    const long long k0 = ((long long)chunk * KS + ks) * 16 + half * 8;
+    const long long mm = ((long long)g * NB + nb) * 32 + cperm(m);
+    const float* src = w + (long long)tap * tap_stride + k0 * sk + mm * sm;
+    unsigned hh[4], ml[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = mm < M ? src[(2 * j) * sk] * sc : 0.0f, b = mm < M ? src[(2 * j + 1) * sk] * sc : 0.0f;
+      split2(a, b, hh[j], ml[j]);
+    }
+    const long long base = ((((((long long)g * nchunks + chunk) * KS + ks) * T + tap) * NB + nb) * 2 * 2 + half) * 32 + m;
+    *reinterpret_cast<uint4*>(img + (base + 0 * 64) * 8) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    *reinterpret_cast<uint4*>(img + (base + 1 * 64) * 8) = make_uint4(ml[0], ml[1], ml[2], ml[3]);
+  }
+}
+
 __device__ __forceinline__ f16x8 lds_frag(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
 
-template <int NB, int RW, bool GEN, int WPS>
-__global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
-                                                           const float* __restrict__ mask, float* __restrict__ y, int N, int H, int W, int K, int M, int act,
+// MODE 0: conv3x3 'same' (forward; data gradient with the flipped / transposed weight image)
+// MODE 1: convT2x2s2 forward = per-pixel GEMM [pixels, Cin] x [Cin, 4 Cout] with a scatter epilogue into the (2i+a, 2j+b) positions of a channel slice (pixel
+//         stride ldy) of the concat buffer (T1:886-887)
+// MODE 2: convT2x2s2 data gradient = per-pixel GEMM over the virtual channels k = (ab, o): chunk -> (ab, o0) selects the parity plane (2i+a, 2j+b) of dU
+//         (pixel stride ldx) that is staged
+template <int MODE, int NB, int RW, bool GEN, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
+                                                           const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
                                                            int total_blocks) {
+  constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
-  constexpr int PR = TH + 2, PWD = 34, NPIX = PR * PWD;
-  constexpr int PLANE = NPIX * 32;                       // bytes of one fp16 plane of the 16-channel pixel patch
-  constexpr int IN_BYTES = 2 * PLANE, W_BYTES = 9 * NB * 2 * 2 * 32 * 16;
-  constexpr int PPIECES = NPIX * 4, WPIECES = W_BYTES / 16;          // 16-B fp32 pieces of the patch (pixel, channel quad); 16-B pieces of the weight slab
+  constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
+  constexpr int PLANE = KS * NPIX * 32;                  // bytes of one fp16 plane of the pixel patch: [k-step][pixel][16 channels]
+  constexpr int IN_BYTES = 2 * PLANE, W_BYTES = KS * T * NB * 2 * 2 * 32 * 16;
+  constexpr int PPIECES = KS * NPIX * 4, WPIECES = W_BYTES / 16;     // 16-B fp32 pieces of the patch (k-step, pixel, channel quad); 16-B pieces of the weight slab
   constexpr int PL = (PPIECES + 255) / 256, WL = (WPIECES + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [IN_BYTES] [W_BYTES] [4 floats: per-wave max |x| of the chunk being staged]
   char* const s_in = smem; char* const s_w = smem + IN_BYTES;
@@ -128,7 +173,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y; const int n = t / tiles_y;
   const int x0 = tx * 32, y0 = ty * TH;
-  const int nchunks = K / 16;
+  const int HI = MODE == 2 ? 2 * H : H, WI = MODE == 2 ? 2 * W : W;          // the staged tensor's image size
+  const int nchunks = K / (16 * KS);
   const unet_bf16* const wimg = wimg_hdr + H2_HEADER / 2;
   const float w_unscale = *reinterpret_cast<const float*>(wimg_hdr);          // 2^-e_w of the layer
 
@@ -140,22 +186,27 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x + (long long)n * H * W * K, (long long)H * W * K * 4);
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x + (long long)n * HI * WI * ldx, (long long)HI * WI * ldx * 4);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unet_bf16*>(wimg), 0, (int)((long long)groups * nchunks * W_BYTES), 0x00020000);
   int poff[PL];
 #pragma unroll
   for (int k = 0; k < PL; ++k) {
     const int idx = tid + k * 256;
-    const int q = idx & 3, pix = idx >> 2;
-    const int r = pix / PWD, c = pix - r * PWD;
-    const int gy = y0 + r - 1, gx = x0 + c - 1;
+    const int q = idx & 3, pp = idx >> 2, ks = pp / NPIX, pix = pp - ks * NPIX;
+    int gy, gx;
+    if (MODE == 0) { const int r = pix / PWD, c = pix - r * PWD; gy = y0 + r - 1; gx = x0 + c - 1; }
+    else { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); }
     const bool ok = idx < PPIECES && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    poff[k] = ok ? ((gy * W + gx) * K + q * 4) * 4 : UNET_OOB;          // halo and overhang pieces read 0 (out-of-range buffer offset)
+    if (MODE == 2) poff[k] = ok ? (((2 * gy) * WI + 2 * gx) * ldx + ks * 16 + q * 4) * 4 : UNET_OOB;
+    else poff[k] = ok ? ((gy * WI + gx) * ldx + ks * 16 + q * 4) * 4 : UNET_OOB;          // halo and overhang pieces read 0 (out-of-range buffer offset)
   }
   unet_u32x4 preg[PL], wreg[WL];
   auto issue_loads = [&](int chunk) __attribute__((always_inline)) {
+    int soff;
+    if (MODE == 2) { const int ct = K >> 2, k0 = chunk * 32, ab = k0 / ct, o0 = k0 - ab * ct; soff = (((ab >> 1) * WI + (ab & 1)) * ldx + o0) * 4; }
+    else soff = chunk * 16 * KS * 4;
 #pragma unroll
-    for (int k = 0; k < PL; ++k) preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, poff[k], chunk * 64, 0);
+    for (int k = 0; k < PL; ++k) preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, poff[k], soff, 0);
   };
   // the weight slab of a chunk: 27-36 KB that every workgroup of the channel group reads -- L2 hits (~250 cycles).  It is requested AFTER the chunk's MFMAs
   // (behind the barrier), so its staging registers share the MFMA operand registers, and lands while the patch is scaled and split
@@ -223,6 +274,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   __syncthreads();
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (chunk + 1 < nchunks) issue_loads(chunk + 1);
+    if (MODE == 0) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       f16x8 px[2][RW + 2];
@@ -249,6 +301,29 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         }
       }
     }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        f16x8 px[2][RW], wf[NB][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < RW; ++r) px[p][r] = lds_frag(s_in + p * PLANE + ks * NPIX * 32 + (((wave * RW + r) * 32 + l31) * 32 + hi * 16));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) wf[nb][p] = lds_frag(s_w + ((((ks * NB + nb) * 2 + p) * 2 + hi) * 512 + l31 * 16));
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+          constexpr int PW[3] = {0, 1, 0}, PX[3] = {1, 0, 0};
+#pragma unroll
+          for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nb][PW[pr]], px[PX[pr]][r], acc[r][nb], 0, 0, 0);
+        }
+      }
+    }
     if (chunk + 1 < nchunks) {
       post_amax();
       __syncthreads();                                     // every wave is done reading this chunk's planes; the four partial maxima are visible
@@ -265,17 +340,21 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   for (int nb = 0; nb < NB; ++nb) {
     const int mb = (g * NB + nb) * 32 + hi * 16;
     if (mb >= M) continue;                                 // zero-padded rows of a tile that overhangs M
+    int ab = 0, oc = mb;
+    if (MODE == 1) { const int ct = M >> 2; ab = mb / ct; oc = mb - ab * ct; }
     float bv[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + mb + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + oc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int py = y0 + wave * RW + r;
       if (py >= H || px_ >= W) continue;
-      const long long o = (((long long)n * H + py) * W + px_) * M + mb;
+      long long o;
+      if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
+      else o = (((long long)n * H + py) * W + px_) * ldy + mb;
       float v[16], mv[16], a[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) a[i] = acc[r][nb][i] * unscale;
@@ -361,25 +440,26 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   }
 }
 
-template <int NB, int RW, int WPS>
-int32_t launch_h2(unet_ctx* ctx, const float* x, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K,
-                  int M, int act, float rate, unsigned long long seed, hipStream_t s) {
+template <int MODE, int NB, int RW, int WPS>
+int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd,
+                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s) {
+  constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
-  constexpr int NPIX = (TH + 2) * 34;
-  constexpr size_t smem = (size_t)2 * NPIX * 32 + (size_t)9 * NB * 2 * 2 * 32 * 16 + 16;
+  constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
+  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (size_t)KS * T * NB * 2 * 2 * 32 * 16 + 16;
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv h2: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
-  const bool gen = act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP;
+  const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP);
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, wimg, bias, mask, y, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);
     return UNET_OK;
   };
   int32_t r;
-  if (gen) r = go(conv_h2_kernel<NB, RW, true, WPS>); else r = go(conv_h2_kernel<NB, RW, false, WPS>);
+  if (gen) r = go(conv_h2_kernel<MODE, NB, RW, (MODE == 0), WPS>); else r = go(conv_h2_kernel<MODE, NB, RW, false, WPS>);
   if (r) return r;
   UNET_CHECK_LAUNCH(ctx, "conv_h2");
   return UNET_OK;
@@ -436,7 +516,47 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
   static const int tile = [] { const char* e = getenv("UNET_H2_TILE"); return e ? atoi(e) : 0; }();          // measurements: 1 = 8-row tiles everywhere, 2 = 16-row tiles for 64-wide groups
-  if (h2_nb(M) == 1) return launch_h2<1, 2, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
-  if (tile == 2 && h > 8) return launch_h2<2, 4, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
-  return launch_h2<2, 2, 2>(ctx, x, img, bias, mask, mask_mode, y, n, h, wd, K, M, act, rate, seed, s);
+  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+  if (tile == 2 && h > 8) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+  return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+}
+
+// ---- ConvT 2x2 stride 2 (T1:886 ...) on the same kernels: forward = MODE 1 (K = cin, M = 4 cout), data gradient = MODE 2 (K = 4 cout, M = cin).
+// The split weight image (4 cin cout weights -> 16 cin cout bytes + header) is rebuilt per launch into a context-owned scratch (common.h: unet_ctx::convt_img).
+bool h2_convT_selected(const unet_ctx* ctx, int cin, int cout) {
+  return h2_mode() != 0 && ctx && ctx->convt_img && cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0 &&
+         (size_t)H2_HEADER + (size_t)16 * cin * cout <= ctx->convt_img_bytes;
+}
+
+static int32_t h2_convT_image(unet_ctx* ctx, const float* w, int K, int M, int NB, long long sk, long long sm, long long nweights, hipStream_t s) {
+  unet_wimg_prep_list L; L.n = 1;
+  L.item[0].w = w; L.item[0].img = static_cast<unet_bf16*>(ctx->convt_img);
+  hipLaunchKernelGGL(h2_wzero_kernel, dim3(1), dim3(64), 0, s, L);
+  hipLaunchKernelGGL(h2_wmax1_kernel, dim3(32), dim3(256), 0, s, w, nweights / 4, static_cast<unsigned*>(ctx->convt_img));
+  hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(64), 0, s, L);
+  const int nchunks = K / 32, groups = (M + 32 * NB - 1) / (32 * NB);
+  const long long total = (long long)groups * nchunks * 2 * 1 * NB * 2 * 32;
+  hipLaunchKernelGGL(h2_wimg_generic_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, w, static_cast<unet_bf16*>(ctx->convt_img), 1, 2, NB, nchunks, 0LL,
+                     sk, sm, total, M);
+  UNET_CHECK_LAUNCH(ctx, "convT_h2_image");
+  return UNET_OK;
+}
+
+// u[n,2i+a,2j+b,o] = bias[o] + sum_c x[n,i,j,c] * K[a,b,o,c]   (Keras ConvT kernel [2][2][cout][cin]); y = channel slice with pixel stride ldy
+int32_t k_convT_h2_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s) {
+  int32_t r = h2_convT_image(ctx, w, cin, 4 * cout, 2, 1, cin, 4LL * cin * cout, s);              // W(k = c, m = ab*cout + o) = K[m*cin + c]
+  if (r) return r;
+  const unet_bf16* img = static_cast<const unet_bf16*>(ctx->convt_img);
+  return launch_h2<1, 2, 4, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
+}
+
+// dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]; dy = channel slice with pixel stride lddy; mask: ReLU of the producer of x
+int32_t k_convT_h2_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s) {
+  const int NB = (cin % 64) == 0 ? 2 : 1;
+  int32_t r = h2_convT_image(ctx, w, 4 * cout, cin, NB, cin, 1, 4LL * cin * cout, s);             // W(k = ab*cout + o, m = c) = K[k*cin + c]
+  if (r) return r;
+  const unet_bf16* img = static_cast<const unet_bf16*>(ctx->convt_img);
+  const int mm = mask ? MASK_RELU : MASK_NONE;
+  if (NB == 2) return launch_h2<2, 2, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
+  return launch_h2<2, 1, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
 }

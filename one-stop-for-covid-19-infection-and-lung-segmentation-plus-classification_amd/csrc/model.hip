@@ -41,6 +41,8 @@ int32_t unet_ctx_create(int32_t device_id, unet_ctx** out) {
   hipGetDevice(&prev);
   if (hipSetDevice(device_id) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&c->bn_slots), sb) != hipSuccess ||
       hipMemset(c->bn_slots, 0, sb) != hipSuccess) { hipSetDevice(prev); delete c; return UNET_E_HIP; }
+  c->convt_img_bytes = (size_t)8 << 20;             // ConvT weight images up to cin * cout = 512 K (u6 of the U-Net: 128 K)
+  if (hipMalloc(&c->convt_img, c->convt_img_bytes) != hipSuccess) { c->convt_img = nullptr; c->convt_img_bytes = 0; }
   hipSetDevice(prev);
   *out = c;
   return UNET_OK;
@@ -48,6 +50,7 @@ int32_t unet_ctx_create(int32_t device_id, unet_ctx** out) {
 
 void unet_ctx_destroy(unet_ctx* ctx) {
   if (ctx && ctx->bn_slots) hipFree(ctx->bn_slots);
+  if (ctx && ctx->convt_img) hipFree(ctx->convt_img);
   delete ctx;
 }
 const char* unet_last_error(const unet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
@@ -241,6 +244,7 @@ int32_t unet_convT2x2_fwd(unet_ctx* ctx, const float* x, const float* w, const f
                           int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
   if (!ctx || !x || !w || !y || ldy < cout || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "convT_fwd: bad args");
   if (algo == UNET_ALGO_MFMA && !mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: unsupported shape");
+  if (algo == UNET_ALGO_AUTO && h2_convT_selected(ctx, cin, cout)) return k_convT_h2_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
   if (algo != UNET_ALGO_NAIVE && mfma_convT_supported(cin, cout)) return k_convT_mfma_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
 }
@@ -249,6 +253,7 @@ int32_t unet_convT2x2_bwd_data(unet_ctx* ctx, const float* dy, int32_t lddy, con
                                int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
   if (!ctx || !dy || !w || !dx || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_data: bad args");
   if (algo == UNET_ALGO_MFMA && !mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: unsupported shape");
+  if (algo == UNET_ALGO_AUTO && h2_convT_selected(ctx, cin, cout)) return k_convT_h2_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
   if (algo != UNET_ALGO_NAIVE && mfma_convT_supported(cin, cout)) return k_convT_mfma_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
 }
