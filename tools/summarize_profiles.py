@@ -39,7 +39,7 @@ def collect(counter):
 def family(name):
     if "conv_wino2d_kernel" in name or "conv_wino2d4_kernel" in name or "conv_wino_kernel" in name:
         return "dom"
-    if "conv_mfma_kernel<0" in name or "conv_bf16_kernel<0" in name:
+    if "conv_mfma_kernel<0" in name or "conv_bf16_kernel<0" in name or "conv_h2_kernel<0" in name or "conv_x3_kernel" in name:
         return "dom"
     if "bn_apply_kernel" in name:
         return "bn_apply"          # fp32: 8 B per element, bf16 storage: 4 B
