@@ -14,7 +14,10 @@
  *     `ld*` arguments are the pixel stride in floats, so an op can read/write a channel
  *     slice of a wider NHWC buffer (zero-copy skip concatenation, T1:887).
  *   - all launches are asynchronous on the passed hipStream_t (`void* stream`); no hidden
- *     synchronisation, no allocation, no global mutable state besides the ctx.
+ *     synchronisation, no allocation after unet_ctx_create.  State outside the caller's buffers: (i) the ctx -- it owns two small device
+ *     scratch areas (BatchNorm atomics slots; the split weight image of a ConvT launch), so launches through ONE ctx belong on one stream
+ *     at a time; (ii) process-wide, read-only after first use: the UNET_* environment switches (kernel-family A/B selectors and tile /
+ *     workgroup-count overrides for measurements, listed in DESIGN.md section 4; every default is the shipped path).
  *   - there is NO CPU fallback: without a gfx950 device unet_ctx_create fails.
  */
 #ifndef UNET_HIP_H
@@ -38,7 +41,9 @@ enum { UNET_DTYPE_F32 = 0, UNET_DTYPE_BF16 = 1 };
 enum { UNET_OK = 0, UNET_E_ARG = -1, UNET_E_HIP = -2, UNET_E_SHAPE = -3, UNET_E_STATE = -4, UNET_E_NODEV = -5 };
 
 /* conv algorithm selector (all are HIP kernels; NAIVE exists as an on-device cross-check) */
-enum { UNET_ALGO_AUTO = 0, UNET_ALGO_NAIVE = 1, UNET_ALGO_MFMA = 2, UNET_ALGO_WINOGRAD = 3 };   /* 3: F(2,3)-along-x on the MFMA units where the shape allows, else 2 */
+/* AUTO: fp32 conv3x3 / ConvT as three fp16 MFMA products of a block-scaled two-term split where the shape allows (fp32-class accuracy), else Winograd / direct
+ * fp32-MFMA kernels; MFMA: direct v_mfma_f32_32x32x2_f32 kernels; WINOGRAD: the prepared-weights path (h2 split or Winograd F(2x2,3x3) / F(2,3) by shape) */
+enum { UNET_ALGO_AUTO = 0, UNET_ALGO_NAIVE = 1, UNET_ALGO_MFMA = 2, UNET_ALGO_WINOGRAD = 3 };
 
 int32_t unet_abi_version(void);
 int32_t unet_ctx_create(int32_t device_id, unet_ctx** out);

@@ -158,9 +158,10 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   constexpr int IN_BYTES = 2 * PLANE, W_BYTES = KS * T * NB * 2 * 2 * 32 * 16;
   constexpr int PPIECES = KS * NPIX * 4, WPIECES = W_BYTES / 16;     // 16-B fp32 pieces of the patch (k-step, pixel, channel quad); 16-B pieces of the weight slab
   constexpr int PL = (PPIECES + 255) / 256, WL = (WPIECES + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];        // [IN_BYTES] [W_BYTES] [4 floats: per-wave max |x| of the chunk being staged]
+  constexpr int W_LDS = WL * 256 * 16;                   // the slab's LDS region is rounded up to whole 256-piece rounds: every thread stores every piece it loaded (see the loop)
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [IN_BYTES] [W_LDS] [4 floats: per-wave max |x| of the chunk being staged]
   char* const s_in = smem; char* const s_w = smem + IN_BYTES;
-  float* const s_amax = reinterpret_cast<float*>(smem + IN_BYTES + W_BYTES);
+  float* const s_amax = reinterpret_cast<float*>(smem + IN_BYTES + W_LDS);
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -260,10 +261,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
     }
 #pragma unroll
-    for (int k = 0; k < WL; ++k) {
-      const int idx = tid + k * 256;
-      if (idx < WPIECES) *reinterpret_cast<unet_u32x4*>(s_w + idx * 16) = wreg[k];
-    }
+    for (int k = 0; k < WL; ++k) *reinterpret_cast<unet_u32x4*>(s_w + (tid + k * 256) * 16) = wreg[k];          // (pieces past the slab: zeros into the padding)
   };
 
   issue_loads(0);
@@ -273,7 +271,9 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   store_lds();
   __syncthreads();
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    if (chunk + 1 < nchunks) issue_loads(chunk + 1);
+    // UNCONDITIONAL (the last chunk's request is simply not used; buffer loads never fault): a branch here gives the loop head two predecessors with
+    // different numbers of loads in flight, and the compiler's waitcnt pass then drains the queue (vmcnt(0)) in front of the first MFMA of every chunk
+    issue_loads(chunk + 1);
     if (MODE == 0) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -325,9 +325,9 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
     }
     if (chunk + 1 < nchunks) {
+      issue_w_loads(chunk + 1);                            // (behind this wave's last MFMA issue: the operand registers are free)
       post_amax();
       __syncthreads();                                     // every wave is done reading this chunk's planes; the four partial maxima are visible
-      issue_w_loads(chunk + 1);
       store_lds();
       __syncthreads();
     }
@@ -446,7 +446,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
-  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (size_t)KS * T * NB * 2 * 2 * 32 * 16 + 16;
+  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 + 16;
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;
@@ -517,7 +517,10 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
   static const int tile = [] { const char* e = getenv("UNET_H2_TILE"); return e ? atoi(e) : 0; }();          // measurements: 1 = 8-row tiles everywhere, 2 = 16-row tiles for 64-wide groups
   if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
-  if (tile == 2 && h > 8) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+  // 16-row tiles (twice the MFMAs per staged chunk, 7 spilled registers at two workgroups per CU) measured 3-5 % faster on the 64 x 64 ... 128 x 128 layers when
+  // they still fill the 512 resident slots, 2-4 % slower on the 256 / 512 pixel layers (fewer, longer workgroups) and much slower when the grid falls below one round
+  const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
+  if ((tile == 2 && h > 8) || (tile == 0 && h <= 128 && wgs16 >= 512)) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
   return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
 }
 
