@@ -25,6 +25,19 @@
 
 #include "common.h"
 
+#ifndef H2_EXPERIMENT
+#define H2_EXPERIMENT 0
+#endif
+#if H2_EXPERIMENT == 5
+// measurement build only (tools/h2_timeline.py): wave 0 of every workgroup stamps s_memtime at its phase boundaries
+__device__ unsigned long long h2_trace[16384 * 16];
+#define H2_STAMP(i) do { if (tid == 0 && blockIdx.x < 16384) h2_trace[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int32_t unet_debug_h2_trace(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(h2_trace), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#else
+#define H2_STAMP(i) do { } while (0)
+#endif
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -158,7 +171,11 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   constexpr int IN_BYTES = 2 * PLANE, W_BYTES = KS * T * NB * 2 * 2 * 32 * 16;
   constexpr int PPIECES = KS * NPIX * 4, WPIECES = W_BYTES / 16;     // 16-B fp32 pieces of the patch (k-step, pixel, channel quad); 16-B pieces of the weight slab
   constexpr int PL = (PPIECES + 255) / 256, WL = (WPIECES + 255) / 256;
-  constexpr int W_LDS = WL * 256 * 16;                   // the slab's LDS region is rounded up to whole 256-piece rounds: every thread stores every piece it loaded (see the loop)
+  constexpr int OUT_PS = 128 + 16;                       // epilogue staging: bytes per pixel of a (row, 32-channel block) + padding against bank conflicts
+  // the slab's LDS region is rounded up to whole 256-piece rounds (every thread stores every piece it loaded) -- except for the 32-channel groups, where the
+  // exact size is what lets a FOURTH workgroup fit a CU's 160 KB (40.2 KB each): those layers are the 512 x 512 ones, bound by the bytes a CU keeps in flight
+  constexpr bool WPAD = NB != 1 || MODE != 0;
+  constexpr int W_LDS = WPAD ? WL * 256 * 16 : W_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [IN_BYTES] [W_LDS] [4 floats: per-wave max |x| of the chunk being staged]
   char* const s_in = smem; char* const s_w = smem + IN_BYTES;
   float* const s_amax = reinterpret_cast<float*>(smem + IN_BYTES + W_LDS);
@@ -261,19 +278,21 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
     }
 #pragma unroll
-    for (int k = 0; k < WL; ++k) *reinterpret_cast<unet_u32x4*>(s_w + (tid + k * 256) * 16) = wreg[k];          // (pieces past the slab: zeros into the padding)
+    for (int k = 0; k < WL; ++k)
+      if (WPAD || tid + k * 256 < WPIECES) *reinterpret_cast<unet_u32x4*>(s_w + (tid + k * 256) * 16) = wreg[k];          // (pieces past the slab: zeros into the padding)
   };
 
+  H2_STAMP(0);
   issue_loads(0);
   issue_w_loads(0);
   post_amax();
   __syncthreads();
+  H2_STAMP(1);
   store_lds();
   __syncthreads();
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    // UNCONDITIONAL (the last chunk's request is simply not used; buffer loads never fault): a branch here gives the loop head two predecessors with
-    // different numbers of loads in flight, and the compiler's waitcnt pass then drains the queue (vmcnt(0)) in front of the first MFMA of every chunk
-    issue_loads(chunk + 1);
+  H2_STAMP(2);
+  // one staged chunk: 9 taps x RW rows x NB blocks x 3 products (ConvT modes: KS k-steps x ...)
+  auto mfma_chunk = [&]() __attribute__((always_inline)) {
     if (MODE == 0) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -324,18 +343,50 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         }
       }
     }
-    if (chunk + 1 < nchunks) {
-      issue_w_loads(chunk + 1);                            // (behind this wave's last MFMA issue: the operand registers are free)
-      post_amax();
-      __syncthreads();                                     // every wave is done reading this chunk's planes; the four partial maxima are visible
-      store_lds();
-      __syncthreads();
+  };
+  for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
+    issue_loads(chunk + 1);
+    mfma_chunk();
+    if (chunk == 0) H2_STAMP(3);
+    issue_w_loads(chunk + 1);                              // (behind this wave's last MFMA issue: the operand registers are free)
+    post_amax();
+    __syncthreads();                                       // every wave is done reading this chunk's planes; the four partial maxima are visible
+    if (chunk == 0) H2_STAMP(4);
+    store_lds();
+    __syncthreads();
+    if (chunk == 0) H2_STAMP(5);
+  }
+  H2_STAMP(6);
+  // ---- last chunk: what the epilogue reads per output element (the ReLU / ELU mask of a data gradient, x of a folded-BatchNorm gradient) is requested
+  // BEFORE its MFMAs and lands under them; requested from the epilogue it is a full memory round trip per tile on layers with 2-4 chunks per tile
+  const int px_ = x0 + l31;
+  const bool want_m = mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB;
+  constexpr bool MPF = MODE != 1 && RW * NB <= 4;          // (64 registers at most; the 16-row tiles keep the epilogue loads)
+  float4 mpre[MPF ? NB : 1][MPF ? RW : 1][4];
+  if (MPF && want_m) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int mb = (g * NB + nb) * 32 + hi * 16;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int py = y0 + wave * RW + r;
+        const bool ok = mb < M && py < H && px_ < W;
+        const long long o = (((long long)n * H + py) * W + px_) * ldy + mb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mpre[nb][r][q] = ok ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
+  mfma_chunk();
+  H2_STAMP(7);
   const float unscale = pow2f(max(-e_run, -126)) * w_unscale;            // 2^-(e_x + e_w)
+  // Output rows leave through LDS: a lane holds 64 B of ONE pixel, so its four 16-B stores land 128+ B apart from its neighbours' and a store instruction
+  // touches 32 cache lines with 32 B each.  Transposed through a 4.5-KB per-wave staging row (the patch planes are dead), eight consecutive lanes write one
+  // full 128-B line: 1/4 of the write requests (measured with the placement faked: -5...-20 % per launch).
+  __syncthreads();                                         // (every wave is past its last fragment read: the planes may be overwritten)
+  char* const s_out = smem + wave * (32 * OUT_PS);
 
   // ---- epilogue: lane (l31, hi) holds, for pixel column l31 of each of its RW rows, channels mb + 0..15
-  const int px_ = x0 + l31;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int mb = (g * NB + nb) * 32 + hi * 16;
@@ -351,18 +402,19 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int py = y0 + wave * RW + r;
-      if (py >= H || px_ >= W) continue;
+      if (py >= H) continue;                               // (wave-uniform)
+      const bool live = px_ < W;                           // lanes past the image edge take part in the LDS transpose only
       long long o;
       if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
       else o = (((long long)n * H + py) * W + px_) * ldy + mb;
       float v[16], mv[16], a[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) a[i] = acc[r][nb][i] * unscale;
-      const bool want_m = mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB;
       if (want_m) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 m4 = *reinterpret_cast<const float4*>(mask + o + q * 4);
+          float4 m4;
+          if (MPF) m4 = mpre[MPF ? nb : 0][MPF ? r : 0][q]; else m4 = live ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
           mv[q * 4] = m4.x; mv[q * 4 + 1] = m4.y; mv[q * 4 + 2] = m4.z; mv[q * 4 + 3] = m4.w;
         }
       }
@@ -435,9 +487,25 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(y + o + q * 4) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(s_out + l31 * OUT_PS + hi * 64 + q * 16) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+      // (LDS executes a wave's instructions in order: the reads below see the writes above, the next row's writes come after these reads)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pj = j * 8 + (lane >> 3), cj = lane & 7, pxj = x0 + pj;
+        const float4 t4 = *reinterpret_cast<const float4*>(s_out + pj * OUT_PS + cj * 16);
+        long long oj;
+        if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
+        else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
+        if (pxj < W) *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
+      }
     }
   }
+  H2_STAMP(8);
+#if H2_EXPERIMENT == 5
+  if (tid == 0 && blockIdx.x < 16384) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); h2_trace[blockIdx.x * 16 + 9] = hw;
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); h2_trace[blockIdx.x * 16 + 10] = xcc; }
+#endif
 }
 
 template <int MODE, int NB, int RW, int WPS>
@@ -446,7 +514,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
-  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 + 16;
+  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16;
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;
@@ -516,7 +584,7 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
   static const int tile = [] { const char* e = getenv("UNET_H2_TILE"); return e ? atoi(e) : 0; }();          // measurements: 1 = 8-row tiles everywhere, 2 = 16-row tiles for 64-wide groups
-  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
   // 16-row tiles (twice the MFMAs per staged chunk, 7 spilled registers at two workgroups per CU) measured 3-5 % faster on the 64 x 64 ... 128 x 128 layers when
   // they still fill the 512 resident slots, 2-4 % slower on the 256 / 512 pixel layers (fewer, longer workgroups) and much slower when the grid falls below one round
   const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
