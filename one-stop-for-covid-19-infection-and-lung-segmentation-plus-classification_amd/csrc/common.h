@@ -21,6 +21,12 @@ struct unet_ctx {
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS x UNET_BN_SLOT_DOUBLES, all zero between launches
   void* convt_img = nullptr;        // device scratch for the split fp16 weight image of a ConvT launch (kernels_conv_h2.hip); launches on one stream only
   size_t convt_img_bytes = 0;
+  // Conv2D / Conv2DTranspose -> BatchNormalization (T1:860-861, 886-888): unet_request_bn_stats() arms the next forward launch; a kernel that can
+  // (kernels_conv_h2.hip) adds the per-channel (sum y, sum y^2) of what it writes to bn_slots and leaves the tensor's address in stats_in_slots,
+  // and the unet_bn_stats / unet_bn_stats_concat call on that tensor folds the slots without reading it
+  int stats_req_c = 0;              // channels of the BatchNorm (0 = not armed)
+  const void* stats_in_slots = nullptr;
+  int stats_in_slots_c = 0;
   std::set<const void*> big_lds_kernels;   // kernels already opted in to > 64 KiB of dynamic LDS on this context's device
   std::string err;
 };

@@ -163,7 +163,7 @@ template <int MODE, int NB, int RW, bool GEN, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
-                                                           int total_blocks) {
+                                                           int total_blocks, double* __restrict__ stats, int stats_c) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
   constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
@@ -385,6 +385,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   // full 128-B line: 1/4 of the write requests (measured with the placement faked: -5...-20 % per launch).
   __syncthreads();                                         // (every wave is past its last fragment read: the planes may be overwritten)
   char* const s_out = smem + wave * (32 * OUT_PS);
+  float* const s_stat = reinterpret_cast<float*>(smem + 4 * 32 * OUT_PS);          // [wave][nb][sum | sum of squares][32 channels]
 
   // ---- epilogue: lane (l31, hi) holds, for pixel column l31 of each of its RW rows, channels mb + 0..15
 #pragma unroll
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + oc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
     }
+    float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1;           // BatchNorm statistics of what this lane stores (channel quad lane & 7)
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int py = y0 + wave * RW + r;
@@ -497,7 +499,39 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
         else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
-        if (pxj < W) *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
+        if (pxj < W) {
+          *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
+          if (MODE != 2 && stats) {
+            st1.x += t4.x; st1.y += t4.y; st1.z += t4.z; st1.w += t4.w;
+            st2.x = fmaf(t4.x, t4.x, st2.x); st2.y = fmaf(t4.y, t4.y, st2.y); st2.z = fmaf(t4.z, t4.z, st2.z); st2.w = fmaf(t4.w, t4.w, st2.w);
+          }
+        }
+      }
+    }
+    if (MODE != 2 && stats) {                              // (wave-uniform) lanes L, L + 8, ... hold the same channel quad: fold them, lanes 0-7 post the wave's sums
+      float sv[8] = {st1.x, st1.y, st1.z, st1.w, st2.x, st2.y, st2.z, st2.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sv[i] += __shfl_xor(sv[i], 8); sv[i] += __shfl_xor(sv[i], 16); sv[i] += __shfl_xor(sv[i], 32);
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s_stat[((wave * NB + nb) * 2 + 0) * 32 + lane * 4 + i] = sv[i]; s_stat[((wave * NB + nb) * 2 + 1) * 32 + lane * 4 + i] = sv[4 + i]; }
+      }
+    }
+  }
+  if (MODE != 2 && stats) {
+    __syncthreads();
+    if (tid < NB * 64) {
+      const int nb = tid >> 6, kind = (tid >> 5) & 1, c32 = tid & 31;
+      const int mb = (g * NB + nb) * 32;
+      if (mb < M) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) t += s_stat[((wv * NB + nb) * 2 + kind) * 32 + c32];
+        int ch = mb + c32;
+        if (MODE == 1) ch = ch % (M >> 2);                 // ConvT: the four (a, b) planes of a channel
+        atomicAdd(stats + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + (kind ? stats_c : 0) + ch, (double)t);
       }
     }
   }
@@ -521,9 +555,16 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv h2: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
   const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP);
+  // an armed statistics request (common.h): forward launches only, dense channel counts the slot copies can hold, no dropout on the stored values
+  double* stats = nullptr; int stats_c = 0;
+  if (MODE != 2 && ctx->stats_req_c > 0) {
+    const int c = ctx->stats_req_c; ctx->stats_req_c = 0;
+    if (!mask && rate == 0.0f && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots) { stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; }
+  }
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
+                       stats_c);
     return UNET_OK;
   };
   int32_t r;

@@ -715,9 +715,14 @@ extern "C" {
 
 extern "C++" template <typename T> static int32_t bn_stats_impl(unet_ctx* ctx, const T* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) {
   if (!ctx || !x || !sums || !bn_c_ok(c) || ldx < c || (ldx & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: bad args c=%d ldx=%d", c, ldx);
-  int ppb = TPB / (c / 4);
-  int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c);
+  ctx->stats_req_c = 0;                                    // (a request no launch took up)
+  if (ctx->stats_in_slots && (ctx->stats_in_slots != (const void*)x || ctx->stats_in_slots_c != c)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: the slot copies hold the fused statistics of another tensor");
+  if (!ctx->stats_in_slots) {
+    int ppb = TPB / (c / 4);
+    int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c);
+  }
+  ctx->stats_in_slots = nullptr;                           // (else: the conv that wrote x left them there -- fold only)
   hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
   UNET_CHECK_LAUNCH(ctx, "bn_stats"); return UNET_OK;
 }
@@ -726,9 +731,14 @@ extern "C++" template <typename T> static int32_t bn_stats_concat_impl(unet_ctx*
                                                                        const float* src_beta, double* sums, int64_t pixels, int32_t c_up, int32_t c_skip, void* stream) {
   if (!ctx || !x_up || !sums || !src_sums || !src_gamma || !src_beta || !bn_c_ok(c_up) || c_skip < 1 || ldx < c_up || (ldx & 3) || src_count < 1 || pixels < 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn_stats_concat: bad args c_up=%d c_skip=%d ldx=%d", c_up, c_skip, ldx);
-  int ppb = TPB / (c_up / 4);
-  int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x_up, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c_up);
+  ctx->stats_req_c = 0;
+  if (ctx->stats_in_slots && (ctx->stats_in_slots != (const void*)x_up || ctx->stats_in_slots_c != c_up)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats_concat: the slot copies hold the fused statistics of another tensor");
+  if (!ctx->stats_in_slots) {
+    int ppb = TPB / (c_up / 4);
+    int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x_up, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c_up);
+  }
+  ctx->stats_in_slots = nullptr;                           // (else: the ConvT that wrote the up half left its sums there)
   hipLaunchKernelGGL(bn_fold_concat_kernel, dim3((c_up + c_skip + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, c_up, c_skip, src_sums, src_count, src_gamma,
                      src_beta, (double)pixels, 1e-3f);
   UNET_CHECK_LAUNCH(ctx, "bn_stats_concat"); return UNET_OK;

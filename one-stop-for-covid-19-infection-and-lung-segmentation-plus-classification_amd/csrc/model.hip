@@ -147,6 +147,14 @@ static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float
 
 extern "C" {
 
+// Conv2D / Conv2DTranspose -> BatchNormalization in training mode (T1:860-861, 886-888): see common.h (unet_ctx::stats_req_c)
+int32_t unet_request_bn_stats(unet_ctx* ctx, int32_t c) {
+  if (!ctx || c < 0) UNET_FAIL(ctx, UNET_E_ARG, "request_bn_stats: bad args");
+  static const int on = [] { const char* e = getenv("UNET_BN_FUSE_STATS"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = statistics always by their own pass
+  ctx->stats_req_c = on ? c : 0;
+  return UNET_OK;
+}
+
 int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t h,
                          int32_t wd, int32_t cin, int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo,
                          float* w_ws, void* stream) {
@@ -611,11 +619,14 @@ void build_programs(unet_model* m) {
     ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
     if (!dt) ADD_OP(F, "wino_weights:fwd", 0, 0, { return prep_weights(0, s); });       // all Winograd weight transforms of the program in one launch
     else ADD_OP(F, "weight_images:fwd", 0, 0, { return prep_weights_bf16(0, s); });
-    auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
+    // bn_next: a training-mode BatchNorm over `cout` channels reads this conv's output next -- its statistics ride in the conv's epilogue where the kernel can
+    auto conv = [&](const std::string& name, const std::string& in, int cin, int cout, bool bn_next = false) {
       const Buf ob = m->act.at(name);
       double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
       double by = eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout;
+      const bool arm = bn_next && training && !dt;
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
+        if (arm) unet_request_bn_stats(ctx, cout);
         if (dt) {
           if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_RELU, 0.0f, 0, s);
           return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU,
@@ -668,7 +679,7 @@ void build_programs(unet_model* m) {
     for (int k = 1; k <= 4; ++k) {
       int c = ENC[k - 1]; std::string ks = std::to_string(k);
       conv("c" + ks + "a", prev, cprev, c);
-      conv("c" + ks + "b", "c" + ks + "a", c, c);
+      conv("c" + ks + "b", "c" + ks + "a", c, c, true);
       bn("bn" + ks, "c" + ks + "b", "bn" + ks, c, true);
       const Buf ib = m->act.at("bn" + ks), xb = m->act.at("c" + ks + "b");
       const std::string pin = "bn" + ks, pout = "p" + ks, xin = "c" + ks + "b";
@@ -690,7 +701,9 @@ void build_programs(unet_model* m) {
       int c = dec[k - 6]; std::string ks = std::to_string(k);
       const Buf ib = m->act.at(prev), ub = m->act.at("u" + ks);
       const std::string uin = prev, un = "u" + ks; const int ci = cprev;
+      const bool arm_up = training && !dt && bn_concat_analytic();          // (the statistics pass of the concat reads only this half then)
       ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * ci * c * nel(ib) / ib.c, eb * (nel(ib) + nel(ub)), {
+        if (arm_up) unet_request_bn_stats(ctx, c);
         if (dt) return k_convT_bf16_fwd(ctx, CBF(m->Av(uin)), m->P(un + "/kernel"), m->P(un + "/bias"), WBF(m->Av(un)), ub.ld, ib.n, ib.h, ib.w, ci, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
         return unet_convT2x2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, algo, s);
       });

@@ -630,3 +630,67 @@ def test_wgrad_random_shapes_all_algorithms_agree(ops, seed):
     for dw, db in outs[1:]:
         assert float((dw - outs[0][0]).norm() / (outs[0][0].norm() + 1e-20)) < 3e-5, (n, h, w, ci, co)
         assert float((db - outs[0][1]).norm() / (outs[0][1].norm() + 1e-20)) < 3e-5, (n, h, w, ci, co)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 72, 32, 32), (3, 24, 40, 64, 64), (2, 16, 32, 128, 128), (1, 19, 45, 32, 64), (2, 8, 8, 256, 256)])
+def test_conv_epilogue_bn_statistics_equal_the_statistics_pass(ops, shape):
+    """Conv2D -> BatchNormalization (T1:860-861): unet_request_bn_stats arms the conv, whose epilogue adds (sum y, sum y^2) per channel of the rows it
+    stores; the unet_bn_stats call on that tensor then only folds them.  Must equal the statistics pass over the same tensor (and the fp64 sums of
+    the oracle's conv output), accumulate like it, and leave nothing armed behind; a conv the h2 kernels do not take (algo 1) ignores the request."""
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(ci * co + h)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.3).astype(np.float32)
+    xd, kd, bd = ops.d(x), ops.d(k), ops.d(b)
+    pixels = n * h * w
+    want_y = O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=True).numpy().reshape(-1, co)
+    want = np.concatenate([want_y.sum(0), (want_y * want_y).sum(0)])
+    for algo in (0, 1):
+        y = ops.z(n, h, w, co); fused = ops.z(2 * co, dtype=torch.float64); plain = ops.z(2 * co, dtype=torch.float64)
+        ops.ck(ops.lib.unet_request_bn_stats(ops.h, co), "arm")
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, xd.data_ptr(), kd.data_ptr(), bd.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, algo, ops.wws(ci, co), ops.s), "conv")
+        ops.ck(ops.lib.unet_bn_stats(ops.h, y.data_ptr(), co, fused.data_ptr(), pixels, co, ops.s), "fold")
+        ops.ck(ops.lib.unet_bn_stats(ops.h, y.data_ptr(), co, plain.data_ptr(), pixels, co, ops.s), "plain pass")             # nothing armed any more: reads y
+        f, p_ = fused.cpu().numpy(), plain.cpu().numpy()
+        assert relerr(f, p_) < 1e-6 and relerr(f, want) < 2e-5, algo
+        mean_f, mean_p = f[:co] / pixels, p_[:co] / pixels
+        assert relerr(f[co:] / pixels - mean_f ** 2, p_[co:] / pixels - mean_p ** 2) < 2e-5
+        ops.ck(ops.lib.unet_request_bn_stats(ops.h, co), "arm again")                                                            # accumulates into non-zero sums
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, xd.data_ptr(), kd.data_ptr(), bd.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, algo, ops.wws(ci, co), ops.s), "conv")
+        ops.ck(ops.lib.unet_bn_stats(ops.h, y.data_ptr(), co, fused.data_ptr(), pixels, co, ops.s), "fold")
+        assert relerr(fused.cpu().numpy(), 2 * f) < 1e-6
+    # the folded statistics belong to ONE tensor: asking for another tensor's fails loudly instead of mixing them
+    y = ops.z(n, h, w, co); other = ops.z(n, h, w, co); sums = ops.z(2 * co, dtype=torch.float64)
+    ops.ck(ops.lib.unet_request_bn_stats(ops.h, co), "arm")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, xd.data_ptr(), kd.data_ptr(), bd.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, ops.wws(ci, co), ops.s), "conv")
+    if ops.lib.unet_conv3x3_exec_ratio(0, h, w, ci, co) < 0.2:
+        assert ops.lib.unet_bn_stats(ops.h, other.data_ptr(), co, sums.data_ptr(), pixels, co, ops.s) != 0
+    ops.ck(ops.lib.unet_bn_stats(ops.h, y.data_ptr(), co, sums.data_ptr(), pixels, co, ops.s), "fold")
+    assert relerr(sums.cpu().numpy(), want) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 12, 20, 64, 32), (1, 9, 33, 128, 64), (2, 8, 8, 512, 256)])
+def test_convT_epilogue_bn_statistics_of_the_up_half(ops, shape):
+    """Conv2DTranspose -> concatenate -> BatchNormalization (T1:886-888): the armed ConvT adds the statistics of the half it writes into the concat;
+    unet_bn_stats_concat then folds them (+ the analytic skip half) without reading the tensor: equal to the unarmed call."""
+    from gpu_util import relerr
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(ci + co)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((2, 2, co, ci)) * (1.0 / ci) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.3).astype(np.float32)
+    ld = 2 * co; pixels = n * 2 * h * 2 * w
+    ge = rng.uniform(0.5, 1.5, co).astype(np.float32); be = (rng.standard_normal(co) * 0.5).astype(np.float32)
+    es = ops.d(np.concatenate([rng.standard_normal(co) * pixels, (rng.uniform(1, 2, co) + 1.0) * pixels]), np.float64)
+    res = []
+    for arm in (1, 0):
+        cat = ops.z(n, 2 * h, 2 * w, ld); sums = ops.z(2 * ld, dtype=torch.float64)
+        if arm: ops.ck(ops.lib.unet_request_bn_stats(ops.h, co), "arm")
+        ops.ck(ops.lib.unet_convT2x2_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), cat.data_ptr(), ld, n, h, w, ci, co, 0, ops.s), "convT")
+        ops.ck(ops.lib.unet_bn_stats_concat(ops.h, cat.data_ptr(), ld, es.data_ptr(), float(pixels), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), sums.data_ptr(), pixels, co, co, ops.s), "stats")
+        res.append(sums.cpu().numpy())
+        up = cat.cpu().numpy()[..., :co].astype(np.float64).reshape(-1, co)
+        assert relerr(res[-1][:co], up.sum(0)) < 1e-6 and relerr(res[-1][ld:ld + co], (up * up).sum(0)) < 1e-6
+    assert relerr(res[0], res[1]) < 1e-6
