@@ -42,7 +42,7 @@ constexpr int APX = 34;                                       // X pixels per st
 // R = dY rows per step.  R = 2 (default): 9 + 4 staged pieces beside the 144 accumulators fit 256 registers -> two workgroups per CU cover each other's
 // staging phases; R = 4: twice the MFMAs per barrier pair but one workgroup per CU (512-register budget): measured 25 % slower (UNET_WGRAD_H2_ROWS=4)
 template <int WA, int WB, int WR, int R>
-__global__ __launch_bounds__(256, R == 4 ? 1 : 2) void wgrad_h2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
+__global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
                                                           int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
                                                           int npairs, long long pstride, int units, int upb) {
   static_assert(WA * WB * WR == 4 && WR <= R, "4 waves");
@@ -287,14 +287,17 @@ int wgrad_h2_rows() {
 
 WgPlanH2 plan_wgrad_h2(int n, int h, int w, int ca, int cb) {
   WgPlanH2 p;
-  const int R = wgrad_h2_rows();
+  int R = wgrad_h2_rows();
   p.WA = (ca % 64) == 0 ? 2 : 1; p.WB = (cb % 64) == 0 ? 2 : 1;
-  p.WR = 4 / (p.WA * p.WB); if (p.WR > R) { p.WB = 2; p.WR = 4 / (p.WA * p.WB); }      // (a 64-wide dY tile may overhang cb: masked)
+  p.WR = 4 / (p.WA * p.WB);
+  // one 32 x 32 channel tile (c1b, c9b: T1:860, 911): four row phases over four dY rows per step -- 144 accumulators + 11 staged pieces still fit 256
+  // registers, so two workgroups per CU stay (a 64-wide dY tile instead would run half of its MFMAs on padding)
+  if (p.WR > R) R = 4;
   p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
   const long long pairs = (long long)p.tiles_a * p.tiles_b, per = 9LL * ca * cb;
   const long long units = (long long)n * p.strips;
   static const long long target_env = [] { const char* e = getenv("UNET_WGRAD_H2_BLOCKS"); return e ? atoll(e) : 0LL; }();
-  const long long target = target_env ? target_env : (R == 4 ? 256LL : 512LL);          // one resident round: 256 CUs x 1 (R = 4) or 2 (R = 2) workgroups
+  const long long target = target_env ? target_env : (R == 4 && p.WA * p.WB > 1 ? 256LL : 512LL);          // one resident round: 256 CUs x 1 (R = 4) or 2 (R = 2) workgroups
   long long want = std::max<long long>(1, target / pairs);
   const long long cap = std::max<long long>(1, (64LL << 20) / per);
   want = std::min(want, cap);
@@ -316,8 +319,10 @@ int h2_wgrad_mode() {
 
 }  // namespace
 
-// (32 x 32-channel layers would run a 64-wide dY tile half empty: they stay on the fp32 Winograd weight gradient)
-bool h2_wgrad_selected(int cin, int cout) { return h2_wgrad_mode() != 0 && cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0 && (cin >= 64 || cout >= 64); }
+bool h2_wgrad_selected(int cin, int cout) {
+  static const int small = [] { const char* e = getenv("UNET_WGRAD_H2_32"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = 32 x 32 layers on the fp32 Winograd weight gradient
+  return h2_wgrad_mode() != 0 && cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0 && (cin >= 64 || cout >= 64 || (small && cin == 32 && cout == 32));
+}
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_wgrad_selected(cin, cout) ? plan_wgrad_h2(n, h, wd, cin, cout).floats * sizeof(float) : 0; }
 
 int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
@@ -336,7 +341,9 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
                                                   p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb)
   if (p.WA == 2 && p.WB == 2) UNET_WG(2, 2, 1);
   else if (p.WA == 2) UNET_WG(2, 1, 2);
-  else UNET_WG(1, 2, 2);
+  else if (p.WB == 2) UNET_WG(1, 2, 2);
+  else hipLaunchKernelGGL((wgrad_h2_kernel<1, 1, 4, 4>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S,
+                          p.units, p.upb);
 #undef UNET_WG
   UNET_CHECK_LAUNCH(ctx, "wgrad_h2");
   return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
