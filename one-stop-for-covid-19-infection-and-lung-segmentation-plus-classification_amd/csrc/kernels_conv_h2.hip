@@ -364,16 +364,21 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   constexpr bool MPF = MODE != 1 && RW * NB <= 4;          // (64 registers at most; the 16-row tiles keep the epilogue loads)
   float4 mpre[MPF ? NB : 1][MPF ? RW : 1][4];
   if (MPF && want_m) {
+    // (requested the way the output rows are stored -- eight consecutive lanes per 128-B line, lane -> (pixel j * 8 + lane / 8, channel quad lane % 8) --
+    //  and turned into the accumulator layout through the epilogue's LDS staging row)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const int mb = (g * NB + nb) * 32 + hi * 16;
+      const int mb0 = (g * NB + nb) * 32;
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         const int py = y0 + wave * RW + r;
-        const bool ok = mb < M && py < H && px_ < W;
-        const long long o = (((long long)n * H + py) * W + px_) * ldy + mb;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mpre[nb][r][q] = ok ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 4; ++j) {
+          const int pxj = x0 + j * 8 + (lane >> 3);
+          const bool ok = mb0 < M && py < H && pxj < W;
+          const long long o = (((long long)n * H + py) * W + pxj) * ldy + mb0 + (lane & 7) * 4;
+          mpre[nb][r][j] = ok ? *reinterpret_cast<const float4*>(mask + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
   }
@@ -413,10 +418,15 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) a[i] = acc[r][nb][i] * unscale;
       if (want_m) {
+        if (MPF) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(s_out + (j * 8 + (lane >> 3)) * OUT_PS + (lane & 7) * 16) = mpre[MPF ? nb : 0][MPF ? r : 0][j];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float4 m4;
-          if (MPF) m4 = mpre[MPF ? nb : 0][MPF ? r : 0][q]; else m4 = live ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (MPF) m4 = *reinterpret_cast<const float4*>(s_out + l31 * OUT_PS + hi * 64 + q * 16);
+          else m4 = live ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
           mv[q * 4] = m4.x; mv[q * 4 + 1] = m4.y; mv[q * 4 + 2] = m4.z; mv[q * 4 + 3] = m4.w;
         }
       }
