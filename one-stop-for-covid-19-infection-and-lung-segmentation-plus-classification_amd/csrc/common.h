@@ -246,6 +246,10 @@ int32_t k_convT_mfma_fwd(unet_ctx*, const float* x, const float* w, const float*
 int32_t k_convT_mfma_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd,
                            int cin, int cout, hipStream_t s);
 size_t mfma_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
+bool h2_convT_wgrad_selected(int cin, int cout);
+size_t h2_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
+int32_t k_convT_h2_wgrad(unet_ctx*, const float* x, const float* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
+                         hipStream_t s);
 int32_t k_convT_mfma_wgrad(unet_ctx*, const float* x, const float* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n,
                            int h, int wd, int cin, int cout, hipStream_t s);
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);

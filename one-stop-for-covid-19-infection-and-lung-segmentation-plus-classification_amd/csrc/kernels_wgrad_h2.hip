@@ -278,6 +278,254 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
   if (wa == 0 && ta == 0 && lane < 32 && bc < CB) P[(long long)TAPS * CA * CB + bc] = bsum;
 }
 
+// ---- ConvT 2x2 stride 2 (T1:886 ...): dK[ab][o][c] = sum_{n,i,j} dU[n, 2i+a, 2j+b, o] * x[n, i, j, c],  db[o] = sum dU.
+// The same machine with A = dU (cout channels, pixel stride ldA inside the concat gradient, 2H x 2W: 2R rows x 64 pixels staged per step) and B = x
+// (cin channels, H x W: R rows x 32 pixels); the four taps are the four parity planes of the staged dU rows -- a lane's eight consecutive K pixels sit two
+// pixel slots apart -- and the bias gradient is the sum over A.
+template <int WA, int WB, int WR, int R>
+__global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
+                                                           int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
+                                                           int npairs, long long pstride, int units, int upb) {
+  static_assert(WA * WB * WR == 4 && WR <= R, "4 waves");
+  constexpr int TAPS = 4, AROWS = 2 * R, AW = 64;
+  constexpr int ASUB = AROWS * AW * 64, BSUB = R * 32 * 64;       // bytes of one 32-channel sub-plane of one fp16 plane
+  constexpr int STAGE1 = WA * ASUB + WB * BSUB;
+  constexpr int RED = WR > 1 ? 2 * TAPS * 16 * 64 * 4 : 0;
+  constexpr int STAGE = 2 * STAGE1;
+  __shared__ __attribute__((aligned(16))) char smem[STAGE > RED ? STAGE : RED];
+  __shared__ float s_bs[4][64];
+  __shared__ float s_amax[2][4];
+  char* const s_a = smem; char* const s_b = smem + WA * ASUB;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave % WR, wb = (wave / WR) % WB, wa = wave / (WR * WB);
+  const int sq = blockIdx.x >> 3;
+  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);
+  if (split >= nsplit) return;
+  const int ta = pair / tiles_b, tb = pair % tiles_b;
+  const int a0 = ta * 32 * WA, b0 = tb * 32 * WB;
+  const int chunk = split % chunks_per_strip; const int ublk = split / chunks_per_strip;
+  const int ya = chunk * rows_per_chunk;
+  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
+  const int HA = 2 * H, WAI = 2 * W;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bsum = 0.0f;
+  int e_a = 120, e_b = 120;
+
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int tr_px = (g4 >> 1) * 8 + (i16 >> 2), tr_ch = ((g4 & 1) * 16 + (i16 & 3) * 4) * 2;
+  const char* const pa = s_a + wa * ASUB + tr_ch;
+  const char* const pb = s_b + wb * BSUB + tr_ch;
+
+  const int u1 = (ublk + 1) * upb < units ? (ublk + 1) * upb : units;
+  for (int unit = ublk * upb; unit < u1; ++unit) {
+    const int cs = unit % strips, n = unit / strips;
+    const int x0 = cs * 32;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + (long long)n * HA * WAI * ldA, (long long)HA * WAI * ldA * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + (long long)n * H * W * CB, (long long)H * W * CB * 4);
+    // a thread fetches channel quad q8 of pixel column pc of a staged B row, and of pixel columns pc and 32 + pc of a staged A row
+    const int q8 = tid & 7, pc = tid >> 3;
+    int abase_t[WA][2], bbase_t[WB];
+#pragma unroll
+    for (int sub = 0; sub < WA; ++sub)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int gx = 2 * x0 + half * 32 + pc, ch = a0 + sub * 32 + q8 * 4;
+        abase_t[sub][half] = (gx < WAI && ch < CA) ? (gx * ldA + ch) * 4 : UNET_OOB;
+      }
+#pragma unroll
+    for (int sub = 0; sub < WB; ++sub) {
+      const int gx = x0 + pc, ch = b0 + sub * 32 + q8 * 4;
+      bbase_t[sub] = (gx < W && ch < CB) ? (gx * CB + ch) * 4 : UNET_OOB;
+    }
+    constexpr int NA = WA * AROWS * 2, NB_ = WB * R;
+    unet_u32x4 areg[NA], breg[NB_];
+    auto issue_loads = [&](int ys) __attribute__((always_inline)) {        // ys = first x row of the step
+#pragma unroll
+      for (int sub = 0; sub < WA; ++sub)
+#pragma unroll
+        for (int row = 0; row < AROWS; ++row) {
+          const int gy = 2 * ys + row;
+          const bool ok = ys + (row >> 1) < yb;                            // (rows past the chunk: not part of this split's bias sum either)
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+            areg[(sub * AROWS + row) * 2 + half] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? abase_t[sub][half] : UNET_OOB, ok ? gy * WAI * ldA * 4 : 0, 0);
+        }
+#pragma unroll
+      for (int sub = 0; sub < WB; ++sub)
+#pragma unroll
+        for (int row = 0; row < R; ++row) {
+          const int gy = ys + row;
+          const bool ok = gy < yb;
+          breg[sub * R + row] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, ok ? bbase_t[sub] : UNET_OOB, ok ? gy * W * CB * 4 : 0, 0);
+        }
+    };
+    auto post_amax = [&]() __attribute__((always_inline)) {
+      float ma = 0.f, mb = 0.f;
+#pragma unroll
+      for (int k = 0; k < NA; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ma = fmaxf(ma, fabsf(__uint_as_float(areg[k][j])));
+#pragma unroll
+      for (int k = 0; k < NB_; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mb = fmaxf(mb, fabsf(__uint_as_float(breg[k][j])));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+      if (lane == 0) { s_amax[0][wave] = ma; s_amax[1][wave] = mb; }
+    };
+    auto store_lds = [&]() __attribute__((always_inline)) {
+      const float ma = fmaxf(fmaxf(s_amax[0][0], s_amax[0][1]), fmaxf(s_amax[0][2], s_amax[0][3]));
+      const float mb = fmaxf(fmaxf(s_amax[1][0], s_amax[1][1]), fmaxf(s_amax[1][2], s_amax[1][3]));
+      const int eba = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(ma) >> 23) & 0xFF));
+      const int ebb = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(mb) >> 23) & 0xFF));
+      int d = 0;
+      if (eba >= 11 && eba - 127 + e_a >= 15) {
+        const int da_ = 138 - eba - e_a;
+        bsum *= pow2f(max(da_, -126));                                     // (the bias sum rides on the A operand here)
+        d += da_; e_a = 138 - eba;
+      }
+      if (ebb >= 11 && ebb - 127 + e_b >= 15) { d += 138 - ebb - e_b; e_b = 138 - ebb; }
+      if (d != 0) {
+        const float f = pow2f(max(d, -126));
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+      }
+      const float sa = pow2f(e_a), sb = pow2f(e_b);
+      auto put = [&](char* dst, const unet_u32x4& v, float sc) __attribute__((always_inline)) {
+        unsigned h0, m0, h1, m1;
+        split2(__uint_as_float(v[0]) * sc, __uint_as_float(v[1]) * sc, h0, m0);
+        split2(__uint_as_float(v[2]) * sc, __uint_as_float(v[3]) * sc, h1, m1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + STAGE1) = make_uint2(m0, m1);
+      };
+#pragma unroll
+      for (int sub = 0; sub < WA; ++sub)
+#pragma unroll
+        for (int row = 0; row < AROWS; ++row)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) put(s_a + ((sub * AROWS + row) * AW + half * 32 + pc) * 64 + q8 * 8, areg[(sub * AROWS + row) * 2 + half], sa);
+#pragma unroll
+      for (int sub = 0; sub < WB; ++sub)
+#pragma unroll
+        for (int row = 0; row < R; ++row) put(s_b + ((sub * R + row) * 32 + pc) * 64 + q8 * 8, breg[sub * R + row], sb);
+    };
+
+    issue_loads(ya);
+    post_amax();
+    __syncthreads();
+    store_lds();
+    __syncthreads();
+    for (int ys = ya; ys < yb; ys += R) {
+      const bool more = ys + R < yb;
+      if (more) issue_loads(ys + R);
+#pragma unroll
+      for (int r = wr; r < R; r += WR) {
+#pragma unroll
+        for (int kst = 0; kst < 2; ++kst) {
+          const char* bp = pb + (r * 32 + kst * 16 + tr_px) * 64;
+          const f16x8 bh = lds_tr_frag(bp, bp + 4 * 64), bm = lds_tr_frag(bp + STAGE1, bp + STAGE1 + 4 * 64);
+          f16x8 ah[4], am[4];
+#pragma unroll
+          for (int ab = 0; ab < 4; ++ab) {
+            const char* ap = pa + ((2 * r + (ab >> 1)) * AW + 2 * (kst * 16 + tr_px) + (ab & 1)) * 64;
+            ah[ab] = lds_tr_frag(ap, ap + 8 * 64); am[ab] = lds_tr_frag(ap + STAGE1, ap + STAGE1 + 8 * 64);
+            if (wb == 0) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) bsum += (float)ah[ab][j] + (float)am[ab][j];
+            }
+          }
+          // product-major: a dependent MFMA never directly follows its producer
+#pragma unroll
+          for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ab], bm, acc[ab], 0, 0, 0);
+#pragma unroll
+          for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ab], bh, acc[ab], 0, 0, 0);
+#pragma unroll
+          for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ab], bh, acc[ab], 0, 0, 0);
+        }
+      }
+      if (more) post_amax();
+      __syncthreads();
+      if (more) { store_lds(); __syncthreads(); }
+    }
+  }
+  const float un_a = pow2f(max(-e_a, -126));
+  const float un = un_a * pow2f(max(-e_b, -126));
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] *= un;
+  bsum *= un_a;
+
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (WR > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    const int grp = wave / WR;
+    s_bs[wave][lane] = bsum;
+#pragma unroll
+    for (int stride = WR / 2; stride >= 1; stride >>= 1) {
+      float* img = red + (size_t)(grp * stride + (wr % stride)) * (TAPS * 16 * 64);
+      if (wr >= stride && wr < 2 * stride) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) img[(t * 16 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (wr < stride) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += img[(t * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (wr == 0) { bsum = s_bs[wave][lane]; for (int k = 1; k < WR; ++k) bsum += s_bs[wave + k][lane]; }
+  }
+  if (wr != 0) return;
+  float* P = part + (long long)split * pstride;
+  const int ar = a0 + wa * 32, bc = b0 + wb * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = acc[t][r];
+    }
+  if (wb == 0 && tb == 0 && lane < 32 && ar + l31 < CA) P[(long long)TAPS * CA * CB + ar + l31] = bsum;
+}
+
+struct WgPlanT { int WA, WB, WR, R, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs, units, upb; size_t floats; };
+
+// ca = cout (dU channels), cb = cin (x channels); h, w = the ConvT's INPUT size
+WgPlanT plan_wgradT_h2(int n, int h, int w, int ca, int cb) {
+  WgPlanT p;
+  p.WA = (ca % 64) == 0 ? 2 : 1; p.WB = 2;                      // (cb is a multiple of 64: h2_convT_wgrad_selected)
+  p.WR = 4 / (p.WA * p.WB);
+  p.R = p.WA == 2 ? 1 : 2;                                       // 64 dU channels: one x row per step keeps the two fp16 planes at 40 KB (two rows: 80 KB, one workgroup per CU)
+  p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
+  const long long pairs = (long long)p.tiles_a * p.tiles_b, per = 4LL * ca * cb;
+  const long long units = (long long)n * p.strips;
+  long long want = std::max<long long>(1, 512 / pairs);
+  want = std::min(want, std::max<long long>(1, (64LL << 20) / per));
+  p.units = (int)units; p.upb = (int)std::max<long long>(1, units / want);
+  const long long ublocks = (units + p.upb - 1) / p.upb;
+  long long cps = std::max<long long>(1, want / ublocks);
+  cps = std::min<long long>(cps, std::max<long long>(1, h / 4));
+  int rpc = (int)((h + cps - 1) / cps); rpc = (rpc + p.R - 1) / p.R * p.R;
+  p.rows_per_chunk = rpc; p.chunks_per_strip = (h + rpc - 1) / rpc;
+  p.nsplit = (int)(ublocks * p.chunks_per_strip); p.nslabs = p.nsplit;
+  p.floats = (size_t)p.nslabs * (per + ca) + wgrad_reduce_scratch_floats(4, ca, cb, ca, p.nslabs);
+  return p;
+}
+
 struct WgPlanH2 { int WA, WB, WR, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs, units, upb; size_t floats; };
 
 int wgrad_h2_rows() {
@@ -347,4 +595,30 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
 #undef UNET_WG
   UNET_CHECK_LAUNCH(ctx, "wgrad_h2");
   return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
+}
+
+// ---- ConvT weight gradient on the h2 kernels: cout (the dU channels) a multiple of 32, cin a multiple of 64
+bool h2_convT_wgrad_selected(int cin, int cout) {
+  static const int on = [] { const char* e = getenv("UNET_H2_CONVT_WGRAD"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = the fp32-MFMA kernel
+  return h2_wgrad_mode() != 0 && on && cout >= 32 && (cout % 32) == 0 && cin >= 64 && (cin % 64) == 0;
+}
+size_t h2_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_convT_wgrad_selected(cin, cout) ? plan_wgradT_h2(n, h, wd, cout, cin).floats * sizeof(float) : 0; }
+
+// x [n,h,wd,cin] dense, dy = dU channel slice (pixel stride lddy) of [n,2h,2wd,.]; dw [2][2][cout][cin], db [cout]
+int32_t k_convT_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
+                         hipStream_t s) {
+  if (!h2_convT_wgrad_selected(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad h2: cin=%d cout=%d unsupported", cin, cout);
+  if (4LL * h * wd * lddy * 4 >= (1LL << 30) || (long long)h * wd * cin * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  const WgPlanT p = plan_wgradT_h2(n, h, wd, cout, cin);
+  if (!ws || ws_bytes < p.floats * sizeof(float)) UNET_FAIL(ctx, UNET_E_ARG, "convT wgrad h2: workspace %zu < %zu bytes", ws_bytes, p.floats * sizeof(float));
+  float* part = static_cast<float*>(ws);
+  const long long S = 4LL * cout * cin + cout;
+  const int npairs = p.tiles_a * p.tiles_b;
+  const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
+  if (p.WA == 2) hipLaunchKernelGGL((wgradT_h2_kernel<2, 2, 1, 1>), grid, dim3(256), 0, s, dy, lddy, x, part, n, h, wd, cout, cin, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip,
+                                    p.nsplit, npairs, S, p.units, p.upb);
+  else hipLaunchKernelGGL((wgradT_h2_kernel<1, 2, 2, 2>), grid, dim3(256), 0, s, dy, lddy, x, part, n, h, wd, cout, cin, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit,
+                          npairs, S, p.units, p.upb);
+  UNET_CHECK_LAUNCH(ctx, "wgradT_h2");
+  return k_wgrad_reduce(ctx, part, p.nslabs, 4, cout, cin, cout, dw, db, s);
 }

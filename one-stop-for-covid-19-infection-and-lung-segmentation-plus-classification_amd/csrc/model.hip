@@ -267,7 +267,7 @@ int32_t unet_convT2x2_bwd_data(unet_ctx* ctx, const float* dy, int32_t lddy, con
 }
 
 size_t unet_convT2x2_bwd_weights_ws_bytes(int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
-  return mfma_convT_supported(cin, cout) ? mfma_convT_wgrad_ws_bytes(n, h, wd, cin, cout) : 0;
+  return std::max(mfma_convT_supported(cin, cout) ? mfma_convT_wgrad_ws_bytes(n, h, wd, cin, cout) : 0, h2_convT_wgrad_ws_bytes(n, h, wd, cin, cout));
 }
 
 int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy, int32_t lddy, float* dw, float* db, void* ws,
@@ -276,6 +276,8 @@ int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy
   if (!ctx || !x || !dy || !dw || !db || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_weights: bad args");
   const bool can = mfma_convT_supported(cin, cout) && ws && ws_bytes >= mfma_convT_wgrad_ws_bytes(n, h, wd, cin, cout);
   if (algo == UNET_ALGO_MFMA && !can) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad mfma: unsupported shape or workspace too small");
+  if (algo == UNET_ALGO_AUTO && h2_convT_wgrad_selected(cin, cout) && ws && ws_bytes >= h2_convT_wgrad_ws_bytes(n, h, wd, cin, cout))
+    return k_convT_h2_wgrad(ctx, x, dy, lddy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, as_stream(stream));      // three fp16 MFMA products of the block-scaled two-term split
   if (algo != UNET_ALGO_NAIVE && can) return k_convT_mfma_wgrad(ctx, x, dy, lddy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_wgrad(ctx, x, dy, lddy, dw, db, n, h, wd, cin, cout, as_stream(stream));
 }
@@ -555,7 +557,7 @@ void plan_workspace(unet_model* m) {
       if (l.kind != 1) continue;
       int k = l.name[1] - '0';                 // u6..u9: input at level (10-k), i.e. spatial >> (10-k)
       int lvl = 10 - k;
-      wgb = std::max(wgb, m->dt ? bf16_convT_wgrad_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout) : mfma_convT_wgrad_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout));
+      wgb = std::max(wgb, m->dt ? bf16_convT_wgrad_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout) : unet_convT2x2_bwd_weights_ws_bytes(m->N, s >> lvl, t >> lvl, l.cin, l.cout));
     }
   }
   m->wgrad_ws_bytes = wgb;
@@ -1025,7 +1027,7 @@ void plan_workspace_pp(unet_model* m) {
   { Buf t; t.off = cv.take(tmp_up); m->act["tmp_up"] = t; }
   for (auto& l : m->layers) {
     if (l.kind == 0) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, m->dt ? unet_conv3x3_bwd_weights_ws_bytes_bf16(N, ob.h, ob.w, l.cin, l.cout) : unet_conv3x3_bwd_weights_ws_bytes(N, ob.h, ob.w, l.cin, l.cout)); }
-    if (l.kind == 1) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, m->dt ? bf16_convT_wgrad_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout) : mfma_convT_wgrad_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout)); }
+    if (l.kind == 1) { const Buf& ob = m->act.at(l.name); wgb = std::max(wgb, m->dt ? bf16_convT_wgrad_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout) : unet_convT2x2_bwd_weights_ws_bytes(N, ob.h / 2, ob.w / 2, l.cin, l.cout)); }
   }
   m->wgrad_ws_bytes = wgb;
   m->off_wgrad_ws = cv.take((wgb + 3) / 4);

@@ -136,7 +136,8 @@ def test_h2_block_scaling_keeps_fp32_accuracy_over_any_range(ops, case):
     assert np.abs(got_db - want_db).max() <= TOL * np.abs(want_db).max() + 1e-30
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 5, 8, 4), (1, 4, 4, 512, 256), (2, 8, 8, 64, 32), (1, 7, 9, 128, 64), (2, 5, 37, 64, 64), (1, 33, 34, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 8, 4), (1, 4, 4, 512, 256), (2, 8, 8, 64, 32), (1, 7, 9, 128, 64), (2, 5, 37, 64, 64), (1, 33, 34, 32, 32), (2, 40, 48, 64, 32),
+                                   (3, 17, 33, 128, 64), (2, 21, 70, 192, 96)])
 def test_convT(ops, shape):
     from gpu_util import relerr
     n, h, w, ci, co = shape
@@ -164,6 +165,12 @@ def test_convT(ops, shape):
         dw = ops.z(2, 2, co, ci); db = ops.z(co); dw.fill_(3.0); db.fill_(-2.0)
         ops.ck(ops.lib.unet_convT2x2_bwd_weights(ops.h, ops.d(x).data_ptr(), ops.d(dcat).data_ptr(), ld, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, algo, ops.s), "convT bwd w")
         assert relerr(dw.cpu().numpy(), kt.grad.numpy()) < TOL and relerr(db.cpu().numpy(), bt.grad.numpy()) < TOL
+    # gradients the size they have at batch 16 x 512^2 (block scaling of the h2 weight gradient: both operands are activations)
+    dsmall = dcat.copy(); dsmall[..., :co] *= 3e-9
+    nb = ops.lib.unet_convT2x2_bwd_weights_ws_bytes(n, h, w, ci, co); ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    dw = ops.z(2, 2, co, ci); db = ops.z(co)
+    ops.ck(ops.lib.unet_convT2x2_bwd_weights(ops.h, ops.d(x * 300.0).data_ptr(), ops.d(dsmall).data_ptr(), ld, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, n, h, w, ci, co, 0, ops.s), "convT bwd w small")
+    assert relerr(dw.cpu().numpy(), kt.grad.numpy() * 9e-7) < TOL and relerr(db.cpu().numpy(), bt.grad.numpy() * 3e-9) < TOL
 
 
 @pytest.mark.parametrize("c,ld_extra", [(32, 0), (64, 64), (128, 0), (512, 0), (256, 256)])
