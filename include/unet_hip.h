@@ -76,8 +76,8 @@ double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin,
 double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
 /* Conv2D / Conv2DTranspose followed by a training-mode BatchNormalization (T1:860-861 `Conv2D(...)(c1)` -> `BatchNormalization()(c1)`, T1:886-888
  * `Conv2DTranspose` -> `concatenate` -> `BatchNormalization`): arms the NEXT unet_conv3x3_fwd / unet_convT2x2_fwd on this context to add the
- * per-channel (sum y, sum y^2) of the tensor it writes (c channels) to the context's accumulators from its epilogue, where its kernel can (the
- * fp32 h2 kernels, no dropout); the unet_bn_stats / unet_bn_stats_concat call that MUST follow on that tensor then folds them instead of reading
+ * per-channel (sum y, sum y^2) of the values it STORES (c channels; after activation and dropout) to the context's accumulators from its epilogue,
+ * where its kernel can (the fp32 h2 kernels); the unet_bn_stats / unet_bn_stats_concat call that MUST follow on that tensor then folds them instead of reading
  * the tensor again (any other kernel ignores the request and that call does its own pass -- same results either way).  c = 0 disarms. */
 int32_t unet_request_bn_stats(unet_ctx*, int32_t c);
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,

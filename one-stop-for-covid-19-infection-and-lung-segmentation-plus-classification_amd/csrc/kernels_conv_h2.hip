@@ -565,11 +565,11 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv h2: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
   const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP);
-  // an armed statistics request (common.h): forward launches only, dense channel counts the slot copies can hold, no dropout on the stored values
+  // an armed statistics request (common.h): forward launches only (the sums are those of the values STORED, after activation and dropout), channel counts the slot copies can hold
   double* stats = nullptr; int stats_c = 0;
   if (MODE != 2 && ctx->stats_req_c > 0) {
     const int c = ctx->stats_req_c; ctx->stats_req_c = 0;
-    if (!mask && rate == 0.0f && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots) { stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; }
+    if ((mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots) { stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; }
   }
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");

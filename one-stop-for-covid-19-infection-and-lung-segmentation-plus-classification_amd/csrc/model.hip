@@ -575,6 +575,23 @@ double nel(const Buf& b) { return (double)b.n * b.h * b.w * b.c; }
     (vec).push_back(std::move(_o));                           \
   } while (0)
 
+// Conv2D -> BatchNormalization (T1:860-861; every block of UPP:858-950 and T2:747-776): where a training-mode statistics pass directly follows the fp32
+// conv3x3 that wrote its input, the conv is armed (unet_request_bn_stats) and its kernel, if it can, leaves the sums for that pass to fold
+void arm_bn_statistics(unet_model* m) {
+  if (m->dt) return;
+  auto& F = m->prog[UNET_PROG_FWD_TRAIN];
+  unet_ctx* ctx = m->ctx;
+  for (size_t i = 1; i < F.size(); ++i) {
+    if (F[i].name.rfind("bn_stats:", 0) != 0 || F[i - 1].name.rfind("conv3x3_fwd:", 0) != 0) continue;
+    const std::string bn = F[i].name.substr(9);
+    const auto g = m->tinfo.find(bn + "/gamma");
+    if (g == m->tinfo.end()) continue;
+    const int c = (int)g->second.count;
+    auto inner = F[i - 1].run;
+    F[i - 1].run = [=](hipStream_t s) -> int32_t { unet_request_bn_stats(ctx, c); return inner(s); };
+  }
+}
+
 void build_programs(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int algo = m->algo;
@@ -621,14 +638,11 @@ void build_programs(unet_model* m) {
     ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
     if (!dt) ADD_OP(F, "wino_weights:fwd", 0, 0, { return prep_weights(0, s); });       // all Winograd weight transforms of the program in one launch
     else ADD_OP(F, "weight_images:fwd", 0, 0, { return prep_weights_bf16(0, s); });
-    // bn_next: a training-mode BatchNorm over `cout` channels reads this conv's output next -- its statistics ride in the conv's epilogue where the kernel can
-    auto conv = [&](const std::string& name, const std::string& in, int cin, int cout, bool bn_next = false) {
+    auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
       const Buf ob = m->act.at(name);
       double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
       double by = eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout;
-      const bool arm = bn_next && training && !dt;
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
-        if (arm) unet_request_bn_stats(ctx, cout);
         if (dt) {
           if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_RELU, 0.0f, 0, s);
           return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU,
@@ -681,7 +695,7 @@ void build_programs(unet_model* m) {
     for (int k = 1; k <= 4; ++k) {
       int c = ENC[k - 1]; std::string ks = std::to_string(k);
       conv("c" + ks + "a", prev, cprev, c);
-      conv("c" + ks + "b", "c" + ks + "a", c, c, true);
+      conv("c" + ks + "b", "c" + ks + "a", c, c);
       bn("bn" + ks, "c" + ks + "b", "bn" + ks, c, true);
       const Buf ib = m->act.at("bn" + ks), xb = m->act.at("c" + ks + "b");
       const std::string pin = "bn" + ks, pout = "p" + ks, xin = "c" + ks + "b";
@@ -1686,6 +1700,7 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
   if (arch == UNET_ARCH_UNET) { build_layers(m); plan_workspace(m); build_programs(m); }
   else if (arch == UNET_ARCH_UNETPP) { build_layers_pp(m); plan_workspace_pp(m); build_programs_pp(m); }
   else { build_layers_cls(m); plan_workspace_cls(m); build_programs_cls(m); }
+  arm_bn_statistics(m);
   *out = m;
   return UNET_OK;
 }
