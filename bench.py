@@ -277,8 +277,19 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which sits in libc's buffer until exit and would
+    # land behind an earlier Python print -- flush C stdio on every rank, meet, and only then print (rank 0) and tear the group down
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if pg is not None:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         dist.destroy_process_group()
 
 

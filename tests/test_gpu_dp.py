@@ -135,9 +135,9 @@ def test_rccl_code_path_at_world_size_one_equals_the_plain_step(tmp_path):
     got = np.load(out)
     eng = HipUNet(64, 64, 1, dropout_rate=0.0); eng.set_weights(wts)
     ref = np.array([eng.train_batch(x, y).cpu().numpy() for _ in range(3)])
-    assert np.abs(got["losses"] - ref).max() < 1e-6
+    assert np.abs(got["losses"] - ref).max() < 5e-6          # (measured: two outcomes 1.3e-6 apart, on either side, after three steps)
     p, ld = eng.predict_batch(x, y)
-    assert np.abs(got["ld"] - ld.cpu().numpy()).max() < 1e-6 and np.allclose(got["sums"], eng.threshold_sums(p, y, [0.3, 0.5]).cpu().numpy(), rtol=1e-6)
+    assert np.abs(got["ld"] - ld.cpu().numpy()).max() < 5e-6 and np.allclose(got["sums"], eng.threshold_sums(p, y, [0.3, 0.5]).cpu().numpy(), rtol=1e-6)
     for k, v in eng.get_weights().items():
         assert np.linalg.norm(got["w/" + k] - v) <= 2e-4 * np.linalg.norm(v) + 1e-6 * np.sqrt(v.size), k      # (Adam's first steps are sign-like: last-bit noise in a gradient becomes O(lr))
 
