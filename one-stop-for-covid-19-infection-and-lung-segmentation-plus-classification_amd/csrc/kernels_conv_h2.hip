@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [IN_BYTES] [W_LDS] [4 floats: per-wave max |x| of the chunk being staged]
   char* const s_in = smem; char* const s_w = smem + IN_BYTES;
   float* const s_amax = reinterpret_cast<float*>(smem + IN_BYTES + W_LDS);
+  float* const s_bias = s_amax + 4;                      // [3][NB * 32]: bias (+ the two other coefficient rows of a folded-BatchNorm gradient) of this channel group
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,6 +284,16 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   };
 
   H2_STAMP(0);
+  // the epilogue's per-channel operands go through LDS: requested from the epilogue they queue behind every other workgroup's patch loads in the CU's
+  // memory pipeline (a 2-4 k-cycle round trip per tile); here they are the first request of the workgroup and land before its first barrier
+  if (tid < NB * 32) {
+    const int ch = g * NB * 32 + tid;
+    const bool ok = ch < M;
+    s_bias[tid] = (bias && ok) ? bias[MODE == 1 ? ch % (M >> 2) : ch] : 0.f;
+    const bool coef = mask_mode >= MASK_BN_BWD && mask && ok;
+    s_bias[NB * 32 + tid] = coef ? bias[M + ch] : 0.f;
+    s_bias[2 * NB * 32 + tid] = coef ? bias[2 * M + ch] : 0.f;
+  }
   issue_loads(0);
   issue_w_loads(0);
   post_amax();
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     float bv[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + oc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b4 = *reinterpret_cast<const float4*>(s_bias + nb * 32 + hi * 16 + q * 4);
       bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
     }
     float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1;           // BatchNorm statistics of what this lane stores (channel quad lane & 7)
@@ -434,7 +445,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         // data gradient of a conv whose input BatchNorm is folded: dx = K0 dz + K1 x + K2, x read where a ReLU layer reads its mask
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 k1 = *reinterpret_cast<const float4*>(bias + M + mb + q * 4), k2 = *reinterpret_cast<const float4*>(bias + 2 * M + mb + q * 4);
+          const float4 k1 = *reinterpret_cast<const float4*>(s_bias + (NB + nb) * 32 + hi * 16 + q * 4), k2 = *reinterpret_cast<const float4*>(s_bias + (2 * NB + nb) * 32 + hi * 16 + q * 4);
           v[q * 4] = fmaf(bv[q * 4], a[q * 4], fmaf(k1.x, mv[q * 4], k2.x));
           v[q * 4 + 1] = fmaf(bv[q * 4 + 1], a[q * 4 + 1], fmaf(k1.y, mv[q * 4 + 1], k2.y));
           v[q * 4 + 2] = fmaf(bv[q * 4 + 2], a[q * 4 + 2], fmaf(k1.z, mv[q * 4 + 2], k2.z));
@@ -558,7 +569,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
-  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16;
+  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16 + 3 * NB * 32 * 4;
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;
