@@ -164,7 +164,7 @@ __global__ __launch_bounds__(TPB) void conv3x3_naive_wgrad_kernel(const float* _
 // accumulators [9 taps + bias] x float4, xor-shuffle + LDS tree per block, then block partials
 // [grid][10][Cout] that reduce_c1_kernel sums in a fixed order (deterministic).
 constexpr int C1_BLOCKS = 1024;
-template <typename T>
+template <typename T, bool X4>
 __global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                                float* __restrict__ part, int N, int H, int W, int Cout) {
   const int lpp = Cout >> 2;
@@ -174,6 +174,42 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1_wgrad_kernel(const float* __re
   for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   const long long pixels = (long long)N * H * W;
   const long long g0 = ((long long)blockIdx.x * TPB + threadIdx.x) / lpp, gs = ((long long)gridDim.x * TPB) / lpp;
+  if (X4) {
+    // four consecutive pixels of a row per thread: four dy loads in flight, 3 x 6 image values for the 4 x 9 products
+    const unsigned W4 = (unsigned)W >> 2;
+    const long long groups = (long long)N * H * W4;
+    for (long long gi = g0; gi < groups; gi += gs) {
+      const unsigned gu = (unsigned)gi, row = gu / W4;
+      const int j0 = (int)(gu - row * W4) * 4, i = (int)(row % (unsigned)H);
+      const long long p0 = (long long)row * W + j0;
+      float4 g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = ld4(dy + (p0 + k) * Cout + sub * 4);
+      float v[3][6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int ii = i + a - 1;
+        const bool rok = ii >= 0 && ii < H;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          const int jj = j0 + b - 1;
+          v[a][b] = (rok && jj >= 0 && jj < W) ? x[p0 + (a - 1) * W + (b - 1)] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            const float xv = v[a][k + b];
+            float4& r = acc[a * 3 + b];
+            r.x = fmaf(xv, g[k].x, r.x); r.y = fmaf(xv, g[k].y, r.y); r.z = fmaf(xv, g[k].z, r.z); r.w = fmaf(xv, g[k].w, r.w);
+          }
+        acc[9].x += g[k].x; acc[9].y += g[k].y; acc[9].z += g[k].z; acc[9].w += g[k].w;
+      }
+    }
+  } else
   for (long long p = g0; p < pixels; p += gs) {
     const unsigned pu = (unsigned)p, tq = pu / (unsigned)W;             // 32-bit index math (pixels < 2^31, checked by the launcher)
     const int j = (int)(pu - tq * (unsigned)W), i = (int)(tq % (unsigned)H);
@@ -376,7 +412,9 @@ static int32_t c1_wgrad_impl(unet_ctx* ctx, const float* x, const T* dy, float* 
   if (!ws || ws_bytes < c1_wgrad_ws_bytes(cout)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_c1_wgrad: workspace too small");
   long long groups = ((long long)n * h * wd * (cout / 4) + TPB - 1) / TPB;
   int blocks = (int)std::min<long long>(C1_BLOCKS, std::max<long long>(groups, 1));
-  hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<T>, dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
+  static const int four = [] { const char* e = getenv("UNET_C1_X4"); return e ? atoi(e) : 1; }();
+  if (four && (wd & 3) == 0) hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<T, true>), dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
+  else hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<T, false>), dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
   float* part = static_cast<float*>(ws); float* part2 = part + (size_t)C1_BLOCKS * 10 * cout;
   const int ngroups = (blocks + 31) / 32;
   hipLaunchKernelGGL(reduce_c1_kernel, dim3((10 * cout + 127) / 128, ngroups), dim3(128), 0, s, part, part2, nullptr, blocks, 32, cout, 0);
