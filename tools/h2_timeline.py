@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase timeline of conv_h2_kernel from s_memtime stamps (measurement build -DH2_EXPERIMENT=5 of kernels_conv_h2.hip; the library
+"""Phase timeline of conv_h2_kernel from s_memtime stamps (measurement build: `make -C <package>/csrc timeline` -> build/exp/libunet_exp5.so; the library
 path is given explicitly, the product library has no such symbol).
     python tools/h2_timeline.py build/exp/libunet_exp5.so N H W CIN COUT [dgrad]"""
 import ctypes

@@ -11,18 +11,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--algo", type=int, default=0); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--warm", type=int, default=25); ap.add_argument("--dtype", default="fp32")
+    ap.add_argument("--algo", type=int, default=0); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--warm", type=int, default=25); ap.add_argument("--dtype", default="fp32"); ap.add_argument("--arch", default="unet")
     a = ap.parse_args()
     import numpy as np
     import torch
     from covidseg_amd import weights as W
     from covidseg_amd.data import synthetic_ct
     from covidseg_amd.engine import HipUNet
-    xs, ys = synthetic_ct(min(a.batch, 4), a.size, seed=0)
+    if a.arch == "classifier":
+        from covidseg_amd.data import synthetic_classification
+        xs, ys = synthetic_classification(min(a.batch, 8), a.size, seed=0); ys = ys.astype(np.float32)
+    else:
+        xs, ys = synthetic_ct(min(a.batch, 4), a.size, seed=0)
     r = (a.batch + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * r)[:a.batch]).cuda(); y = torch.from_numpy(np.concatenate([ys] * r)[:a.batch]).cuda()
-    eng = HipUNet(a.size, a.size, 1, conv_algo=a.algo, dtype=a.dtype)
-    eng.set_weights(W.init_weights(0))
+    eng = HipUNet(a.size, a.size, 1, conv_algo=a.algo, dtype=a.dtype, arch=a.arch, dropout_rate=0.25)
+    eng.set_weights(W.init_weights(0, 1, a.arch, (a.size, a.size)))
     for _ in range(a.warm):          # the chip needs ~1 s of load to reach its sustained clocks
         eng.train_batch(x, y)
     torch.cuda.synchronize()
