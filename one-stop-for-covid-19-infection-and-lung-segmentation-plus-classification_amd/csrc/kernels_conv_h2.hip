@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int pxj = x0 + j * 8 + (lane >> 3);
-          const bool ok = mb0 < M && py < H && pxj < W;
+          const bool ok = mb0 + (lane & 7) * 4 < M && py < H && pxj < W;
           const long long o = (((long long)n * H + py) * W + pxj) * ldy + mb0 + (lane & 7) * 4;
           mpre[nb][r][j] = ok ? *reinterpret_cast<const float4*>(mask + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   // ---- epilogue: lane (l31, hi) holds, for pixel column l31 of each of its RW rows, channels mb + 0..15
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int mb = (g * NB + nb) * 32 + hi * 16;
-    if (mb >= M) continue;                                 // zero-padded rows of a tile that overhangs M
+    const int mb0 = (g * NB + nb) * 32, mb = mb0 + hi * 16;
+    if (mb0 >= M) continue;                                // (wave-uniform) zero-padded block of a tile that overhangs M; M % 32 == 16: the hi half of the last block is padding
     int ab = 0, oc = mb;
     if (MODE == 1) { const int ct = M >> 2; ab = mb / ct; oc = mb - ab * ct; }
     float bv[16];
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     for (int r = 0; r < RW; ++r) {
       const int py = y0 + wave * RW + r;
       if (py >= H) continue;                               // (wave-uniform)
-      const bool live = px_ < W;                           // lanes past the image edge take part in the LDS transpose only
+      const bool live = px_ < W && mb < M;                 // lanes past the image edge / in the padded half block take part in the LDS transpose only
       long long o;
       if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
       else o = (((long long)n * H + py) * W + px_) * ldy + mb;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
         else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
-        if (pxj < W) {
+        if (pxj < W && mb0 + cj * 4 < M) {
           *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
           if (MODE != 2 && stats) {
             st1.x += t4.x; st1.y += t4.y; st1.z += t4.z; st1.w += t4.w;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     if (tid < NB * 64) {
       const int nb = tid >> 6, kind = (tid >> 5) & 1, c32 = tid & 31;
       const int mb = (g * NB + nb) * 32;
-      if (mb < M) {
+      if (mb + c32 < M) {
         float t = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) t += s_stat[((wv * NB + nb) * 2 + kind) * 32 + c32];
@@ -605,10 +605,10 @@ int h2_mode() {
 static int h2_nb(int M) { return (M % 64) == 0 ? 2 : 1; }      // n-blocks of 32 output channels per workgroup
 
 // a launch with K contraction channels and M output channels runs on the h2 kernels (both the weight preparation and the launch ask this)
-bool h2_conv3x3_selected(int K, int M) { return h2_mode() != 0 && K >= 16 && (K % 16) == 0 && M >= 32 && (M % 32) == 0; }
+bool h2_conv3x3_selected(int K, int M) { return h2_mode() != 0 && K >= 16 && (K % 16) == 0 && M >= 16 && (M % 16) == 0; }
 
-// bytes of the split weight image: 256-B header + 36 * K * M (fits the 16 * cin * cout floats every caller reserves for transformed weights)
-size_t h2_wimg_bytes(int K, int M) { return (size_t)H2_HEADER + (size_t)36 * K * M; }
+// bytes of the split weight image: 256-B header + 36 * K * M' (M' = M rounded up to whole 32-channel blocks; fits unet_conv3x3_w_ws_floats)
+size_t h2_wimg_bytes(int K, int M) { return (size_t)H2_HEADER + (size_t)36 * K * ((M + 31) / 32 * 32); }
 
 int32_t k_h2_weights_multi(unet_ctx* ctx, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s) {
   if (count < 1) return UNET_OK;
@@ -642,7 +642,7 @@ int32_t k_h2_weights(unet_ctx* ctx, const float* w, void* img, int cin, int cout
 // x [n,h,wd,K] dense NHWC fp32, wimg from k_h2_weights (K contraction channels, M output channels), y [n,h,wd,M] fp32
 int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K,
                          int M, int act, float rate, uint64_t seed, hipStream_t s) {
-  if (K < 16 || (K % 16) || M < 32 || (M % 32)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: K=%d (multiple of 16) M=%d (multiple of 32)", K, M);
+  if (K < 16 || (K % 16) || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: K=%d M=%d (multiples of 16)", K, M);
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
   static const int tile = [] { const char* e = getenv("UNET_H2_TILE"); return e ? atoi(e) : 0; }();          // measurements: 1 = 8-row tiles everywhere, 2 = 16-row tiles for 64-wide groups

@@ -569,7 +569,7 @@ int h2_wgrad_mode() {
 
 bool h2_wgrad_selected(int cin, int cout) {
   static const int small = [] { const char* e = getenv("UNET_WGRAD_H2_32"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = 32 x 32 layers on the fp32 Winograd weight gradient
-  return h2_wgrad_mode() != 0 && cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0 && (cin >= 64 || cout >= 64 || (small && cin == 32 && cout == 32));
+  return h2_wgrad_mode() != 0 && cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0 && (cin >= 64 || cout >= 64 || small);          // (16- / 48-channel tensors: the last 32-channel tile is masked)
 }
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_wgrad_selected(cin, cout) ? plan_wgrad_h2(n, h, wd, cin, cout).floats * sizeof(float) : 0; }
 

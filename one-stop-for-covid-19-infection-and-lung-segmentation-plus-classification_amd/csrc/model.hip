@@ -190,7 +190,8 @@ double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_
   return 1.0;
 }
 
-size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return (size_t)16 * (cin > 0 ? cin : 0) * (cout > 0 ? cout : 0); }
+// (channel counts below 32 are padded to one 32-channel block in the h2 weight image, either direction)
+size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return cin > 0 && cout > 0 ? (size_t)16 * std::max(cin, 32) * std::max(cout, 32) + 64 : 0; }
 
 int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* mask_src, int32_t mask_mode, float mask_rate,
                               uint64_t mask_seed, float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
@@ -210,7 +211,7 @@ int32_t unet_conv3x3_bnfold_supported(int32_t algo, int32_t h, int32_t wd, int32
 }
 size_t unet_conv3x3_bnfold_ws_floats(int32_t n, int32_t cin, int32_t cout) {
   if (n < 1 || cin < 1 || cout < 1) return 0;
-  return bn_fold_scratch_floats(cin, cout) + (size_t)16 * cin * cout + wgrad_bn_fold_scratch_floats(n, cout);
+  return bn_fold_scratch_floats(cin, cout) + unet_conv3x3_w_ws_floats(cin, cout) + wgrad_bn_fold_scratch_floats(n, cout);
 }
 int32_t unet_conv3x3_bnfold_fwd(unet_ctx* ctx, const float* x, const float* bnp, const float* w, const float* bias, float* y, int32_t n, int32_t h, int32_t wd,
                                 int32_t cin, int32_t cout, int32_t act, int32_t algo, float* ws, void* stream) {
@@ -233,7 +234,7 @@ int32_t unet_conv3x3_bnfold_bwd_weights(unet_ctx* ctx, const float* x, const flo
   int32_t r = conv3x3_wgrad_dispatch(ctx, x, dy, dw, db, gws, gws_bytes, n, h, wd, cin, cout, algo, s);
   if (r) return r;
   if (bn_bwd_sums && !w) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bnfold_bwd_weights: bn_bwd_sums needs the kernel w");
-  return k_wgrad_bn_fold_fix(ctx, dy, n, h, wd, cin, cout, bnp, bnp + cin, dw, db, ws + bn_fold_scratch_floats(cin, cout) + (size_t)16 * cin * cout, s,
+  return k_wgrad_bn_fold_fix(ctx, dy, n, h, wd, cin, cout, bnp, bnp + cin, dw, db, ws + bn_fold_scratch_floats(cin, cout) + unet_conv3x3_w_ws_floats(cin, cout), s,
                              bn_bwd_sums ? w : nullptr, bn_bwd_sums ? bnp + 2 * cin : nullptr, bn_bwd_sums ? bnp + 3 * cin : nullptr, bn_bwd_sums);
 }
 
@@ -494,9 +495,9 @@ void plan_workspace(unet_model* m) {
     m->act["c" + ks + "a"] = mk(cv, N, S, T, c);
     m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
   }
-  { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, (size_t)16 * l.cin * l.cout); m->off_wt = cv.take(wt); }   // transformed-weight scratch
+  { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, unet_conv3x3_w_ws_floats(l.cin, l.cout)); m->off_wt = cv.take(wt); }   // transformed-weight scratch
   // per-layer scratch of the prepared weights: 16 Winograd taps (fp32) or the 9-tap bf16 image
-  for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : unet_conv3x3_w_ws_floats(l.cin, l.cout));
   // decoder BatchNorm folded into the conv that consumes it: whenever that conv runs on the F(2x2,3x3) kernels (the only ones with the border-class bias)
   if (bn_fold_enabled()) {
     for (int k = 6; k <= 9; ++k) {
@@ -516,7 +517,7 @@ void plan_workspace(unet_model* m) {
     // the data gradient (cout -> cin channels) on the F(2x2,3x3) kernels too: the BatchNorm backward moves into its epilogue
     if (bn_fold_enabled() >= 2 && (m->dt || (use_wino(m->algo, ob.w, cout, cin, reinterpret_cast<const float*>(m)) && wino_uses_2d(ob.h, cin)))) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
   }
-  for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : (size_t)16 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : unet_conv3x3_w_ws_floats(l.cin, l.cout));
   // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
     const std::string& nm = kv.first; const Buf& b = kv.second;
@@ -1009,7 +1010,7 @@ void plan_workspace_pp(unet_model* m) {
     m->act[nm + "a"] = mk(cv, N, hh, ww, nd.c); m->act[nm + "abn"] = mk(cv, N, hh, ww, nd.c);
     m->act[nm + "b"] = mk(cv, N, hh, ww, nd.c); m->act[nm] = mk(cv, N, hh, ww, nd.c); m->act[nm + "bbn"] = m->act[nm];
   }
-  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)16 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, unet_conv3x3_w_ws_floats(l.cin, l.cout));
   m->off_wt = cv.take(wt0);
   // conv_block = [Conv -> Dropout -> BN] x 2 (UPP:860-868): the first BatchNorm feeds only the second conv -> folded into it, fp32 on the
   // F(2x2,3x3) kernels
@@ -1403,7 +1404,7 @@ void plan_workspace_cls(unet_model* m) {
   const int K = hh * ww * CLS_C[2];
   m->dense_ws_bytes = unet_dense_ws_bytes(N, K, CLS_HIDDEN);
   m->off_dense_ws = cv.take((m->dense_ws_bytes + 3) / 4);
-  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, (size_t)16 * l.cin * l.cout);
+  for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, unet_conv3x3_w_ws_floats(l.cin, l.cout));
   m->off_wt = cv.take(wt0);
   // Conv(relu) -> BN -> Conv (T2:748-751): the first BatchNorm of a block feeds only the block's second conv -> folded into it.  fp32: where that conv
   // runs on the F(2x2,3x3) kernels (the 32- and 64-channel blocks)

@@ -178,7 +178,7 @@ def test_full_size_bf16_conv_agrees_with_the_fp32_kernels(ops, shape):
     assert float((y.float() - yr).norm() / yr.norm()) < BF16_OUT
     dx = ops.z(n, h, w, ci, dtype=torch.bfloat16); dxr = ops.z(n, h, w, ci)
     ops.ck(ops.lib.unet_conv3x3_bwd_data_bf16(ops.h, dyb.data_ptr(), kb.data_ptr(), xb.data_ptr(), 1, 0.0, 0, dx.data_ptr(), ops.wws(ci, co), n, h, w, ci, co, ops.s), "dgrad bf16")
-    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, dy32.data_ptr(), kb.data_ptr(), x32.data_ptr(), 1, 0.0, 0, dxr.data_ptr(), ops.z(16 * ci * co).data_ptr(), n, h, w, ci, co, 2, ops.s), "dgrad fp32")
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, dy32.data_ptr(), kb.data_ptr(), x32.data_ptr(), 1, 0.0, 0, dxr.data_ptr(), ops.z(int(ops.lib.unet_conv3x3_w_ws_floats(ci, co))).data_ptr(), n, h, w, ci, co, 2, ops.s), "dgrad fp32")
     assert float((dx.float() - dxr).norm() / dxr.norm()) < BF16_OUT
     nb = ops.lib.unet_conv3x3_bwd_weights_ws_bytes_bf16(n, h, w, ci, co); nr = ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, ci, co)
     ws = torch.empty(max(nb, nr, 16), dtype=torch.uint8, device="cuda")

@@ -23,7 +23,7 @@ def T64(a):
 CONV_SHAPES = [(2, 9, 13, 3, 5), (1, 16, 16, 1, 32), (2, 16, 16, 32, 32), (2, 12, 20, 32, 64), (1, 8, 8, 64, 128),
                (2, 6, 10, 128, 64), (1, 4, 4, 256, 512), (3, 14, 14, 64, 64), (1, 34, 70, 32, 32), (2, 64, 48, 1, 32), (1, 9, 13, 1, 32), (2, 4, 3, 512, 512),
                # channel counts that are not multiples of 32 (the classifier's 16-wide layers, T2:748-750): tiles overhang
-               (2, 16, 16, 16, 16), (1, 12, 20, 16, 32), (2, 8, 8, 32, 16), (1, 10, 10, 24, 80), (1, 8, 8, 8, 48), (2, 16, 16, 1, 16),
+               (2, 16, 16, 16, 16), (1, 12, 20, 16, 32), (2, 8, 8, 32, 16), (1, 10, 10, 24, 80), (1, 8, 8, 8, 48), (2, 16, 16, 1, 16), (1, 10, 10, 48, 48), (2, 12, 20, 16, 48), (1, 9, 33, 48, 16),
                # wide rows: several 64-column Winograd tiles, ragged right edge, odd width
                (1, 6, 128, 32, 64), (2, 5, 150, 16, 32), (1, 9, 67, 64, 128), (1, 3, 64, 8, 8),
                # narrow images: the 2-D Winograd kernel packs two row pairs x 16 tiles into an MFMA M-tile
@@ -58,7 +58,7 @@ def test_conv3x3_bwd(ops, shape, algo):
     O.conv3x3_bias_relu(xt, kt, bt, relu=False).backward(T64(dy))
     # data gradient, with and without the fused ReLU mask of the producer of x
     for masked in (False, True):
-        dx = ops.z(n, h, w, ci); wt = ops.z(16 * ci * co)
+        dx = ops.z(n, h, w, ci); wt = ops.z(int(ops.lib.unet_conv3x3_w_ws_floats(ci, co)))
         xm = ops.d(x)
         ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), xm.data_ptr() if masked else None, 1 if masked else 0, 0.0, 0, dx.data_ptr(), wt.data_ptr(),
                                              n, h, w, ci, co, algo, ops.s), "conv bwd data")
@@ -519,7 +519,7 @@ def test_conv3x3_elu_dropout_and_mask_modes(ops, shape, algo):
     xt, kt = T64(a).requires_grad_(True), T64(k)
     O.conv3x3_bias_relu(xt, kt, torch.zeros(co, dtype=torch.float64), relu=False).backward(T64(dy))
     g = xt.grad.numpy(); elup = np.where(a > 0, 1.0, a + 1.0)
-    wt = ops.z(16 * ci * co); dx = ops.z(n, h, w, ci)
+    wt = ops.z(int(ops.lib.unet_conv3x3_w_ws_floats(ci, co))); dx = ops.z(n, h, w, ci)
     ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), ops.d(a).data_ptr(), 2, 0.0, 0, dx.data_ptr(), wt.data_ptr(), n, h, w, ci, co, algo, ops.s), "mask elu")
     assert relerr(dx.cpu().numpy(), g * elup) < TOL
     ones = np.ones((n, h, w, ci), np.float32); km = ops.z(n, h, w, ci)           # keep mask of (rate, seed) on this tensor shape
@@ -640,7 +640,7 @@ def test_wgrad_random_shapes_all_algorithms_agree(ops, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 40, 72, 32, 32), (3, 24, 40, 64, 64), (2, 16, 32, 128, 128), (1, 19, 45, 32, 64), (2, 8, 8, 256, 256)])
+@pytest.mark.parametrize("shape", [(2, 40, 72, 32, 32), (3, 24, 40, 64, 64), (2, 16, 32, 128, 128), (1, 19, 45, 32, 64), (2, 8, 8, 256, 256), (2, 20, 36, 16, 16), (1, 12, 40, 32, 48)])
 def test_conv_epilogue_bn_statistics_equal_the_statistics_pass(ops, shape):
     """Conv2D -> BatchNormalization (T1:860-861): unet_request_bn_stats arms the conv, whose epilogue adds (sum y, sum y^2) per channel of the rows it
     stores; the unet_bn_stats call on that tensor then only folds them.  Must equal the statistics pass over the same tensor (and the fp64 sums of

@@ -26,7 +26,7 @@ def main():
     print(f"{'layer':6s} {'S':>4s} {'cin':>4s} {'cout':>4s} {'direct ms':>10s} {'TF':>7s} {'wino ms':>9s} {'TF':>7s} {'speedup':>8s} {'maxdiff':>9s}")
     for name, S, ci, co in LAYERS:
         x = torch.randn(n, S, S, ci, device="cuda"); k = torch.randn(3, 3, ci, co, device="cuda") * 0.1; b = torch.randn(co, device="cuda")
-        ws = torch.empty(16 * ci * co, device="cuda")
+        ws = torch.empty(int(lib.unet_conv3x3_w_ws_floats(ci, co)), device="cuda")
         ys = []
         res = []
         for algo in (2, 3):
