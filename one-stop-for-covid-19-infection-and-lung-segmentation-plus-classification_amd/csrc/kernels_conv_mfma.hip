@@ -999,14 +999,15 @@ __global__ __launch_bounds__(256) void border_sums_kernel(const T* __restrict__ 
   __syncthreads();
   if (sl == 0) { for (int k = 1; k < nsl; ++k) acc += s_p[k * C + co]; out[(((long long)n * BORDER_SEG + seg) * 8 + kind) * C + co] = acc; }
 }
-// S[tap][o] from db and the border sums (NS = images x segments of them).  grid (9, C / 64), 256 threads = 64 channels x 4 slices of NS
-__global__ __launch_bounds__(256) void fold_tap_sums_kernel(const float* __restrict__ border, const float* __restrict__ db, float* __restrict__ S, int NS, int C) {
-  __shared__ float s_r[3][4][64];
+// S[tap][o] from db and the border sums (NS = images x segments of them).  grid (9, C / 64), 1024 threads = 64 channels x 16 slices of NS (a batch of 256
+// images is 1024 entries: with 4 slices the three dependent loads per entry made this 0.2 ms of pure latency)
+__global__ __launch_bounds__(1024) void fold_tap_sums_kernel(const float* __restrict__ border, const float* __restrict__ db, float* __restrict__ S, int NS, int C) {
+  __shared__ float s_r[3][16][64];
   const int tap = blockIdx.x, a = tap / 3, b = tap - a * 3, l = threadIdx.x & 63, sl = threadIdx.x >> 6, o = blockIdx.y * 64 + l;
   const int er = a == 0 ? 0 : (a == 2 ? 1 : -1), ec = b == 0 ? 0 : (b == 2 ? 1 : -1);      // excluded row (0: first, 1: last), column
   float kr = 0.f, kc = 0.f, kk = 0.f;
   if (o < C)
-    for (int n = sl; n < NS; n += 4) {
+    for (int n = sl; n < NS; n += 16) {
       const float* p = border + (long long)n * 8 * C + o;
       if (er >= 0) kr += p[er * C];
       if (ec >= 0) kc += p[(2 + ec) * C];
@@ -1015,9 +1016,8 @@ __global__ __launch_bounds__(256) void fold_tap_sums_kernel(const float* __restr
   s_r[0][sl][l] = kr; s_r[1][sl][l] = kc; s_r[2][sl][l] = kk;
   __syncthreads();
   if (sl == 0 && o < C) {
-    kr = (s_r[0][0][l] + s_r[0][1][l]) + (s_r[0][2][l] + s_r[0][3][l]);
-    kc = (s_r[1][0][l] + s_r[1][1][l]) + (s_r[1][2][l] + s_r[1][3][l]);
-    kk = (s_r[2][0][l] + s_r[2][1][l]) + (s_r[2][2][l] + s_r[2][3][l]);
+    kr = kc = kk = 0.f;
+    for (int k = 0; k < 16; ++k) { kr += s_r[0][k][l]; kc += s_r[1][k][l]; kk += s_r[2][k][l]; }          // fixed order
     S[tap * C + o] = ((db[o] - kr) - kc) + kk;
   }
 }
@@ -1066,7 +1066,7 @@ static int32_t wgrad_bn_fold_fix_impl(unet_ctx* ctx, const T* dy, int n, int h, 
   if (!dy || !scale || !shift || !dw || !db || !scratch || !wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: bad args (cout=%d)", cout);
   float* border = scratch; float* S = scratch + (size_t)n * BORDER_SEG * 8 * cout;
   hipLaunchKernelGGL(border_sums_kernel<T>, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
-  hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, border, db, S, n * BORDER_SEG, cout);
+  hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(1024), 0, s, border, db, S, n * BORDER_SEG, cout);
   if (bn_bwd_sums) {
     if (!w || !mean || !istd) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: the BatchNorm backward sums need w, mean, istd");
     hipLaunchKernelGGL(fold_bn_bwd_sums_kernel, dim3((unsigned)cin), dim3(256), 0, s, w, dw, S, mean, istd, bn_bwd_sums, cin, cout);
