@@ -349,6 +349,7 @@ struct Op {
   std::function<int32_t(hipStream_t)> run;
   double flops = 0, bytes = 0, ms = 0;
   int64_t calls = 0;
+  int side = 0, join_after = 0;                        // backward overlap (plan_bwd_overlap): runs on the model's side stream / the main stream waits for it right behind this op
 };
 
 }  // namespace
@@ -366,6 +367,7 @@ struct unet_model {
   const float *x = nullptr, *yt = nullptr; float* pout = nullptr;
   float drop_rate = 0.0f; uint64_t drop_seed = 0;
   float cw0 = 1.0f, cw1 = 1.0f;                       // classifier: class weights of the loss
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // backward overlap: weight gradients beside the data-gradient chain
   size_t off_dense_ws = 0, dense_ws_bytes = 0;
   // workspace plan (offsets in floats)
   std::map<std::string, Buf> act, grad;
@@ -590,6 +592,21 @@ void arm_bn_statistics(unet_model* m) {
     const int c = (int)g->second.count;
     auto inner = F[i - 1].run;
     F[i - 1].run = [=](hipStream_t s) -> int32_t { unet_request_bn_stats(ctx, c); return inner(s); };
+  }
+}
+
+// (Experiment, off by default: see unet_model_run.)  A weight gradient needs only its layer's dy and x and nothing waits for it before the optimizer (or a
+// gradient bucket of the data-parallel path): the backward program can run them on a side stream beside the data-gradient chain -- kernels bound by different things (a deep layer's MFMA-bound
+// weight gradient beside a shallow layer's HBM-bound data gradient) fill each other's gaps.  All users of the split-K workspace are on that stream,
+// so they stay serialised among themselves; the weight gradient of a conv with a folded BatchNorm feeds the BatchNorm's backward sums, which the very
+// next data gradient needs: the main stream joins right behind its fix-up op.  unet_model_run joins at the end of every call.
+void plan_bwd_overlap(unet_model* m) {
+  auto& B = m->prog[UNET_PROG_BWD];
+  for (size_t i = 0; i < B.size(); ++i) {
+    const std::string& nm = B[i].name;
+    const bool wg = nm.rfind("conv3x3_wgrad:", 0) == 0 || nm.rfind("convT_wgrad:", 0) == 0, fix = nm.rfind("wgrad_bn_fold_fix:", 0) == 0;
+    if (wg || fix) B[i].side = 1;
+    if (fix) B[i].join_after = 1;
   }
 }
 
@@ -1702,11 +1719,18 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
   else if (arch == UNET_ARCH_UNETPP) { build_layers_pp(m); plan_workspace_pp(m); build_programs_pp(m); }
   else { build_layers_cls(m); plan_workspace_cls(m); build_programs_cls(m); }
   arm_bn_statistics(m);
+  plan_bwd_overlap(m);
   *out = m;
   return UNET_OK;
 }
 
-void unet_model_destroy(unet_model* m) { delete m; }
+void unet_model_destroy(unet_model* m) {
+  if (!m) return;
+  if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+  delete m;
+}
 int64_t unet_model_param_count(const unet_model* m) { return m ? m->n_params : 0; }
 int64_t unet_model_state_count(const unet_model* m) { return m ? m->n_state : 0; }
 int32_t unet_model_dtype(const unet_model* m) { return m ? m->dt : UNET_E_ARG; }
@@ -1775,10 +1799,34 @@ int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, 
   hipStream_t s = as_stream(stream);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) { UNET_HIP(ctx, hipEventCreate(&e0)); UNET_HIP(ctx, hipEventCreate(&e1)); }
+  // measured (1 x MI355X, 512^2 x 16, same box): 17.46-17.98 ms per step with the overlap, 17.35 without -- two matrix kernels sharing the CUs slow each
+  // other down by more than their gaps are worth.  Off by default; UNET_BWD_OVERLAP=1 re-measures it
+  static const int overlap = [] { const char* e = getenv("UNET_BWD_OVERLAP"); return e ? atoi(e) : 0; }();
+  const bool use_side = overlap && prog == UNET_PROG_BWD && !ctx->profiling;
+  if (use_side && !m->side) {
+    UNET_HIP(ctx, hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    UNET_HIP(ctx, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    UNET_HIP(ctx, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  }
+  bool side_busy = false;
+  auto join = [&]() -> int32_t {
+    if (!side_busy) return UNET_OK;
+    UNET_HIP(ctx, hipEventRecord(m->ev_join, m->side));
+    UNET_HIP(ctx, hipStreamWaitEvent(s, m->ev_join, 0));
+    side_busy = false;
+    return UNET_OK;
+  };
   for (int i = begin; i < end; ++i) {
     if (ctx->profiling) UNET_HIP(ctx, hipEventRecord(e0, s));
-    int32_t r = P[i].run(s);
+    int32_t r;
+    if (use_side && P[i].side) {
+      UNET_HIP(ctx, hipEventRecord(m->ev_fork, s));            // (everything the op reads was produced by ops in front of it in program order)
+      UNET_HIP(ctx, hipStreamWaitEvent(m->side, m->ev_fork, 0));
+      r = P[i].run(m->side);
+      side_busy = true;
+    } else r = P[i].run(s);
     if (r) { ctx->err = P[i].name + ": " + ctx->err; return r; }
+    if (use_side && P[i].join_after) { r = join(); if (r) return r; }
     if (ctx->profiling) {
       UNET_HIP(ctx, hipEventRecord(e1, s));
       UNET_HIP(ctx, hipEventSynchronize(e1));
@@ -1786,7 +1834,8 @@ int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, 
       P[i].ms += ms; P[i].calls += 1;
     }
   }
-  if (ctx->profiling) { hipEventDestroy(e0); hipEventDestroy(e1); }
+  { int32_t r = join(); if (r) return r; }
+  if (ctx->profiling) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   return UNET_OK;
 }
 
