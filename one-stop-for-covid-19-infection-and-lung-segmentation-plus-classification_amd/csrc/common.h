@@ -27,6 +27,10 @@ struct unet_ctx {
   int stats_req_c = 0;              // channels of the BatchNorm (0 = not armed)
   const void* stats_in_slots = nullptr;
   int stats_in_slots_c = 0;
+  // one-shot: the next h2 conv3x3 forward with a ReLU epilogue also writes the sign bits of what it stores (MASK_RELU_BITS layout) here and leaves the
+  // address in signs_done; the data gradients that would re-read the fp32 tensor as their mask read 1/32 of the bytes
+  unsigned long long* signs_req = nullptr;
+  const void* signs_done = nullptr;
   std::set<const void*> big_lds_kernels;   // kernels already opted in to > 64 KiB of dynamic LDS on this context's device
   std::string err;
 };
@@ -160,6 +164,9 @@ enum { MASK_BN_BWD = 5 };
 enum { MASK_BN_BWD_ELU = 6, MASK_BN_BWD_ELU_DROP = 7 };
 // ... or by the ReLU mask of x's producer (classifier: Conv(relu) -> BN -> Conv, T2:748-751): out = x > 0 ? K0 dz + K1 x + K2 : 0
 enum { MASK_BN_BWD_RELU = 8 };
+// h2 kernels only: the ReLU mask as ONE BIT per element, written by the forward launch that produced the tensor (unet_ctx::signs_req):
+// u64 words [n][y][x / 8][c / 32][4]; word k of an (8 pixels x 32 channels) cell holds bit (pixel % 8) * 8 + (channel % 32) / 4 for channel % 4 == k
+enum { MASK_RELU_BITS = 9 };
 int32_t k_bn_bwd_coef(unet_ctx*, const float* bnp, const double* sums, double count, float* coef, int c, hipStream_t s);
 __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep_scale component */, float rate) {
   if (mode == MASK_RELU) return m > 0.0f ? 1.0f : 0.0f;
@@ -206,7 +213,7 @@ int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const floa
                          int act, float rate, uint64_t seed, hipStream_t s);
 bool h2_convT_selected(const unet_ctx* ctx, int cin, int cout);
 int32_t k_convT_h2_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s);
-int32_t k_convT_h2_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s);
+int32_t k_convT_h2_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s, int mask_bits = 0);
 bool h2_wgrad_selected(int cin, int cout);
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);

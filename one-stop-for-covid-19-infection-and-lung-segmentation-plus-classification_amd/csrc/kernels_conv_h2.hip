@@ -163,7 +163,7 @@ template <int MODE, int NB, int RW, bool GEN, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
-                                                           int total_blocks, double* __restrict__ stats, int stats_c) {
+                                                           int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
   constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     const int ch = g * NB * 32 + tid;
     const bool ok = ch < M;
     s_bias[tid] = (bias && ok) ? bias[MODE == 1 ? ch % (M >> 2) : ch] : 0.f;
-    const bool coef = mask_mode >= MASK_BN_BWD && mask && ok;
+    const bool bn_bwd_mode = mask_mode >= MASK_BN_BWD && mask_mode <= MASK_BN_BWD_RELU;
+    const bool coef = bn_bwd_mode && mask && ok;
     s_bias[NB * 32 + tid] = coef ? bias[M + ch] : 0.f;
     s_bias[2 * NB * 32 + tid] = coef ? bias[2 * M + ch] : 0.f;
   }
@@ -371,10 +372,24 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   // ---- last chunk: what the epilogue reads per output element (the ReLU / ELU mask of a data gradient, x of a folded-BatchNorm gradient) is requested
   // BEFORE its MFMAs and lands under them; requested from the epilogue it is a full memory round trip per tile on layers with 2-4 chunks per tile
   const int px_ = x0 + l31;
-  const bool want_m = mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB;
+  const bool want_m = mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB && mask_mode != MASK_RELU_BITS;
   constexpr bool MPF = MODE != 1 && RW * NB <= 4;          // (64 registers at most; the 16-row tiles keep the epilogue loads)
   float4 mpre[MPF ? NB : 1][MPF ? RW : 1][4];
-  if (MPF && want_m) {
+  if (MPF && mask_mode == MASK_RELU_BITS) {
+    // one bit per element: the 32 B of this lane's (8 pixels x 32 channels) cell -- the same address for the 16 lanes of a cell
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int blk = g * NB + nb;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int py = y0 + wave * RW + r;
+        const bool ok = blk * 32 < M && py < H && x0 + (l31 & ~7) < W;
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(mask) + ((((long long)n * H + py) * (W >> 3) + (x0 >> 3) + (l31 >> 3)) * (M >> 5) + blk) * 4;
+        mpre[nb][r][0] = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        mpre[nb][r][1] = ok ? *reinterpret_cast<const float4*>(p + 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  } else if (MPF && want_m) {
     // (requested the way the output rows are stored -- eight consecutive lanes per 128-B line, lane -> (pixel j * 8 + lane / 8, channel quad lane % 8) --
     //  and turned into the accumulator layout through the epilogue's LDS staging row)
 #pragma unroll
@@ -428,7 +443,24 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       float v[16], mv[16], a[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) a[i] = acc[r][nb][i] * unscale;
-      if (want_m) {
+      if (mask_mode == MASK_RELU_BITS) {
+        float4 w01, w23;
+        if (MPF) { w01 = mpre[MPF ? nb : 0][MPF ? r : 0][0]; w23 = mpre[MPF ? nb : 0][MPF ? r : 0][1]; }
+        else {
+          const bool ok = py < H && x0 + (l31 & ~7) < W;
+          const unsigned long long* p = reinterpret_cast<const unsigned long long*>(mask) + ((((long long)n * H + py) * (W >> 3) + (x0 >> 3) + (l31 >> 3)) * (M >> 5) + (g * NB + nb)) * 4;
+          w01 = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+          w23 = ok ? *reinterpret_cast<const float4*>(p + 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // word k = (lo, hi) dwords; this lane's bits: (pixel % 8) * 8 + hi * 4 + q
+        const bool up = (l31 & 4) != 0;
+        const unsigned d[4] = {__float_as_uint(up ? w01.y : w01.x), __float_as_uint(up ? w01.w : w01.z), __float_as_uint(up ? w23.y : w23.x), __float_as_uint(up ? w23.w : w23.z)};
+        const int sh = (l31 & 3) * 8 + hi * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) mv[q * 4 + k] = ((d[k] >> (sh + q)) & 1u) ? 1.0f : 0.0f;
+      } else if (want_m) {
         if (MPF) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(s_out + (j * 8 + (lane >> 3)) * OUT_PS + (lane & 7) * 16) = mpre[MPF ? nb : 0][MPF ? r : 0][j];
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
           mv[q * 4] = m4.x; mv[q * 4 + 1] = m4.y; mv[q * 4 + 2] = m4.z; mv[q * 4 + 3] = m4.w;
         }
       }
-      if (mask_mode >= MASK_BN_BWD) {
+      if (mask_mode >= MASK_BN_BWD && mask_mode <= MASK_BN_BWD_RELU) {
         // data gradient of a conv whose input BatchNorm is folded: dx = K0 dz + K1 x + K2, x read where a ReLU layer reads its mask
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -473,14 +505,14 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        if (mask_mode == MASK_RELU) {
+        if (mask_mode == MASK_RELU || mask_mode == MASK_RELU_BITS) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = mv[i] > 0.f ? v[i] : 0.f;
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = apply_act(v[i], act);
-        if (mask_mode >= MASK_BN_BWD) {                    // (v already holds K0 dz + K1 x + K2) then the ELU (+ dropout) derivative of x's producer
+        if (mask_mode >= MASK_BN_BWD && mask_mode <= MASK_BN_BWD_RELU) {                    // (v already holds K0 dz + K1 x + K2) then the ELU (+ dropout) derivative of x's producer
           if (mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP) {
             const int mm = mask_mode == MASK_BN_BWD_ELU_DROP ? MASK_ELU_DROP : MASK_ELU;
 #pragma unroll
@@ -520,6 +552,13 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
         else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
+        if (MODE == 0 && signs) {                          // (wave-uniform) sign bits of the stored values: four ballots per 8 pixels x 32 channels
+          const bool vld = pxj < W && mb0 + cj * 4 < M;
+          const unsigned long long b0 = __builtin_amdgcn_ballot_w64(vld && t4.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(vld && t4.y > 0.f);
+          const unsigned long long b2 = __builtin_amdgcn_ballot_w64(vld && t4.z > 0.f), b3 = __builtin_amdgcn_ballot_w64(vld && t4.w > 0.f);
+          if (lane < 4 && x0 + j * 8 < W)
+            signs[((((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * (M >> 5) + (g * NB + nb)) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        }
         if (pxj < W && mb0 + cj * 4 < M) {
           *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
           if (MODE != 2 && stats) {
@@ -582,10 +621,16 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
     const int c = ctx->stats_req_c; ctx->stats_req_c = 0;
     if ((mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots) { stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; }
   }
+  if (mask_mode == MASK_RELU_BITS && ((M & 31) || (wd & 7))) UNET_FAIL(ctx, UNET_E_SHAPE, "conv h2: the bit mask needs M %% 32 == 0 and W %% 8 == 0 (M=%d W=%d)", M, wd);
+  unsigned long long* signs = nullptr;
+  if (MODE == 0 && ctx->signs_req) {
+    unsigned long long* q = ctx->signs_req; ctx->signs_req = nullptr;
+    if (act == ACT_RELU && rate == 0.0f && (mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && !(M & 31) && !(wd & 7)) { signs = q; ctx->signs_done = q; }
+  }
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
-                       stats_c);
+                       stats_c, signs);
     return UNET_OK;
   };
   int32_t r;
@@ -684,12 +729,12 @@ int32_t k_convT_h2_fwd(unet_ctx* ctx, const float* x, const float* w, const floa
 }
 
 // dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]; dy = channel slice with pixel stride lddy; mask: ReLU of the producer of x
-int32_t k_convT_h2_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s) {
+int32_t k_convT_h2_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s, int mask_bits) {
   const int NB = (cin % 64) == 0 ? 2 : 1;
   int32_t r = h2_convT_image(ctx, w, 4 * cout, cin, NB, cin, 1, 4LL * cin * cout, s);             // W(k = ab*cout + o, m = c) = K[k*cin + c]
   if (r) return r;
   const unet_bf16* img = static_cast<const unet_bf16*>(ctx->convt_img);
-  const int mm = mask ? MASK_RELU : MASK_NONE;
+  const int mm = mask ? (mask_bits ? MASK_RELU_BITS : MASK_RELU) : MASK_NONE;
   if (NB == 2) return launch_h2<2, 2, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
   return launch_h2<2, 1, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
 }

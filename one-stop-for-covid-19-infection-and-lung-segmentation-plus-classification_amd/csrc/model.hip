@@ -67,6 +67,10 @@ static bool use_mfma(int algo, int cin, int cout) {
 }
 
 // Winograd pays when its 64-column row tiles are reasonably full; `uws` = scratch for the transformed weights (may be null)
+static int relu_bits_enabled() {
+  static const int on = [] { const char* e = getenv("UNET_RELU_BITS"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = data gradients re-read the fp32 activation as their ReLU mask
+  return on;
+}
 // decoder BatchNorm statistics: skip half analytic, up half measured (unet_bn_stats_concat); 0 = read the whole concat as before
 static bool bn_concat_analytic() {
   static const int on = [] { const char* e = getenv("UNET_BN_CONCAT_ANALYTIC"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
@@ -376,6 +380,7 @@ struct unet_model {
   size_t off_bn_bsums = 0;                            // all bwd BN sums (double)
   std::map<std::string, size_t> bn_sum_off, bn_bsum_off, bnp_off;   // per-BN offsets (doubles / floats)
   size_t off_loss_sums = 0, off_loss_out = 0, off_wt = 0, off_wgrad_ws = 0; size_t wgrad_ws_bytes = 0;
+  std::map<std::string, size_t> sign_off;            // U-Net fp32 training: activation name -> its one-bit-per-element ReLU mask (MASK_RELU_BITS), offset in floats
   std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the Winograd-transformed weights (forward / data-gradient form),
                                                       // filled by ONE batched launch at the start of a program
   // U-Net fp32: convs whose input BatchNorm is folded into them: conv name -> scratch of (scaled weights, bias table) / of the
@@ -520,6 +525,22 @@ void plan_workspace(unet_model* m) {
     if (bn_fold_enabled() >= 2 && (m->dt || (use_wino(m->algo, ob.w, cout, cin, reinterpret_cast<const float*>(m)) && wino_uses_2d(ob.h, cin)))) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
   }
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : unet_conv3x3_w_ws_floats(l.cin, l.cout));
+  // ReLU masks as sign bits (MASK_RELU_BITS): the output of a conv that is the mask of the next conv's / ConvT's data gradient -- c<k>a for the conv pairs,
+  // c5b ... c8b for the ConvTs -- where producer and consumer both run on the h2 kernels (decided exactly as the launches decide)
+  if (!m->dt && relu_bits_enabled()) {
+    static float dummy;
+    auto h2_conv = [&](int w, int K, int M) { return use_wino(m->algo, w, K, M, &dummy) && h2_conv3x3_selected(K, M); };
+    for (auto& l : m->layers) {
+      if (l.kind != 0 || l.cin <= 1) continue;
+      const Buf ob = m->act.at(l.name);
+      if ((l.cout & 31) || (ob.w & 7) || !h2_conv(ob.w, l.cin, l.cout)) continue;
+      const char last = l.name.back();
+      bool used = false;
+      if (last == 'a') used = h2_conv(ob.w, l.cout, l.cout);                                      // mask of c<k>b's data gradient (K = M = cout)
+      else if (l.name == "c5b" || l.name == "c6b" || l.name == "c7b" || l.name == "c8b") used = m->algo == UNET_ALGO_AUTO && h2_convT_selected(m->ctx, l.cout, l.cout / 2);
+      if (used) m->sign_off[l.name] = cv.take((size_t)ob.n * ob.h * ob.w * l.cout / 32);
+    }
+  }
   // --- training extras: gradient twins ---
   for (auto& kv : m->act) {
     const std::string& nm = kv.first; const Buf& b = kv.second;
@@ -668,8 +689,14 @@ void build_programs(unet_model* m) {
         }
         const float* xin = in.empty() ? m->x : m->A(in);
         const auto pf = m->wprep_f.find(name);
-        return conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
-                                    ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second));
+        const auto so = training ? m->sign_off.find(name) : m->sign_off.end();
+        unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
+        ctx->signs_req = sg; ctx->signs_done = nullptr;
+        int32_t r = conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
+                                         ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second));
+        ctx->signs_req = nullptr;
+        if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd %s: the launch did not write the ReLU sign bits its data gradient was planned with", name.c_str());
+        return r;
       });
     };
     // skip_src: the encoder BatchNorm whose output is the second half of the concat `in` -- its statistics are analytic (unet_bn_stats_concat)
@@ -755,7 +782,13 @@ void build_programs(unet_model* m) {
           const float* tab = m->wsf(fo) + (size_t)9 * cin * cout;
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(xn)), m->wsf(fo), tab, reinterpret_cast<const unet_bf16*>(tab), MASK_BIAS_TAB, WBF(m->Av(cn)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU,
                                             0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s, nullptr);
-          return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(uo), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0, s);
+          const auto so = training ? m->sign_off.find(cn) : m->sign_off.end();
+          unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
+          ctx->signs_req = sg; ctx->signs_done = nullptr;
+          int32_t r = k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(uo), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0, s);
+          ctx->signs_req = nullptr;
+          if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd %s: the launch did not write the ReLU sign bits its data gradient was planned with", cn.c_str());
+          return r;
         });
       } else
       conv("c" + ks + "a", "bn" + ks, 2 * c, c);
@@ -844,10 +877,15 @@ void build_programs(unet_model* m) {
         return;
       }
       if (want_dx) {
-        ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? cin : 0)) + 4.0 * 9.0 * cin * cout, {
+        const bool bits = mask_in && m->sign_off.count(in) != 0;
+        ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? (bits ? cin / 32.0 : cin) : 0)) + 4.0 * 9.0 * cin * cout, {
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mask_in ? CBF(m->Av(in)) : nullptr, mask_in ? MASK_RELU : MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h,
                                             ob.w, cout, cin, ACT_NONE, 0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s, CBF(static_cast<void*>(m->wsf(m->wprep_b.at(name)))));
           const auto pb = m->wprep_b.find(name);
+          const auto so = mask_in ? m->sign_off.find(in) : m->sign_off.end();
+          if (so != m->sign_off.end())                        // one bit per element instead of the fp32 activation (written by the forward conv that produced `in`)
+            return conv3x3_fwd_dispatch(ctx, m->D(name), m->P(name + "/kernel"), nullptr, m->wsf(so->second), MASK_RELU_BITS, m->D(in), ob.n, ob.h,
+                                        ob.w, cout, cin, ACT_NONE, 0.0f, 0, algo, s, m->wsf(m->off_wt), 1, pb == m->wprep_b.end() ? nullptr : m->wsf(pb->second));
           return conv3x3_fwd_dispatch(ctx, m->D(name), m->P(name + "/kernel"), nullptr, mask_in ? m->A(in) : nullptr, mask_in ? MASK_RELU : MASK_NONE, m->D(in), ob.n, ob.h,
                                       ob.w, cout, cin, ACT_NONE, 0.0f, 0, algo, s, m->wsf(m->off_wt), 1, pb == m->wprep_b.end() ? nullptr : m->wsf(pb->second));
         });
@@ -902,6 +940,8 @@ void build_programs(unet_model* m) {
       });
       ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, eb * (2 * nel(ib) + nel(ug)), {
         if (dt) return k_convT_bf16_dgrad(ctx, CBF(m->Dv(un)), ug.ld, m->P(un + "/kernel"), CBF(m->Av(prev)), WBF(m->Dv(prev)), ib.n, ib.h, ib.w, cprev, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
+        const auto so = m->sign_off.find(prev);
+        if (so != m->sign_off.end()) return k_convT_h2_dgrad(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->wsf(so->second), m->D(prev), ib.n, ib.h, ib.w, cprev, c, s, 1);
         return unet_convT2x2_bwd_data(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->A(prev), m->D(prev), ib.n, ib.h, ib.w, cprev, c, algo, s);
       });
       if (k == 7) bucket("u7/kernel", "out/bias");
