@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 8
+#define UNET_ABI_VERSION 9
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -57,7 +57,7 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   UNET_MASK_RELU 1[m>0]   UNET_MASK_ELU  m>0 ? 1 : m+1   UNET_MASK_ELU_DROP  m = dropout(elu(z)), keep mask recomputed
  *   from the counter-based RNG stream (rate, seed) of that dropout */
 enum { UNET_ACT_NONE = 0, UNET_ACT_RELU = 1, UNET_ACT_ELU = 2 };
-enum { UNET_MASK_NONE = 0, UNET_MASK_RELU = 1, UNET_MASK_ELU = 2, UNET_MASK_ELU_DROP = 3 };
+enum { UNET_MASK_NONE = 0, UNET_MASK_RELU = 1, UNET_MASK_ELU = 2, UNET_MASK_ELU_DROP = 3, UNET_MASK_RELU_BITS = 9 /* see unet_request_relu_bits */ };
 
 /* ------------------------------------------------------------------------------------
  * Op level.  Replaces: Conv2D(C,(3,3),activation='relu',padding='same')   T1:859-911
@@ -80,6 +80,15 @@ double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_
  * where its kernel can (the fp32 h2 kernels); the unet_bn_stats / unet_bn_stats_concat call that MUST follow on that tensor then folds them instead of reading
  * the tensor again (any other kernel ignores the request and that call does its own pass -- same results either way).  c = 0 disarms. */
 int32_t unet_request_bn_stats(unet_ctx*, int32_t c);
+/* The ReLU mask of a data gradient as ONE BIT per element instead of the stored fp32 activation (the backward of the T1:859-860 conv pairs reads
+ * `c1 > 0` only).  unet_request_relu_bits arms the NEXT unet_conv3x3_fwd (act = UNET_ACT_RELU, no dropout) on this context to also write the sign bits
+ * of what it stores into `bits` (unet_relu_bits_bytes(n, h, w, cout) bytes of device memory; layout: 64-bit words [n][y][x / 8][c / 32][4], word k of an
+ * 8-pixel x 32-channel cell holds bit (x % 8) * 8 + (c % 32) / 4 for the channels with c % 4 == k); that call fails with UNET_E_SHAPE if its kernel
+ * cannot (ask unet_relu_bits_supported(algo, h, w, cin, cout) first: cout % 32 == 0, w % 8 == 0, the fp32 h2 kernels).  unet_conv3x3_bwd_data then takes
+ * mask_src = bits with mask_mode = UNET_MASK_RELU_BITS where unet_relu_bits_supported(algo, h, w, cout, cin) holds for ITS launch (K = cout, M = cin). */
+int32_t unet_relu_bits_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
+size_t unet_relu_bits_bytes(int32_t n, int32_t h, int32_t wd, int32_t c);
+int32_t unet_request_relu_bits(unet_ctx*, void* bits);
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
                          int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
                          int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, float* w_ws, void* stream);

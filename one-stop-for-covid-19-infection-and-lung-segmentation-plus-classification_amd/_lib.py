@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA, ALGO_WINOGRAD = 0, 1, 2, 3
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
@@ -42,6 +42,9 @@ _PROTOS = {
     "unet_conv3x3_exec_ratio": (f64, [i32, i32, i32, i32, i32]),
     "unet_conv3x3_wgrad_exec_ratio": (f64, [i32, i32, i32, i32, i32]),
     "unet_request_bn_stats": (i32, [vp, i32]),
+    "unet_relu_bits_supported": (i32, [i32, i32, i32, i32, i32]),
+    "unet_relu_bits_bytes": (sz, [i32, i32, i32, i32]),
+    "unet_request_relu_bits": (i32, [vp, vp]),
     "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, i32, vp, vp]),
     "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, i32, f32, u64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),

@@ -159,13 +159,30 @@ int32_t unet_request_bn_stats(unet_ctx* ctx, int32_t c) {
   return UNET_OK;
 }
 
+// ReLU masks as one bit per element (MASK_RELU_BITS, common.h): which (forward conv, data gradient) pairs can use them, how big the bit tensor is, arming
+int32_t unet_relu_bits_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
+  static float dummy;
+  if (cin < 1 || cout < 1 || (cout & 31) || (wd & 7) || h < 1) return 0;
+  return use_wino(algo, wd, cin, cout, &dummy) && h2_conv3x3_selected(cin, cout) ? 1 : 0;
+}
+size_t unet_relu_bits_bytes(int32_t n, int32_t h, int32_t wd, int32_t c) { return n > 0 && h > 0 && wd > 0 && c > 0 ? (size_t)n * h * wd * c / 8 : 0; }
+int32_t unet_request_relu_bits(unet_ctx* ctx, void* bits) {
+  if (!ctx) return UNET_E_ARG;
+  ctx->signs_req = static_cast<unsigned long long*>(bits); ctx->signs_done = nullptr;
+  return UNET_OK;
+}
+
 int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t n, int32_t h,
                          int32_t wd, int32_t cin, int32_t cout, int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo,
                          float* w_ws, void* stream) {
   if (!ctx || !x || !w || !y || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || act < 0 || act > 2 || drop_rate < 0 || drop_rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: bad args");
   if (algo == UNET_ALGO_WINOGRAD && !w_ws) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: the Winograd path needs w_ws (unet_conv3x3_w_ws_floats)");
-  return conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, algo, as_stream(stream), w_ws, 0);
+  const void* armed = ctx->signs_req;
+  int32_t r = conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, algo, as_stream(stream), w_ws, 0);
+  ctx->signs_req = nullptr;
+  if (!r && armed && ctx->signs_done != armed) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_fwd: armed with unet_request_relu_bits but this launch cannot write them (unet_relu_bits_supported, act = ReLU, no dropout)");
+  return r;
 }
 
 int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout) {
@@ -200,9 +217,11 @@ size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout) { return cin > 0 && c
 int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, const float* mask_src, int32_t mask_mode, float mask_rate,
                               uint64_t mask_seed, float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
                               int32_t algo, void* stream) {
-  if (!ctx || !dy || !w || !dx || !wt_ws || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || mask_mode < 0 || mask_mode > 3 ||
+  if (!ctx || !dy || !w || !dx || !wt_ws || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || mask_mode < 0 || (mask_mode > 3 && mask_mode != MASK_RELU_BITS) ||
       (mask_mode != MASK_NONE && !mask_src) || mask_rate < 0 || mask_rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data: bad args");
+  if (mask_mode == MASK_RELU_BITS && !unet_relu_bits_supported(algo, h, wd, cout, cin))
+    UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bwd_data: no bit-mask form for h=%d w=%d cin=%d cout=%d algo=%d (unet_relu_bits_supported(algo, h, w, cout, cin))", h, wd, cin, cout, algo);
   // data gradient = 3x3 convolution of dy (cout channels) with the flipped/transposed kernel -> cin channels
   return conv3x3_fwd_dispatch(ctx, dy, w, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
                               as_stream(stream), wt_ws, 1);

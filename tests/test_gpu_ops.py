@@ -701,3 +701,42 @@ def test_convT_epilogue_bn_statistics_of_the_up_half(ops, shape):
         up = cat.cpu().numpy()[..., :co].astype(np.float64).reshape(-1, co)
         assert relerr(res[-1][:co], up.sum(0)) < 1e-6 and relerr(res[-1][ld:ld + co], (up * up).sum(0)) < 1e-6
     assert relerr(res[0], res[1]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 24, 40, 32, 32), (1, 16, 72, 64, 64), (2, 9, 16, 128, 32), (1, 33, 8, 32, 96)])
+def test_relu_masks_as_one_bit_per_element(ops, shape):
+    """The backward of a Conv(relu) -> Conv pair (T1:859-860) reads the first conv's output only as `> 0`: unet_request_relu_bits makes the forward conv
+    write that as one bit per element, unet_conv3x3_bwd_data(mask_mode = UNET_MASK_RELU_BITS) reads 1/32 of the bytes.  The bits must be exactly
+    (y > 0) in the documented layout, and the data gradient bit-identical to the one masked with the fp32 tensor."""
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(ci + co + w)
+    x = rng.standard_normal((n, h, w, ci)).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.2).astype(np.float32)
+    assert ops.lib.unet_relu_bits_supported(0, h, w, ci, co) == 1 and ops.lib.unet_relu_bits_supported(1, h, w, ci, co) == 0
+    nbytes = int(ops.lib.unet_relu_bits_bytes(n, h, w, co)); assert nbytes == n * h * w * co // 8
+    bits = torch.full((nbytes // 8,), -1, dtype=torch.int64, device="cuda")
+    y = ops.z(n, h, w, co)
+    ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits.data_ptr()), "arm")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, ops.wws(ci, co), ops.s), "conv + bits")
+    yv = y.cpu().numpy()
+    words = bits.cpu().numpy().view(np.uint64).reshape(n, h, w // 8, co // 32, 4)
+    pos = (yv > 0).reshape(n, h, w // 8, 8, co // 32, 8, 4)                              # [n][y][x / 8][x % 8][c / 32][(c % 32) / 4][c % 4]
+    want = np.zeros((n, h, w // 8, co // 32, 4), np.uint64)
+    for p in range(8):
+        for q in range(8):
+            want |= pos[:, :, :, p, :, q, :].astype(np.uint64) << np.uint64(p * 8 + q)
+    assert (words == want).all() and 0.2 < (yv > 0).mean() < 0.8
+    # an armed conv that cannot write them fails loudly (direct kernels), and leaves nothing armed
+    ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits.data_ptr()), "arm")
+    assert ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 1, ops.wws(ci, co), ops.s) != 0
+    torch.cuda.synchronize()
+    # data gradient of a following conv (co -> co2 forward, so its dx has co channels): bit mask == fp32 mask, bit for bit
+    co2 = 64
+    k2 = (rng.standard_normal((3, 3, co, co2)) * 0.1).astype(np.float32); dy = rng.standard_normal((n, h, w, co2)).astype(np.float32)
+    assert ops.lib.unet_relu_bits_supported(0, h, w, co2, co) == 1
+    dx_f = ops.z(n, h, w, co); dx_b = ops.z(n, h, w, co)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k2).data_ptr(), y.data_ptr(), 1, 0.0, 0, dx_f.data_ptr(), ops.wws(co, co2), n, h, w, co, co2, 0, ops.s), "dgrad fp32 mask")
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k2).data_ptr(), bits.data_ptr(), 9, 0.0, 0, dx_b.data_ptr(), ops.wws(co, co2), n, h, w, co, co2, 0, ops.s), "dgrad bit mask")
+    assert torch.equal(dx_f, dx_b) and float(dx_f.abs().sum()) > 0
+    assert ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k2).data_ptr(), bits.data_ptr(), 9, 0.0, 0, dx_b.data_ptr(), ops.wws(co, co2), n, h, w, co, co2, 1, ops.s) != 0
