@@ -301,3 +301,26 @@ def test_intermediate_output_conv2d_9_matches_oracle():
     with torch.no_grad():
         acts = O.forward(m.get_weights(), x, training=False, dtype=torch.float64, want_acts=True)[1]
     assert f.shape == (3, 4, 4, 512) and relerr(f, acts["c5a"].numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_forty_step_trajectory_h2_vs_fp32_mfma():
+    """fp32-class accuracy over TRAINING, not only per op: 40 Adam steps of the U-Net (128 x 128, batch 4, dropout off) on the h2 kernels (three fp16 MFMA
+    products of the block-scaled split) against the two fp32-MFMA kernel families of round 1 (Winograd F(2x2,3x3), direct) -- each in
+    its own process, the switches are read once.  Training amplifies last-bit differences chaotically (two reruns of the SAME kernels drift 1.6e-3 apart
+    through the fp64 atomics' summation order; Winograd vs direct 8.6e-3 at the worst step, 5e-4 in the median), so the bar is the envelope the fp32
+    families span among themselves: first step identical to 1e-6, median distance of h2 within 3x theirs, worst step < 5e-2, same loss at the end."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(env):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "traj_case.py"), "40", "128", "4"], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return np.array(json.loads(out.stdout.strip().splitlines()[-1])["traj"])
+    off = {"UNET_H2": "0", "UNET_H2_WGRAD": "0", "UNET_X3": "0"}
+    h2 = run({}); wino = run(off); direct = run(dict(off, UNET_WINO="0", UNET_WINO_WGRAD="0"))
+    assert h2[-1, 0] < 0.2 * h2[0, 0]                                                     # it trains: the loss falls by 5x and more
+    d_ref = np.abs(wino - direct)[:, 0]
+    for other in (wino, direct):
+        d = np.abs(h2 - other)[:, 0]
+        assert d[0] < 1e-6 and np.median(d) < 3 * np.median(d_ref) + 1e-4 and d.max() < 5e-2 and d[-1] < 2e-3, (d.max(), np.median(d), np.median(d_ref), d[-1])
