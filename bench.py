@@ -258,7 +258,7 @@ def main():
     if rank == 0:
         total_imgs = B * world * args.steps
         out = {
-            "metric": (f"CT images/sec (fwd+bwd) U-Net 512x512x1 bs{B}" if args.arch == "unet" else
+            "metric": (f"CT images/sec (fwd+bwd) U-Net {S}x{S}x1 bs{B}" if args.arch == "unet" else
                        f"CT images/sec (fwd+bwd) {'U-Net++' if args.arch == 'unetpp' else 'slice classifier'} {S}x{S}x1 bs{B}"), "value": round(total_imgs / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16 storage, f32 accumulate/params", "data": "synthetic",
