@@ -225,7 +225,10 @@ def main():
                     "effective_tflops": round(effective, 2),
                     "note": "achieved / frac = 16-bit MFMA FLOPs the matrix cores EXECUTE (3 or 6 products per fp32 multiply) / time vs the 2.5 PFLOP/s dense fp16 / bf16 peak; "
                             "effective_tflops = ALGORITHMIC fp32 FLOPs (SURVEY 8d) of the same launches / the same time (the fp32 MFMA peak is 157.3)",
-                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+                    "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    # measured on this chip, not in this run (profiles/r02_mfma_power_probe.txt): back-to-back fp16 MFMAs from registers with random, half-zero
+                    # operands sustain 1.74 PFLOP/s at the package power cap (sclk ~1700 MHz); `peak` / `frac` stay the guide's nominal 2.5 PFLOP/s
+                    "power_capped_peak": 1740.0, "frac_of_power_capped_peak": round(prod / 1740.0, 4)}
         else:
             roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino2d4_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
                                                f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)",
