@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
   const int px_ = x0 + l31;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int mb = (g * NB + nb) * 32 + hi * 16;
-    if (mb >= M) continue;                                  // zero-padded rows of a tile that overhangs M (M % 16 == 0)
+    const int mb0 = (g * NB + nb) * 32;
+    if (mb0 >= M) continue;                                 // (wave-uniform) zero-padded block of a tile that overhangs M
+    // M % 32 == 16: the hi half of the last block is padding -- those lanes (and the lanes past the image edge below) compute on a valid neighbour's
+    // addresses and only take part in the LDS transpose of the stores
+    const int mb = mb0 + hi * 16 < M ? mb0 + hi * 16 : mb0;
     int ab = 0, oc = mb;
     if (MODE == 1) { const int ct = M >> 2; ab = mb / ct; oc = mb - ab * ct; }
     float bv[16];
@@ -206,10 +209,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int py = y0 + wave * RW + r;
-      if (py >= H || px_ >= W) continue;
+      if (py >= H) continue;                                // (wave-uniform)
+      const int pxs = px_ < W ? px_ : W - 1;
       long long o;
-      if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * px_ + (ab & 1)) * ldy + oc;
-      else o = (((long long)n * H + py) * W + px_) * ldy + mb;
+      if (MODE == 1) o = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxs + (ab & 1)) * ldy + oc;
+      else o = (((long long)n * H + py) * W + pxs) * ldy + mb;
       float v[16];
       if (MODE == 0 && mask_mode >= MASK_BN_BWD) {
         // data gradient of a conv whose input BatchNorm is folded: dx = K0 dz + K1 x + K2, x read where a ReLU layer reads its mask
@@ -290,8 +294,22 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
           }
         }
       }
-      *reinterpret_cast<uint4*>(y + o) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-      *reinterpret_cast<uint4*>(y + o + 8) = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+      // the row leaves through a per-wave LDS staging row (both tile buffers are dead behind the K loop's last barrier): a lane holds 32 B of ONE pixel,
+      // so its two 16-B stores landed 64+ B from its neighbours'; transposed, four consecutive lanes write the 64 B of a pixel's block (kernels_conv_h2.hip)
+      char* const s_out = smem + wave * (32 * 80);
+      *reinterpret_cast<uint4*>(s_out + l31 * 80 + hi * 32) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      *reinterpret_cast<uint4*>(s_out + l31 * 80 + hi * 32 + 16) = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pj = j * 16 + (lane >> 2), cj = lane & 3, pxj = x0 + pj;
+        const uint4 t4 = *reinterpret_cast<const uint4*>(s_out + pj * 80 + cj * 16);
+        int abj = 0, ocj = mb0;
+        if (MODE == 1) { const int ct = M >> 2; abj = mb0 / ct; ocj = mb0 - abj * ct; }
+        long long oj;
+        if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (abj >> 1)) * (2 * W) + 2 * pxj + (abj & 1)) * ldy + ocj;
+        else oj = (((long long)n * H + py) * W + pxj) * ldy + mb0;
+        if (pxj < W && mb0 + cj * 8 < M) *reinterpret_cast<uint4*>(y + oj + cj * 8) = t4;
+      }
     }
   }
 }
