@@ -6,10 +6,15 @@ WORLD_SIZE; a bare `python bench.py --gpus N` (N > 1) re-launches itself under t
 `--config 2` = BASELINE.json configs[2] (task-3 lung U-Net, same graph, batch 8 per GPU = global 64 on 8 GPUs).
 
 Prints ONE JSON line (rank 0).  Besides the driver contract it carries
-  roofline     : the dominant kernel (fp32 MFMA 3x3 convolution, forward + data-gradient launches):
-                 algorithmic FLOPs of its launches in a step / their summed hipEvent durations
+  roofline     : the dominant kernel family (conv3x3 forward + data-gradient launches: fp32 tensors, products on the fp16 matrix
+                 pipe as a block-scaled two-term split): matrix FLOPs its launches EXECUTE in a step / their summed
+                 hipEvent durations vs that pipe's dense peak; algorithmic bytes / FLOPs beside it
+  fp32_strict_img_s : the same step with every product on v_mfma_f32_32x32x2_f32 (--algo 2: exact fp32 multiply-add, the
+                 out-of-domain fallback family) -- what the fp16 split buys, and what the IEEE-fp32 path costs
   cpu_baseline : the CPU oracle (torch-CPU restatement, kind "port") timed on the host cores on a
                  bounded sample of the same workload (rank 0, N=1 only)
+Before the W warm-up steps the chip is run for SETTLE_S seconds of untimed steps: its clocks need >= 1 s of load to settle at the
+power-capped operating point (a 20-step run started cold reads ~5 % low or high depending on where in the ramp it lands).
 """
 import argparse
 import json
@@ -69,7 +74,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 2], help="BASELINE.json configs index: 1 = infection U-Net 512x512x1 bs16 per GPU (headline); "
                     "2 = lung U-Net (task 3, same graph T3:850-913) 512x512x1 at batch 8 per GPU = global 64 on 8 GPUs")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto (MFMA), 1 direct kernels")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto (fp16-split h2 kernels where the shape allows), 1 direct VALU kernels, 2 strict fp32 MFMA kernels")
+    ap.add_argument("--no-strict-leg", action="store_true", help="skip the untimed fp32_strict_img_s measurement (--algo 2 engine, 8 steps)")
+    ap.add_argument("--settle", type=float, default=2.0, help="seconds of untimed steps ahead of the warm-up (clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
     ap.add_argument("--arch", default="unet", choices=["unet", "unetpp", "classifier"], help="unetpp = the U-Net++ graph (BASELINE "
@@ -83,12 +90,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1
-        import socket
+        # (--standalone: torchrun picks and owns the rendezvous port itself -- no bind-close-reuse race)
         import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
     import numpy as np
@@ -109,11 +114,16 @@ def main():
     torch.cuda.set_device(local)
     pg = None
     if world > 1 or os.environ.get("UNET_BENCH_FORCE_PG"):          # UNET_BENCH_FORCE_PG=1: run the process-group code at world 1 (RCCL path smoke on a 1-GPU box)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        kw = {}
+        if "MASTER_PORT" not in os.environ:                       # world 1 without a launcher (UNET_BENCH_FORCE_PG): a private file store, no port at all
+            import tempfile
+            kw["init_method"] = "file://" + os.path.join(tempfile.mkdtemp(prefix="unet_bench_pg_"), "store")
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
         pg = dist.group.WORLD
 
     B, S = args.batch, args.size
@@ -149,6 +159,28 @@ def main():
     eng.set_profiling(False)
     ops = eng.op_profile(B, 0) + eng.op_profile(B, 1)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S))); eng.reset_optimizer()
+
+    # ---- untimed setup 3 (rank 0, N=1, the headline configuration only): the same step on the strict-fp32 kernel family (exact fp32 MFMA products)
+    strict = None
+    if rank == 0 and world == 1 and not args.no_strict_leg and args.dtype == "fp32" and args.algo == 0:
+        e2 = HipUNet(S, S, 1, device=local, conv_algo=2, dropout_rate=0.25, seed=rank, arch=args.arch, dtype=args.dtype)
+        e2.set_weights(W.init_weights(0, 1, args.arch, (S, S)))
+        for _ in range(4):
+            e2.train_batch(x, y)
+        torch.cuda.synchronize(); ts = time.perf_counter()
+        for _ in range(8):
+            e2.train_batch(x, y)
+        torch.cuda.synchronize()
+        strict = round(8 * B / (time.perf_counter() - ts), 1)
+        del e2
+        torch.cuda.empty_cache()
+
+    # ---- untimed: clock settle.  The chip needs >= 1 s of this load before its clocks sit at the power-capped operating point
+    ts = time.perf_counter()
+    while time.perf_counter() - ts < args.settle:
+        for _ in range(5):
+            eng.train_batch(x, y)
+        torch.cuda.synchronize()
 
     # ---- the measurement the contract defines: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize
     for _ in range(args.warmup):
@@ -264,7 +296,9 @@ def main():
             "metric": (f"CT images/sec (fwd+bwd) U-Net {S}x{S}x1 bs{B}" if args.arch == "unet" else
                        f"CT images/sec (fwd+bwd) {'U-Net++' if args.arch == 'unetpp' else 'slice classifier'} {S}x{S}x1 bs{B}"), "value": round(total_imgs / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16 storage, f32 accumulate/params", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32" if args.algo != 0 else "f32 storage / accumulate / parameters; conv products as a two-term fp16 split (3 fp16 MFMAs per multiply, ~2^-22 per product; --algo 2 = strict fp32)")
+                     if args.dtype == "fp32" else "bf16 storage, f32 accumulate/params", "data": "synthetic",
             "config": {"workload": (f"U-Net lung seg (task3 graph T3:850-913), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam" if args.arch == "unet" and args.config == 2 else
                                     f"U-Net infection seg (task1 graph T1:853-916), {S}x{S}x1, batch {B}/GPU, fp32, fwd+loss+bwd+Keras-Adam"
                                     if args.arch == "unet" else
@@ -274,10 +308,12 @@ def main():
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
                                    + {"unet": "configs[2]" if args.config == 2 else "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
-                       "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: fp32 conv3x3 as three fp16 MFMA products of a block-scaled two-term split (h2; fp32-class accuracy), winograd F(2x2,3x3) on mfma_f32_32x32x2 for the 32x32-channel weight gradients, ConvT on mfma_f32_32x32x2", 1: "direct", 2: "mfma_f32_32x32x2", 3: "winograd"}[args.algo],
+                       "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: every conv3x3 / ConvT forward, data gradient and weight gradient as three v_mfma_f32_32x32x16_f16 products of a block-scaled two-term fp16 split (h2; fp32-class accuracy, DESIGN.md 4g); Cin=1 first layer and 1x1 head on fp32 VALU", 1: "direct fp32 VALU kernels", 2: "strict fp32: v_mfma_f32_32x32x2_f32 direct kernels"}[args.algo],
                        "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
+        if strict is not None:
+            out["fp32_strict_img_s"] = strict
         if cpu is not None:
             out["cpu_baseline"] = cpu
     # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which sits in libc's buffer until exit and would

@@ -14,10 +14,10 @@
  *     `ld*` arguments are the pixel stride in floats, so an op can read/write a channel
  *     slice of a wider NHWC buffer (zero-copy skip concatenation, T1:887).
  *   - all launches are asynchronous on the passed hipStream_t (`void* stream`); no hidden
- *     synchronisation, no allocation after unet_ctx_create.  State outside the caller's buffers: (i) the ctx -- it owns two small device
- *     scratch areas (BatchNorm atomics slots; the split weight image of a ConvT launch), so launches through ONE ctx belong on one stream
- *     at a time; (ii) process-wide, read-only after first use: the UNET_* environment switches (kernel-family A/B selectors and tile /
- *     workgroup-count overrides for measurements, listed in DESIGN.md section 4; every default is the shipped path).
+ *     synchronisation, no allocation after unet_ctx_create.  State outside the caller's buffers: the ctx -- it owns two small device
+ *     scratch areas (BatchNorm reduction slots; the split weight image of a ConvT launch), so launches through ONE ctx belong on one stream
+ *     at a time -- and its options (unet_ctx_set_option).  The library reads NO environment variables: the kernel family is the `algo`
+ *     argument of every convolution entry point / of unet_model_create, the graph-level choices are ctx options.
  *   - there is NO CPU fallback: without a gfx950 device unet_ctx_create fails.
  */
 #ifndef UNET_HIP_H
@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 9
+#define UNET_ABI_VERSION 10
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -40,10 +40,13 @@ enum { UNET_DTYPE_F32 = 0, UNET_DTYPE_BF16 = 1 };
 /* status codes */
 enum { UNET_OK = 0, UNET_E_ARG = -1, UNET_E_HIP = -2, UNET_E_SHAPE = -3, UNET_E_STATE = -4, UNET_E_NODEV = -5 };
 
-/* conv algorithm selector (all are HIP kernels; NAIVE exists as an on-device cross-check) */
-/* AUTO: fp32 conv3x3 / ConvT as three fp16 MFMA products of a block-scaled two-term split where the shape allows (fp32-class accuracy), else Winograd / direct
- * fp32-MFMA kernels; MFMA: direct v_mfma_f32_32x32x2_f32 kernels; WINOGRAD: the prepared-weights path (h2 split or Winograd F(2x2,3x3) / F(2,3) by shape) */
-enum { UNET_ALGO_AUTO = 0, UNET_ALGO_NAIVE = 1, UNET_ALGO_MFMA = 2, UNET_ALGO_WINOGRAD = 3 };
+/* kernel family of the convolutions (all are HIP kernels):
+ *   AUTO  : fp32 conv3x3 / ConvT forward, data gradient and weight gradient as three v_mfma_f32_32x32x16_f16 products of a block-scaled two-term fp16 split
+ *           (fp32-class accuracy inside the domain DESIGN.md 4g states) wherever the channel counts allow (multiples of 16 / 32), else as MFMA;
+ *   MFMA  : STRICT fp32 -- v_mfma_f32_32x32x2_f32 kernels (exact fp32 multiply-add), VALU kernels for the shapes those do not take; the fallback for
+ *           tensors outside the split's domain and the on-device reference of its accuracy claims;
+ *   NAIVE : fp32 VALU kernels only (cross-check). */
+enum { UNET_ALGO_AUTO = 0, UNET_ALGO_NAIVE = 1, UNET_ALGO_MFMA = 2 };
 
 int32_t unet_abi_version(void);
 int32_t unet_ctx_create(int32_t device_id, unet_ctx** out);
@@ -51,6 +54,19 @@ void unet_ctx_destroy(unet_ctx* ctx);
 const char* unet_last_error(const unet_ctx* ctx);
 /* 1 = op-level timing with hipEvents (bench.py roofline leg); adds a sync per op */
 int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
+/* Options of a context (defaults = the shipped path).  A model reads them when it is CREATED (unet_model_create), op-level entry points when they launch;
+ * so one process can hold models / contexts of different settings side by side.
+ *   RELU_BITS (1)          ReLU masks of the data gradients as one bit per element, written by the producing conv (0: the fp32 activation is re-read)
+ *   BN_FOLD (2)            decoder BatchNormalization folded into the conv behind it: 0 = explicit statistics / apply passes, 1 = forward + weight gradient +
+ *                          backward sums folded, 2 = also the BatchNorm backward applied in the data-gradient epilogue
+ *   ENC_BN_FUSED (1)       encoder tail backward without a statistics pass (sums from the pooled tensors + closed-form skip term, one fused apply pass)
+ *   BN_CONCAT_ANALYTIC (1) decoder BatchNorm statistics: skip half from the encoder layer's sums, only the upsampled half measured
+ *   BN_FUSE_STATS (1)      BatchNorm statistics accumulated by the producing conv's epilogue (unet_request_bn_stats honoured)
+ *   DETERMINISTIC (0)      1 = every reduction in a fixed order: no floating-point atomics anywhere (BatchNorm / loss / metric sums through per-workgroup
+ *                          slots folded in index order; statistics by their own pass), so reruns are bit-identical; costs ~3 % of the step */
+enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6 };
+int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
+int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */
 
 /* activations of the conv epilogue and "mask modes" of the backward epilogues (derivative of the activation -- and of the
  * dropout fused behind it -- that produced a stored tensor m):
@@ -64,15 +80,15 @@ enum { UNET_MASK_NONE = 0, UNET_MASK_RELU = 1, UNET_MASK_ELU = 2, UNET_MASK_ELU_
  *   y[n,i,j,o] = act(b[o] + sum_{a,b,c} x[n,i+a-1,j+b-1,c] * w[a,b,c,o]);  w is HWIO.
  * act: 'relu' (U-Net, T1:859) or 'elu' (U-Net++, task1_unet_plus_plus.py:876); drop_rate > 0 fuses the Keras Dropout
  * layer that follows the conv (task1_unet_plus_plus.py:862, 877) into the epilogue (inverted dropout, training only).
- * w_ws: device scratch of unet_conv3x3_w_ws_floats(cin, cout) floats for transformed weights (Winograd path); may be NULL, then
- * only the direct algorithms are used.
+ * w_ws: device scratch of unet_conv3x3_w_ws_floats(cin, cout) floats for the prepared (split fp16) weight image of the h2 kernels; may be
+ * NULL, then only the strict fp32 kernels are used.
  * ---------------------------------------------------------------------------------- */
 size_t unet_conv3x3_w_ws_floats(int32_t cin, int32_t cout);
-/* which algorithm a forward / data-gradient launch of this shape resolves to (UNET_ALGO_WINOGRAD, _MFMA or _NAIVE [direct kernels]) */
+/* which family a forward / data-gradient launch of this shape resolves to: UNET_ALGO_AUTO (the fp16-split h2 kernels), _MFMA (strict fp32 MFMA) or _NAIVE (VALU) */
 int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout);
-/* executed / algorithmic multiplies of that launch: 1 (direct), 2/3 (Winograd F(2,3) along x), 4/9 (F(2x2,3x3)) */
+/* fp32-MFMA-time equivalent of that launch's matrix work: 1 (strict / VALU), 3 * 157.3 / 2500 (h2: three fp16 MFMA products per multiply) */
 double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
-/* ... and of the weight-gradient launch (unet_conv3x3_bwd_weights with the workspace it asks for): 1, 2/3 or 4/9 */
+/* ... and of the weight-gradient launch (unet_conv3x3_bwd_weights with the workspace it asks for) */
 double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
 /* Conv2D / Conv2DTranspose followed by a training-mode BatchNormalization (T1:860-861 `Conv2D(...)(c1)` -> `BatchNormalization()(c1)`, T1:886-888
  * `Conv2DTranspose` -> `concatenate` -> `BatchNormalization`): arms the NEXT unet_conv3x3_fwd / unet_convT2x2_fwd on this context to add the
@@ -94,7 +110,7 @@ int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float*
                          int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, float* w_ws, void* stream);
 /* dx = conv3x3(dy, flip/transposed w) * mask_factor(mask_src): the derivative of the activation (+dropout) of the layer
  * that PRODUCED x is fused here (backward of the T1:859-860 conv pairs).  mask_rate/mask_seed: UNET_MASK_ELU_DROP only.
- * wt_ws: unet_conv3x3_w_ws_floats(cin, cout) floats of scratch for the flipped / Winograd-transformed weights. */
+ * wt_ws: unet_conv3x3_w_ws_floats(cin, cout) floats of scratch for the flipped / transposed weights or their split image. */
 int32_t unet_conv3x3_bwd_data(unet_ctx*, const float* dy, const float* w, const float* mask_src,
                               int32_t mask_mode, float mask_rate, uint64_t mask_seed,
                               float* dx, float* wt_ws, int32_t n, int32_t h, int32_t wd,
@@ -104,8 +120,8 @@ int32_t unet_conv3x3_bwd_data(unet_ctx*, const float* dy, const float* w, const 
  * weights scaled per input channel, and because Keras pads z (not x) with zeros, a bias per border class: a pixel on the first / last
  * row or column sees fewer taps of the shift (16 classes, exact).  The forward then reads the raw x.  The weight gradient runs on the raw
  * x as well and is corrected: dw = scale[c] dw_raw + shift[c] S[tap][o], S = db minus the border row / column sums of dy the tap
- * excludes (plus the corner).  Only where unet_conv3x3_bnfold_supported() says so (the F(2x2,3x3) forward kernels; cout a divisor of
- * 256); ws: unet_conv3x3_bnfold_ws_floats floats, shared by the two calls of a step; gws: as unet_conv3x3_bwd_weights.
+ * excludes (plus the corner).  Only where unet_conv3x3_bnfold_supported() says so (the h2 kernels: UNET_ALGO_AUTO, cin and cout multiples of 16; cout a
+ * divisor of 256); ws: unet_conv3x3_bnfold_ws_floats floats, shared by the two calls of a step; gws: as unet_conv3x3_bwd_weights.
  * bn_bwd_sums (optional, with the kernel w and bnp = scale, shift, mean, invstd): the BatchNorm's backward sums double[2*cin] =
  * (sum dz, sum dz*xhat) as unet_bn_bwd_stats accumulates them, but WITHOUT reading dz or x -- dz is this conv's data gradient, so
  * sum_p dz_c = sum_{tap,o} w[tap][c][o] S[tap][o] and sum_p dz_c x_c = sum_{tap,o} w[tap][c][o] dw_raw[tap][c][o]. */

@@ -10,9 +10,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
-ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA, ALGO_WINOGRAD = 0, 1, 2, 3
+ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2          # fp16-split h2 kernels where the shape allows / VALU kernels / strict fp32 MFMA kernels
+# unet_ctx_set_option (include/unet_hip.h UNET_OPT_*)
+OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6}
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
@@ -37,6 +39,8 @@ _PROTOS = {
     "unet_ctx_destroy": (None, [vp]),
     "unet_last_error": (C.c_char_p, [vp]),
     "unet_ctx_set_profiling": (i32, [vp, i32]),
+    "unet_ctx_set_option": (i32, [vp, i32, i32]),
+    "unet_ctx_get_option": (i32, [vp, i32]),
     "unet_conv3x3_w_ws_floats": (sz, [i32, i32]),
     "unet_conv3x3_pick_algo": (i32, [i32, i32, i32, i32]),
     "unet_conv3x3_exec_ratio": (f64, [i32, i32, i32, i32, i32]),
@@ -192,7 +196,14 @@ class Context:
         self.device = device
 
     @classmethod
-    def get(cls, device: int) -> "Context":
+    def get(cls, device: int, options: dict | None = None) -> "Context":
+        """The shared default-option context of a device, or -- with options -- a private context carrying them
+        (unet_ctx_set_option: a model reads the options when it is created, the op-level entry points when they launch)."""
+        if options:
+            ctx = cls(device)
+            for k, v in options.items():
+                ctx.check(ctx.lib.unet_ctx_set_option(ctx.handle, OPTIONS[k], int(v)), f"set_option({k})")
+            return ctx
         if device not in cls._cache:
             cls._cache[device] = cls(device)
         return cls._cache[device]

@@ -13,12 +13,22 @@
 // final fp64 atomics over the copies (512 workgroups hammering the same 16 cache lines cost ~40 us per launch), a tiny kernel then
 // folds the copies into the caller's sums and clears them.  Owned by the context => statistics ops of ONE context must be issued on
 // one stream at a time (use a context per stream otherwise).
-constexpr int UNET_BN_SLOTS = 64, UNET_BN_SLOT_DOUBLES = 2048;
+// Deterministic mode (UNET_OPT_DETERMINISTIC): UNET_BN_SLOTS_DET copies, every workgroup of a reduction kernel owns ONE copy (grids are capped at the copy
+// count), so each atomic lands on a zero it alone writes, and the fold kernel sums the copies in index order: bit-identical reruns.
+constexpr int UNET_BN_SLOTS = 64, UNET_BN_SLOTS_DET = 1024, UNET_BN_SLOT_DOUBLES = 2048;
 struct unet_ctx {
   int device = 0;
   int num_cu = 256;
   int profiling = 0;
-  double* bn_slots = nullptr;       // device, UNET_BN_SLOTS x UNET_BN_SLOT_DOUBLES, all zero between launches
+  // unet_ctx_set_option (include/unet_hip.h: UNET_OPT_*): graph-level choices a model reads when it is created, op-level choices the launches read
+  int opt_relu_bits = 1;            // ReLU masks of the data gradients as one bit per element (0: re-read the fp32 activation)
+  int opt_bn_fold = 2;              // decoder BatchNorm folded into the conv behind it: 0 explicit passes, 1 forward + weight gradient + sums, 2 + backward in the dgrad epilogue
+  int opt_enc_bn_fused = 1;         // encoder tail backward without a statistics pass
+  int opt_bn_concat_analytic = 1;   // decoder BatchNorm statistics: skip half analytic
+  int opt_bn_fuse_stats = 1;        // BatchNorm statistics from the producing conv's epilogue
+  int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
+  double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
+  int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
   void* convt_img = nullptr;        // device scratch for the split fp16 weight image of a ConvT launch (kernels_conv_h2.hip); launches on one stream only
   size_t convt_img_bytes = 0;
   // Conv2D / Conv2DTranspose -> BatchNormalization (T1:860-861, 886-888): unet_request_bn_stats() arms the next forward launch; a kernel that can
@@ -154,7 +164,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //   MASK_RELU: 1[m>0]      MASK_ELU: m>0 ? 1 : m+1  (elu' expressed through its output)
 //   MASK_ELU_DROP: m = dropout(elu(z)): keep ? s * elu'(m/s) : 0, keep/s recomputed from the Philox stream
 enum { MASK_NONE = 0, MASK_RELU = 1, MASK_ELU = 2, MASK_ELU_DROP = 3 };
-// internal to the F(2x2,3x3) forward kernels: `mask` is not a mask but the border-class bias table of a conv whose input BatchNorm was
+// internal to the h2 / bf16 forward kernels: `mask` is not a mask but the border-class bias table of a conv whose input BatchNorm was
 // folded into its weights (k_bn_fold_prepare): [16][Cout], class = 4 * (row == 0 | (row == H-1) << 1) + (col == 0 | (col == W-1) << 1)
 enum { MASK_BIAS_TAB = 4 };
 // internal to the same kernels, data-gradient launches: the BatchNorm backward of the conv's (folded) input BatchNorm applied in the epilogue --
@@ -179,52 +189,38 @@ __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep
 // (definitions in the .hip files; all return a unet status code)
 // act: ACT_*; mask_mode: MASK_* (data-gradient epilogue); rate/seed: the fused output dropout (forward) or the dropout
 // of the mask tensor's producer (MASK_ELU_DROP)
-// Winograd F(2,3)-along-x kernels (kernels_conv_wino.hip): u = transformed weights [12][cin'][cout'] in caller scratch
-bool wino_conv3x3_supported(int cin, int cout);
-bool wino_uses_2d(int h, int cout);
-// conv3x3(BN-affine(x)) with the affine folded into the conv: w_scaled[tap][c][o] = w * scale[c], table[16][cout] = the bias
+// conv3x3(BN-affine(x)) with the affine folded into the conv (kernels_bnfold.hip): w_scaled[tap][c][o] = w * scale[c], table[16][cout] = the bias
 // per border class (bias + the shift's contribution through the taps that stay inside the image); the forward then runs on the RAW x with
-// (bias = table, mask = table, mask_mode = MASK_BIAS_TAB) -- 2-D Winograd kernels only (wino_uses_2d) -- and the weight gradient on raw x is
+// (bias = table, mask = table, mask_mode = MASK_BIAS_TAB) on the h2 kernels, and the weight gradient on raw x is
 // corrected afterwards: dw = scale[c] * dw_raw + shift[c] * S[tap][o] (k_wgrad_bn_fold_fix; S from db and the border sums of dy).
 size_t bn_fold_scratch_floats(int cin, int cout);      // [w_scaled 9*cin*cout][table 16*cout][partials]
-int32_t k_bn_fold_prepare(unet_ctx*, const float* w, const float* bias, const float* scale, const float* shift, int cin, int cout, float* scratch, hipStream_t s);
+int32_t k_bn_fold_prepare(unet_ctx*, const float* w, const float* bias, const float* scale, const float* shift, int cin, int cout, float* scratch, hipStream_t s, bool want_scaled = true);
 size_t wgrad_bn_fold_scratch_floats(int n, int cout);
 bool wgrad_bn_fold_supported(int cout);
 int32_t k_wgrad_bn_fold_fix(unet_ctx*, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db, float* scratch,
                             hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
 int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx*, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
                                  float* scratch, hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
-int wino_tile_cols(int wd);                                          // 64 or 32 columns per row tile of the 2-D kernel                                 // F(2x2,3x3) instead of F(2,3)-along-x for this output shape
-int32_t k_conv3x3_wino_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
-                             int cin, int cout, hipStream_t s);      // kernels_conv_mfma.hip (shares the split-K machinery)
-size_t wino_u_floats(int cin, int cout);
-int32_t k_wino_weights(unet_ctx*, const float* w, float* u, int cin, int cout, int flip, int h, hipStream_t s);
-constexpr int UNET_WINO_PREP_MAX = 40;
-struct unet_wino_prep { const float* w; float* u; int cin, cout, flip, two_d; };
-struct unet_wino_prep_list { unet_wino_prep item[UNET_WINO_PREP_MAX]; int n; };          // passed by value as a kernel argument (1.3 KiB)
-int32_t k_wino_weights_multi(unet_ctx*, unet_wino_prep_list* L, const int* h, hipStream_t s);
-// fp32 conv3x3 on the bf16 matrix cores through the exact 3-term bf16 split (kernels_conv_x3.hip); K = contraction channels, M = output channels of a launch
-// ... and through the block-scaled 2-term fp16 split (kernels_conv_h2.hip): three fp16 MFMA products per multiply; asked before x3
-bool h2_conv3x3_selected(int K, int M);
+constexpr int UNET_WINO_PREP_MAX = 36;          // layers per batched weight-preparation launch (the list travels as a kernel argument: < 4 KiB)
+// fp32 conv3x3 / ConvT on the fp16 matrix cores through the block-scaled 2-term fp16 split (kernels_conv_h2.hip, kernels_wgrad_h2.hip): three fp16 MFMA products per
+// multiply.  The family of UNET_ALGO_AUTO wherever the channel counts allow; K = contraction channels, M = output channels of a launch
+bool h2_conv3x3_selected(int algo, int K, int M);
 size_t h2_wimg_bytes(int K, int M);
-int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s);
+// (cs: optional per-input-channel factor of a forward image -- the scale of a BatchNorm folded into the conv; the scaled weights are never materialised)
+int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s, const float* cs = nullptr);
 int32_t k_h2_weights_multi(unet_ctx*, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s);
+// any mix of layers in TWO launches; kind 0 / 1 = conv3x3 forward / data-gradient image, 2 / 3 = ConvT forward / data-gradient image (h2_convT_img_bytes each)
+int32_t k_h2_prep_multi(unet_ctx*, const float* const* w, const float* const* cs, void* const* img, const int* cin, const int* cout, const int* kind, int count, hipStream_t s);
+size_t h2_convT_img_bytes(int cin, int cout);
 int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
                          int act, float rate, uint64_t seed, hipStream_t s);
-bool h2_convT_selected(const unet_ctx* ctx, int cin, int cout);
-int32_t k_convT_h2_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s);
-int32_t k_convT_h2_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s, int mask_bits = 0);
-bool h2_wgrad_selected(int cin, int cout);
+bool h2_convT_selected(const unet_ctx* ctx, int algo, int cin, int cout);
+int32_t k_convT_h2_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s, const void* prepared = nullptr);
+int32_t k_convT_h2_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s, int mask_bits = 0,
+                         const void* prepared = nullptr);
+bool h2_wgrad_selected(int algo, int cin, int cout);
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);
-bool x3_conv3x3_selected(int K, int M);
-size_t x3_wimg_bytes(int K, int M);
-int32_t k_x3_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s);
-int32_t k_x3_weights_multi(unet_ctx*, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s);
-int32_t k_conv3x3_x3_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
-                         int act, float rate, uint64_t seed, hipStream_t s);
-int32_t k_conv3x3_wino_fwd(unet_ctx*, const float* x, const float* u, const float* bias, const float* mask, int mask_mode, float* y, int n,
-                           int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                             float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 int32_t k_conv3x3_c1_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int n, int h,
@@ -246,14 +242,13 @@ bool mfma_conv3x3_supported(int cin, int cout);
 int32_t k_conv3x3_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                            float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 bool mfma_wgrad_supported(int ca, int cb);
-double wino_wgrad_exec_ratio(int h);
 bool mfma_convT_supported(int cin, int cout);
 int32_t k_convT_mfma_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd,
                          int cin, int cout, hipStream_t s);
 int32_t k_convT_mfma_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd,
                            int cin, int cout, hipStream_t s);
 size_t mfma_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
-bool h2_convT_wgrad_selected(int cin, int cout);
+bool h2_convT_wgrad_selected(int algo, int cin, int cout);
 size_t h2_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_convT_h2_wgrad(unet_ctx*, const float* x, const float* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
                          hipStream_t s);

@@ -358,11 +358,9 @@ bool bf16_conv3x3_supported(int cin, int cout) { return cin >= 16 && (cin % 16) 
 bool bf16_convT_supported(int cin, int cout) { return cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0; }
 
 static void bf16_conv_tile(int cout, int* NB, int* RW) {       // see the tile-choice note in k_conv3x3_bf16_fwd
-  static const int force = [] { const char* e = getenv("UNET_BF16_TILE"); return e ? atoi(e) : 0; }();
-  static const int narrow_max = [] { const char* e = getenv("UNET_BF16_NARROW_MAX"); return e ? atoi(e) : 32; }();
+  constexpr int narrow_max = 32;
   *NB = (cout % 64) == 0 ? 2 : 1; *RW = 4;
   if (cout <= narrow_max) { *NB = 1; *RW = 2; }
-  if (force) { *NB = force / 10; *RW = force % 10; if ((cout % 64) != 0) *NB = 1; }
 }
 
 // item k: weights w (the layer's forward kernel), image scratch, (cin, cout) as k_conv3x3_bf16_fwd takes them (already swapped for flip = 1)
@@ -639,7 +637,7 @@ WgPlan plan_wgrad_bf16(int mode, int n, int h, int w, int ca, int cb) {
   p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
   const long long pairs = (long long)p.tiles_a * p.tiles_b, per = (long long)taps * ca * cb;
   const long long units = (long long)n * p.strips;
-  static const long long target = [] { const char* e = getenv("UNET_WGRAD_BF16_BLOCKS"); return e ? atoll(e) : 512LL; }();   // 256 CUs x 2 resident workgroups (1024 measured 15 % slower: twice the partial-slab traffic)
+  constexpr long long target = 512;   // 256 CUs x 2 resident workgroups (1024 measured 15 % slower: twice the partial-slab traffic)
   long long want = std::max<long long>(1, target / pairs);          // pixel splits wanted
   const long long cap = std::max<long long>(1, (64LL << 20) / per);
   want = std::min(want, cap);

@@ -4,7 +4,7 @@
 // comfortable part of the fp16 range is, to 22 significant bits, the sum of TWO fp16 numbers: x ~ h + m, h = RN_f16(x), m = RN_f16(x - h)
 // (11 + 11 bits; x - h is exact in fp32), so
 //     x * w = xh wh + xh wm + xm wh + O(2^-22 |x w|)
-// -- three fp16 MFMAs with fp32 accumulation per multiply, 3/16 of the fp32-MFMA time, half of the bf16 three-term split of kernels_conv_x3.hip.
+// -- three fp16 MFMAs with fp32 accumulation per multiply, 3/16 of the fp32-MFMA time (an exact three-term bf16 split needs six products: measured, not kept).
 // What fp16 lacks is RANGE (activation gradients are ~1e-8), so both operands are block-scaled by exact powers of two:
 //   * weights: one exponent per layer, from the layer's max |w| (h2_wmax_kernel), folded into the weight image; max |w| 2^e lands in [2^11, 2^12);
 //   * activations / gradients: one exponent per workgroup, tracked along the K loop.  While a 16-channel chunk of the input patch is staged, the workgroup
@@ -15,7 +15,7 @@
 // Measured on the box (tools/probe/split3_probe.hip, K = 16 ... 4608, against float64): relative L2 error 7.1e-8 / 2.2e-7 / 8.5e-7 for the three fp16
 // products vs 7.1e-8 / 3.2e-7 / 1.3e-6 for v_mfma_f32_32x32x2_f32: the same accuracy class as the fp32 matrix path it replaces.
 //
-// Kernel structure = the implicit GEMM of kernels_bf16.hip / kernels_conv_x3.hip: A = weights (32 output channels x 16 k), B = 32 pixels of an image row,
+// Kernel structure = the implicit GEMM of kernels_bf16.hip: A = weights (32 output channels x 16 k), B = 32 pixels of an image row,
 // a lane ends with 16 consecutive output channels of one pixel.  Per 16-channel chunk: (TH + 2) x 34 pixel patch as two fp16 planes + the weight slab
 // (two planes) in LDS, single-buffered; the next chunk travels global -> registers under the current chunk's MFMAs and is scaled, split and stored
 // between two barriers while the CU's other workgroup(s) keep the matrix pipes busy (58 KB and ~200 registers per workgroup: two per CU).
@@ -58,79 +58,49 @@ __device__ __forceinline__ int scale_exp_for(int eb) { return 138 - eb; }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }          // -126 <= e <= 127
 
 // ---------------------------------------------------------------------------------------------------------------------
-// weights: max |w| of a layer (one workgroup per layer), then the split image
-//   img = [header 256 B][((((((g*nchunks + chunk)*9 + tap)*NB + nb)*2 + plane)*2 + half)*32 + m][8 fp16]
-//   k = chunk*16 + half*8 + j,  mm = (g*NB + nb)*32 + cperm(m),  W(tap,k,mm) = w[(flip ? 8-tap : tap)*tap_stride + k*sk + mm*sm] * 2^e_w
+// weights: the split fp16 image of a layer (conv3x3: T = 9 taps, KS = 1 k-step per staged chunk; ConvT: T = 1, KS = 2), TWO launches for any number of layers:
+//   img = [header 256 B][(((((((g*nchunks + chunk)*KS + ks)*T + tap)*NB + nb)*2 + plane)*2 + half)*32 + m][8 fp16]
+//   k = (chunk*KS + ks)*16 + half*8 + j,  mm = (g*NB + nb)*32 + cperm(m),  W(tap,k,mm) = w[(flip ? T-1-tap : tap)*tap_stride + k*sk + mm*sm] * cs[k] * 2^e_w
+//   (cs = optional per-input-channel factor: the scale of a BatchNorm folded into the conv, DESIGN.md 4f -- the scaled weights are never materialised)
+// header floats: [0] = 2^-e_w, [1] = 2^e_w (written by block 0 of the image kernel), [8 .. 8 + H2_MAXB) = per-workgroup partial max |w cs| of h2_wmax_kernel.
+// Every block of the image kernel folds the partial maxima itself (same values, same order -> same exponent): no atomics, no zeroing, no third launch.
 // ---------------------------------------------------------------------------------------------------------------------
-// header words of an image: [0] = 2^-e_w, [1] = 2^e_w (floats, written by h2_wscale_kernel), [2] = bit pattern of max |w| (atomicMax target)
-__global__ __launch_bounds__(64) void h2_wzero_kernel(unet_wimg_prep_list L) {
-  if (threadIdx.x < (unsigned)L.n) reinterpret_cast<unsigned*>(L.item[threadIdx.x].img)[2] = 0u;
-}
-__global__ __launch_bounds__(256) void h2_wmax_kernel(unet_wimg_prep_list L) {          // grid (blocks, layers)
-  const unet_wimg_prep& p = L.item[blockIdx.y];
-  const long long n4 = 9LL * p.tap_stride / 4;               // tap_stride = cin * cout (a multiple of 4)
+constexpr int H2_MAXB = 48;                                  // workgroups per layer of the max pass
+struct h2_prep { const float* w; const float* cs; unet_bf16* img; long long tap_stride, sk, sm, total, nw4; int T, KS, nb, nchunks, flip, m, cs_div, cs_mod; };
+struct h2_prep_list { h2_prep item[UNET_WINO_PREP_MAX]; int n; };          // passed by value as a kernel argument (3.4 KiB)
+
+__global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {          // grid (H2_MAXB, layers)
+  const h2_prep& p = L.item[blockIdx.y];
   float mx = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.nw4; i += (long long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(p.w)[i];
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    float m4 = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (p.cs) m4 *= fabsf(p.cs[(int)((i * 4 / p.cs_div) % p.cs_mod)]);          // (the four elements of a float4 share their input channel: cs_div is a multiple of 4)
+    mx = fmaxf(mx, m4);
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.img) + 2, __float_as_uint(mx));          // non-negative floats order like their bit patterns
-}
-__global__ __launch_bounds__(256) void h2_wmax1_kernel(const float* __restrict__ w, long long n4, unsigned* __restrict__ hdr) {          // one tensor of n4 float4
-  float mx = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(w)[i];
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(hdr + 2, __float_as_uint(mx));
-}
-__global__ __launch_bounds__(64) void h2_wscale_kernel(unet_wimg_prep_list L) {
-  if (threadIdx.x >= (unsigned)L.n) return;
-  float* hdr = reinterpret_cast<float*>(L.item[threadIdx.x].img);
-  const int eb = (int)((reinterpret_cast<unsigned*>(hdr)[2] >> 23) & 0xFF);
-  int e = eb >= 11 ? scale_exp_for(eb) : 0;
-  e = min(max(e, -100), 100);
-  hdr[0] = pow2f(-e); hdr[1] = pow2f(e);
-}
-__global__ __launch_bounds__(256) void h2_wimg_multi_kernel(unet_wimg_prep_list L) {          // blockIdx.y = layer
-  const unet_wimg_prep& p = L.item[blockIdx.y];
-  const int NB = p.nb, nchunks = p.nchunks, M = p.m;
-  const float sc = reinterpret_cast<const float*>(p.img)[1];
-  unet_bf16* const img = p.img + H2_HEADER / 2;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < p.total8; e += (long long)gridDim.x * 256) {          // e indexes (g, chunk, tap, nb, half, m)
-    long long r = e;
-    const int m = (int)(r & 31); r >>= 5;
-    const int half = (int)(r & 1); r >>= 1;
-    const int nb = (int)(r % NB); r /= NB;
-    const int tap = (int)(r % 9); r /= 9;
-    const int chunk = (int)(r % nchunks); const int g = (int)(r / nchunks);
-    const long long k0 = (long long)chunk * 16 + half * 8;
-    const long long mm = ((long long)g * NB + nb) * 32 + cperm(m);
-    const float* src = p.w + (long long)(p.flip ? 8 - tap : tap) * p.tap_stride + k0 * p.sk + mm * p.sm;
-    unsigned hh[4], ml[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a = mm < M ? src[(2 * j) * p.sk] * sc : 0.0f, b = mm < M ? src[(2 * j + 1) * p.sk] * sc : 0.0f;
-      split2(a, b, hh[j], ml[j]);
-    }
-    const long long base = (((((long long)g * nchunks + chunk) * 9 + tap) * NB + nb) * 2 * 2 + half) * 32 + m;        // plane 0; plane 1 is 2 * 32 rows further
-    *reinterpret_cast<uint4*>(img + (base + 0 * 64) * 8) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-    *reinterpret_cast<uint4*>(img + (base + 1 * 64) * 8) = make_uint4(ml[0], ml[1], ml[2], ml[3]);
-  }
+  __shared__ float s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) reinterpret_cast<float*>(p.img)[8 + blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
-// generic form (T taps, KS k-steps per chunk): img = [header][(((((((g*nchunks + chunk)*KS + ks)*T + tap)*NB + nb)*2 + plane)*2 + half)*32 + m][8 fp16],
-// k = (chunk*KS + ks)*16 + half*8 + j; W(tap, k, mm) = w[tap*tap_stride + k*sk + mm*sm] * 2^e_w.  One layer per launch (the ConvT kernels)
-__global__ __launch_bounds__(256) void h2_wimg_generic_kernel(const float* __restrict__ w, unet_bf16* __restrict__ img_hdr, int T, int KS, int NB, int nchunks, long long tap_stride,
-                                                             long long sk, long long sm, long long total, int M) {
-  const float sc = reinterpret_cast<const float*>(img_hdr)[1];
-  unet_bf16* const img = img_hdr + H2_HEADER / 2;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {          // e indexes (g, chunk, ks, tap, nb, half, m)
-    long long r = e;
+__global__ __launch_bounds__(256) void h2_wimg_kernel(h2_prep_list L, int maxb) {          // blockIdx.y = layer
+  const h2_prep& p = L.item[blockIdx.y];
+  const int NB = p.nb, nchunks = p.nchunks, M = p.m, T = p.T, KS = p.KS;
+  float* const hdr = reinterpret_cast<float*>(p.img);
+  float mx = (int)(threadIdx.x & 63) < maxb ? hdr[8 + (threadIdx.x & 63)] : 0.f;          // (every wave folds the partial maxima: no barrier)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const int eb = (int)((__float_as_uint(mx) >> 23) & 0xFF);
+  int e = eb >= 11 ? scale_exp_for(eb) : 0;
+  e = min(max(e, -100), 100);
+  const float sc = pow2f(e);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = pow2f(-e); hdr[1] = sc; }
+  unet_bf16* const img = p.img + H2_HEADER / 2;
+  for (long long el = (long long)blockIdx.x * 256 + threadIdx.x; el < p.total; el += (long long)gridDim.x * 256) {          // el indexes (g, chunk, ks, tap, nb, half, m)
+    long long r = el;
     const int m = (int)(r & 31); r >>= 5;
     const int half = (int)(r & 1); r >>= 1;
     const int nb = (int)(r % NB); r /= NB;
@@ -139,14 +109,15 @@ __global__ __launch_bounds__(256) void h2_wimg_generic_kernel(const float* __res
     const int chunk = (int)(r % nchunks); const int g = (int)(r / nchunks);
     const long long k0 = ((long long)chunk * KS + ks) * 16 + half * 8;
     const long long mm = ((long long)g * NB + nb) * 32 + cperm(m);
-    const float* src = w + (long long)tap * tap_stride + k0 * sk + mm * sm;
+    const float* src = p.w + (long long)(p.flip ? T - 1 - tap : tap) * p.tap_stride + k0 * p.sk + mm * p.sm;
     unsigned hh[4], ml[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = mm < M ? src[(2 * j) * sk] * sc : 0.0f, b = mm < M ? src[(2 * j + 1) * sk] * sc : 0.0f;
+      float a = mm < M ? src[(2 * j) * p.sk] * sc : 0.0f, b = mm < M ? src[(2 * j + 1) * p.sk] * sc : 0.0f;
+      if (p.cs) { a *= p.cs[k0 + 2 * j]; b *= p.cs[k0 + 2 * j + 1]; }
       split2(a, b, hh[j], ml[j]);
     }
-    const long long base = ((((((long long)g * nchunks + chunk) * KS + ks) * T + tap) * NB + nb) * 2 * 2 + half) * 32 + m;
+    const long long base = ((((((long long)g * nchunks + chunk) * KS + ks) * T + tap) * NB + nb) * 2 * 2 + half) * 32 + m;        // plane 0; plane 1 is 2 * 32 rows further
     *reinterpret_cast<uint4*>(img + (base + 0 * 64) * 8) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
     *reinterpret_cast<uint4*>(img + (base + 1 * 64) * 8) = make_uint4(ml[0], ml[1], ml[2], ml[3]);
   }
@@ -640,48 +611,71 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   return UNET_OK;
 }
 
-int h2_mode() {
-  static const int on = [] { const char* e = getenv("UNET_H2"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = the x3 / fp32-MFMA Winograd kernels
-  return on;
-}
-
 }  // namespace
 
 static int h2_nb(int M) { return (M % 64) == 0 ? 2 : 1; }      // n-blocks of 32 output channels per workgroup
 
-// a launch with K contraction channels and M output channels runs on the h2 kernels (both the weight preparation and the launch ask this)
-bool h2_conv3x3_selected(int K, int M) { return h2_mode() != 0 && K >= 16 && (K % 16) == 0 && M >= 16 && (M % 16) == 0; }
+// a launch with K contraction channels and M output channels runs on the h2 kernels: the family of UNET_ALGO_AUTO wherever the channel counts allow
+// (UNET_ALGO_MFMA = the strict fp32 family, kernels_conv_mfma.hip); both the weight preparation and the launch ask this
+bool h2_conv3x3_selected(int algo, int K, int M) { return algo == UNET_ALGO_AUTO && K >= 16 && (K % 16) == 0 && M >= 16 && (M % 16) == 0; }
 
 // bytes of the split weight image: 256-B header + 36 * K * M' (M' = M rounded up to whole 32-channel blocks; fits unet_conv3x3_w_ws_floats)
 size_t h2_wimg_bytes(int K, int M) { return (size_t)H2_HEADER + (size_t)36 * K * ((M + 31) / 32 * 32); }
 
-int32_t k_h2_weights_multi(unet_ctx* ctx, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s) {
+static int h2_nb_convT_fwd() { return 2; }
+static int h2_nb_convT_dgrad(int cin) { return (cin % 64) == 0 ? 2 : 1; }
+
+// One item of a preparation batch.  kind 0: conv3x3 forward image (K = cin, M = cout), 1: conv3x3 data-gradient image (flipped taps, K = cout, M = cin),
+// 2: ConvT forward (K = cin, M = 4 cout; Keras kernel [2][2][cout][cin]), 3: ConvT data gradient (K = 4 cout, M = cin).  cs: per-INPUT-channel factor of a
+// kind-0 image (folded BatchNorm scale) or null
+static void h2_fill_prep(h2_prep* p, const float* w, const float* cs, void* img, int cin, int cout, int kind) {
+  p->w = w; p->cs = cs; p->img = static_cast<unet_bf16*>(img); p->flip = 0; p->cs_div = 4; p->cs_mod = 1;
+  int K, M;
+  if (kind <= 1) {
+    const int flip = kind;
+    K = flip ? cout : cin; M = flip ? cin : cout;
+    p->T = 9; p->KS = 1; p->nb = h2_nb(M); p->nchunks = K / 16; p->flip = flip;
+    p->tap_stride = (long long)cin * cout; p->sk = flip ? 1 : cout; p->sm = flip ? cout : 1;
+    p->nw4 = 9LL * cin * cout / 4;
+    p->cs_div = cout; p->cs_mod = cin;                       // w[tap][c][o]: input channel of flat element i = (i / cout) % cin  (cout % 4 == 0)
+  } else if (kind == 2) {
+    K = cin; M = 4 * cout;
+    p->T = 1; p->KS = 2; p->nb = h2_nb_convT_fwd(); p->nchunks = K / 32; p->tap_stride = 0; p->sk = 1; p->sm = cin;          // W(k = c, m = ab*cout + o) = K[m*cin + c]
+    p->nw4 = (long long)cin * cout;
+  } else {
+    K = 4 * cout; M = cin;
+    p->T = 1; p->KS = 2; p->nb = h2_nb_convT_dgrad(cin); p->nchunks = K / 32; p->tap_stride = 0; p->sk = cin; p->sm = 1;      // W(k = ab*cout + o, m = c) = K[k*cin + c]
+    p->nw4 = (long long)cin * cout;
+  }
+  p->m = M;
+  const int groups = (M + 32 * p->nb - 1) / (32 * p->nb);
+  p->total = (long long)groups * p->nchunks * p->KS * p->T * p->nb * 2 * 32;
+}
+
+// count items (w, cs, img, cin, cout, kind) -> their split images, in TWO launches
+int32_t k_h2_prep_multi(unet_ctx* ctx, const float* const* w, const float* const* cs, void* const* img, const int* cin, const int* cout, const int* kind, int count, hipStream_t s) {
   if (count < 1) return UNET_OK;
-  if (count > UNET_WINO_PREP_MAX) UNET_FAIL(ctx, UNET_E_ARG, "h2_weights_multi: too many layers");
-  unet_wimg_prep_list L; L.n = count;
+  if (count > UNET_WINO_PREP_MAX) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: too many layers");
+  h2_prep_list L; L.n = count;
   long long most = 1;
   for (int k = 0; k < count; ++k) {
-    unet_wimg_prep* p = &L.item[k];
-    const int K = flip[k] ? cout[k] : cin[k], M = flip[k] ? cin[k] : cout[k];
-    const int nb = h2_nb(M), groups = (M + 32 * nb - 1) / (32 * nb), nchunks = K / 16;
-    p->w = w[k]; p->img = static_cast<unet_bf16*>(img[k]); p->tap_stride = (long long)cin[k] * cout[k]; p->flip = flip[k];
-    p->sk = flip[k] ? 1 : cout[k]; p->sm = flip[k] ? cout[k] : 1;
-    p->nb = nb; p->nchunks = nchunks; p->m = M;
-    p->total8 = (long long)groups * nchunks * 9 * nb * 2 * 32;
-    most = std::max(most, p->total8);
+    if (cs && cs[k] && (kind[k] != 0 || (cout[k] & 3))) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: a channel factor goes with a conv3x3 forward image");
+    h2_fill_prep(&L.item[k], w[k], cs ? cs[k] : nullptr, img[k], cin[k], cout[k], kind[k]);
+    most = std::max(most, L.item[k].total);
   }
-  static_assert(UNET_WINO_PREP_MAX <= 64, "one lane per layer");
-  hipLaunchKernelGGL(h2_wzero_kernel, dim3(1), dim3(64), 0, s, L);
-  hipLaunchKernelGGL(h2_wmax_kernel, dim3(48, (unsigned)count), dim3(256), 0, s, L);
-  hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(64), 0, s, L);
-  hipLaunchKernelGGL(h2_wimg_multi_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 256), (unsigned)count), dim3(256), 0, s, L);
-  UNET_CHECK_LAUNCH(ctx, "h2_weights_multi");
+  hipLaunchKernelGGL(h2_wmax_kernel, dim3(H2_MAXB, (unsigned)count), dim3(256), 0, s, L);
+  hipLaunchKernelGGL(h2_wimg_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 256), (unsigned)count), dim3(256), 0, s, L, (int)H2_MAXB);
+  UNET_CHECK_LAUNCH(ctx, "h2_prep_multi");
   return UNET_OK;
 }
 
-int32_t k_h2_weights(unet_ctx* ctx, const float* w, void* img, int cin, int cout, int flip, hipStream_t s) {
-  const float* ws[1] = {w}; void* is[1] = {img};
-  return k_h2_weights_multi(ctx, ws, is, &cin, &cout, &flip, 1, s);
+int32_t k_h2_weights_multi(unet_ctx* ctx, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s) {
+  return k_h2_prep_multi(ctx, w, nullptr, img, cin, cout, flip, count, s);          // (flip 0 / 1 = kind 0 / 1)
+}
+
+int32_t k_h2_weights(unet_ctx* ctx, const float* w, void* img, int cin, int cout, int flip, hipStream_t s, const float* cs) {
+  const float* ws[1] = {w}; const float* css[1] = {cs}; void* is[1] = {img};
+  return k_h2_prep_multi(ctx, ws, css, is, &cin, &cout, &flip, 1, s);
 }
 
 // x [n,h,wd,K] dense NHWC fp32, wimg from k_h2_weights (K contraction channels, M output channels), y [n,h,wd,M] fp32
@@ -690,50 +684,47 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   if (K < 16 || (K % 16) || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: K=%d M=%d (multiples of 16)", K, M);
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
-  static const int tile = [] { const char* e = getenv("UNET_H2_TILE"); return e ? atoi(e) : 0; }();          // measurements: 1 = 8-row tiles everywhere, 2 = 16-row tiles for 64-wide groups
   if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
   // 16-row tiles (twice the MFMAs per staged chunk, 7 spilled registers at two workgroups per CU) measured 3-5 % faster on the 64 x 64 ... 128 x 128 layers when
   // they still fill the 512 resident slots, 2-4 % slower on the 256 / 512 pixel layers (fewer, longer workgroups) and much slower when the grid falls below one round
   const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
-  if ((tile == 2 && h > 8) || (tile == 0 && h <= 128 && wgs16 >= 512)) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+  if (h <= 128 && wgs16 >= 512) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
   return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
 }
 
 // ---- ConvT 2x2 stride 2 (T1:886 ...) on the same kernels: forward = MODE 1 (K = cin, M = 4 cout), data gradient = MODE 2 (K = 4 cout, M = cin).
 // The split weight image (4 cin cout weights -> 16 cin cout bytes + header) is rebuilt per launch into a context-owned scratch (common.h: unet_ctx::convt_img).
-bool h2_convT_selected(const unet_ctx* ctx, int cin, int cout) {
-  return h2_mode() != 0 && ctx && ctx->convt_img && cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0 &&
+bool h2_convT_selected(const unet_ctx* ctx, int algo, int cin, int cout) {
+  return algo == UNET_ALGO_AUTO && ctx && ctx->convt_img && cin >= 32 && (cin % 32) == 0 && cout >= 32 && (cout % 32) == 0 &&
          (size_t)H2_HEADER + (size_t)16 * cin * cout <= ctx->convt_img_bytes;
 }
 
-static int32_t h2_convT_image(unet_ctx* ctx, const float* w, int K, int M, int NB, long long sk, long long sm, long long nweights, hipStream_t s) {
-  unet_wimg_prep_list L; L.n = 1;
-  L.item[0].w = w; L.item[0].img = static_cast<unet_bf16*>(ctx->convt_img);
-  hipLaunchKernelGGL(h2_wzero_kernel, dim3(1), dim3(64), 0, s, L);
-  hipLaunchKernelGGL(h2_wmax1_kernel, dim3(32), dim3(256), 0, s, w, nweights / 4, static_cast<unsigned*>(ctx->convt_img));
-  hipLaunchKernelGGL(h2_wscale_kernel, dim3(1), dim3(64), 0, s, L);
-  const int nchunks = K / 32, groups = (M + 32 * NB - 1) / (32 * NB);
-  const long long total = (long long)groups * nchunks * 2 * 1 * NB * 2 * 32;
-  hipLaunchKernelGGL(h2_wimg_generic_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, w, static_cast<unet_bf16*>(ctx->convt_img), 1, 2, NB, nchunks, 0LL,
-                     sk, sm, total, M);
-  UNET_CHECK_LAUNCH(ctx, "convT_h2_image");
-  return UNET_OK;
-}
-
 // u[n,2i+a,2j+b,o] = bias[o] + sum_c x[n,i,j,c] * K[a,b,o,c]   (Keras ConvT kernel [2][2][cout][cin]); y = channel slice with pixel stride ldy
-int32_t k_convT_h2_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s) {
-  int32_t r = h2_convT_image(ctx, w, cin, 4 * cout, 2, 1, cin, 4LL * cin * cout, s);              // W(k = c, m = ab*cout + o) = K[m*cin + c]
-  if (r) return r;
-  const unet_bf16* img = static_cast<const unet_bf16*>(ctx->convt_img);
+size_t h2_convT_img_bytes(int cin, int cout) { return (size_t)H2_HEADER + (size_t)16 * cin * cout; }
+
+// `prepared`: the image of kind 2 (forward) / 3 (data gradient) built by k_h2_prep_multi at the start of a program; null: built here into the context's scratch
+int32_t k_convT_h2_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s, const void* prepared) {
+  if (!prepared) {
+    const float* ws[1] = {w}; void* is[1] = {ctx->convt_img}; const int kind = 2;
+    int32_t r = k_h2_prep_multi(ctx, ws, nullptr, is, &cin, &cout, &kind, 1, s);
+    if (r) return r;
+    prepared = ctx->convt_img;
+  }
+  const unet_bf16* img = static_cast<const unet_bf16*>(prepared);
   return launch_h2<1, 2, 4, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
 }
 
 // dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]; dy = channel slice with pixel stride lddy; mask: ReLU of the producer of x
-int32_t k_convT_h2_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s, int mask_bits) {
-  const int NB = (cin % 64) == 0 ? 2 : 1;
-  int32_t r = h2_convT_image(ctx, w, 4 * cout, cin, NB, cin, 1, 4LL * cin * cout, s);             // W(k = ab*cout + o, m = c) = K[k*cin + c]
-  if (r) return r;
-  const unet_bf16* img = static_cast<const unet_bf16*>(ctx->convt_img);
+int32_t k_convT_h2_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s, int mask_bits,
+                         const void* prepared) {
+  const int NB = h2_nb_convT_dgrad(cin);
+  if (!prepared) {
+    const float* ws[1] = {w}; void* is[1] = {ctx->convt_img}; const int kind = 3;
+    int32_t r = k_h2_prep_multi(ctx, ws, nullptr, is, &cin, &cout, &kind, 1, s);
+    if (r) return r;
+    prepared = ctx->convt_img;
+  }
+  const unet_bf16* img = static_cast<const unet_bf16*>(prepared);
   const int mm = mask ? (mask_bits ? MASK_RELU_BITS : MASK_RELU) : MASK_NONE;
   if (NB == 2) return launch_h2<2, 2, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
   return launch_h2<2, 1, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);

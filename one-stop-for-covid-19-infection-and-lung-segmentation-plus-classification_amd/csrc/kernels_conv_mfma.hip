@@ -1,5 +1,7 @@
-// fp32 implicit-GEMM 3x3 convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact
-// fp32, 64 FLOP/clk/SIMD = the chip's 157 TFLOP/s fp32 peak; there is no TF32 on gfx950).
+// The STRICT fp32 kernel family (UNET_ALGO_MFMA; also what UNET_ALGO_AUTO falls back to for channel counts the fp16-split h2
+// kernels do not take): fp32 implicit-GEMM 3x3 convolution / ConvT / weight gradients on the CDNA4 matrix cores with
+// v_mfma_f32_32x32x2_f32 -- exact fp32 multiply-add (bitwise an fmaf chain), 64 FLOP/clk/SIMD = the chip's 157 TFLOP/s fp32 peak; there is
+// no TF32 on gfx950.  The out-of-domain fallback of kernels_conv_h2.hip and the on-device cross-check of its accuracy claims.
 //
 // Forward / data-gradient (same kernel, the data gradient passes flipped+transposed weights):
 //   GEMM view  M = output pixels, N = Cout, K = 9*Cin.
@@ -241,14 +243,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
   }
 }
 
-inline int conv_ablation() {
-  static const int v = [] { const char* e = getenv("UNET_CONV_ABL"); return e ? atoi(e) : 0; }();
-  return v;
-}
-inline int conv_prefetch_enabled() {        // UNET_CONV_PF: 0 = never, 1 = 128-wide tiles only, 2 = always (default)
-  static const int v = [] { const char* e = getenv("UNET_CONV_PF"); return e ? atoi(e) : 2; }();
-  return v;
-}
 
 template <int MODE, int TN, int TH, int WR, int WC>
 int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, const float* bias, const float* mask, int mask_mode, float* y,
@@ -258,15 +252,10 @@ int32_t launch_conv(unet_ctx* ctx, const float* x, int ldx, const float* w, cons
     UNET_FAIL(ctx, UNET_E_SHAPE, "conv mfma: one image / the weight tensor must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH;
   dim3 grid((unsigned)(tiles_x * tiles_y * n), (unsigned)((cout + TN - 1) / TN));
-  if (MODE == 0 && conv_ablation()) {          // timing experiments (tools/conv_ablate.py); never set in production
-    const int a = conv_ablation();
-    if (a == 1) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, false, 1>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
-    else if (a == 2) hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, false, 2>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
-    else hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, false, false, 3>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, cin, cout, act, mask_mode, rate, seed, tiles_x, tiles_y);
-  } else {
-    // default prefetch: always.  (In isolation the register prefetch is +7 % on the 128-wide tile and -5 % on the 32-wide one,
-    // where it costs a wave of occupancy; inside the training step "always" measured +0.7 % over "128-wide only".)
-    const bool pf = conv_prefetch_enabled() && (TN >= 128 || conv_prefetch_enabled() > 1);
+  {
+    // register prefetch of the next chunk: always (in isolation +7 % on the 128-wide tile and -5 % on the 32-wide one, where it costs a wave of
+    // occupancy; inside the training step "always" measured +0.7 % over "128-wide only")
+    const bool pf = true;
     const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode >= MASK_ELU);
 #define UNET_LAUNCH_CONV(PF_, GEN_)                                                                                                  \
   hipLaunchKernelGGL((conv_mfma_kernel<MODE, TN, TH, WR, WC, PF_, GEN_>), grid, dim3(256), 0, s, x, ldx, w, bias, mask, y, ldy, n, h, wd, \
@@ -299,7 +288,7 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
                                                         float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
                                                         int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
                                                         int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
-  static_assert(MODE == 0 || MODE == 1, "the Winograd-domain gradient (run_wgrad<2>) has its own kernel: wgrad_wino_kernel");
+  static_assert(MODE == 0 || MODE == 1, "conv3x3 / ConvT");
   constexpr int TAPS = MODE == 0 ? 9 : 4;
   constexpr int ROWF = 34 * 32;                    // floats per ring row (conv3x3)
   constexpr int AL = MODE != 1 ? 5 : 16, BL = 4;   // float4 staging registers per lane (A rows, B row)
@@ -435,288 +424,6 @@ __global__ __launch_bounds__(64, 2) void wgrad_mfma_kernel(const float* __restri
   else { if (tb == 0 && lane < 32 && a0 + l31 < CA) part_b[(long long)split * pstride + a0 + l31] = bsum; }
 }
 
-// Winograd-domain conv3x3 weight gradient, two waves per workgroup (see MODE 2 above for the math).  The 12 accumulator tiles
-// dU[ky][k] are split by k between the waves (wave 0: k = 0,1; wave 1: k = 3,2 -> 96 accumulator registers each, so the next-row
-// register prefetch fits again and 3 waves share a SIMD); both read the same raw LDS rows.  With e0,e1,e2 = columns (w, w+1, w+2)
-// of the tile's 4-pixel input window both waves form slot 0 = e0-e2 (V0 resp. V3) and slot 1 = e1 + sgn*(w ? e0 : e2) (V1 resp.
-// V2); the dY factors are slot 0 = (w ? -dy1 : dy0), slot 1 = dy0 + sgn*dy1: no divergent code, one basic block per row step.
-__global__ __launch_bounds__(128, 2) void wgrad_wino_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
-                                                            float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
-                                                            int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
-                                                            int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
-  constexpr int ROWF = 34 * 32;
-  constexpr int AL = 3, BL = 2;                       // float4 staging registers per lane (272 / 256 items over 128 lanes)
-  __shared__ __attribute__((aligned(16))) float s_a[ROWF];                 // newest X row only (older rows live in the register window)
-  __shared__ __attribute__((aligned(16))) float s_b[32 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware block map (workgroup L runs on XCD L % 8): all (a, b) channel-tile pairs of one pixel split go to the SAME XCD back to
-  // back, so the X / dY rows of that split are fetched into one L2 once instead of once per pair on eight different L2s.
-  const int npairs = tiles_a_x_b, sq = blockIdx.x >> 3;
-  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);
-  if (split >= nsplit) return;                                  // grid padded to 8 * ceil(nsplit / 8) * npairs workgroups
-  const int ta = pair / tiles_b, tb = pair % tiles_b;
-  const int a0 = ta * 32, b0 = tb * 32;
-  const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
-  const int cs = t2 % strips, n = t2 / strips;
-  const int x0 = cs * 32;
-  const int ya = chunk * rows_per_chunk;
-  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
-
-  f32x16 acc[3][2];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  float bsum = 0.0f;
-  const float* An = A + (long long)n * H * W * ldA;
-  const float* Bn = B + (long long)n * H * W * ldB;
-
-  int aoff[AL], alds[AL], boff[BL], blds[BL];
-#pragma unroll
-  for (int k = 0; k < AL; ++k) {
-    const int idx = min(tid + 128 * k, 34 * 8 - 1);               // surplus lanes redo the last item: no branch in the loop
-    const int pix = idx >> 3, q = idx & 7; const int gx = x0 - 1 + pix;
-    aoff[k] = (gx >= 0 && gx < W && a0 + q * 4 < CA) ? (gx * ldA + a0 + q * 4) * 4 : UNET_COL_OOB;
-    alds[k] = pix * 32 + q * 4;
-  }
-#pragma unroll
-  for (int k = 0; k < BL; ++k) {
-    const int idx = tid + 128 * k; const int pix = idx >> 3, q = idx & 7; const int gx = x0 + pix;
-    boff[k] = (gx < W && b0 + q * 4 < CB) ? (gx * ldB + b0 + q * 4) * 4 : UNET_COL_OOB;
-    blds[k] = pix * 32 + q * 4;
-  }
-  f32x4 areg[AL], breg[BL];
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(An, (long long)H * W * ldA * 4), rs_b = make_rsrc(Bn, (long long)H * W * ldB * 4);
-  const int nsteps = yb - ya + 2;                        // step t: ring row yy = ya-1+t (X row yy, dY row yy-1)
-  auto issue = [&](int t) __attribute__((always_inline)) {
-    const int yy = ya - 1 + t, yd = yy - 1;
-    const int ra = (yy >= 0 && yy < H) ? yy * W * ldA * 4 : UNET_OOB, rb = (yd >= ya && yd < yb) ? yd * W * ldB * 4 : UNET_OOB;
-#pragma unroll
-    for (int k = 0; k < AL; ++k) areg[k] = buf_ld4(rs_a, aoff[k] + ra);
-#pragma unroll
-    for (int k = 0; k < BL; ++k) breg[k] = buf_ld4(rs_b, boff[k] + rb);
-  };
-  const float sgn = w ? -1.0f : 1.0f;
-
-  // Register-resident row window: the two transformed A operands of every tile pair (8 pairs x 2 slots) of the LAST THREE X rows
-  // stay in registers (48 VGPRs), so a row is read from LDS and transformed once instead of three times (as ky = 2, 1, 0 of three
-  // consecutive output rows): 5 instead of 11 LDS reads per 6 MFMAs.  LDS then only holds the newest X row and the dY row.
-  // The row loop is unrolled by 3 so the window slot of a step is a compile-time constant.
-  float win[3][8][2];
-  auto step = [&](int t, auto phc) __attribute__((always_inline)) {
-    constexpr int PH = decltype(phc)::value;
-#pragma unroll
-    for (int k = 0; k < AL; ++k) *reinterpret_cast<f32x4*>(&s_a[alds[k]]) = areg[k];
-#pragma unroll
-    for (int k = 0; k < BL; ++k) *reinterpret_cast<f32x4*>(&s_b[blds[k]]) = breg[k];
-    __syncthreads();
-    if (t + 1 < nsteps) issue(t + 1);                      // next row's loads fly under this row's MFMAs (two rows ahead measured slower)
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp) {                       // newest X row (= ky 2 of this step's output row) -> window slot PH
-      const float* r = &s_a[(2 * (2 * pp + hi) + w) * 32 + l31];          // px 0 <-> column x0-1: window px 2tt .. 2tt+3
-      const float e0 = r[0], e1 = r[32], e2 = r[64];
-      const float z = w ? e0 : e2;
-      win[PH][pp][0] = e0 - e2; win[PH][pp][1] = e1 + sgn * z;
-    }
-    if (t >= 2) {
-#pragma unroll
-      for (int pp = 0; pp < 8; ++pp) {
-        const int tt = 2 * pp + hi;                        // MFMA k-pair = 2 consecutive Winograd tiles of the strip
-        const float dy0 = s_b[(2 * tt) * 32 + l31], dy1 = s_b[(2 * tt + 1) * 32 + l31];
-        if (w == 0) bsum += dy0 + dy1;
-        const float bm0 = w ? -dy1 : dy0, bm1 = dy0 + sgn * dy1;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {                   // X row of tap ky was staged (2 - ky) steps ago
-          const int sl = (PH + 1 + ky) % 3;
-          acc[ky][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(win[sl][pp][0], bm0, acc[ky][0], 0, 0, 0);
-          acc[ky][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(win[sl][pp][1], bm1, acc[ky][1], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-  };
-  issue(0);
-  for (int t = 0; t < nsteps; t += 3) {                     // window slot = t % 3: static inside the 3-step body
-    step(t, std::integral_constant<int, 0>{});
-    if (t + 1 < nsteps) step(t + 1, std::integral_constant<int, 1>{});
-    if (t + 2 < nsteps) step(t + 2, std::integral_constant<int, 2>{});
-  }
-
-  // partial tiles: slot j of wave w is Winograd index k = w ? 3 - j : j; quad transpose -> 16-byte stores (see wgrad_mfma_kernel)
-  float* P = part + (long long)split * pstride;
-  const int e = l31 & 3, q4 = l31 & ~3;
-  const bool odd1 = e & 1, odd2 = e & 2;
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int tap = ky * 4 + (w ? 3 - j : j);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v0 = acc[ky][j][4 * g + 0], v1 = acc[ky][j][4 * g + 1], v2 = acc[ky][j][4 * g + 2], v3 = acc[ky][j][4 * g + 3];
-        {
-          const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
-          const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
-          if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
-        }
-        {
-          const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
-          const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
-          if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
-        }
-        const int i = e + 8 * g + 4 * hi;
-        if (a0 + i < CA && b0 + q4 < CB) *reinterpret_cast<float4*>(&P[((long long)tap * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
-      }
-    }
-  bsum += __shfl_xor(bsum, 32, 64);
-  if (w == 0 && ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * pstride + b0 + l31] = bsum;
-}
-
-// Weight gradient in the 2-D Winograd domain F(2x2,3x3): 16 instead of 24 (F(2,3) along x) or 36 (direct) MFMAs per 2x2 output tile.
-//   dU[xi][nu][ci][co] = sum over 2x2 output tiles of V[xi][nu][ci] * dM[xi][nu][co],   V = B^T d B (4x4 input tile d),  dM = A dY A^T,
-//   dW = G^T dU G (16 -> 9, applied by reduce_final_wino2d_kernel).
-// Workgroup = 4 waves, wave = xi (the y index): it forms ITS row combination of the 4-row input window (R = rowP + sgn * rowQ: 0-2, 1+2,
-// 2-1, 1-3) and of the dY row pair (S = c0 * dy_r0 + c1 * dy_r1: dy0, dy0+dy1, dy0-dy1, -dy1), then the x transforms in registers, and
-// owns the four nu accumulator tiles (64 registers).  A step = one output ROW PAIR of a 32-column strip = 16 tiles = 8 MFMA k-pairs per
-// (xi, nu).  LDS keeps the rows TRANSPOSED ([channel][pixel], pitch 34: conflict-free ds_read_b64), so a lane fetches the 4 columns of
-// its tile with two 8-byte reads per row: 6 reads per 4 MFMAs.  X rows live in a 4-slot ring (two new rows per step), the next step's
-// rows are register-prefetched under the MFMAs.  (A two-wave form -- wave 0: xi = 1, 2 from rows 1, 2; wave 1: xi = 0, 3 -- reads a third
-// less from LDS but needs 128 accumulator registers per wave: 2 instead of 3 waves per SIMD, measured 10 % slower.)
-__global__ __launch_bounds__(256, 4) void wgrad_wino2d_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, int ldB,
-                                                              float* __restrict__ part, float* __restrict__ part_b, int N, int H, int W,
-                                                              int CA, int CB, int tiles_b, int strips, int rows_per_chunk,
-                                                              int chunks_per_strip, int nsplit, int tiles_a_x_b, long long pstride) {
-  constexpr int PIT = 34, ROW = 32 * PIT;
-  constexpr int XP = 2 * 34 * 8, YP = 2 * 32 * 8;          // 16-byte pieces per batch: two X rows (34 px), two dY rows (32 px)
-  constexpr int XL = (XP + 255) / 256, YL = YP / 256;
-  __shared__ __attribute__((aligned(16))) float s_x[4 * ROW];
-  __shared__ __attribute__((aligned(16))) float s_y[4 * ROW];                  // the four dY row combinations dy0, dy0+dy1, dy0-dy1, dy1, formed while staging
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int npairs = tiles_a_x_b, sq = blockIdx.x >> 3;
-  const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);      // XCD-aware block map, as wgrad_wino_kernel
-  if (split >= nsplit) return;
-  const int ta = pair / tiles_b, tb = pair % tiles_b;
-  const int a0 = ta * 32, b0 = tb * 32;
-  const int chunk = split % chunks_per_strip; const int t2 = split / chunks_per_strip;
-  const int cs = t2 % strips, n = t2 / strips;
-  const int x0 = cs * 32;
-  const int ya = chunk * rows_per_chunk;                                          // even (plan_wgrad rounds the chunk height up)
-  const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
-  const int npr = (yb - ya + 1) >> 1;                                             // row pairs of this chunk
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-  float bsum = 0.0f;
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + (long long)n * H * W * ldA, (long long)H * W * ldA * 4);
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + (long long)n * H * W * ldB, (long long)H * W * ldB * 4);
-
-  int xoff[XL], xlds[XL], yoff[YL], ylds[YL];               // column part of the global offset; LDS float index | row-in-batch << 20
-#pragma unroll
-  for (int k = 0; k < XL; ++k) {
-    const int idx = min(tid + 256 * k, XP - 1);             // surplus lanes redo the last piece
-    const int i = idx / 272, rem = idx - i * 272, pix = rem >> 3, q = rem & 7, gx = x0 - 1 + pix;
-    xoff[k] = (gx >= 0 && gx < W && a0 + q * 4 < CA) ? (gx * ldA + a0 + q * 4) * 4 : UNET_COL_OOB;
-    xlds[k] = (q * 4 * PIT + pix) | (i << 20);
-  }
-#pragma unroll
-  for (int k = 0; k < YL; ++k) {
-    const int idx = tid + 256 * k;
-    const int i = idx >> 8, rem = idx & 255, pix = rem >> 3, q = rem & 7, gx = x0 + pix;
-    yoff[k] = (gx < W && b0 + q * 4 < CB) ? (gx * ldB + b0 + q * 4) * 4 : UNET_COL_OOB;
-    ylds[k] = (q * 4 * PIT + pix) | (i << 20);
-  }
-  f32x4 xreg[XL], yreg[YL];
-  // batch b = X rows ya-1+2b, ya+2b  and (b >= 1) the dY rows of pair b-1
-  auto issue = [&](int b) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < XL; ++k) {
-      const int yr = ya - 1 + 2 * b + (xlds[k] >> 20);
-      xreg[k] = buf_ld4(rs_a, xoff[k] + ((yr >= 0 && yr < H) ? yr * W * ldA * 4 : UNET_OOB));
-    }
-#pragma unroll
-    for (int k = 0; k < YL; ++k) {
-      const int yd = ya + 2 * (b - 1) + (ylds[k] >> 20);
-      yreg[k] = buf_ld4(rs_b, yoff[k] + ((b >= 1 && yd < yb) ? yd * W * ldB * 4 : UNET_OOB));
-    }
-  };
-  auto store = [&](int b) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < XL; ++k) {
-      float* d = s_x + ((2 * b + (xlds[k] >> 20)) & 3) * ROW + (xlds[k] & 0xFFFFF);
-      d[0] = xreg[k][0]; d[PIT] = xreg[k][1]; d[2 * PIT] = xreg[k][2]; d[3 * PIT] = xreg[k][3];
-    }
-    if (b >= 1) {                                          // piece k = row k of the pair, same (pixel, channel quad) for both: combine here, once,
-      float* d = s_y + (ylds[0] & 0xFFFFF);                // instead of in every wave of the main loop
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = yreg[0][j], c = yreg[1][j];
-        d[j * PIT] = a; d[ROW + j * PIT] = a + c; d[2 * ROW + j * PIT] = a - c; d[3 * ROW + j * PIT] = c;
-      }
-    }
-  };
-  // wave-uniform row combinations: X window rows (P, Q) with sign, dY rows with (c0, c1)
-  const int rowP = (w == 0) ? 0 : (w == 2 ? 2 : 1), rowQ = (w == 0 || w == 1) ? 2 : (w == 2 ? 1 : 3);
-  const float sgx = (w == 1) ? 1.0f : -1.0f;
-
-  issue(0); store(0); issue(1);
-  for (int s = 0; s < npr; ++s) {
-    store(s + 1);
-    __syncthreads();
-    if (s + 2 <= npr) issue(s + 2);
-    const float* rp = s_x + ((2 * s + rowP) & 3) * ROW + l31 * PIT + 2 * hi;
-    const float* rq = s_x + ((2 * s + rowQ) & 3) * ROW + l31 * PIT + 2 * hi;
-    const float* ys = s_y + w * ROW + l31 * PIT + 2 * hi;    // this wave's dY combination (xi = 3 reads +dy1: its sign is applied by the final reduction)
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp) {                       // MFMA k-pair = tiles 2pp (lanes 0-31) and 2pp+1 (lanes 32-63)
-      const float2 p01 = *reinterpret_cast<const float2*>(rp + 4 * pp), p23 = *reinterpret_cast<const float2*>(rp + 4 * pp + 2);
-      const float2 q01 = *reinterpret_cast<const float2*>(rq + 4 * pp), q23 = *reinterpret_cast<const float2*>(rq + 4 * pp + 2);
-      const float2 sv = *reinterpret_cast<const float2*>(ys + 4 * pp);
-      const float e0 = fmaf(sgx, q01.x, p01.x), e1 = fmaf(sgx, q01.y, p01.y), e2 = fmaf(sgx, q23.x, p23.x), e3 = fmaf(sgx, q23.y, p23.y);
-      const float s0 = sv.x, s1 = sv.y;
-      if (w == 1) bsum += s0 + s1;                         // wave 1 sees dy_r0 + dy_r1: the bias gradient rides along
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e2, s0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 + e2, s0 + s1, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e2 - e1, s0 - s1, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(e1 - e3, s1, acc[3], 0, 0, 0);       // dM3 = -s1: sign applied by the final reduction
-    }
-    __syncthreads();
-  }
-
-  // partial tiles dU[xi = w][nu]; quad transpose -> 16-byte stores (see wgrad_mfma_kernel)
-  float* P = part + (long long)split * pstride;
-  const int e = l31 & 3, q4 = l31 & ~3;
-  const bool odd1 = e & 1, odd2 = e & 2;
-#pragma unroll
-  for (int nu = 0; nu < 4; ++nu) {
-    const int tap = w * 4 + nu;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v0 = acc[nu][4 * g + 0], v1 = acc[nu][4 * g + 1], v2 = acc[nu][4 * g + 2], v3 = acc[nu][4 * g + 3];
-      {
-        const float s01 = odd1 ? v0 : v1, s23 = odd1 ? v2 : v3;
-        const float r01 = __shfl_xor(s01, 1, 64), r23 = __shfl_xor(s23, 1, 64);
-        if (odd1) { v0 = r01; v2 = r23; } else { v1 = r01; v3 = r23; }
-      }
-      {
-        const float s02 = odd2 ? v0 : v2, s13 = odd2 ? v1 : v3;
-        const float r02 = __shfl_xor(s02, 2, 64), r13 = __shfl_xor(s13, 2, 64);
-        if (odd2) { v0 = r02; v1 = r13; } else { v2 = r02; v3 = r13; }
-      }
-      const int i = e + 8 * g + 4 * hi;
-      if (a0 + i < CA && b0 + q4 < CB) *reinterpret_cast<float4*>(&P[((long long)tap * CA + a0 + i) * CB + b0 + q4]) = make_float4(v0, v1, v2, v3);
-    }
-  }
-  bsum += __shfl_xor(bsum, 32, 64);
-  if (w == 1 && ta == 0 && lane < 32 && b0 + l31 < CB) part_b[(long long)split * pstride + b0 + l31] = bsum;
-}
-
 // Sum the split-K partials in a fixed order.  Two levels so that a tiny output (e.g. 9x32x32) with
 // thousands of splits still spreads over the chip: level 1 reduces groups of splits (grid.y = groups),
 // level 2 reduces the group sums.  4 independent accumulators keep 4 loads in flight per thread.
@@ -745,13 +452,11 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 }
 
 // Last reduction level, weights and bias in ONE launch.  src = `count` slabs of `stride` floats, each [taps][ca*cb] weight partials
-// followed by the bias partials.  WINO: the slab is in the Winograd domain dU[ky][k] (12 taps); the 12 -> 9 transform (transpose of
-// the weight transform G: dg0 = dU0 + (dU1+dU2)/2, dg1 = (dU1-dU2)/2, dg2 = (dU1+dU2)/2 + dU3) is applied on the fly.
-template <int WINO>       // 0: plain, 1: 12 -> 9 (F(2,3) along x); the 16 -> 9 form of F(2x2,3x3) is reduce_final_wino2d_kernel
+// followed by the bias partials.
 __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ src, long long stride, int count, int n4 /* ca*cb/4 */, int taps,
                                                            int nb4 /* bias floats / 4 */, float* __restrict__ dw, float* __restrict__ db) {
   const long long st = (long long)n4 * 4;
-  const int nw = (WINO == 1 ? 3 : taps) * n4;
+  const int nw = taps * n4;
   auto sum = [&](long long off) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     int c = 0;
@@ -763,68 +468,14 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
   };
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nw + nb4; i += gridDim.x * 256) {
-    if (i >= nw) { *reinterpret_cast<float4*>(db + (long long)(i - nw) * 4) = sum((long long)taps * st + (long long)(i - nw) * 4); continue; }
-    if (WINO == 0) { *reinterpret_cast<float4*>(dw + (long long)i * 4) = sum((long long)i * 4); continue; }
-    const int ky = i / n4, j = i - ky * n4;
-    const long long o = (long long)ky * 4 * st + (long long)j * 4;
-    const float4 u0 = sum(o), u1 = sum(o + st), u2 = sum(o + 2 * st), u3 = sum(o + 3 * st);
-    float* q = dw + (long long)ky * 3 * st + (long long)j * 4;
-    const float4 hs = make_float4(0.5f * (u1.x + u2.x), 0.5f * (u1.y + u2.y), 0.5f * (u1.z + u2.z), 0.5f * (u1.w + u2.w));
-    *reinterpret_cast<float4*>(q) = make_float4(u0.x + hs.x, u0.y + hs.y, u0.z + hs.z, u0.w + hs.w);
-    *reinterpret_cast<float4*>(q + st) = make_float4(0.5f * (u1.x - u2.x), 0.5f * (u1.y - u2.y), 0.5f * (u1.z - u2.z), 0.5f * (u1.w - u2.w));
-    *reinterpret_cast<float4*>(q + 2 * st) = make_float4(hs.x + u3.x, hs.y + u3.y, hs.z + u3.z, hs.w + u3.w);
+    if (i >= nw) *reinterpret_cast<float4*>(db + (long long)(i - nw) * 4) = sum((long long)taps * st + (long long)(i - nw) * 4);
+    else *reinterpret_cast<float4*>(dw + (long long)i * 4) = sum((long long)i * 4);
   }
-}
-
-// Final level for the F(2x2,3x3) weight gradient: 16 Winograd taps -> 9 kernel taps, dW = G^T dU G.  A workgroup = 16 (ci, co) quads x
-// 16 taps: every thread sums ITS (tap, quad) over the slabs (16x the parallelism of one thread per quad: the 32 x 32-channel layers
-// have only 256 quads), the 16 x 16 sums meet in LDS and 144 threads apply the two 4 -> 3 transforms.  Extra workgroups sum the bias.
-__global__ __launch_bounds__(256) void reduce_final_wino2d_kernel(const float* __restrict__ src, long long stride, int count, int n4, int nb4,
-                                                                  int wblocks, float* __restrict__ dw, float* __restrict__ db) {
-  const long long st = (long long)n4 * 4;
-  auto sum = [&](long long off) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    int c = 0;
-    for (; c + 1 < count; c += 2) {
-      const float4 u = *reinterpret_cast<const float4*>(src + (long long)c * stride + off), v = *reinterpret_cast<const float4*>(src + (long long)(c + 1) * stride + off);
-      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
-    }
-    if (c < count) { const float4 u = *reinterpret_cast<const float4*>(src + (long long)c * stride + off); a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
-    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-  };
-  if ((int)blockIdx.x >= wblocks) {                      // bias gradient: plain sums
-    const int i = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
-    if (i < nb4) *reinterpret_cast<float4*>(db + (long long)i * 4) = sum(16 * st + (long long)i * 4);
-    return;
-  }
-  __shared__ float4 s_u[16][16];
-  const int tq = threadIdx.x & 15, tap = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + tq;
-  s_u[tap][tq] = j < n4 ? sum((long long)tap * st + (long long)j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  if (threadIdx.x >= 144) return;
-  const int q = threadIdx.x & 15, kk = threadIdx.x >> 4, ky = kk / 3, kx = kk - ky * 3;
-  const int jq = blockIdx.x * 16 + q;
-  if (jq >= n4) return;
-  // rows of G^T: (1, 1/2, 1/2, 0), (0, 1/2, -1/2, 0), (0, 1/2, 1/2, 1)
-  // (the kernel accumulates xi = 3 and nu = 3 with the opposite sign -- it skips the negations of -dy1 and -s1 --: folded in here)
-  const float gy[4] = {ky == 0 ? 1.f : 0.f, 0.5f, ky == 1 ? -0.5f : 0.5f, ky == 2 ? -1.f : 0.f};
-  const float gx[4] = {kx == 0 ? 1.f : 0.f, 0.5f, kx == 1 ? -0.5f : 0.5f, kx == 2 ? -1.f : 0.f};
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      const float c = gy[xi] * gx[nu];
-      const float4 u = s_u[xi * 4 + nu][q];
-      r.x = fmaf(c, u.x, r.x); r.y = fmaf(c, u.y, r.y); r.z = fmaf(c, u.z, r.z); r.w = fmaf(c, u.w, r.w);
-    }
-  *reinterpret_cast<float4*>(dw + (long long)kk * st + (long long)jq * 4) = r;
 }
 
 struct WgradPlan { int tiles_a, tiles_b, strips, nsplit, rows_per_chunk, chunks_per_strip, groups, per_group; size_t part_floats, bias_floats, part2_floats; };
 
-WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias, bool even_rows = false) {
+WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias) {
   WgradPlan p;
   p.tiles_a = (ca + 31) / 32; p.tiles_b = (cb + 31) / 32; p.strips = (w + 31) / 32;      // a tile may overhang (channels % 32 != 0)
   const long long pairs = (long long)p.tiles_a * p.tiles_b;
@@ -832,17 +483,13 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias, b
   // K-split: every (image, 32-column strip) is cut into row chunks; aim at ~4096 waves (2 waves/SIMD x 256 CUs x 2 rounds),
   // at least 8 rows per chunk (the 3x3 ring re-reads 2 halo rows per chunk), at most 192 MiB of partials
   const long long units = (long long)n * p.strips;
-  static const long long target_env = [] { const char* e = getenv("UNET_WGRAD_BLOCKS"); return e ? atoll(e) : 0LL; }();
-  // one resident round: 256 CUs x 6 two-wave workgroups (1-D Winograd / direct kernels; measured best of 1536..6144), x 4 four-wave
-  // workgroups of the F(2x2,3x3) kernel (1024: best of 768..3072)
-  const long long target = target_env ? target_env : (even_rows ? 1024LL : 1536LL);
+  const long long target = 1536;                      // one resident round: 256 CUs x 6 one-wave workgroups (measured best of 1536..6144)
   long long want = (target + pairs - 1) / pairs;
   const long long cap = std::max<long long>(1, (48LL << 20) / per);
   want = std::min(want, cap);
   long long cps = std::max<long long>(1, (want + units - 1) / units);
   cps = std::min<long long>(cps, std::max<long long>(1, h / 8));
   p.rows_per_chunk = (int)((h + cps - 1) / cps);
-  if (even_rows) p.rows_per_chunk += p.rows_per_chunk & 1;                 // the F(2x2,3x3) kernel walks row pairs
   p.chunks_per_strip = (h + p.rows_per_chunk - 1) / p.rows_per_chunk;
   p.nsplit = (int)(units * p.chunks_per_strip);
   p.part_floats = (size_t)p.nsplit * per; p.bias_floats = (size_t)p.nsplit * cbias;
@@ -859,28 +506,21 @@ WgradPlan plan_wgrad(int taps, int n, int h, int w, int ca, int cb, int cbias, b
 template <int MODE>
 int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ldB, float* dw, float* db, void* ws, size_t ws_bytes, int n,
                   int h, int w, int ca, int cb, hipStream_t s) {
-  const int taps = MODE == 0 ? 9 : (MODE == 1 ? 4 : (MODE == 2 ? 12 : 16)); const int cbias = MODE != 1 ? cb : ca;
+  const int taps = MODE == 0 ? 9 : 4; const int cbias = MODE != 1 ? cb : ca;
   if ((long long)(MODE == 1 ? 4 : 1) * h * w * ldA * 4 >= (1LL << 30) || (long long)h * w * ldB * 4 >= (1LL << 30))
     UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad mfma: one image must stay below 1 GiB (32-bit buffer offsets); use UNET_ALGO_NAIVE");
-  const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias, MODE == 3);
+  const WgradPlan p = plan_wgrad(taps, n, h, w, ca, cb, cbias);
   const long long per = (long long)taps * ca * cb, S = per + cbias;      // one split's partial slab: weights, then bias sums
   const size_t need = (p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float);
   if (!ws || ws_bytes < need) UNET_FAIL(ctx, UNET_E_ARG, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   float* part = static_cast<float*>(ws); float* part_b = part + per;
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));            // see the block map in the kernels
-  if constexpr (MODE == 3)
-    hipLaunchKernelGGL(wgrad_wino2d_kernel, grid, dim3(256), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk,
-                       p.chunks_per_strip, p.nsplit, npairs, S);
-  else if constexpr (MODE == 2)
-    hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(128), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips, p.rows_per_chunk,
-                       p.chunks_per_strip, p.nsplit, npairs, S);
-  else
-    hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, grid, dim3(64), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips,
+  hipLaunchKernelGGL(wgrad_mfma_kernel<MODE>, grid, dim3(64), 0, s, A, ldA, B, ldB, part, part_b, n, h, w, ca, cb, p.tiles_b, p.strips,
                        p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S);
   UNET_CHECK_LAUNCH(ctx, "wgrad_mfma");
   // deterministic two-level reduction of the split slabs: level 1 sums groups of splits (skipped when there are few), the final
-  // level also writes the bias gradient and (MODE 2) applies the 12 -> 9 Winograd transform: 2 launches instead of 5
+  // level also writes the bias gradient
   const float* src = part; int count = p.nsplit;
   if (p.groups > 1) {
     float* part2 = part + (size_t)p.nsplit * S;
@@ -889,14 +529,8 @@ int32_t run_wgrad(unet_ctx* ctx, const float* A, int ldA, const float* B, int ld
     src = part2; count = p.groups;
   }
   const int n4 = ca * cb / 4, nb4 = cbias / 4;
-  const int items = (MODE == 3 ? 1 : MODE == 2 ? 3 : taps) * n4 + nb4;
-  const dim3 gf((unsigned)std::min(2048, (items + 255) / 256));
-  if (MODE == 3) {
-    const int wblocks = (n4 + 15) / 16;
-    hipLaunchKernelGGL(reduce_final_wino2d_kernel, dim3((unsigned)(wblocks + (nb4 + 255) / 256)), dim3(256), 0, s, src, S, count, n4, nb4, wblocks, dw, db);
-  }
-  else if (MODE == 2) hipLaunchKernelGGL(reduce_final_kernel<1>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
-  else hipLaunchKernelGGL(reduce_final_kernel<0>, gf, dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  const int items = taps * n4 + nb4;
+  hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)std::min(2048, (items + 255) / 256)), dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
 }
@@ -928,7 +562,7 @@ int32_t k_wgrad_reduce(unet_ctx* ctx, float* part, int nslabs, int taps, int ca,
   }
   const int n4 = ca * cb / 4, nb4 = cbias / 4;
   const int items = taps * n4 + nb4;
-  hipLaunchKernelGGL(reduce_final_kernel<0>, dim3((unsigned)std::min(2048, (items + 255) / 256)), dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3((unsigned)std::min(2048, (items + 255) / 256)), dim3(256), 0, s, src, S, count, n4, taps, nb4, dw, db);
   UNET_CHECK_LAUNCH(ctx, "wgrad_reduce");
   return UNET_OK;
 }
@@ -964,140 +598,10 @@ int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float
   return launch_conv<2, 32, 4, 4, 1>(ctx, dy, lddy, w, nullptr, mask, mm, dx, cin, n, h, wd, cout, cin, ACT_NONE, 0.0f, 0, s);
 }
 
-size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // large enough for the direct AND the Winograd form
+size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // large enough for this family AND the h2 form
   if (!mfma_wgrad_supported(cin, cout)) return 0;
-  const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout), q = plan_wgrad(12, n, h, wd, cin, cout, cout), r = plan_wgrad(16, n, h, wd, cin, cout, cout, true);
-  return std::max(std::max(std::max(p.part_floats + p.bias_floats + p.part2_floats, q.part_floats + q.bias_floats + q.part2_floats), r.part_floats + r.bias_floats + r.part2_floats) * sizeof(float),
-                  h2_wgrad_ws_bytes(n, h, wd, cin, cout));
-}
-
-// ---- weight gradient of a conv whose input BatchNorm was folded into it (common.h: k_bn_fold_prepare) --------------------------------------
-// The gradient kernels ran on the raw x; with z = scale[c] * x + shift[c] inside the image and 0 outside,
-//   dW[a][b][c][o] = scale[c] * dW_raw[a][b][c][o] + shift[c] * S[a][b][o],   S[a][b][o] = sum of dy[.., o] over the pixels whose tap (a, b) stays inside
-// = db[o] minus the border row / column the tap excludes plus the corner both exclude.
-namespace {
-// out[n * SEG + seg][8][C]: sums of dy over (segment seg of) row 0, row H-1, column 0, column W-1 and the corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
-// of image n.  grid (8 * SEG, N)
-constexpr int BORDER_SEG = 4;
-template <typename T>
-__global__ __launch_bounds__(256) void border_sums_kernel(const T* __restrict__ dy, float* __restrict__ out, int H, int W, int C) {
-  __shared__ float s_p[256];
-  const int kind = blockIdx.x & 7, seg = blockIdx.x >> 3, n = blockIdx.y;
-  const int co = threadIdx.x % C, sl = threadIdx.x / C, nsl = 256 / C;
-  const T* img = dy + (long long)n * H * W * C;
-  float acc = 0.f;
-  if (kind < 2) {
-    const T* r = img + (long long)(kind ? H - 1 : 0) * W * C;
-    const int per = (W + BORDER_SEG - 1) / BORDER_SEG, j1 = min(W, (seg + 1) * per);
-    for (int j = seg * per + sl; j < j1; j += nsl) acc += ld1(r + (long long)j * C + co);
-  } else if (kind < 4) {
-    const T* q = img + (long long)(kind == 3 ? W - 1 : 0) * C;
-    const int per = (H + BORDER_SEG - 1) / BORDER_SEG, i1 = min(H, (seg + 1) * per);
-    for (int i = seg * per + sl; i < i1; i += nsl) acc += ld1(q + (long long)i * W * C + co);
-  } else if (sl == 0 && seg == 0) { const int i = (kind & 2) ? H - 1 : 0, j = (kind & 1) ? W - 1 : 0; acc = ld1(img + ((long long)i * W + j) * C + co); }
-  s_p[threadIdx.x] = acc;
-  __syncthreads();
-  if (sl == 0) { for (int k = 1; k < nsl; ++k) acc += s_p[k * C + co]; out[(((long long)n * BORDER_SEG + seg) * 8 + kind) * C + co] = acc; }
-}
-// S[tap][o] from db and the border sums (NS = images x segments of them).  grid (9, C / 64), 1024 threads = 64 channels x 16 slices of NS (a batch of 256
-// images is 1024 entries: with 4 slices the three dependent loads per entry made this 0.2 ms of pure latency)
-__global__ __launch_bounds__(1024) void fold_tap_sums_kernel(const float* __restrict__ border, const float* __restrict__ db, float* __restrict__ S, int NS, int C) {
-  __shared__ float s_r[3][16][64];
-  const int tap = blockIdx.x, a = tap / 3, b = tap - a * 3, l = threadIdx.x & 63, sl = threadIdx.x >> 6, o = blockIdx.y * 64 + l;
-  const int er = a == 0 ? 0 : (a == 2 ? 1 : -1), ec = b == 0 ? 0 : (b == 2 ? 1 : -1);      // excluded row (0: first, 1: last), column
-  float kr = 0.f, kc = 0.f, kk = 0.f;
-  if (o < C)
-    for (int n = sl; n < NS; n += 16) {
-      const float* p = border + (long long)n * 8 * C + o;
-      if (er >= 0) kr += p[er * C];
-      if (ec >= 0) kc += p[(2 + ec) * C];
-      if (er >= 0 && ec >= 0) kk += p[(4 + er * 2 + ec) * C];
-    }
-  s_r[0][sl][l] = kr; s_r[1][sl][l] = kc; s_r[2][sl][l] = kk;
-  __syncthreads();
-  if (sl == 0 && o < C) {
-    kr = kc = kk = 0.f;
-    for (int k = 0; k < 16; ++k) { kr += s_r[0][k][l]; kc += s_r[1][k][l]; kk += s_r[2][k][l]; }          // fixed order
-    S[tap * C + o] = ((db[o] - kr) - kc) + kk;
-  }
-}
-// (sum dz, sum dz * xhat) of the folded BatchNorm's backward WITHOUT reading dz or x: dz is the data gradient of this conv, so per input channel c
-//   sum_p dz_c(p)        = sum_{tap,o} W[tap][c][o] * S[tap][o]
-//   sum_p dz_c(p) x_c(p) = sum_{tap,o} W[tap][c][o] * dW_raw[tap][c][o]        (dW_raw = the weight gradient on the raw x, before the correction)
-// and sum dz * xhat = istd * (sum dz x - mean * sum dz).  grid cin, 256 threads over the 9 * cout (tap, o) pairs; added into sums[2 * cin] (doubles).
-__global__ __launch_bounds__(256) void fold_bn_bwd_sums_kernel(const float* __restrict__ w, const float* __restrict__ dw_raw, const float* __restrict__ S,
-                                                               const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ sums, int cin, int cout) {
-  __shared__ double s_a[256], s_b[256];
-  const int c = blockIdx.x;
-  float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < 9 * cout; i += 256) {
-    const int tap = i / cout, o = i - tap * cout;
-    const long long j = ((long long)tap * cin + c) * cout + o;
-    const float wv = w[j];
-    a = fmaf(wv, dw_raw[j], a); b = fmaf(wv, S[i], b);
-  }
-  s_a[threadIdx.x] = (double)a; s_b[threadIdx.x] = (double)b;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if ((int)threadIdx.x < st) { s_a[threadIdx.x] += s_a[threadIdx.x + st]; s_b[threadIdx.x] += s_b[threadIdx.x + st]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { sums[c] += s_b[0]; sums[cin + c] += (double)istd[c] * (s_a[0] - (double)mean[c] * s_b[0]); }
-}
-__global__ void fold_fix_kernel(float* __restrict__ dw, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ S, int cin, int cout4,
-                                long long total4) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % cout4); const long long r = i / cout4; const int c = (int)(r % cin), tap = (int)(r / cin);
-    const float sc = scale[c], sh = shift[c];
-    const float4 sv = reinterpret_cast<const float4*>(S)[tap * cout4 + q];
-    float4 v = reinterpret_cast<float4*>(dw)[i];
-    v.x = fmaf(sc, v.x, sh * sv.x); v.y = fmaf(sc, v.y, sh * sv.y); v.z = fmaf(sc, v.z, sh * sv.z); v.w = fmaf(sc, v.w, sh * sv.w);
-    reinterpret_cast<float4*>(dw)[i] = v;
-  }
-}
-}  // namespace
-
-bool wgrad_bn_fold_supported(int cout) { return cout >= 4 && cout <= 256 && 256 % cout == 0; }
-size_t wgrad_bn_fold_scratch_floats(int n, int cout) { return (size_t)(n > 0 ? n : 0) * BORDER_SEG * 8 * cout + 9 * (size_t)cout; }
-// w / mean / istd / bn_bwd_sums (all or none): also accumulate the folded BatchNorm's backward sums (sum dz, sum dz * xhat) -- from W, the raw dw and S
-template <typename T>
-static int32_t wgrad_bn_fold_fix_impl(unet_ctx* ctx, const T* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                                      float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
-  if (!dy || !scale || !shift || !dw || !db || !scratch || !wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: bad args (cout=%d)", cout);
-  float* border = scratch; float* S = scratch + (size_t)n * BORDER_SEG * 8 * cout;
-  hipLaunchKernelGGL(border_sums_kernel<T>, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
-  hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(1024), 0, s, border, db, S, n * BORDER_SEG, cout);
-  if (bn_bwd_sums) {
-    if (!w || !mean || !istd) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: the BatchNorm backward sums need w, mean, istd");
-    hipLaunchKernelGGL(fold_bn_bwd_sums_kernel, dim3((unsigned)cin), dim3(256), 0, s, w, dw, S, mean, istd, bn_bwd_sums, cin, cout);
-  }
-  const long long total4 = 9LL * cin * cout / 4;
-  hipLaunchKernelGGL(fold_fix_kernel, dim3((unsigned)std::min<long long>((total4 + 255) / 256, 2048)), dim3(256), 0, s, dw, scale, shift, S, cin, cout / 4, total4);
-  UNET_CHECK_LAUNCH(ctx, "wgrad_bn_fold_fix");
-  return UNET_OK;
-}
-int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
-  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums);
-}
-int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx* ctx, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                                 float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
-  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums);
-}
-
-static int wgrad_wino_form() {
-  static const int form = [] { const char* e = getenv("UNET_WINO_WGRAD_2D"); return e ? atoi(e) : 1; }();      // A/B switch: 0 = F(2,3) along x
-  return form;
-}
-// executed / algorithmic multiplies of the Winograd-domain weight gradient of this shape: 4/9 (F(2x2,3x3)) or 2/3 (F(2,3) along x)
-double wino_wgrad_exec_ratio(int h) { return (wgrad_wino_form() && h >= 2) ? 4.0 / 9.0 : 2.0 / 3.0; }
-
-int32_t k_conv3x3_wino_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,
-                             int wd, int cin, int cout, hipStream_t s) {
-  if (!mfma_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad winograd: cin=%d cout=%d unsupported", cin, cout);
-  const int form = wgrad_wino_form();
-  if (form && h >= 2) return run_wgrad<3>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
-  return run_wgrad<2>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
+  const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout);
+  return std::max((p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float), h2_wgrad_ws_bytes(n, h, wd, cin, cout));
 }
 
 int32_t k_conv3x3_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,

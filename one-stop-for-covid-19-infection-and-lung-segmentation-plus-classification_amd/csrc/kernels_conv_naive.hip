@@ -344,8 +344,7 @@ static int32_t c1_fwd_impl(unet_ctx* ctx, const float* x, const float* w, const 
                          int cout, int act, float rate, uint64_t seed, hipStream_t s) {
   if ((cout & 3) || TPB % (cout / 4) || (long long)n * h * wd >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1: cout=%d / %d x %d x %d pixels unsupported", cout, n, h, wd);
   long long threads = (long long)n * h * wd * (cout / 4);
-  static const int four = [] { const char* e = getenv("UNET_C1_X4"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = one pixel per thread
-  if (four && (wd & 3) == 0) {
+  if ((wd & 3) == 0) {                                   // four pixels of a row per thread
     hipLaunchKernelGGL(conv3x3_c1x4_kernel<T>, dim3(grid_for(threads / 4, 4096)), dim3(TPB), 0, s, x, w, bias, y, n, h, wd, cout, act, rate, (unsigned long long)seed);
     UNET_CHECK_LAUNCH(ctx, "conv3x3_c1x4_fwd"); return UNET_OK;
   }
@@ -412,8 +411,7 @@ static int32_t c1_wgrad_impl(unet_ctx* ctx, const float* x, const T* dy, float* 
   if (!ws || ws_bytes < c1_wgrad_ws_bytes(cout)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_c1_wgrad: workspace too small");
   long long groups = ((long long)n * h * wd * (cout / 4) + TPB - 1) / TPB;
   int blocks = (int)std::min<long long>(C1_BLOCKS, std::max<long long>(groups, 1));
-  static const int four = [] { const char* e = getenv("UNET_C1_X4"); return e ? atoi(e) : 1; }();
-  if (four && (wd & 3) == 0) hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<T, true>), dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
+  if ((wd & 3) == 0) hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<T, true>), dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
   else hipLaunchKernelGGL((conv3x3_c1_wgrad_kernel<T, false>), dim3(blocks), dim3(TPB), 0, s, x, dy, static_cast<float*>(ws), n, h, wd, cout);
   float* part = static_cast<float*>(ws); float* part2 = part + (size_t)C1_BLOCKS * 10 * cout;
   const int ngroups = (blocks + 31) / 32;

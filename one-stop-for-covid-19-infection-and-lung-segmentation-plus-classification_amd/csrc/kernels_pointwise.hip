@@ -13,13 +13,12 @@ constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident blocks; grid-stride be
 // BN statistics end in 2C fp64 atomics per block on a handful of cache lines: measured 0.2 ms of pure
 // atomic serialisation at 2048 blocks, so the reduction kernels run 2 blocks per CU instead
 // Workgroups of the reduction kernels.  Every workgroup ends in 2C fp64 atomics (spread over UNET_BN_SLOTS copies of the target), so
-// more workgroups buy memory-level parallelism and pay atomic traffic; measured optima per kernel (UNET_BN_BLOCKS overrides all three):
-static const int HEAD_BLOCKS = [] { const char* e = getenv("UNET_HEAD_BLOCKS"); return e ? atoi(e) : 8192; }();   // head_fwd: one load in flight per thread, wants many workgroups (0.20 -> 0.18 ms); head_bwd ends in 33 atomics on two cache lines: 1024 (0.25 -> 0.215)
-static const int HEAD_LPP_KERNEL = [] { const char* e = getenv("UNET_HEAD_LPP"); return e ? atoi(e) : 1; }();        // A/B switch for measurements
-static const int BN_BLOCKS_ENV = [] { const char* e = getenv("UNET_BN_BLOCKS"); return e ? atoi(e) : 0; }();
-static const int BN_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 512;          // one tensor in        (0.86 -> 0.68 ms per step with the slots)
-static const int BN_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 1024;     // two tensors in       (1.06 -> 0.79)
-static const int POOL_BWD_STATS_BLOCKS = BN_BLOCKS_ENV ? BN_BLOCKS_ENV : 768;    // read-modify-write    (0.73 -> 0.63)
+// more workgroups buy memory-level parallelism and pay atomic traffic; measured optima per kernel:
+constexpr int HEAD_BLOCKS = 8192;   // head_fwd: one load in flight per thread, wants many workgroups (0.20 -> 0.18 ms); head_bwd ends in 33 atomics on two cache lines: 1024 (0.25 -> 0.215)
+constexpr int BN_STATS_BLOCKS = 512;          // one tensor in        (0.86 -> 0.68 ms per step with the slots)
+constexpr int BN_BWD_STATS_BLOCKS = 1024;     // two tensors in       (1.06 -> 0.79)
+constexpr int POOL_BWD_STATS_BLOCKS = 768;    // read-modify-write    (0.73 -> 0.63)
+static_assert(BN_STATS_BLOCKS <= UNET_BN_SLOTS_DET && BN_BWD_STATS_BLOCKS <= UNET_BN_SLOTS_DET && POOL_BWD_STATS_BLOCKS <= UNET_BN_SLOTS_DET, "deterministic mode: one slot copy per workgroup");
 
 
 // ---------------------------------------------------------------------------------------
@@ -31,7 +30,7 @@ template <int MODE, typename T>
 __global__ __launch_bounds__(TPB) void bn_stats_kernel(const T* __restrict__ a, int lda,
                                                        const T* __restrict__ x, int ldx,
                                                        const float* __restrict__ bnp, double* sums,
-                                                       long long pixels, int C) {
+                                                       long long pixels, int C, int nslots) {
   const int lpp = C >> 2, ppb = TPB / lpp;
   const int tid = threadIdx.x, q = tid % lpp, pl = tid / lpp;
   float4 s1 = make_float4(0, 0, 0, 0), s2 = s1;
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const T* __restrict__ a, 
       s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w;
       s2.x += w.x; s2.y += w.y; s2.z += w.z; s2.w += w.w;
     }
-    double* d1 = sums + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies
+    double* d1 = sums + (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies (deterministic mode: one writer per copy)
     atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y);
     atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
     atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y);
@@ -288,7 +287,7 @@ template <typename T>
 __global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dyp,
                                                                T* dx, int lddx, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, double* sums, int N, int H, int W,
-                                                               int C, float rate, uint64_t seed) {
+                                                               int C, float rate, uint64_t seed, int nslots) {
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
   const int tid = threadIdx.x, q = tid % lpp;                        // lpp divides TPB: a thread keeps its channel quad
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const T* __restri
       float4 u = sh1[tid + k * lpp], w2 = sh2[tid + k * lpp];
       s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w; s2.x += w2.x; s2.y += w2.y; s2.z += w2.z; s2.w += w2.w;
     }
-    double* d1 = sums + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies
+    double* d1 = sums + (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies (deterministic mode: one writer per copy)
     atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y); atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
     atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y); atomicAdd(d2 + 2, (double)s2.z); atomicAdd(d2 + 3, (double)s2.w);
   }
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(TPB) void pool_bwd_bnstats_kernel(const T* __restri
 // With the sums known, ONE pass does pool backward + skip add + BatchNorm backward + ReLU mask: pool_bn_bwd_apply_kernel.
 template <typename T>
 __global__ __launch_bounds__(TPB) void pool_bwd_sums_kernel(const T* __restrict__ pooled, const T* __restrict__ dyp, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, double* sums, long long total, int C, float rate, uint64_t seed) {
+                                                            const float* __restrict__ beta, double* sums, long long total, int C, float rate, uint64_t seed, int nslots) {
   const int lpp = C >> 2, tid = threadIdx.x, q = tid % lpp;                        // lpp divides TPB: a thread keeps its channel quad
   const float4 g4 = ld4(gamma + q * 4), b4 = ld4(beta + q * 4);
   const float4 ig = make_float4(g4.x != 0.f ? 1.f / g4.x : 0.f, g4.y != 0.f ? 1.f / g4.y : 0.f, g4.z != 0.f ? 1.f / g4.z : 0.f, g4.w != 0.f ? 1.f / g4.w : 0.f);
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(TPB) void pool_bwd_sums_kernel(const T* __restrict_
       float4 u = sh1[tid + k * lpp], w2 = sh2[tid + k * lpp];
       s1.x += u.x; s1.y += u.y; s1.z += u.z; s1.w += u.w; s2.x += w2.x; s2.y += w2.y; s2.z += w2.z; s2.w += w2.w;
     }
-    double* d1 = sums + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies
+    double* d1 = sums + (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES + q * 4; double* d2 = d1 + C;    // `sums` = the slot copies (deterministic mode: one writer per copy)
     atomicAdd(d1 + 0, (double)s1.x); atomicAdd(d1 + 1, (double)s1.y); atomicAdd(d1 + 2, (double)s1.z); atomicAdd(d1 + 3, (double)s1.w);
     atomicAdd(d2 + 0, (double)s2.x); atomicAdd(d2 + 1, (double)s2.y); atomicAdd(d2 + 2, (double)s2.z); atomicAdd(d2 + 3, (double)s2.w);
   }
@@ -433,7 +432,8 @@ template <typename T>
 __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ pout,
                                                        const float* __restrict__ yt, double* sums,
-                                                       long long pixels, int cin) {
+                                                       long long pixels, int cin, int nslots) {
+  if (nslots) sums += (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES;          // deterministic mode: `sums` = the slot copies, one writer per copy
   const int lpp = cin >> 2;
   const int sub = threadIdx.x & (lpp - 1);
   const float4 wv = ld4(w + sub * 4);
@@ -477,7 +477,8 @@ __global__ __launch_bounds__(TPB) void head_fwd_kernel(const T* __restrict__ x, 
 template <typename T, int LPP>
 __global__ __launch_bounds__(TPB) void head_fwd_lpp_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ pout,
-                                                           const float* __restrict__ yt, double* sums, long long pixels) {
+                                                           const float* __restrict__ yt, double* sums, long long pixels, int nslots) {
+  if (nslots) sums += (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES;          // deterministic mode: `sums` = the slot copies, one writer per copy
   constexpr int cin = LPP * 4;
   const int sub = threadIdx.x & (LPP - 1);
   const float4 wv = ld4(w + sub * 4);
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(TPB) void head_bwd_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ pin, const float* __restrict__ yt,
                                                        const double* __restrict__ sums, double inv_count,
                                                        T* __restrict__ dx, float* dw, float* db,
-                                                       long long pixels, int cin, int relu_mask) {
+                                                       long long pixels, int cin, int relu_mask, double* slots, int nslots) {
   const int lpp = cin >> 2;
   const int sub = threadIdx.x & (lpp - 1);
   const float4 wv = ld4(w + sub * 4);
@@ -570,10 +571,18 @@ __global__ __launch_bounds__(TPB) void head_bwd_kernel(const T* __restrict__ x, 
   if (threadIdx.x < lpp) {
     float4 s = rw[0][threadIdx.x];
     for (int k = 1; k < TPB / 64; ++k) { float4 u = rw[k][threadIdx.x]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
-    atomicAdd(dw + threadIdx.x * 4 + 0, s.x); atomicAdd(dw + threadIdx.x * 4 + 1, s.y);
-    atomicAdd(dw + threadIdx.x * 4 + 2, s.z); atomicAdd(dw + threadIdx.x * 4 + 3, s.w);
+    if (nslots) {                                          // deterministic mode: one writer per slot copy ([cin] dw, then db), folded in index order afterwards
+      double* d = slots + (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES + threadIdx.x * 4;
+      atomicAdd(d + 0, (double)s.x); atomicAdd(d + 1, (double)s.y); atomicAdd(d + 2, (double)s.z); atomicAdd(d + 3, (double)s.w);
+    } else {
+      atomicAdd(dw + threadIdx.x * 4 + 0, s.x); atomicAdd(dw + threadIdx.x * 4 + 1, s.y);
+      atomicAdd(dw + threadIdx.x * 4 + 2, s.z); atomicAdd(dw + threadIdx.x * 4 + 3, s.w);
+    }
   }
-  if (threadIdx.x == 0) { float s = 0; for (int k = 0; k < TPB / 64; ++k) s += rb[k]; atomicAdd(db, s); }
+  if (threadIdx.x == 0) {
+    float s = 0; for (int k = 0; k < TPB / 64; ++k) s += rb[k];
+    if (nslots) atomicAdd(slots + (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES + cin, (double)s); else atomicAdd(db, s);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -605,7 +614,8 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const 
 constexpr int THR_CHUNK = 8;
 __global__ __launch_bounds__(TPB) void metrics_sweep_kernel(const float* __restrict__ p, const float* __restrict__ gt,
                                                             const float* __restrict__ thr, int nthr, double* out,
-                                                            long long n) {
+                                                            long long n, int nslots) {
+  if (nslots) out += (size_t)(blockIdx.x % nslots) * UNET_BN_SLOT_DOUBLES;          // deterministic mode: `out` = the slot copies, one writer (blockIdx.x) per copy
   const int t0 = blockIdx.y * THR_CHUNK;
   float th[THR_CHUNK], tp[THR_CHUNK], pr[THR_CHUNK], sg = 0;
 #pragma unroll
@@ -669,14 +679,16 @@ __global__ __launch_bounds__(TPB) void zero_kernel(float4* __restrict__ p, long 
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// sums[i] += sum over the slot copies; the copies are cleared for the next launch
-__global__ void bn_slot_fold_kernel(double* __restrict__ slots, double* __restrict__ sums, int n2c) {
+// sums[i] += sum over the slot copies IN INDEX ORDER; the copies are cleared for the next launch.  OUT = double (statistics) or float (the head's
+// weight gradient in deterministic mode)
+template <typename OUT>
+__global__ void bn_slot_fold_kernel(double* __restrict__ slots, OUT* __restrict__ sums, int n2c, int nslots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n2c) return;
   double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < UNET_BN_SLOTS; ++k) { double* p = slots + (size_t)k * UNET_BN_SLOT_DOUBLES + i; s += *p; *p = 0.0; }
-  sums[i] += s;
+#pragma unroll 8
+  for (int k = 0; k < nslots; ++k) { double* p = slots + (size_t)k * UNET_BN_SLOT_DOUBLES + i; s += *p; *p = 0.0; }
+  sums[i] += (OUT)s;
 }
 
 // Statistics of a concat([up, skip]) whose skip half is the OUTPUT of an earlier training-mode BatchNorm: y = gamma * xhat + beta has, over the
@@ -684,13 +696,13 @@ __global__ void bn_slot_fold_kernel(double* __restrict__ slots, double* __restri
 // without reading the tensor.  Thread i < c_up folds the measured sums of the up half out of the slot copies (as bn_slot_fold_kernel), thread
 // c_up + j writes the analytic pair of skip channel j.  Layout of `sums`: [c_up + c_skip sums][c_up + c_skip sums of squares].
 __global__ void bn_fold_concat_kernel(double* __restrict__ slots, double* __restrict__ sums, int c_up, int c_skip, const double* __restrict__ src_sums,
-                                      double src_count, const float* __restrict__ src_gamma, const float* __restrict__ src_beta, double pixels, float eps) {
+                                      double src_count, const float* __restrict__ src_gamma, const float* __restrict__ src_beta, double pixels, float eps, int nslots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int c2 = c_up + c_skip;
   if (i < c_up) {
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < UNET_BN_SLOTS; ++k) {
+#pragma unroll 8
+    for (int k = 0; k < nslots; ++k) {
       double* p = slots + (size_t)k * UNET_BN_SLOT_DOUBLES + i;
       s1 += p[0]; p[0] = 0.0; s2 += p[c_up]; p[c_up] = 0.0;
     }
@@ -716,14 +728,19 @@ extern "C" {
 extern "C++" template <typename T> static int32_t bn_stats_impl(unet_ctx* ctx, const T* x, int32_t ldx, double* sums, int64_t pixels, int32_t c, void* stream) {
   if (!ctx || !x || !sums || !bn_c_ok(c) || ldx < c || (ldx & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: bad args c=%d ldx=%d", c, ldx);
   ctx->stats_req_c = 0;                                    // (a request no launch took up)
-  if (ctx->stats_in_slots && (ctx->stats_in_slots != (const void*)x || ctx->stats_in_slots_c != c)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats: the slot copies hold the fused statistics of another tensor");
+  if (ctx->stats_in_slots && (ctx->stats_in_slots != (const void*)x || ctx->stats_in_slots_c != c)) {
+    // the slot copies hold the fused statistics of ANOTHER tensor (an aborted program, a partial op range, a caller that skipped the call that must follow an armed
+    // conv): recover instead of failing for ever -- clear the slots on the stream and take the statistics by the normal pass
+    UNET_HIP(ctx, hipMemsetAsync(ctx->bn_slots, 0, sizeof(double) * UNET_BN_SLOTS_DET * UNET_BN_SLOT_DOUBLES, as_stream(stream)));
+    ctx->stats_in_slots = nullptr; ctx->stats_in_slots_c = 0;
+  }
   if (!ctx->stats_in_slots) {
     int ppb = TPB / (c / 4);
     int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c);
+    hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c, ctx->bn_nslots());
   }
   ctx->stats_in_slots = nullptr;                           // (else: the conv that wrote x left them there -- fold only)
-  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
+  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c, ctx->bn_nslots());
   UNET_CHECK_LAUNCH(ctx, "bn_stats"); return UNET_OK;
 }
 
@@ -732,15 +749,18 @@ extern "C++" template <typename T> static int32_t bn_stats_concat_impl(unet_ctx*
   if (!ctx || !x_up || !sums || !src_sums || !src_gamma || !src_beta || !bn_c_ok(c_up) || c_skip < 1 || ldx < c_up || (ldx & 3) || src_count < 1 || pixels < 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn_stats_concat: bad args c_up=%d c_skip=%d ldx=%d", c_up, c_skip, ldx);
   ctx->stats_req_c = 0;
-  if (ctx->stats_in_slots && (ctx->stats_in_slots != (const void*)x_up || ctx->stats_in_slots_c != c_up)) UNET_FAIL(ctx, UNET_E_ARG, "bn_stats_concat: the slot copies hold the fused statistics of another tensor");
+  if (ctx->stats_in_slots && (ctx->stats_in_slots != (const void*)x_up || ctx->stats_in_slots_c != c_up)) {          // (see bn_stats_impl: recover, do not fail for ever)
+    UNET_HIP(ctx, hipMemsetAsync(ctx->bn_slots, 0, sizeof(double) * UNET_BN_SLOTS_DET * UNET_BN_SLOT_DOUBLES, as_stream(stream)));
+    ctx->stats_in_slots = nullptr; ctx->stats_in_slots_c = 0;
+  }
   if (!ctx->stats_in_slots) {
     int ppb = TPB / (c_up / 4);
     int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x_up, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c_up);
+    hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x_up, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c_up, ctx->bn_nslots());
   }
   ctx->stats_in_slots = nullptr;                           // (else: the ConvT that wrote the up half left its sums there)
   hipLaunchKernelGGL(bn_fold_concat_kernel, dim3((c_up + c_skip + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, c_up, c_skip, src_sums, src_count, src_gamma,
-                     src_beta, (double)pixels, 1e-3f);
+                     src_beta, (double)pixels, 1e-3f, ctx->bn_nslots());
   UNET_CHECK_LAUNCH(ctx, "bn_stats_concat"); return UNET_OK;
 }
 
@@ -770,8 +790,8 @@ extern "C++" template <typename T> static int32_t bn_bwd_stats_impl(unet_ctx* ct
   if (!ctx || !dy || !x || !bnp || !sums || !bn_c_ok(c) || ((ldx | lddy) & 3)) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_stats: bad args");
   int ppb = TPB / (c / 4);
   int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_BWD_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((bn_stats_kernel<1, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, ctx->bn_slots, (long long)pixels, c);
-  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
+  hipLaunchKernelGGL((bn_stats_kernel<1, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), dy, lddy, x, ldx, bnp, ctx->bn_slots, (long long)pixels, c, ctx->bn_nslots());
+  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c, ctx->bn_nslots());
   UNET_CHECK_LAUNCH(ctx, "bn_bwd_stats"); return UNET_OK;
 }
 
@@ -839,8 +859,8 @@ extern "C++" template <typename T> static int32_t maxpool_bwd_bnstats_impl(unet_
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   int grid = (int)std::min<long long>(cdiv64(total, TPB), POOL_BWD_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(pool_bwd_bnstats_kernel<T>, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, ctx->bn_slots, n, h, wd, c, rate, seed);
-  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
+  hipLaunchKernelGGL(pool_bwd_bnstats_kernel<T>, dim3(grid), dim3(TPB), 0, as_stream(stream), y, ldy, dy, dx, lddx, gamma, beta, ctx->bn_slots, n, h, wd, c, rate, seed, ctx->bn_nslots());
+  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c, ctx->bn_nslots());
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd + bn stats"); return UNET_OK;
 }
 
@@ -851,8 +871,8 @@ extern "C++" template <typename T> static int32_t maxpool_bwd_sums_impl(unet_ctx
   const long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   int grid = (int)std::min<long long>(cdiv64(total, TPB * 4), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(pool_bwd_sums_kernel<T>, dim3(grid), dim3(TPB), 0, as_stream(stream), pooled, dy_pooled, gamma, beta, ctx->bn_slots, total, c, rate, seed);
-  hipLaunchKernelGGL(bn_slot_fold_kernel, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c);
+  hipLaunchKernelGGL(pool_bwd_sums_kernel<T>, dim3(grid), dim3(TPB), 0, as_stream(stream), pooled, dy_pooled, gamma, beta, ctx->bn_slots, total, c, rate, seed, ctx->bn_nslots());
+  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c, ctx->bn_nslots());
   UNET_CHECK_LAUNCH(ctx, "maxpool bwd sums"); return UNET_OK;
 }
 
@@ -878,13 +898,18 @@ extern "C++" template <typename T> static int32_t bn_maxpool_bwd_apply_impl(unet
 extern "C++" template <typename T> static int32_t head_fwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* bias, float* p, const float* y_true,
                       double* loss_sums, int64_t pixels, int32_t cin, void* stream) {
   if (!x || !w || !bias || !p || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || (y_true && !loss_sums)) UNET_FAIL(ctx, UNET_E_ARG, "head_fwd: bad args (cin/4 must be a power of two <= 64)");
-  if (cin == 32 && HEAD_LPP_KERNEL) {            // the U-Net / U-Net++ heads
-    static const int lpp_blocks = [] { const char* e = getenv("UNET_HEAD_LPP_BLOCKS"); return e ? atoi(e) : 2048; }();     // 8 loads in flight per lane: 2048 workgroups measured best (0.119 ms fp32 / 0.085 bf16; 8192: 0.141)
+  // deterministic mode: the four loss sums go through the context's slot copies (one workgroup per copy) and are folded in index order
+  const bool det = ctx->opt_deterministic && y_true;
+  const int nslots = det ? ctx->bn_nslots() : 0;
+  double* target = det ? ctx->bn_slots : loss_sums;
+  if (cin == 32) {            // the U-Net / U-Net++ heads
+    const int lpp_blocks = det ? nslots : 2048;     // 8 loads in flight per lane: 2048 workgroups measured best (0.119 ms fp32 / 0.085 bf16; 8192: 0.141)
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels, TPB * 2), lpp_blocks));
-    hipLaunchKernelGGL((head_fwd_lpp_kernel<T, 8>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels);
-    UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
+    hipLaunchKernelGGL((head_fwd_lpp_kernel<T, 8>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, target, (long long)pixels, nslots);
+  } else {
+    hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels * (cin / 4) / 4, TPB), det ? nslots : HEAD_BLOCKS))), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, target, (long long)pixels, cin, nslots);
   }
-  hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)std::max<long long>(1, std::min<long long>(cdiv64(pixels * (cin / 4) / 4, TPB), HEAD_BLOCKS))), dim3(TPB), 0, as_stream(stream), x, w, bias, p, y_true, loss_sums, (long long)pixels, cin);
+  if (det) hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3(1), dim3(128), 0, as_stream(stream), ctx->bn_slots, loss_sums, 4, nslots);
   UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
 }
 
@@ -898,7 +923,13 @@ extern "C++" template <typename T> static int32_t head_bwd_impl(unet_ctx* ctx, c
                       const double* loss_sums, double count, T* dx, float* dw, float* db, int64_t pixels, int32_t cin,
                       int32_t relu_mask, void* stream) {
   if (!x || !w || !p || !y_true || !loss_sums || !dx || !dw || !db || (cin & 3) || !pow2(cin / 4) || cin / 4 > 64 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "head_bwd: bad args");
-  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(std::min(grid_for(pixels * (cin / 4) / 4), 1024)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin, relu_mask);
+  const int nslots = ctx->opt_deterministic ? ctx->bn_nslots() : 0;
+  hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(std::min(grid_for(pixels * (cin / 4) / 4), 1024)), dim3(TPB), 0, as_stream(stream), x, w, p, y_true, loss_sums, 1.0 / count, dx, dw, db, (long long)pixels, cin, relu_mask,
+                     ctx->bn_slots, nslots);
+  if (nslots) {                                            // (dw and db are adjacent in the flat gradient buffer or not: two folds)
+    hipLaunchKernelGGL(bn_slot_fold_kernel<float>, dim3(1), dim3(128), 0, as_stream(stream), ctx->bn_slots, dw, cin, nslots);
+    hipLaunchKernelGGL(bn_slot_fold_kernel<float>, dim3(1), dim3(128), 0, as_stream(stream), ctx->bn_slots + cin, db, 1, nslots);
+  }
   UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
 }
 
@@ -913,7 +944,17 @@ int32_t unet_seg_metrics_sweep(unet_ctx* ctx, const float* p, const float* gt, c
                                double* out, int64_t count, void* stream) {
   if (!p || !gt || !thresholds || !out || nthr < 1 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "metrics_sweep: bad args");
   int gx = (int)std::min<int64_t>(cdiv64(count, TPB * 8), 1024); if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(metrics_sweep_kernel, dim3(gx, (nthr + THR_CHUNK - 1) / THR_CHUNK), dim3(TPB), 0, as_stream(stream), p, gt, thresholds, nthr, out, (long long)count);
+  // deterministic mode: thresholds in rounds of what one slot copy holds; one workgroup column per copy, folded in index order
+  if (ctx && ctx->opt_deterministic) {
+    const int nslots = ctx->bn_nslots(), per = UNET_BN_SLOT_DOUBLES / 3 / THR_CHUNK * THR_CHUNK;
+    for (int t0 = 0; t0 < nthr; t0 += per) {
+      const int nt = std::min(per, nthr - t0);
+      hipLaunchKernelGGL(metrics_sweep_kernel, dim3(gx, (nt + THR_CHUNK - 1) / THR_CHUNK), dim3(TPB), 0, as_stream(stream), p, gt, thresholds + t0, nt, ctx->bn_slots, (long long)count, nslots);
+      hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((3 * nt + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, out + 3 * t0, 3 * nt, nslots);
+    }
+    UNET_CHECK_LAUNCH(ctx, "metrics_sweep"); return UNET_OK;
+  }
+  hipLaunchKernelGGL(metrics_sweep_kernel, dim3(gx, (nthr + THR_CHUNK - 1) / THR_CHUNK), dim3(TPB), 0, as_stream(stream), p, gt, thresholds, nthr, out, (long long)count, 0);
   UNET_CHECK_LAUNCH(ctx, "metrics_sweep"); return UNET_OK;
 }
 

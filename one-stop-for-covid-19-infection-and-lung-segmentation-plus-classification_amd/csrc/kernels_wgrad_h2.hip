@@ -528,10 +528,7 @@ WgPlanT plan_wgradT_h2(int n, int h, int w, int ca, int cb) {
 
 struct WgPlanH2 { int WA, WB, WR, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs, units, upb; size_t floats; };
 
-int wgrad_h2_rows() {
-  static const int r = [] { const char* e = getenv("UNET_WGRAD_H2_ROWS"); return e && atoi(e) == 4 ? 4 : 2; }();          // measured: 2 rows, two workgroups per CU
-  return r;
-}
+constexpr int wgrad_h2_rows() { return 2; }          // measured: 2 dY rows per step at two workgroups per CU (4 rows at one workgroup per CU: 25 % slower)
 
 WgPlanH2 plan_wgrad_h2(int n, int h, int w, int ca, int cb) {
   WgPlanH2 p;
@@ -544,8 +541,7 @@ WgPlanH2 plan_wgrad_h2(int n, int h, int w, int ca, int cb) {
   p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
   const long long pairs = (long long)p.tiles_a * p.tiles_b, per = 9LL * ca * cb;
   const long long units = (long long)n * p.strips;
-  static const long long target_env = [] { const char* e = getenv("UNET_WGRAD_H2_BLOCKS"); return e ? atoll(e) : 0LL; }();
-  const long long target = target_env ? target_env : (R == 4 && p.WA * p.WB > 1 ? 256LL : 512LL);          // one resident round: 256 CUs x 1 (R = 4) or 2 (R = 2) workgroups
+  const long long target = R == 4 && p.WA * p.WB > 1 ? 256LL : 512LL;          // one resident round: 256 CUs x 1 (R = 4) or 2 (R = 2) workgroups
   long long want = std::max<long long>(1, target / pairs);
   const long long cap = std::max<long long>(1, (64LL << 20) / per);
   want = std::min(want, cap);
@@ -560,18 +556,12 @@ WgPlanH2 plan_wgrad_h2(int n, int h, int w, int ca, int cb) {
   return p;
 }
 
-int h2_wgrad_mode() {
-  static const int on = [] { const char* e = getenv("UNET_H2_WGRAD"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = the fp32-MFMA Winograd weight gradient
-  return on;
-}
-
 }  // namespace
 
-bool h2_wgrad_selected(int cin, int cout) {
-  static const int small = [] { const char* e = getenv("UNET_WGRAD_H2_32"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = 32 x 32 layers on the fp32 Winograd weight gradient
-  return h2_wgrad_mode() != 0 && cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0 && (cin >= 64 || cout >= 64 || small);          // (16- / 48-channel tensors: the last 32-channel tile is masked)
+bool h2_wgrad_selected(int algo, int cin, int cout) {
+  return algo == UNET_ALGO_AUTO && cin >= 16 && (cin % 16) == 0 && cout >= 16 && (cout % 16) == 0;          // (16- / 48-channel tensors: the last 32-channel tile is masked)
 }
-size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_wgrad_selected(cin, cout) ? plan_wgrad_h2(n, h, wd, cin, cout).floats * sizeof(float) : 0; }
+size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_wgrad_selected(UNET_ALGO_AUTO, cin, cout) ? plan_wgrad_h2(n, h, wd, cin, cout).floats * sizeof(float) : 0; }
 
 int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
                            hipStream_t s) {
@@ -583,9 +573,7 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
   const long long S = 9LL * cin * cout + cout;
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
-#define UNET_WG(WA_, WB_, WR_) if (wgrad_h2_rows() == 4) hipLaunchKernelGGL((wgrad_h2_kernel<WA_, WB_, WR_, 4>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, \
-                                                  p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb); \
-                               else hipLaunchKernelGGL((wgrad_h2_kernel<WA_, WB_, WR_, 2>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, \
+#define UNET_WG(WA_, WB_, WR_) hipLaunchKernelGGL((wgrad_h2_kernel<WA_, WB_, WR_, 2>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, \
                                                   p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb)
   if (p.WA == 2 && p.WB == 2) UNET_WG(2, 2, 1);
   else if (p.WA == 2) UNET_WG(2, 1, 2);
@@ -598,16 +586,15 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
 }
 
 // ---- ConvT weight gradient on the h2 kernels: cout (the dU channels) a multiple of 32, cin a multiple of 64
-bool h2_convT_wgrad_selected(int cin, int cout) {
-  static const int on = [] { const char* e = getenv("UNET_H2_CONVT_WGRAD"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = the fp32-MFMA kernel
-  return h2_wgrad_mode() != 0 && on && cout >= 32 && (cout % 32) == 0 && cin >= 64 && (cin % 64) == 0;
+bool h2_convT_wgrad_selected(int algo, int cin, int cout) {
+  return algo == UNET_ALGO_AUTO && cout >= 32 && (cout % 32) == 0 && cin >= 64 && (cin % 64) == 0;
 }
-size_t h2_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_convT_wgrad_selected(cin, cout) ? plan_wgradT_h2(n, h, wd, cout, cin).floats * sizeof(float) : 0; }
+size_t h2_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_convT_wgrad_selected(UNET_ALGO_AUTO, cin, cout) ? plan_wgradT_h2(n, h, wd, cout, cin).floats * sizeof(float) : 0; }
 
 // x [n,h,wd,cin] dense, dy = dU channel slice (pixel stride lddy) of [n,2h,2wd,.]; dw [2][2][cout][cin], db [cout]
 int32_t k_convT_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, int lddy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
                          hipStream_t s) {
-  if (!h2_convT_wgrad_selected(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad h2: cin=%d cout=%d unsupported", cin, cout);
+  if (!h2_convT_wgrad_selected(UNET_ALGO_AUTO, cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad h2: cin=%d cout=%d unsupported", cin, cout);
   if (4LL * h * wd * lddy * 4 >= (1LL << 30) || (long long)h * wd * cin * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const WgPlanT p = plan_wgradT_h2(n, h, wd, cout, cin);
   if (!ws || ws_bytes < p.floats * sizeof(float)) UNET_FAIL(ctx, UNET_E_ARG, "convT wgrad h2: workspace %zu < %zu bytes", ws_bytes, p.floats * sizeof(float));

@@ -36,114 +36,98 @@ int32_t unet_ctx_create(int32_t device_id, unet_ctx** out) {
   unet_ctx* c = new unet_ctx();
   c->device = device_id;
   c->num_cu = prop.multiProcessorCount;
-  const size_t sb = sizeof(double) * UNET_BN_SLOTS * UNET_BN_SLOT_DOUBLES;
+  const size_t sb = sizeof(double) * UNET_BN_SLOTS_DET * UNET_BN_SLOT_DOUBLES;
   int prev = 0;
-  hipGetDevice(&prev);
+  (void)hipGetDevice(&prev);
   if (hipSetDevice(device_id) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&c->bn_slots), sb) != hipSuccess ||
-      hipMemset(c->bn_slots, 0, sb) != hipSuccess) { hipSetDevice(prev); delete c; return UNET_E_HIP; }
+      hipMemset(c->bn_slots, 0, sb) != hipSuccess) { (void)hipSetDevice(prev); delete c; return UNET_E_HIP; }
   c->convt_img_bytes = (size_t)8 << 20;             // ConvT weight images up to cin * cout = 512 K (u6 of the U-Net: 128 K)
   if (hipMalloc(&c->convt_img, c->convt_img_bytes) != hipSuccess) { c->convt_img = nullptr; c->convt_img_bytes = 0; }
-  hipSetDevice(prev);
+  (void)hipSetDevice(prev);
   *out = c;
   return UNET_OK;
 }
 
 void unet_ctx_destroy(unet_ctx* ctx) {
-  if (ctx && ctx->bn_slots) hipFree(ctx->bn_slots);
-  if (ctx && ctx->convt_img) hipFree(ctx->convt_img);
+  if (ctx && ctx->bn_slots) (void)hipFree(ctx->bn_slots);
+  if (ctx && ctx->convt_img) (void)hipFree(ctx->convt_img);
   delete ctx;
 }
 const char* unet_last_error(const unet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on) { if (!ctx) return UNET_E_ARG; ctx->profiling = on; return UNET_OK; }
+
+static int* ctx_option(unet_ctx* ctx, int32_t option) {
+  switch (option) {
+    case UNET_OPT_RELU_BITS: return &ctx->opt_relu_bits;
+    case UNET_OPT_BN_FOLD: return &ctx->opt_bn_fold;
+    case UNET_OPT_ENC_BN_FUSED: return &ctx->opt_enc_bn_fused;
+    case UNET_OPT_BN_CONCAT_ANALYTIC: return &ctx->opt_bn_concat_analytic;
+    case UNET_OPT_BN_FUSE_STATS: return &ctx->opt_bn_fuse_stats;
+    case UNET_OPT_DETERMINISTIC: return &ctx->opt_deterministic;
+    default: return nullptr;
+  }
+}
+int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value) {
+  if (!ctx) return UNET_E_ARG;
+  int* p = ctx_option(ctx, option);
+  const int hi = option == UNET_OPT_BN_FOLD ? 2 : 1;
+  if (!p || value < 0 || value > hi) UNET_FAIL(ctx, UNET_E_ARG, "ctx_set_option: option %d value %d", option, value);
+  *p = value;
+  return UNET_OK;
+}
+int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option) {
+  if (!ctx) return UNET_E_ARG;
+  const int* p = ctx_option(ctx, option);
+  if (!p) UNET_FAIL(ctx, UNET_E_ARG, "ctx_get_option: unknown option %d", option);
+  return *p;
+}
 
 }  // extern "C"
 
 // =========================================================================================
 // convolution dispatch (shared by the op-level ABI and the model programs)
 // =========================================================================================
+// Kernel families: UNET_ALGO_AUTO = the fp16-split h2 kernels wherever the channel counts allow (K, M multiples of 16), else the strict family;
+// UNET_ALGO_MFMA = strict fp32: v_mfma_f32_32x32x2_f32 kernels (exact fp32 multiply-add), VALU kernels for the shapes those do not take (Cin = 1, odd
+// channel counts); UNET_ALGO_NAIVE = VALU kernels only (on-device cross-check).
 static bool use_mfma(int algo, int cin, int cout) {
   if (algo == UNET_ALGO_NAIVE) return false;
   return mfma_conv3x3_supported(cin, cout);
 }
-
-// Winograd pays when its 64-column row tiles are reasonably full; `uws` = scratch for the transformed weights (may be null)
-static int relu_bits_enabled() {
-  static const int on = [] { const char* e = getenv("UNET_RELU_BITS"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = data gradients re-read the fp32 activation as their ReLU mask
-  return on;
-}
-// decoder BatchNorm statistics: skip half analytic, up half measured (unet_bn_stats_concat); 0 = read the whole concat as before
-static bool bn_concat_analytic() {
-  static const int on = [] { const char* e = getenv("UNET_BN_CONCAT_ANALYTIC"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
-  return on != 0;
-}
-
-// decoder BatchNorm folded into the conv behind it (no normalised copy of the concat); 0 = materialise it with bn_apply as before
-// encoder tail backward: sums from the pooled tensors + closed-form skip term, one fused apply pass (0 = pool_bwd_bnstats + bn_bwd_apply)
-static bool enc_bn_fused() {
-  static const int on = [] { const char* e = getenv("UNET_ENC_BN_FUSED"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
-  return on != 0;
-}
-// 0 = materialise the normalised concat (bn_apply) and run the BatchNorm backward as two passes; 1 = forward + weight gradient + backward sums folded;
-// 2 (default) = also the BatchNorm backward applied in the data-gradient epilogue
-static int bn_fold_enabled() {
-  static const int on = [] { const char* e = getenv("UNET_BN_FOLD"); return e ? atoi(e) : 2; }();   // A/B switch for measurements
-  return on;
-}
-
-static bool use_wino(int algo, int wd, int cin, int cout, const float* uws) {
-  if (!uws || !wino_conv3x3_supported(cin, cout)) return false;
-  if (algo == UNET_ALGO_WINOGRAD) return true;
-  if (algo != UNET_ALGO_AUTO) return false;
-  static const int enabled = [] { const char* e = getenv("UNET_WINO"); return e ? atoi(e) : 1; }();   // A/B switch for measurements
-  if (!enabled) return false;
-  // 1.5x fewer MFMAs, but its row tiles are 64 columns wide (the direct kernel's 32): compare how full the last tile is
-  const double ud = (double)wd / (32.0 * ((wd + 31) / 32));
-  if (wino_uses_2d(2, cout)) {                            // F(2x2,3x3): 64- or 32-column tiles, 2.25x fewer MFMAs
-    const int tc = wino_tile_cols(wd);
-    return 2.25 * ((double)wd / (tc * ((wd + tc - 1) / tc))) >= 1.3 * ud;
-  }
-  const double uw = (double)wd / (64.0 * ((wd + 63) / 64));
-  return 1.5 * uw >= 1.15 * ud;
-}
+// the launch runs on the h2 kernels (and therefore consumes a prepared split weight image; `uws` = scratch for it, may be null -> strict family)
+static bool use_h2(int algo, int cin, int cout, const void* uws) { return uws && h2_conv3x3_selected(algo, cin, cout); }
 
 // `w` are Keras-layout weights [3][3][cin][cout] when flip == 0; for the data gradient (flip == 1) the caller passes the FORWARD
 // weights [3][3][cout][cin] of the layer and the roles of cin/cout below are already swapped (cin = channels of dy).
 static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                                     float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, int algo,
                                     hipStream_t s, float* uws = nullptr, int flip = 0, const float* prepared = nullptr) {
-  if (use_wino(algo, wd, cin, cout, uws)) {
-    if (prepared) return k_conv3x3_wino_fwd(ctx, x, prepared, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);     // transformed by the program's batch launch
-    int32_t r = flip ? k_wino_weights(ctx, w, uws, cout, cin, 1, h, s) : k_wino_weights(ctx, w, uws, cin, cout, 0, h, s);
+  if (use_h2(algo, cin, cout, uws)) {
+    if (prepared) return k_conv3x3_h2_fwd(ctx, x, prepared, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);     // image built by the program's batch launch
+    int32_t r = flip ? k_h2_weights(ctx, w, uws, cout, cin, 1, s) : k_h2_weights(ctx, w, uws, cin, cout, 0, s);
     if (r) return r;
-    return k_conv3x3_wino_fwd(ctx, x, uws, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
+    return k_conv3x3_h2_fwd(ctx, x, uws, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   }
+  if (mask_mode >= MASK_BIAS_TAB) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3: the folded-BatchNorm / bit-mask epilogues exist on the h2 kernels only (cin=%d cout=%d algo=%d)", cin, cout, algo);
   if (flip) {                                   // direct algorithms want the flipped/transposed copy
+    if (!uws) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 data gradient: needs the weight scratch");
     int32_t r = k_flip_transpose_w3x3(ctx, w, uws, cout, cin, s);
     if (r) return r;
     w = uws;
   }
-  if (algo == UNET_ALGO_WINOGRAD) algo = UNET_ALGO_AUTO;
-  if (algo == UNET_ALGO_MFMA && !mfma_conv3x3_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 mfma: cin=%d cout=%d unsupported", cin, cout);
   if (use_mfma(algo, cin, cout)) return k_conv3x3_mfma_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
   if (cin == 1 && !mask && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0)
     return k_conv3x3_c1_fwd(ctx, x, w, bias, y, n, h, wd, cout, act, rate, seed, s);
   return k_conv3x3_naive_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
 }
 
-static int wgrad_wino_enabled() {
-  static const int wino = [] { const char* e = getenv("UNET_WINO_WGRAD"); return e ? atoi(e) : 1; }();      // A/B switch for measurements
-  return wino;
-}
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
                                       size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
   if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout)) {
-    const int wino = wgrad_wino_enabled();
-    if (algo == UNET_ALGO_AUTO && h2_wgrad_selected(cin, cout) && ws_bytes >= h2_wgrad_ws_bytes(n, h, wd, cin, cout))
+    if (h2_wgrad_selected(algo, cin, cout) && ws_bytes >= h2_wgrad_ws_bytes(n, h, wd, cin, cout))
       return k_conv3x3_h2_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);      // three fp16 MFMA products of the block-scaled two-term split
-    if (algo == UNET_ALGO_WINOGRAD || (algo == UNET_ALGO_AUTO && wino)) return k_conv3x3_wino_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   }
-  if (algo == UNET_ALGO_MFMA) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 wgrad mfma: unsupported shape or workspace too small");
   if (cin == 1 && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0 && cout <= 256 && ws && ws_bytes >= c1_wgrad_ws_bytes(cout))
     return k_conv3x3_c1_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cout, s);
   return k_conv3x3_naive_wgrad(ctx, x, dy, dw, db, n, h, wd, cin, cout, s);
@@ -154,16 +138,14 @@ extern "C" {
 // Conv2D / Conv2DTranspose -> BatchNormalization in training mode (T1:860-861, 886-888): see common.h (unet_ctx::stats_req_c)
 int32_t unet_request_bn_stats(unet_ctx* ctx, int32_t c) {
   if (!ctx || c < 0) UNET_FAIL(ctx, UNET_E_ARG, "request_bn_stats: bad args");
-  static const int on = [] { const char* e = getenv("UNET_BN_FUSE_STATS"); return e ? atoi(e) : 1; }();          // A/B switch: 0 = statistics always by their own pass
-  ctx->stats_req_c = on ? c : 0;
+  ctx->stats_req_c = (ctx->opt_bn_fuse_stats && !ctx->opt_deterministic) ? c : 0;          // (deterministic mode: statistics by their own fixed-order pass)
   return UNET_OK;
 }
 
 // ReLU masks as one bit per element (MASK_RELU_BITS, common.h): which (forward conv, data gradient) pairs can use them, how big the bit tensor is, arming
 int32_t unet_relu_bits_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
-  static float dummy;
   if (cin < 1 || cout < 1 || (cout & 31) || (wd & 7) || h < 1) return 0;
-  return use_wino(algo, wd, cin, cout, &dummy) && h2_conv3x3_selected(cin, cout) ? 1 : 0;
+  return h2_conv3x3_selected(algo, cin, cout) ? 1 : 0;
 }
 size_t unet_relu_bits_bytes(int32_t n, int32_t h, int32_t wd, int32_t c) { return n > 0 && h > 0 && wd > 0 && c > 0 ? (size_t)n * h * wd * c / 8 : 0; }
 int32_t unet_request_relu_bits(unet_ctx* ctx, void* bits) {
@@ -177,7 +159,6 @@ int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const fl
                          float* w_ws, void* stream) {
   if (!ctx || !x || !w || !y || n < 1 || h < 1 || wd < 1 || cin < 1 || cout < 1 || act < 0 || act > 2 || drop_rate < 0 || drop_rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: bad args");
-  if (algo == UNET_ALGO_WINOGRAD && !w_ws) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: the Winograd path needs w_ws (unet_conv3x3_w_ws_floats)");
   const void* armed = ctx->signs_req;
   int32_t r = conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, algo, as_stream(stream), w_ws, 0);
   ctx->signs_req = nullptr;
@@ -186,29 +167,24 @@ int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const fl
 }
 
 int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout) {
-  static float dummy;
-  if (use_wino(algo, wd, cin, cout, &dummy)) return UNET_ALGO_WINOGRAD;
+  (void)wd;
+  if (h2_conv3x3_selected(algo, cin, cout)) return UNET_ALGO_AUTO;
   if (algo != UNET_ALGO_NAIVE && mfma_conv3x3_supported(cin, cout)) return UNET_ALGO_MFMA;
   return UNET_ALGO_NAIVE;
 }
 
-/* executed / algorithmic multiply count of a forward or data-gradient launch of this shape: 1 (direct), 2/3 (F(2,3) along x), 4/9 (F(2x2,3x3)) */
+/* fp32-MFMA-time equivalent of a forward or data-gradient launch of this shape: 1 (strict fp32 / VALU kernels), 3 * 157.3 / 2500 (h2: three fp16 MFMA
+ * products per multiply on a pipe 2500 / 157.3 times faster than the fp32 MFMA) */
 double unet_conv3x3_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
-  static float dummy;
-  if (!use_wino(algo, wd, cin, cout, &dummy)) return 1.0;
-  // x3 kernels: six bf16 MFMA products per multiply on a pipe 2500 / 157.3 times faster than the fp32 MFMA -> this fraction of the fp32-MFMA time
-  if (h2_conv3x3_selected(cin, cout)) return 3.0 * 157.3 / 2500.0;          // h2 kernels: three fp16 MFMA products per multiply
-  if (x3_conv3x3_selected(cin, cout)) return 6.0 * 157.3 / 2500.0;
-  return wino_uses_2d(h, cout) ? 4.0 / 9.0 : 2.0 / 3.0;
+  (void)h; (void)wd;
+  return h2_conv3x3_selected(algo, cin, cout) ? 3.0 * 157.3 / 2500.0 : 1.0;
 }
 
 /* the same for the weight-gradient launch (given the workspace unet_conv3x3_bwd_weights_ws_bytes asks for) */
 double unet_conv3x3_wgrad_exec_ratio(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
-  (void)wd;
+  (void)h; (void)wd;
   if (algo == UNET_ALGO_NAIVE || !mfma_wgrad_supported(cin, cout)) return 1.0;
-  if (algo == UNET_ALGO_AUTO && h2_wgrad_selected(cin, cout)) return 3.0 * 157.3 / 2500.0;
-  if (algo == UNET_ALGO_WINOGRAD || (algo == UNET_ALGO_AUTO && wgrad_wino_enabled())) return wino_wgrad_exec_ratio(h);
-  return 1.0;
+  return h2_wgrad_selected(algo, cin, cout) ? 3.0 * 157.3 / 2500.0 : 1.0;
 }
 
 // (channel counts below 32 are padded to one 32-channel block in the h2 weight image, either direction)
@@ -229,8 +205,7 @@ int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, co
 
 /* ---- conv3x3 over a BatchNorm-affine input without the normalised tensor (the decoder blocks BN -> Conv, T1:888-889 ...) ---- */
 int32_t unet_conv3x3_bnfold_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
-  static float dummy;
-  return (h >= 1 && wd >= 1 && cin >= 1 && cout >= 1 && use_wino(algo, wd, cin, cout, &dummy) && wino_uses_2d(h, cout) && wgrad_bn_fold_supported(cout)) ? 1 : 0;
+  return (h >= 1 && wd >= 1 && cin >= 1 && cout >= 1 && h2_conv3x3_selected(algo, cin, cout) && (cout % 32) == 0 && wgrad_bn_fold_supported(cout)) ? 1 : 0;
 }
 size_t unet_conv3x3_bnfold_ws_floats(int32_t n, int32_t cin, int32_t cout) {
   if (n < 1 || cin < 1 || cout < 1) return 0;
@@ -242,12 +217,12 @@ int32_t unet_conv3x3_bnfold_fwd(unet_ctx* ctx, const float* x, const float* bnp,
   if (!unet_conv3x3_bnfold_supported(algo, h, wd, cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bnfold_fwd: no folded form for h=%d w=%d cin=%d cout=%d (unet_conv3x3_bnfold_supported)", h, wd, cin, cout);
   hipStream_t s = as_stream(stream);
   float* u = ws + bn_fold_scratch_floats(cin, cout);
-  int32_t r = k_bn_fold_prepare(ctx, w, bias, bnp, bnp + cin, cin, cout, ws, s);
+  int32_t r = k_bn_fold_prepare(ctx, w, bias, bnp, bnp + cin, cin, cout, ws, s, false);
   if (r) return r;
-  r = k_wino_weights(ctx, ws, u, cin, cout, 0, h, s);
+  r = k_h2_weights(ctx, w, u, cin, cout, 0, s, bnp);          // (the image kernel applies the BatchNorm scale per input channel)
   if (r) return r;
   const float* tab = ws + (size_t)9 * cin * cout;
-  return k_conv3x3_wino_fwd(ctx, x, u, tab, tab, MASK_BIAS_TAB, y, n, h, wd, cin, cout, act, 0.0f, 0, s);
+  return k_conv3x3_h2_fwd(ctx, x, u, tab, tab, MASK_BIAS_TAB, y, n, h, wd, cin, cout, act, 0.0f, 0, s);
 }
 int32_t unet_conv3x3_bnfold_bwd_weights(unet_ctx* ctx, const float* x, const float* bnp, const float* dy, const float* w, float* dw, float* db, double* bn_bwd_sums, void* gws,
                                         size_t gws_bytes, float* ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
@@ -275,8 +250,7 @@ int32_t unet_conv3x3_bwd_weights(unet_ctx* ctx, const float* x, const float* dy,
 int32_t unet_convT2x2_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int32_t ldy, int32_t n,
                           int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
   if (!ctx || !x || !w || !y || ldy < cout || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "convT_fwd: bad args");
-  if (algo == UNET_ALGO_MFMA && !mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: unsupported shape");
-  if (algo == UNET_ALGO_AUTO && h2_convT_selected(ctx, cin, cout)) return k_convT_h2_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
+  if (h2_convT_selected(ctx, algo, cin, cout)) return k_convT_h2_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
   if (algo != UNET_ALGO_NAIVE && mfma_convT_supported(cin, cout)) return k_convT_mfma_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_fwd(ctx, x, w, bias, y, ldy, n, h, wd, cin, cout, as_stream(stream));
 }
@@ -284,8 +258,7 @@ int32_t unet_convT2x2_fwd(unet_ctx* ctx, const float* x, const float* w, const f
 int32_t unet_convT2x2_bwd_data(unet_ctx* ctx, const float* dy, int32_t lddy, const float* w, const float* relu_src, float* dx,
                                int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t algo, void* stream) {
   if (!ctx || !dy || !w || !dx || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_data: bad args");
-  if (algo == UNET_ALGO_MFMA && !mfma_convT_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "convT mfma: unsupported shape");
-  if (algo == UNET_ALGO_AUTO && h2_convT_selected(ctx, cin, cout)) return k_convT_h2_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
+  if (h2_convT_selected(ctx, algo, cin, cout)) return k_convT_h2_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
   if (algo != UNET_ALGO_NAIVE && mfma_convT_supported(cin, cout)) return k_convT_mfma_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_dgrad(ctx, dy, lddy, w, relu_src, dx, n, h, wd, cin, cout, as_stream(stream));
 }
@@ -299,8 +272,7 @@ int32_t unet_convT2x2_bwd_weights(unet_ctx* ctx, const float* x, const float* dy
                                   void* stream) {
   if (!ctx || !x || !dy || !dw || !db || lddy < cout) UNET_FAIL(ctx, UNET_E_ARG, "convT_bwd_weights: bad args");
   const bool can = mfma_convT_supported(cin, cout) && ws && ws_bytes >= mfma_convT_wgrad_ws_bytes(n, h, wd, cin, cout);
-  if (algo == UNET_ALGO_MFMA && !can) UNET_FAIL(ctx, UNET_E_SHAPE, "convT wgrad mfma: unsupported shape or workspace too small");
-  if (algo == UNET_ALGO_AUTO && h2_convT_wgrad_selected(cin, cout) && ws && ws_bytes >= h2_convT_wgrad_ws_bytes(n, h, wd, cin, cout))
+  if (h2_convT_wgrad_selected(algo, cin, cout) && ws && ws_bytes >= h2_convT_wgrad_ws_bytes(n, h, wd, cin, cout))
     return k_convT_h2_wgrad(ctx, x, dy, lddy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, as_stream(stream));      // three fp16 MFMA products of the block-scaled two-term split
   if (algo != UNET_ALGO_NAIVE && can) return k_convT_mfma_wgrad(ctx, x, dy, lddy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, as_stream(stream));
   return k_convT_naive_wgrad(ctx, x, dy, lddy, dw, db, n, h, wd, cin, cout, as_stream(stream));
@@ -372,7 +344,6 @@ struct Op {
   std::function<int32_t(hipStream_t)> run;
   double flops = 0, bytes = 0, ms = 0;
   int64_t calls = 0;
-  int side = 0, join_after = 0;                        // backward overlap (plan_bwd_overlap): runs on the model's side stream / the main stream waits for it right behind this op
 };
 
 }  // namespace
@@ -390,7 +361,6 @@ struct unet_model {
   const float *x = nullptr, *yt = nullptr; float* pout = nullptr;
   float drop_rate = 0.0f; uint64_t drop_seed = 0;
   float cw0 = 1.0f, cw1 = 1.0f;                       // classifier: class weights of the loss
-  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // backward overlap: weight gradients beside the data-gradient chain
   size_t off_dense_ws = 0, dense_ws_bytes = 0;
   // workspace plan (offsets in floats)
   std::map<std::string, Buf> act, grad;
@@ -525,30 +495,32 @@ void plan_workspace(unet_model* m) {
   // per-layer scratch of the prepared weights: 16 Winograd taps (fp32) or the 9-tap bf16 image
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : unet_conv3x3_w_ws_floats(l.cin, l.cout));
   // decoder BatchNorm folded into the conv that consumes it: whenever that conv runs on the F(2x2,3x3) kernels (the only ones with the border-class bias)
-  if (bn_fold_enabled()) {
+  if (m->ctx->opt_bn_fold) {
     for (int k = 6; k <= 9; ++k) {
       const std::string ks = std::to_string(k), cn = "c" + ks + "a";
       const Buf ob = m->act.at(cn); const int cin = 2 * ob.c, cout = ob.c;
       if (!wgrad_bn_fold_supported(cout)) continue;
       if (m->dt) { if (!bf16_conv3x3_supported(cin, cout) || !bf16_conv3x3_supported(cout, cin)) continue; }      // bf16 storage: the direct MFMA kernel has both epilogues
-      else if (!use_wino(m->algo, ob.w, cin, cout, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, cout)) continue;
+      else if (!h2_conv3x3_selected(m->algo, cin, cout)) continue;
       m->fold_off[cn] = cv.take(bn_fold_scratch_floats(cin, cout));
       m->folded_bn["bn" + ks] = {"cat" + ks, cin};
     }
   }
+  // ConvT layers on the h2 kernels: their split images (forward / data-gradient form) are built with the conv3x3 images in the program's batch launch
+  if (!m->dt) for (auto& l : m->layers) if (l.kind == 1 && h2_convT_selected(m->ctx, m->algo, l.cin, l.cout)) m->wprep_f[l.name] = cv.take((h2_convT_img_bytes(l.cin, l.cout) + 3) / 4);
   m->ws_floats_infer = cv.cur;
+  if (!m->dt) for (auto& l : m->layers) if (l.kind == 1 && h2_convT_selected(m->ctx, m->algo, l.cin, l.cout)) m->wprep_b[l.name] = cv.take((h2_convT_img_bytes(l.cin, l.cout) + 3) / 4);
   for (auto& kv : m->fold_off) {
     const Buf ob = m->act.at(kv.first); const int cin = 2 * ob.c, cout = ob.c;
     m->fold_g_off[kv.first] = cv.take(wgrad_bn_fold_scratch_floats(N, cout));
     // the data gradient (cout -> cin channels) on the F(2x2,3x3) kernels too: the BatchNorm backward moves into its epilogue
-    if (bn_fold_enabled() >= 2 && (m->dt || (use_wino(m->algo, ob.w, cout, cin, reinterpret_cast<const float*>(m)) && wino_uses_2d(ob.h, cin)))) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
+    if (m->ctx->opt_bn_fold >= 2 && (m->dt || h2_conv3x3_selected(m->algo, cout, cin))) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
   }
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : unet_conv3x3_w_ws_floats(l.cin, l.cout));
   // ReLU masks as sign bits (MASK_RELU_BITS): the output of a conv that is the mask of the next conv's / ConvT's data gradient -- c<k>a for the conv pairs,
   // c5b ... c8b for the ConvTs -- where producer and consumer both run on the h2 kernels (decided exactly as the launches decide)
-  if (!m->dt && relu_bits_enabled()) {
-    static float dummy;
-    auto h2_conv = [&](int w, int K, int M) { return use_wino(m->algo, w, K, M, &dummy) && h2_conv3x3_selected(K, M); };
+  if (!m->dt && m->ctx->opt_relu_bits) {
+    auto h2_conv = [&](int w, int K, int M) { (void)w; return h2_conv3x3_selected(m->algo, K, M); };
     for (auto& l : m->layers) {
       if (l.kind != 0 || l.cin <= 1) continue;
       const Buf ob = m->act.at(l.name);
@@ -556,7 +528,7 @@ void plan_workspace(unet_model* m) {
       const char last = l.name.back();
       bool used = false;
       if (last == 'a') used = h2_conv(ob.w, l.cout, l.cout);                                      // mask of c<k>b's data gradient (K = M = cout)
-      else if (l.name == "c5b" || l.name == "c6b" || l.name == "c7b" || l.name == "c8b") used = m->algo == UNET_ALGO_AUTO && h2_convT_selected(m->ctx, l.cout, l.cout / 2);
+      else if (l.name == "c5b" || l.name == "c6b" || l.name == "c7b" || l.name == "c8b") used = h2_convT_selected(m->ctx, m->algo, l.cout, l.cout / 2);
       if (used) m->sign_off[l.name] = cv.take((size_t)ob.n * ob.h * ob.w * l.cout / 32);
     }
   }
@@ -635,21 +607,6 @@ void arm_bn_statistics(unet_model* m) {
   }
 }
 
-// (Experiment, off by default: see unet_model_run.)  A weight gradient needs only its layer's dy and x and nothing waits for it before the optimizer (or a
-// gradient bucket of the data-parallel path): the backward program can run them on a side stream beside the data-gradient chain -- kernels bound by different things (a deep layer's MFMA-bound
-// weight gradient beside a shallow layer's HBM-bound data gradient) fill each other's gaps.  All users of the split-K workspace are on that stream,
-// so they stay serialised among themselves; the weight gradient of a conv with a folded BatchNorm feeds the BatchNorm's backward sums, which the very
-// next data gradient needs: the main stream joins right behind its fix-up op.  unet_model_run joins at the end of every call.
-void plan_bwd_overlap(unet_model* m) {
-  auto& B = m->prog[UNET_PROG_BWD];
-  for (size_t i = 0; i < B.size(); ++i) {
-    const std::string& nm = B[i].name;
-    const bool wg = nm.rfind("conv3x3_wgrad:", 0) == 0 || nm.rfind("convT_wgrad:", 0) == 0, fix = nm.rfind("wgrad_bn_fold_fix:", 0) == 0;
-    if (wg || fix) B[i].side = 1;
-    if (fix) B[i].join_after = 1;
-  }
-}
-
 void build_programs(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int algo = m->algo;
@@ -662,7 +619,7 @@ void build_programs(unet_model* m) {
   auto& FI = m->prog[UNET_PROG_FWD_INFER];
   auto& BW = m->prog[UNET_PROG_BWD];
   const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
-  // layers whose 3x3 weights the Winograd kernels consume (decided per layer by use_wino exactly as the conv dispatch does)
+  // layers whose 3x3 weights are consumed as a prepared image (decided per layer exactly as the conv dispatch does)
   struct PrepItem { std::string name; int cin, cout, h, w; };
   std::vector<PrepItem> prep_items;
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) { const Buf& ob = m->act.at(l.name); prep_items.push_back({l.name, l.cin, l.cout, ob.h, ob.w}); }
@@ -676,17 +633,22 @@ void build_programs(unet_model* m) {
     }
     return k_wimg_multi(ctx, &L, ci, co, s);
   };
-  auto prep_weights = [=](int flip, hipStream_t s) -> int32_t {
-    unet_wino_prep_list L; L.n = 0; int hs[UNET_WINO_PREP_MAX];
+  std::vector<PrepItem> convt_items;
+  for (auto& l : m->layers) if (l.kind == 1 && m->wprep_f.count(l.name)) convt_items.push_back({l.name, l.cin, l.cout, 0, 0});
+  auto prep_weights = [=](int flip, hipStream_t s) -> int32_t {          // fp32: the split fp16 weight images of every conv3x3 / ConvT launch that runs on the h2 kernels: two launches
+    const float* ws_[UNET_WINO_PREP_MAX]; void* is_[UNET_WINO_PREP_MAX]; int ci_[UNET_WINO_PREP_MAX], co_[UNET_WINO_PREP_MAX], kd_[UNET_WINO_PREP_MAX], nx = 0;
     for (auto& it : prep_items) {
-      const int ci = flip ? it.cout : it.cin, co = flip ? it.cin : it.cout;          // channels the launch consumes / produces
+      const int K = flip ? it.cout : it.cin, M = flip ? it.cin : it.cout;          // channels the launch consumes / produces
       if (flip && it.name == "c1a") continue;
       if (!flip && m->fold_off.count(it.name)) continue;          // prepared after its BatchNorm's finalize (bn_fold_prepare)
-      if (!use_wino(algo, it.w, ci, co, m->wsf(m->off_wt)) || L.n >= UNET_WINO_PREP_MAX) continue;
-      L.item[L.n] = {m->P(it.name + "/kernel"), m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)), it.cin, it.cout, flip, 0};
-      hs[L.n++] = it.h;
+      if (!h2_conv3x3_selected(algo, K, M) || nx >= UNET_WINO_PREP_MAX) continue;
+      ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = flip; ++nx;
     }
-    return k_wino_weights_multi(ctx, &L, hs, s);
+    for (auto& it : convt_items) {
+      if (nx >= UNET_WINO_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch");
+      ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = flip ? 3 : 2; ++nx;
+    }
+    return k_h2_prep_multi(ctx, ws_, nullptr, is_, ci_, co_, kd_, nx, s);
   };
 
   // ------------------------------------------------------------------ forward (train / infer)
@@ -694,7 +656,7 @@ void build_programs(unet_model* m) {
     auto& F = training ? FT : FI;
     auto& SY = m->syncref[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
     ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
-    if (!dt) ADD_OP(F, "wino_weights:fwd", 0, 0, { return prep_weights(0, s); });       // all Winograd weight transforms of the program in one launch
+    if (!dt) ADD_OP(F, "weight_images:fwd", 0, 0, { return prep_weights(0, s); });       // all split weight images of the program in one batch of launches
     else ADD_OP(F, "weight_images:fwd", 0, 0, { return prep_weights_bf16(0, s); });
     auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
       const Buf ob = m->act.at(name);
@@ -724,7 +686,7 @@ void build_programs(unet_model* m) {
       const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
       const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
       if (training) {
-        if (!skip_src.empty() && bn_concat_analytic()) {
+        if (!skip_src.empty() && ctx->opt_bn_concat_analytic) {
           const size_t sso = m->bn_sum_off.at(skip_src);
           const int cu = c / 2, cs = c - c / 2;
           ADD_OP(F, "bn_stats:" + name, 0, eb * pixels * cu, {
@@ -781,10 +743,12 @@ void build_programs(unet_model* m) {
       int c = dec[k - 6]; std::string ks = std::to_string(k);
       const Buf ib = m->act.at(prev), ub = m->act.at("u" + ks);
       const std::string uin = prev, un = "u" + ks; const int ci = cprev;
-      const bool arm_up = training && !dt && bn_concat_analytic();          // (the statistics pass of the concat reads only this half then)
+      const bool arm_up = training && !dt && ctx->opt_bn_concat_analytic;          // (the statistics pass of the concat reads only this half then)
       ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * ci * c * nel(ib) / ib.c, eb * (nel(ib) + nel(ub)), {
         if (arm_up) unet_request_bn_stats(ctx, c);
         if (dt) return k_convT_bf16_fwd(ctx, CBF(m->Av(uin)), m->P(un + "/kernel"), m->P(un + "/bias"), WBF(m->Av(un)), ub.ld, ib.n, ib.h, ib.w, ci, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
+        const auto pf = m->wprep_f.find(un);
+        if (pf != m->wprep_f.end()) return k_convT_h2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, s, m->wsf(pf->second));
         return unet_convT2x2_fwd(ctx, m->A(uin), m->P(un + "/kernel"), m->P(un + "/bias"), m->Aw(un), ub.ld, ib.n, ib.h, ib.w, ci, c, algo, s);
       });
       bn("bn" + ks, "cat" + ks, "bn" + ks, 2 * c, false, "bn" + std::to_string(10 - k));      // cat_k = [u_k, bn_{10-k} output]
@@ -793,9 +757,9 @@ void build_programs(unet_model* m) {
         const Buf ob = m->act.at(cn); const int cin = 2 * c, cout = c;
         const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn), uo = m->wprep_f.at(cn);
         ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * cin * cout * 2, 4.0 * 9 * cin * cout * 4, {
-          int32_t r = k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + cin, cin, cout, m->wsf(fo), s);
+          int32_t r = k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + cin, cin, cout, m->wsf(fo), s, dt != 0);
           if (r || dt) return r;                                // bf16 storage: the conv below builds its weight image from the scaled fp32 weights
-          return k_wino_weights(ctx, m->wsf(fo), m->wsf(uo), cin, cout, 0, ob.h, s);
+          return k_h2_weights(ctx, m->P(cn + "/kernel"), m->wsf(uo), cin, cout, 0, s, m->wsf(bo));          // fp32: the image kernel applies the scale per input channel
         });
         ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout, {
           const float* tab = m->wsf(fo) + (size_t)9 * cin * cout;
@@ -804,7 +768,7 @@ void build_programs(unet_model* m) {
           const auto so = training ? m->sign_off.find(cn) : m->sign_off.end();
           unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
           ctx->signs_req = sg; ctx->signs_done = nullptr;
-          int32_t r = k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(uo), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0, s);
+          int32_t r = k_conv3x3_h2_fwd(ctx, m->A(xn), m->wsf(uo), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0, s);
           ctx->signs_req = nullptr;
           if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd %s: the launch did not write the ReLU sign bits its data gradient was planned with", cn.c_str());
           return r;
@@ -842,7 +806,7 @@ void build_programs(unet_model* m) {
     });
     const Buf hb = m->act.at("c9b");
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
-    if (!dt) ADD_OP(BW, "wino_weights:bwd", 0, 0, { return prep_weights(1, s); });
+    if (!dt) ADD_OP(BW, "weight_images:bwd", 0, 0, { return prep_weights(1, s); });
     else ADD_OP(BW, "weight_images:bwd", 0, 0, { return prep_weights_bf16(1, s); });
     ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, hp * (eb * 64 + 8.0), {
       if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
@@ -891,7 +855,7 @@ void build_programs(unet_model* m) {
           if (r) return r;
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), m->wsf(co), CBF(m->Av(xraw)), MASK_BN_BWD, WBF(m->Dv(xraw)), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0,
                                             WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s, CBF(static_cast<void*>(m->wsf(m->wprep_b.at(name)))));
-          return k_conv3x3_wino_fwd(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->wsf(co), m->A(xraw), MASK_BN_BWD, m->D(xraw), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0, s);
+          return k_conv3x3_h2_fwd(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->wsf(co), m->A(xraw), MASK_BN_BWD, m->D(xraw), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0, s);
         });
         return;
       }
@@ -960,7 +924,10 @@ void build_programs(unet_model* m) {
       ADD_OP(BW, "convT_dgrad:" + un, 2.0 * 4 * cprev * c * nel(ib) / ib.c, eb * (2 * nel(ib) + nel(ug)), {
         if (dt) return k_convT_bf16_dgrad(ctx, CBF(m->Dv(un)), ug.ld, m->P(un + "/kernel"), CBF(m->Av(prev)), WBF(m->Dv(prev)), ib.n, ib.h, ib.w, cprev, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
         const auto so = m->sign_off.find(prev);
-        if (so != m->sign_off.end()) return k_convT_h2_dgrad(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->wsf(so->second), m->D(prev), ib.n, ib.h, ib.w, cprev, c, s, 1);
+        const auto pb = m->wprep_b.find(un);
+        const void* img = pb == m->wprep_b.end() ? nullptr : m->wsf(pb->second);
+        if (so != m->sign_off.end()) return k_convT_h2_dgrad(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->wsf(so->second), m->D(prev), ib.n, ib.h, ib.w, cprev, c, s, 1, img);
+        if (img) return k_convT_h2_dgrad(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->A(prev), m->D(prev), ib.n, ib.h, ib.w, cprev, c, s, 0, img);
         return unet_convT2x2_bwd_data(ctx, m->D(un), ug.ld, m->P(un + "/kernel"), m->A(prev), m->D(prev), ib.n, ib.h, ib.w, cprev, c, algo, s);
       });
       if (k == 7) bucket("u7/kernel", "out/bias");
@@ -974,7 +941,7 @@ void build_programs(unet_model* m) {
       const Buf xb = m->act.at("bn" + ks), gb = m->grad.at("bn" + ks);
       const std::string bnn = "bn" + ks, pn = "p" + ks;
       const size_t so = m->bn_bsum_off.at(bnn);
-      if (enc_bn_fused()) {
+      if (ctx->opt_enc_bn_fused) {
         // no pass for the statistics: sums from the pooled tensors + the closed-form skip term, then pool backward + skip add + BatchNorm backward + ReLU mask in ONE pass
         const std::string dn = "bn" + std::to_string(10 - k), cb = "c" + ks + "b";
         const size_t sod = m->bn_bsum_off.at(dn), bod = m->bnp_off.at(dn), bo = m->bnp_off.at(bnn);
@@ -1090,12 +1057,12 @@ void plan_workspace_pp(unet_model* m) {
   m->off_wt = cv.take(wt0);
   // conv_block = [Conv -> Dropout -> BN] x 2 (UPP:860-868): the first BatchNorm feeds only the second conv -> folded into it, fp32 on the
   // F(2x2,3x3) kernels
-  if (bn_fold_enabled() >= 2) {
+  if (m->ctx->opt_bn_fold >= 2) {
     for (auto& nd : pp_nodes()) {
-      const std::string nm = nd.name; const Buf ob = m->act.at(nm + "b"); const int c = nd.c;
+      const std::string nm = nd.name; const int c = nd.c;
       if (!wgrad_bn_fold_supported(c)) continue;
       if (m->dt) { if (!bf16_conv3x3_supported(c, c)) continue; }       // bf16 storage: the direct MFMA kernel has the same epilogues
-      else if (!use_wino(m->algo, ob.w, c, c, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, c)) continue;
+      else if (!h2_conv3x3_selected(m->algo, c, c) || (c % 32)) continue;          // (whole 32-channel blocks: the half-padded 16-channel form is not validated for the folded epilogues)
       m->fold_off[nm + "b"] = cv.take(bn_fold_scratch_floats(c, c));
       m->folded_bn[nm + "abn"] = {nm + "a", c};
     }
@@ -1231,16 +1198,16 @@ void build_programs_pp(unet_model* m) {
           const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn);
           const uint64_t sd = seed_of(cn);
           ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * c * c * 2, 4.0 * 9 * c * c * 4, {
-            return k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + c, c, c, m->wsf(fo), s);
+            return k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + c, c, c, m->wsf(fo), s, dt != 0);
           });
           ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * c * c * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * 2 * c + 4.0 * 9.0 * c * c, {
             const float r = (tr && m->drop_rate > 0.0f) ? PP_BLOCK_DROP : 0.0f;
             const float* tab = m->wsf(fo) + (size_t)9 * c * c;
             if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(xn)), m->wsf(fo), tab, reinterpret_cast<const unet_bf16*>(tab), MASK_BIAS_TAB, WBF(m->Av(cn)), ob.n, ob.h, ob.w, c, c, ACT_ELU, r,
                                               m->drop_seed + sd, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
-            int32_t e = k_wino_weights(ctx, m->wsf(fo), m->wsf(m->off_wt), c, c, 0, ob.h, s);
+            int32_t e = k_h2_weights(ctx, m->P(cn + "/kernel"), m->wsf(m->off_wt), c, c, 0, s, m->wsf(bo));
             if (e) return e;
-            return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(m->off_wt), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, c, c, ACT_ELU, r, m->drop_seed + sd, s);
+            return k_conv3x3_h2_fwd(ctx, m->A(xn), m->wsf(m->off_wt), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, c, c, ACT_ELU, r, m->drop_seed + sd, s);
           });
         } else
         conv(it + "b", it + "abn", c, c, PP_BLOCK_DROP);
@@ -1387,9 +1354,9 @@ void build_programs_pp(unet_model* m) {
           if (r) return r;
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(cn)), m->P(cn + "/kernel"), m->wsf(co), CBF(m->Av(xn)), drop ? MASK_BN_BWD_ELU_DROP : MASK_BN_BWD_ELU, WBF(m->Dv(xn)), ob.n, ob.h, ob.w, c, c,
                                             ACT_NONE, drop ? PP_BLOCK_DROP : 0.0f, m->drop_seed + sda, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
-          r = k_wino_weights(ctx, m->P(cn + "/kernel"), m->wsf(m->off_wt), c, c, 1, ob.h, s);
+          r = k_h2_weights(ctx, m->P(cn + "/kernel"), m->wsf(m->off_wt), c, c, 1, s);
           if (r) return r;
-          return k_conv3x3_wino_fwd(ctx, m->D(cn), m->wsf(m->off_wt), m->wsf(co), m->A(xn), drop ? MASK_BN_BWD_ELU_DROP : MASK_BN_BWD_ELU, m->D(xn), ob.n, ob.h, ob.w, c, c, ACT_NONE,
+          return k_conv3x3_h2_fwd(ctx, m->D(cn), m->wsf(m->off_wt), m->wsf(co), m->A(xn), drop ? MASK_BN_BWD_ELU_DROP : MASK_BN_BWD_ELU, m->D(xn), ob.n, ob.h, ob.w, c, c, ACT_NONE,
                                     drop ? PP_BLOCK_DROP : 0.0f, m->drop_seed + sda, s);
         });
       } else {
@@ -1483,17 +1450,16 @@ void plan_workspace_cls(unet_model* m) {
   for (auto& l : m->layers) if (l.kind == 0) wt0 = std::max(wt0, unet_conv3x3_w_ws_floats(l.cin, l.cout));
   m->off_wt = cv.take(wt0);
   // Conv(relu) -> BN -> Conv (T2:748-751): the first BatchNorm of a block feeds only the block's second conv -> folded into it.  fp32: where that conv
-  // runs on the F(2x2,3x3) kernels (the 32- and 64-channel blocks)
-  if (bn_fold_enabled() >= 2) {
+  // runs on the h2 kernels in both directions
+  if (m->ctx->opt_bn_fold >= 2) {
     for (int k = 1; k <= 3; ++k) {
       const int c = CLS_C[k - 1]; const std::string cn = "c" + std::to_string(k) + "b";
-      const Buf ob = m->act.at(cn);
       if (!wgrad_bn_fold_supported(c)) continue;
-      // (bf16 storage has the epilogues too -- UNET_CLS_FOLD_BF16=1 -- but measured 1 % slower here: these layers are short-K, the per-step weight image of
+      // (bf16 storage has the epilogues too but measured 1 % slower here: these layers are short-K, the per-step weight image of
       //  the scaled weights and the x read in the data-gradient epilogue cost what the two saved passes gain)
-      static const int bf16_too = [] { const char* e = getenv("UNET_CLS_FOLD_BF16"); return e ? atoi(e) : 0; }();
+      constexpr int bf16_too = 0;          // (measured 1 % slower on this graph in bf16 storage: short-K layers)
       if (m->dt) { if (!bf16_too || !bf16_conv3x3_supported(c, c)) continue; }
-      else if (!use_wino(m->algo, ob.w, c, c, reinterpret_cast<const float*>(m)) || !wino_uses_2d(ob.h, c)) continue;
+      else if (!h2_conv3x3_selected(m->algo, c, c) || (c % 32)) continue;          // (whole 32-channel blocks: the half-padded 16-channel form is not validated for the folded epilogues)
       m->fold_off[cn] = cv.take(bn_fold_scratch_floats(c, c));
       m->folded_bn["bn" + std::to_string(k) + "a"] = {"c" + std::to_string(k) + "a", c};
     }
@@ -1587,15 +1553,15 @@ void build_programs_cls(unet_model* m) {
         const Buf ob = m->act.at(cn);
         const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn);
         ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * c * c * 2, 4.0 * 9 * c * c * 4, {
-          return k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + c, c, c, m->wsf(fo), s);
+          return k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + c, c, c, m->wsf(fo), s, dt != 0);
         });
         ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * c * c * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * 2 * c + 4.0 * 9.0 * c * c, {
           const float* tab = m->wsf(fo) + (size_t)9 * c * c;
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(xn)), m->wsf(fo), tab, reinterpret_cast<const unet_bf16*>(tab), MASK_BIAS_TAB, WBF(m->Av(cn)), ob.n, ob.h, ob.w, c, c, ACT_RELU, 0.0f, 0,
                                             WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
-          int32_t e = k_wino_weights(ctx, m->wsf(fo), m->wsf(m->off_wt), c, c, 0, ob.h, s);
+          int32_t e = k_h2_weights(ctx, m->P(cn + "/kernel"), m->wsf(m->off_wt), c, c, 0, s, m->wsf(bo));
           if (e) return e;
-          return k_conv3x3_wino_fwd(ctx, m->A(xn), m->wsf(m->off_wt), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, c, c, ACT_RELU, 0.0f, 0, s);
+          return k_conv3x3_h2_fwd(ctx, m->A(xn), m->wsf(m->off_wt), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, c, c, ACT_RELU, 0.0f, 0, s);
         });
       } else
       conv("c" + ks + "b", "bn" + ks + "a", c, c);
@@ -1680,7 +1646,7 @@ void build_programs_cls(unet_model* m) {
     const int c = CLS_C[k - 1], cin = k == 1 ? m->in_ch : CLS_C[k - 2];
     const std::string ks = std::to_string(k), ca = "c" + ks + "a", cb = "c" + ks + "b", ba = "bn" + ks + "a", bb = "bn" + ks + "b", pk = "p" + ks;
     const Buf xb = m->act.at(bb);
-    if (enc_bn_fused()) {
+    if (ctx->opt_enc_bn_fused) {
       // Conv -> BN -> MaxPool tail (T2:752-754): the BatchNorm's backward sums come from the pooled tensors alone (only arg-max elements carry gradient and their
       // BatchNorm output is the pooled activation), then pool backward + BatchNorm backward + ReLU mask in one pass
       const Buf cbuf = m->act.at(cb), cg = m->grad.at(cb);
@@ -1730,9 +1696,9 @@ void build_programs_cls(unet_model* m) {
         if (r) return r;
         if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(cb)), m->P(cb + "/kernel"), m->wsf(co), CBF(m->Av(ca)), MASK_BN_BWD_RELU, WBF(m->Dv(ca)), ob.n, ob.h, ob.w, c, c, ACT_NONE, 0.0f, 0,
                                           WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s);
-        r = k_wino_weights(ctx, m->P(cb + "/kernel"), m->wsf(m->off_wt), c, c, 1, ob.h, s);
+        r = k_h2_weights(ctx, m->P(cb + "/kernel"), m->wsf(m->off_wt), c, c, 1, s);
         if (r) return r;
-        return k_conv3x3_wino_fwd(ctx, m->D(cb), m->wsf(m->off_wt), m->wsf(co), m->A(ca), MASK_BN_BWD_RELU, m->D(ca), ob.n, ob.h, ob.w, c, c, ACT_NONE, 0.0f, 0, s);
+        return k_conv3x3_h2_fwd(ctx, m->D(cb), m->wsf(m->off_wt), m->wsf(co), m->A(ca), MASK_BN_BWD_RELU, m->D(ca), ob.n, ob.h, ob.w, c, c, ACT_NONE, 0.0f, 0, s);
       });
     } else {
     conv_bwd(cb, ba, c, c, true);
@@ -1778,16 +1744,12 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
   else if (arch == UNET_ARCH_UNETPP) { build_layers_pp(m); plan_workspace_pp(m); build_programs_pp(m); }
   else { build_layers_cls(m); plan_workspace_cls(m); build_programs_cls(m); }
   arm_bn_statistics(m);
-  plan_bwd_overlap(m);
   *out = m;
   return UNET_OK;
 }
 
 void unet_model_destroy(unet_model* m) {
   if (!m) return;
-  if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
-  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   delete m;
 }
 int64_t unet_model_param_count(const unet_model* m) { return m ? m->n_params : 0; }
@@ -1858,34 +1820,13 @@ int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, 
   hipStream_t s = as_stream(stream);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) { UNET_HIP(ctx, hipEventCreate(&e0)); UNET_HIP(ctx, hipEventCreate(&e1)); }
-  // measured (1 x MI355X, 512^2 x 16, same box): 17.46-17.98 ms per step with the overlap, 17.35 without -- two matrix kernels sharing the CUs slow each
-  // other down by more than their gaps are worth.  Off by default; UNET_BWD_OVERLAP=1 re-measures it
-  static const int overlap = [] { const char* e = getenv("UNET_BWD_OVERLAP"); return e ? atoi(e) : 0; }();
-  const bool use_side = overlap && prog == UNET_PROG_BWD && !ctx->profiling;
-  if (use_side && !m->side) {
-    UNET_HIP(ctx, hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-    UNET_HIP(ctx, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    UNET_HIP(ctx, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-  }
-  bool side_busy = false;
-  auto join = [&]() -> int32_t {
-    if (!side_busy) return UNET_OK;
-    UNET_HIP(ctx, hipEventRecord(m->ev_join, m->side));
-    UNET_HIP(ctx, hipStreamWaitEvent(s, m->ev_join, 0));
-    side_busy = false;
-    return UNET_OK;
-  };
+  // (weight gradients on a second stream beside the data-gradient chain were measured 1-3 % SLOWER on this chip -- two matrix kernels sharing the CUs
+  //  cost each other more than their gaps are worth -- and are not built: every launch of a model stays on the caller's stream)
+  if (begin == 0 && prog != UNET_PROG_BWD) { ctx->stats_req_c = 0; ctx->stats_in_slots = nullptr; ctx->stats_in_slots_c = 0; ctx->signs_req = nullptr; }   // a program starts clean whatever an aborted run left armed
   for (int i = begin; i < end; ++i) {
     if (ctx->profiling) UNET_HIP(ctx, hipEventRecord(e0, s));
-    int32_t r;
-    if (use_side && P[i].side) {
-      UNET_HIP(ctx, hipEventRecord(m->ev_fork, s));            // (everything the op reads was produced by ops in front of it in program order)
-      UNET_HIP(ctx, hipStreamWaitEvent(m->side, m->ev_fork, 0));
-      r = P[i].run(m->side);
-      side_busy = true;
-    } else r = P[i].run(s);
-    if (r) { ctx->err = P[i].name + ": " + ctx->err; return r; }
-    if (use_side && P[i].join_after) { r = join(); if (r) return r; }
+    const int32_t r = P[i].run(s);
+    if (r) { ctx->err = P[i].name + ": " + ctx->err; if (ctx->profiling) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } return r; }
     if (ctx->profiling) {
       UNET_HIP(ctx, hipEventRecord(e1, s));
       UNET_HIP(ctx, hipEventSynchronize(e1));
@@ -1893,7 +1834,6 @@ int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, 
       P[i].ms += ms; P[i].calls += 1;
     }
   }
-  { int32_t r = join(); if (r) return r; }
   if (ctx->profiling) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   return UNET_OK;
 }

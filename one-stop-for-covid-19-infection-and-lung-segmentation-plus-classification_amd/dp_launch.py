@@ -4,12 +4,13 @@ The reference trains single-process (Keras on one device, T3:989-1009); BASELINE
 global batch of 64 on 8 MI355X.  With UNET_GPUS=N (N > 1) in the environment a runner called from ONE process -- app.py's `six`
 through dropin/run_app.py, or directly -- re-launches itself as N ranks:
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node=N --master-addr 127.0.0.1 -m covidseg_amd.dp_launch <runner> 
+    python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node=N -m covidseg_amd.dp_launch <runner>
 
 Every rank builds the same model (same seed), walks the same shuffled mini-batches and takes its contiguous shard of each
 (keras_like.dp_shard); the engine reduces the BatchNorm / Dice sums inline and the gradient buckets on a side stream (engine.py, dp.py), so
 N ranks x batch B/N compute the single-device batch-B step.  Rank 0 prints and writes the checkpoints; the launching process gets the
-runner's scalar outputs back through a JSON file.
+runner's outputs back through a JSON file -- a REDUCED return value: scalars and lists (arrays arrive as nested lists), no "model" entry
+(the trained weights are in the checkpoint files rank 0 wrote: load them with UNetModel.load_weights).
 
 Environment: UNET_GPUS (ranks), UNET_DP_BACKEND (nccl | gloo: the gloo path stages reductions through the host, used by the single-GPU
 tests), UNET_DP_ONE_DEVICE=1 (all ranks on cuda:0, tests)."""
@@ -17,7 +18,6 @@ from __future__ import annotations
 
 import json
 import os
-import socket
 import subprocess
 import sys
 import tempfile
@@ -64,10 +64,9 @@ def maybe_launch(runner_name: str, kw: dict):
         env["UNET_DP_KW"] = json.dumps(_jsonable(kw))
         env["UNET_DP_RESULT"] = os.path.join(tmp, "result.json")
         env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), "-m", "covidseg_amd.dp_launch", runner_name]
+        # --standalone: torchrun picks and owns the rendezvous port (no bind-close-reuse race with other processes)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+               "-m", "covidseg_amd.dp_launch", runner_name]
         rc = subprocess.run(cmd, env=env).returncode
         if rc != 0:
             raise RuntimeError(f"data-parallel run of {runner_name} on {n} ranks failed (exit code {rc})")
@@ -90,6 +89,8 @@ def main(argv):
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     kw = json.loads(os.environ.get("UNET_DP_KW", "{}"))
+    for k in ("device", "process_group"):         # set by this launcher per rank below: a forwarded copy would collide
+        kw.pop(k, None)
     if os.environ.get("UNET_DP_INIT_NPZ"):
         kw["init_weights"] = dict(np.load(os.environ["UNET_DP_INIT_NPZ"]))
     real_stdout = sys.stdout

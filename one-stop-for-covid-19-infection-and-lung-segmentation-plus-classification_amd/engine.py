@@ -30,7 +30,7 @@ class HipUNet:
 
     def __init__(self, h: int, w: int, in_ch: int = 1, device: int | None = None, conv_algo: int = _lib.ALGO_AUTO,
                  process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR,
-                 arch: str = "unet", dtype: str = "fp32", force_dp: bool = False):
+                 arch: str = "unet", dtype: str = "fp32", force_dp: bool = False, options: dict | None = None):
         torch = _torch()
         self.lib = _lib.load()
         # dtype "bf16": activations / activation gradients stored as bf16 in the workspace (BASELINE.json configs[3], [4]); image,
@@ -42,7 +42,8 @@ class HipUNet:
                                     "the hot path has no CPU fallback")
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.dev = torch.device("cuda", self.device_index)
-        self.ctx = _lib.Context.get(self.device_index)
+        # options: {"deterministic": 1, "bn_fold": 0, ...} (_lib.OPTIONS; include/unet_hip.h UNET_OPT_*) -> a private context carrying them
+        self.ctx = _lib.Context.get(self.device_index, options)
         self.h, self.w, self.in_ch, self.algo = h, w, in_ch, conv_algo
         self.arch = arch                       # "unet" (T1:853-916) or "unetpp" (task1_unet_plus_plus.py:858-950; its dropout
         self._arch_id = {"unet": _lib.ARCH_UNET, "unetpp": _lib.ARCH_UNETPP, "classifier": _lib.ARCH_CLASSIFIER}[arch]   # rates fixed: >0 = on
@@ -52,7 +53,8 @@ class HipUNet:
         self.pg_grad = process_group
         self.world, self.rank = 1, 0
         # force_dp: walk the data-parallel program (sync points, side stream, second communicator) even at world size 1 -- every SUM all-reduce is
-        # then the identity, so the step must equal the plain one bit for bit: how the RCCL code path is exercised on a 1-GPU box
+        # then the identity, so the step equals the plain one up to the order of the floating-point atomics (bit for bit under
+        # options={"deterministic": 1}): how the RCCL code path is exercised on a 1-GPU box
         self._dp = False
         if process_group is not None:
             import torch.distributed as dist

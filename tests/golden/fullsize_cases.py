@@ -7,6 +7,7 @@ import numpy as np
 CASES = {
     # name: (arch, size, batch, data seed, weight seed)
     "unet_512_bs16": ("unet", 512, 16, 11, 21),          # configs[1]: U-Net infection seg 512x512x1 bs16
+    "unet_512_bs8": ("unet", 512, 8, 14, 24),            # configs[2]: U-Net lung seg (T3:850-913, the same graph) 512x512x1, the per-rank batch 8 of global 64 on 8 GPUs
     "unetpp_256_bs32": ("unetpp", 256, 32, 12, 22),      # configs[3]: U-Net++ 256x256 bs32
     "cls_224_bs256": ("classifier", 224, 256, 13, 23),   # configs[4]: slice classifier 224x224 bs256 (1 channel, as the reference feeds it)
 }

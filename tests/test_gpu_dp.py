@@ -70,7 +70,7 @@ def test_two_ranks_equal_single_process_full_batch(tmp_path, arch):
     for k, v in wref.items():                                         # identical replicas after 2 optimizer steps
         a = got["w/" + k]
         # (Adam turns round-off in a near-zero gradient into an O(lr) step: absolute term for the classifier's dead / BN-shadowed units)
-        assert np.linalg.norm(a - v) <= 2e-4 * np.linalg.norm(v) + (1e-4 if arch == "classifier" else 1e-6) * np.sqrt(v.size), k
+        assert np.linalg.norm(a - v) <= 2e-4 * np.linalg.norm(v) + (3e-4 if arch == "classifier" else 1e-6) * np.sqrt(v.size), k          # (3e-4: one sign-flipped Adam step of a zero-gradient bias = 2 * 2 * lr = 2e-3 on one element)
 
 
 def test_two_ranks_bf16_storage_match_full_batch(tmp_path):

@@ -1,20 +1,31 @@
-"""Print every error of the full-size known-answer cases (tests/test_gpu_fullsize.py asserts them): python tools/fullsize_report.py [case] [dtype]"""
-import os, sys
+"""Print every error of the full-size known-answer cases (tests/test_gpu_fullsize.py asserts them) and, with --json FILE, write the per-tensor relative errors
+of the parameter gradients -- the measured figures tests/golden/fullsize_measured.json holds:  python tools/fullsize_report.py [--json out.json] [case ...]"""
+import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import test_gpu_fullsize as T
 import fullsize_cases as FC
 
-for name in ([sys.argv[1]] if len(sys.argv) > 1 else list(FC.CASES)):
-    dtype = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-    z, arch, ld, p, g, wa = T._run(name, dtype)
+args = sys.argv[1:]
+jout = None
+if "--json" in args:
+    i = args.index("--json"); jout = args[i + 1]; del args[i:i + 2]
+res = {}
+for name in (args or list(FC.CASES)):
+    z, arch, ld, p, g, wa = T._run(name, "fp32")
     ps = p if arch == "classifier" else p[::T.P_STRIDE]
-    print(f"== {name} {dtype}: loss {ld[0]:.8f} vs {float(z['loss']):.8f}, metric {ld[1]:.8f} vs {float(z['metric']):.8f}, max|dp| {np.abs(ps - z['p_sample']).max():.2e}, dmean {abs(p.mean(dtype=np.float64) - float(z['p_mean'])):.2e}")
+    print(f"== {name}: loss {ld[0]:.8f} vs {float(z['loss']):.8f}, metric {ld[1]:.8f} vs {float(z['metric']):.8f}, max|dp| {np.abs(ps - z['p_sample']).max():.2e}, dmean {abs(p.mean(dtype=np.float64) - float(z['p_mean'])):.2e}")
+    res[name] = {}
     for k in [k[6:] for k in z.files if k.startswith("gnorm/")]:
         want = float(z["gnorm/" + k]); got = float(np.linalg.norm(g[k].astype(np.float64)))
         full = f" relerr {T.relerr(g[k], z['grad/' + k]):.2e} cos {T.cosine(g[k], z['grad/' + k]):.6f}" if "grad/" + k in z.files else ""
-        print(f"  {k:20s} norm {got:.6e} want {want:.6e} rel {abs(got - want) / (want + 1e-30):.2e}  dsum {abs(float(g[k].astype(np.float64).sum()) - float(z['gsum/' + k])):.2e}{full}")
+        res[name][k] = {"norm_rel": abs(got - want) / (want + 1e-30), "fp32ref": float(z["fp32ref_relerr/" + k])}
+        if "grad/" + k in z.files:
+            res[name][k]["relerr"] = T.relerr(g[k], z["grad/" + k])
+        print(f"  {k:20s} norm {got:.6e} want {want:.6e} rel {abs(got - want) / (want + 1e-30):.2e}  E_fp32cpu {float(z['fp32ref_relerr/' + k]):.2e}  dsum {abs(float(g[k].astype(np.float64).sum()) - float(z['gsum/' + k])):.2e}{full}")
     for k in [k[8:] for k in z.files if k.startswith("bn_mean/")]:
         mu = wa[k + "/mean"].astype(np.float64) / 0.01; va = (wa[k + "/var"].astype(np.float64) - 0.99) / 0.01
         print(f"  bn {k:12s} dmean {np.abs(mu - z['bn_mean/' + k]).max():.2e} (max {np.abs(z['bn_mean/' + k]).max():.2e})  dvar {np.abs(va - z['bn_var/' + k]).max():.2e} (max {np.abs(z['bn_var/' + k]).max():.2e})")
+if jout:
+    json.dump(res, open(jout, "w"), indent=1)
