@@ -39,8 +39,13 @@ __device__ __forceinline__ f16x8 lds_tr_frag(const char* p0, const char* p1) {
 
 constexpr int APX = 34;                                       // X pixels per staged row (32 + halo)
 
-// R = dY rows per step.  R = 2 (default): 9 + 4 staged pieces beside the 144 accumulators fit 256 registers -> two workgroups per CU cover each other's
-// staging phases; R = 4: twice the MFMAs per barrier pair but one workgroup per CU (512-register budget): measured 25 % slower (UNET_WGRAD_H2_ROWS=4)
+// R = dY rows per step.  R = 2 (default): the staged pieces beside the 144 accumulators fit 256 registers -> two workgroups per CU cover each other's
+// staging phases (R = 4 at one workgroup per CU measured 25 % slower); R = 4 only for the single 32 x 32 channel tile (four row phases).
+// The X rows live in a RING of R + 2 LDS row slots (image row y of the current unit sits in slot (y + 1 - ya) mod (R + 2)): a step fetches and stages only its
+// R NEW rows -- the two rows it shares with the step before stay where they are -- so the staging arithmetic (scale, two-term split: ~20 VALU per 16-byte
+// piece; the kernel is instruction-issue bound: 4 - 5.6 VALU + ~2 LDS instructions per MFMA before the ring) falls by a third.  If a new row forces the
+// running exponent of the X operand down, the two kept rows are fetched again and re-split at the new scale (rare: the maximum has to grow 8x).
+// The bias gradient (column sums of the dY operand) is taken by the workgroups of the FIRST X channel tile only.
 template <int WA, int WB, int WR, int R>
 __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
                                                           int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
@@ -113,19 +118,32 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
     }
     constexpr int NA = WA * AROWS, NB_ = WB * R;                 // main pieces per thread
     unet_u32x4 areg[NA + 1], breg[NB_];
-    auto issue_loads = [&](int ys) __attribute__((always_inline)) {        // ys = first dY row of the step
+    auto issue_kept = [&](int ys) __attribute__((always_inline)) {          // the two rows a ring step keeps (rare path of store_lds)
+#pragma unroll
+      for (int sub = 0; sub < WA; ++sub)
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const int gy = ys - 1 + row;
+          const bool ok = gy >= 0 && gy < H;
+          areg[sub * AROWS + row] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? abase_t[sub] : UNET_OOB, ok ? gy * W * CA * 4 : 0, 0);
+        }
+      const int gy = ys - 1 + h_row;
+      areg[NA] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (h_row < 2 && gy >= 0 && gy < H) ? hbase_t + gy * W * CA * 4 : UNET_OOB, 0, 0);
+    };
+    auto issue_loads = [&](int ys, int j0) __attribute__((always_inline)) {        // ys = first dY row of the step
       const int ysa = ys - 1;                                            // image row of staged X row 0 (the halo row above)
 #pragma unroll
       for (int sub = 0; sub < WA; ++sub)
 #pragma unroll
         for (int row = 0; row < AROWS; ++row) {
+          if (row < j0) continue;
           const int gy = ysa + row;                                      // wave-uniform
           const bool ok = gy >= 0 && gy < H;
           areg[sub * AROWS + row] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? abase_t[sub] : UNET_OOB, ok ? gy * W * CA * 4 : 0, 0);
         }
       {
         const int gy = ysa + h_row;
-        areg[NA] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (gy >= 0 && gy < H) ? hbase_t + gy * W * CA * 4 : UNET_OOB, 0, 0);
+        areg[NA] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (h_row >= j0 && gy >= 0 && gy < H) ? hbase_t + gy * W * CA * 4 : UNET_OOB, 0, 0);
       }
 #pragma unroll
       for (int sub = 0; sub < WB; ++sub)
@@ -150,13 +168,13 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
       for (int o = 32; o >= 1; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
       if (lane == 0) { s_amax[0][wave] = ma; s_amax[1][wave] = mb; }
     };
-    auto store_lds = [&]() __attribute__((always_inline)) {
+    auto store_lds = [&](int ys, int base, int j0) __attribute__((always_inline)) {
       const float ma = fmaxf(fmaxf(s_amax[0][0], s_amax[0][1]), fmaxf(s_amax[0][2], s_amax[0][3]));
       const float mb = fmaxf(fmaxf(s_amax[1][0], s_amax[1][1]), fmaxf(s_amax[1][2], s_amax[1][3]));
       const int eba = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(ma) >> 23) & 0xFF));
       const int ebb = __builtin_amdgcn_readfirstlane((int)((__float_as_uint(mb) >> 23) & 0xFF));
-      int d = 0;
-      if (eba >= 11 && eba - 127 + e_a >= 15) { d += 138 - eba - e_a; e_a = 138 - eba; }      // re-centre the block maximum at [2^11, 2^12)
+      int d = 0; bool a_moved = false;
+      if (eba >= 11 && eba - 127 + e_a >= 15) { d += 138 - eba - e_a; e_a = 138 - eba; a_moved = true; }      // re-centre the block maximum at [2^11, 2^12)
       if (ebb >= 11 && ebb - 127 + e_b >= 15) {
         const int db_ = 138 - ebb - e_b;
         bsum *= pow2f(max(db_, -126));
@@ -181,29 +199,42 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
 #pragma unroll
       for (int sub = 0; sub < WA; ++sub)
 #pragma unroll
-        for (int row = 0; row < AROWS; ++row) put(s_a + ((sub * AROWS + row) * APX + pc) * 64 + q8 * 8, areg[sub * AROWS + row], sa);
-      if (tid < HALO_T) put(s_a + ((h_sub * AROWS + h_row) * APX + h_px) * 64 + q8 * 8, areg[NA], sa);
+        for (int row = 0; row < AROWS; ++row) { if (row < j0) continue; int sl = base + row; sl = sl >= AROWS ? sl - AROWS : sl; put(s_a + ((sub * AROWS + sl) * APX + pc) * 64 + q8 * 8, areg[sub * AROWS + row], sa); }
+      if (tid < HALO_T && h_row >= j0) { int sl = base + h_row; sl = sl >= AROWS ? sl - AROWS : sl; put(s_a + ((h_sub * AROWS + sl) * APX + h_px) * 64 + q8 * 8, areg[NA], sa); }
+      if (a_moved && j0 > 0) {                                   // (workgroup-uniform, rare) the two kept rows sit in LDS at the old scale: fetch and split them again
+        issue_kept(ys);
+#pragma unroll
+        for (int sub = 0; sub < WA; ++sub)
+#pragma unroll
+          for (int row = 0; row < 2; ++row) { int sl = base + row; sl = sl >= AROWS ? sl - AROWS : sl; put(s_a + ((sub * AROWS + sl) * APX + pc) * 64 + q8 * 8, areg[sub * AROWS + row], sa); }
+        if (tid < HALO_T && h_row < 2) { int sl = base + h_row; sl = sl >= AROWS ? sl - AROWS : sl; put(s_a + ((h_sub * AROWS + sl) * APX + h_px) * 64 + q8 * 8, areg[NA], sa); }
+      }
 #pragma unroll
       for (int sub = 0; sub < WB; ++sub)
 #pragma unroll
         for (int row = 0; row < R; ++row) put(s_b + ((sub * R + row) * 32 + pc) * 64 + q8 * 8, breg[sub * R + row], sb);
     };
 
-    issue_loads(ya);
+    issue_loads(ya, 0);
     post_amax();
     __syncthreads();
-    store_lds();
+    store_lds(ya, 0, 0);
     __syncthreads();
+    int base = 0;
     for (int ys = ya; ys < yb; ys += R) {
       const bool more = ys + R < yb;
-      if (more) issue_loads(ys + R);
+      int nbase = base + R; nbase = nbase >= AROWS ? nbase - AROWS : nbase;
+      int roff[AROWS];
+#pragma unroll
+      for (int j = 0; j < AROWS; ++j) { int sl = base + j; sl = sl >= AROWS ? sl - AROWS : sl; roff[j] = sl * APX * 64; }
+      if (more) issue_loads(ys + R, 2);
 #pragma unroll
       for (int r = wr; r < R; r += WR) {
 #pragma unroll
         for (int kst = 0; kst < 2; ++kst) {
           const char* bp = pb + (r * 32 + kst * 16 + tr_px) * 64;
           const f16x8 bh = lds_tr_frag(bp, bp + 4 * 64), bm = lds_tr_frag(bp + STAGE1, bp + STAGE1 + 4 * 64);
-          if (wa == 0) {
+          if (wa == 0 && ta == 0) {                                  // (wave-uniform) the bias gradient: only the first X channel tile's workgroups sum their dY operand
 #pragma unroll
             for (int j = 0; j < 8; ++j) bsum += (float)bh[j] + (float)bm[j];
           }
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
             f16x8 ah[3], am[3];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const char* ap = pa + ((r + ky) * APX + kst * 16 + tr_px + kx) * 64;
+              const char* ap = pa + roff[r + ky] + (kst * 16 + tr_px + kx) * 64;
               ah[kx] = lds_tr_frag(ap, ap + 4 * 64); am[kx] = lds_tr_frag(ap + STAGE1, ap + STAGE1 + 4 * 64);
             }
 #pragma unroll
@@ -228,7 +259,8 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
       }
       if (more) post_amax();
       __syncthreads();
-      if (more) { store_lds(); __syncthreads(); }
+      if (more) { store_lds(ys + R, nbase, 2); __syncthreads(); }
+      base = nbase;
     }
   }
   const float un_b = pow2f(max(-e_b, -126));
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
           for (int ab = 0; ab < 4; ++ab) {
             const char* ap = pa + ((2 * r + (ab >> 1)) * AW + 2 * (kst * 16 + tr_px) + (ab & 1)) * 64;
             ah[ab] = lds_tr_frag(ap, ap + 8 * 64); am[ab] = lds_tr_frag(ap + STAGE1, ap + STAGE1 + 8 * 64);
-            if (wb == 0) {
+            if (wb == 0 && tb == 0) {                                // (wave-uniform) the bias gradient rides on dU: the first x channel tile's workgroups only
 #pragma unroll
               for (int j = 0; j < 8; ++j) bsum += (float)ah[ab][j] + (float)am[ab][j];
             }

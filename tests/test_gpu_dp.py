@@ -118,6 +118,53 @@ def _nccl_world1_worker(rank, port, wfile, x, y, out):
     dist.barrier(); dist.destroy_process_group()
 
 
+def _fullsize_worker(rank, world, port, case, out):
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fullsize_cases as FC
+    from covidseg_amd.engine import HipUNet
+    arch, size, n, _, _ = FC.CASES[case]
+    _, w, x, y = FC.build(case)
+    eng = HipUNet(size, size, 1, device=0, process_group=dist.group.WORLD, dropout_rate=0.0, arch=arch)
+    eng.set_weights(w)
+    m = n // world
+    ld = eng.forward_backward(x[rank * m:(rank + 1) * m], y[rank * m:(rank + 1) * m]).cpu().numpy()
+    g = eng.get_grads()
+    if rank == 0:
+        np.savez(out, ld=ld, **{"g/" + k: v for k, v in g.items()})
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_configs2_workload_on_two_ranks_matches_the_fp64_golden(tmp_path):
+    """BASELINE.json configs[2] (runner_lung_segmentation's U-Net, T3:850-913, 512 x 512 x 1, data parallel) AT ITS SIZE as far as one GPU allows: the per-rank batch
+    of 8 split over TWO ranks of 4 (both on this box's GPU, gloo group staged through the host: the sync-BN / global-Dice reductions and the SUM-reduced gradient
+    buckets are the production code, only the transport differs from RCCL) against the float64 known answer of the batch-8 step
+    (tests/golden/fullsize_unet_512_bs8.npz; the single-process form of the same case: tests/test_gpu_fullsize.py).  Loss / dice_coeff 1e-5, every parameter
+    gradient's norm within max(3e-4, 4 x E_k) (E_k: the fp32-CPU run's distance from fp64, stored in the fixture), the seven full tensors likewise."""
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fullsize_cases as FC
+    case = "unet_512_bs8"
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_fullsize_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    got = np.load(out)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fullsize_{case}.npz"))
+    assert abs(got["ld"][0] - float(z["loss"])) < 1e-5 and abs(got["ld"][1] - float(z["metric"])) < 1e-5, (got["ld"], float(z["loss"]), float(z["metric"]))
+    keys = [k[6:] for k in z.files if k.startswith("gnorm/")]
+    tol = {k: max(3e-4, 4.0 * min(float(z["fp32ref_relerr/" + k]), 2.5e-3)) for k in keys}
+    for k in keys:
+        want = float(z["gnorm/" + k]); a = got["g/" + k].astype(np.float64)
+        assert abs(np.linalg.norm(a) - want) <= tol[k] * want + 1e-8 * np.sqrt(a.size), (k, tol[k])
+    for k in FC.FULL_GRADS["unet"]:
+        a = got["g/" + k].astype(np.float64); b = z["grad/" + k].astype(np.float64)
+        assert max(np.linalg.norm(a - b) - 1e-8 * np.sqrt(a.size), 0.0) <= tol[k] * np.linalg.norm(b), k
+
+
 def test_rccl_code_path_at_world_size_one_equals_the_plain_step(tmp_path):
     """The production multi-GPU path -- backend "nccl" (= RCCL), device-side all-reduces of the inline fp64 sums, the gradient buckets on the
     side stream through the second communicator, the event chain back into Adam -- executed on the one GPU of this box: with a single rank

@@ -87,7 +87,7 @@ def test_conv3x3_bwd(ops, shape, algo):
         assert elem_ratio(dw.cpu().numpy(), kt.grad.numpy(), ab["dw_a1"]) <= 1.0, (shape, algo)
 
 
-@pytest.mark.parametrize("case", ["tiny_gradients", "huge", "per_chunk_ranges", "per_chunk_ranges_wide", "outlier_pixels", "zeros_and_denormals"])
+@pytest.mark.parametrize("case", ["tiny_gradients", "huge", "per_chunk_ranges", "per_chunk_ranges_wide", "outlier_pixels", "zeros_and_denormals", "row_ramp"])
 def test_h2_block_scaling_keeps_fp32_accuracy_over_any_range(ops, case):
     """The h2 kernels run fp32 convolutions as three fp16 MFMA products of a two-term split; what makes that safe is the block
     scaling by exact powers of two (per layer for the weights, a running exponent per workgroup for activations / gradients).  Forward, data gradient and
@@ -115,6 +115,11 @@ def test_h2_block_scaling_keeps_fp32_accuracy_over_any_range(ops, case):
         k /= sc[None, None, :, None]                                                                   # ... so every chunk contributes equally to the forward sum
     elif case == "outlier_pixels":
         x[:, 3, 5, :] *= np.float32(3e4); dy[:, 7, 11, :] *= np.float32(3e4)                           # one pixel per image 3e4 x larger than the rest
+    elif case == "row_ramp":
+        # every row pair 16x larger than the one before: the weight-gradient kernel keeps two X rows of the previous step in its LDS ring, and each step here forces
+        # its running exponent down -> the kept rows must be fetched again and re-split at the new scale (kernels_wgrad_h2.hip); a kept row left at the old scale
+        # would be wrong by 16x while contributing 1/16 of the newest rows' share
+        x *= np.exp2(4.0 * (np.arange(h) // 2)).astype(np.float32)[None, :, None, None]
     else:
         x[:, :, ::2] = 0.0; dy[:, ::3] = 0.0; x[0, 0, 1, :8] = np.float32(1e-41); k[0, 0, :4] = 0.0    # zeros, a few denormals
     xt, kt = T64(x).requires_grad_(True), T64(k).requires_grad_(True)
@@ -135,7 +140,7 @@ def test_h2_block_scaling_keeps_fp32_accuracy_over_any_range(ops, case):
     # domain on purpose (chunk magnitudes 2^12 / 2^24 apart inside one K loop, 3e4-sized outlier pixels) add the stated absolute floor 2^-36 * (tile maximum) * sum |w|
     from gpu_util import conv_abs_sums, elem_ratio
     ab = conv_abs_sums(x, k, dy)
-    floor = 1.0 if case in ("per_chunk_ranges", "per_chunk_ranges_wide", "outlier_pixels") else 0.0
+    floor = 1.0 if case in ("per_chunk_ranges", "per_chunk_ranges_wide", "outlier_pixels", "row_ramp") else 0.0
     ry = elem_ratio(got_y, want_y, ab["y_a1"], ab["y_a2"], floor); rdx = elem_ratio(got_dx, want_dx, ab["dx_a1"], ab["dx_a2"], floor)
     rdw = elem_ratio(got_dw, want_dw, ab["dw_a1"], ab["dw_a2"], floor)
     print(f"h2 per-element error / bound [{case}]: y {ry:.3f} dx {rdx:.3f} dw {rdw:.3f}")
