@@ -403,6 +403,10 @@ typedef struct unet_sync_point {
   int32_t kind;       /* 0 = bn fwd sums, 1 = loss sums, 2 = bn bwd sums, 3 = grad bucket ready */
   void* ptr;          /* device pointer of the doubles (kinds 0-2) / floats (kind 3) to SUM-reduce */
   int64_t count;      /* number of elements */
+  int32_t use_op;     /* kinds 0-2: the first op that READS the reduced values (> after_op).  use_op > after_op + 1 means the ops in between do not depend on
+                         the reduction: the host may run it on a side stream beside them and make the compute stream wait just before use_op (the backward
+                         programs place an independent weight gradient there).  Kind 3: the number of ops of the program (the optimizer is the reader). */
+  int32_t reserved;
 } unet_sync_point;
 
 /* arch: UNET_ARCH_UNET (T1:853-916), UNET_ARCH_UNETPP (task1_unet_plus_plus.py:858-950) or UNET_ARCH_CLASSIFIER (the Sequential

@@ -29,7 +29,7 @@ i32, i64, u64, f32, f64, sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_d
 
 
 class SyncPoint(C.Structure):
-    _fields_ = [("after_op", i32), ("kind", i32), ("ptr", vp), ("count", i64)]
+    _fields_ = [("after_op", i32), ("kind", i32), ("ptr", vp), ("count", i64), ("use_op", i32), ("reserved", i32)]
 
 
 # name -> (restype, argtypes); pointers to device memory are passed as void* integers

@@ -378,7 +378,7 @@ struct unet_model {
   std::map<std::string, std::pair<std::string, int>> folded_bn;
   std::vector<Op> prog[3];
   std::vector<unet_sync_point> sync[3];
-  struct SyncRef { int after_op, kind; bool in_ws; size_t off_bytes; int64_t count; };
+  struct SyncRef { int after_op, kind; bool in_ws; size_t off_bytes; int64_t count; int use_op = -1; };          // use_op -1: the op right behind after_op
   std::vector<SyncRef> syncref[3];
 
   float* wsf(size_t off) const { return reinterpret_cast<float*>(ws) + off; }
@@ -817,11 +817,18 @@ void build_programs(unet_model* m) {
     });
     // conv backward: wgrad (x, dy) then dgrad (dy -> dx, optional relu mask = activation that produced x)
     // xraw: the conv's input BatchNorm is folded (fold_off): the weight gradient runs on the raw tensor `xraw` and is corrected afterwards
-    auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, bool mask_in, const std::string& xraw = "") {
+    // Data parallelism: a batch-global reduction (BatchNorm backward sums) sits between the op that produces the local sums and the op that consumes the
+    // global ones.  A weight gradient depends on neither, so the program places one BEHIND every such producer: conv_bwd(..., defer_wgrad) parks the layer's
+    // weight-gradient op in DEF, flush_def() emits it where a reduction is in flight, and the sync point's use_op tells the host how long it may run beside
+    // the compute stream (include/unet_hip.h).  One rank: the same ops in a slightly different order.
+    std::vector<Op> DEF;
+    auto flush_def = [&]() { for (auto& o : DEF) BW.push_back(std::move(o)); DEF.clear(); };
+    auto conv_bwd = [&](const std::string& name, const std::string& in, int cin, int cout, bool want_dx, bool mask_in, const std::string& xraw = "", bool defer_wgrad = false) {
       const Buf ob = m->act.at(name);
       const double px = (double)ob.n * ob.h * ob.w;
       const std::string xsrc = xraw.empty() ? in : xraw;
-      ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
+      auto& WV = (defer_wgrad && xraw.empty()) ? DEF : BW;
+      ADD_OP(WV, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
         if (dt) {
           if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
           return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(xsrc)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w,
@@ -850,6 +857,9 @@ void build_programs(unet_model* m) {
           return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(bnn + "/gamma"), m->G(bnn + "/beta"), cin, s);
         });
         SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)cin});
+        const size_t syi = SY.size() - 1;
+        flush_def();                                          // (the block's second conv's weight gradient runs while the sums are reduced)
+        SY[syi].use_op = (int)BW.size();
         ADD_OP(BW, "conv3x3_dgrad_bn_bwd:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + 2 * cin) + 4.0 * 9.0 * cin * cout, {
           int32_t r = k_bn_bwd_coef(ctx, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, px * gcount, m->wsf(co), cin, s);
           if (r) return r;
@@ -910,8 +920,9 @@ void build_programs(unet_model* m) {
       int c = dec[k - 6]; std::string ks = std::to_string(k);
       std::string prev = (k == 6) ? "c5b" : "c" + std::to_string(k - 1) + "b";
       int cprev = (k == 6) ? 512 : dec[k - 7];
-      conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
+      conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true, "", m->fold_c_off.count("c" + ks + "a") != 0);          // (its weight gradient: behind c<k>a's sums)
       conv_bwd("c" + ks + "a", "bn" + ks, 2 * c, c, true, false, m->fold_off.count("c" + ks + "a") ? "cat" + ks : "");
+      flush_def();
       if (!m->fold_c_off.count("c" + ks + "a")) bn_bwd("bn" + ks, "bn" + ks, "cat" + ks, "cat" + ks, 2 * c, 0, m->fold_off.count("c" + ks + "a") != 0);
       const Buf ib = m->act.at(prev), ug = m->grad.at("u" + ks);
       const std::string un = "u" + ks;
@@ -934,8 +945,8 @@ void build_programs(unet_model* m) {
       if (k == 6) bucket("u6/kernel", "c6b/bias");
     }
     conv_bwd("c5b", "c5a", 512, 512, true, true);
-    conv_bwd("c5a", "p4", 256, 512, true, false);
-    bucket("c5a/kernel", "c5b/bias");
+    conv_bwd("c5a", "p4", 256, 512, true, false, "", ctx->opt_enc_bn_fused != 0);          // (its weight gradient: behind the pooled sums of level 4)
+    if (!ctx->opt_enc_bn_fused) bucket("c5a/kernel", "c5b/bias");
     for (int k = 4; k >= 1; --k) {
       int c = ENC[k - 1]; std::string ks = std::to_string(k);
       const Buf xb = m->act.at("bn" + ks), gb = m->grad.at("bn" + ks);
@@ -959,6 +970,10 @@ void build_programs(unet_model* m) {
           return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(bnn + "/gamma"), m->G(bnn + "/beta"), c, s);
         });
         SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)c});
+        const size_t syi = SY.size() - 1;
+        flush_def();                                          // (the weight gradient of the conv that consumed this level's pooled tensor runs while the sums are reduced)
+        if (k == 4) bucket("c5a/kernel", "c5b/bias");
+        SY[syi].use_op = (int)BW.size();
         ADD_OP(BW, "bn_pool_bwd_apply:" + bnn, 0, eb * 3.25 * nel(xb), {
           if (dt) return unet_bn_maxpool_bwd_apply_bf16(ctx, CBF(m->Av(cb)), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, CBF(m->Dv(bnn)), gb.ld, CBF(m->Dv(pn)),
                                                         WBF(m->Dv(cb)), cg.ld, xb.n, xb.h, xb.w, xb.c, m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
@@ -978,8 +993,9 @@ void build_programs(unet_model* m) {
       }
       conv_bwd("c" + ks + "b", "c" + ks + "a", c, c, true, true);
       int cprev = (k == 1) ? m->in_ch : ENC[k - 2];
-      conv_bwd("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cprev, c, k > 1, false);
+      conv_bwd("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cprev, c, k > 1, false, "", k > 1 && ctx->opt_enc_bn_fused != 0);
     }
+    flush_def();
     bucket("c1a/kernel", "bn4/beta");
   }
 #undef CBF
@@ -1716,7 +1732,8 @@ void resolve_sync(unet_model* m) {
     m->sync[p].clear();
     for (auto& r : m->syncref[p]) {
       unet_sync_point sp;
-      sp.after_op = r.after_op; sp.kind = r.kind; sp.count = r.count;
+      sp.after_op = r.after_op; sp.kind = r.kind; sp.count = r.count; sp.reserved = 0;
+      sp.use_op = r.kind == 3 ? (int)m->prog[p].size() : (r.use_op > r.after_op ? r.use_op : r.after_op + 1);
       sp.ptr = r.in_ws ? (void*)(m->ws ? m->ws + r.off_bytes : nullptr) : (void*)(m->grads ? (char*)m->grads + r.off_bytes : nullptr);
       m->sync[p].push_back(sp);
     }

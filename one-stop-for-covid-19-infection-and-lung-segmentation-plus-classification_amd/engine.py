@@ -87,7 +87,8 @@ class HipUNet:
             assert cnt.value == int(np.prod(shape)), (name, cnt.value, shape)
             self._tinfo[name] = (bool(st.value), off.value, cnt.value, shape)
         self.lib.unet_model_destroy(probe)
-        self._comm_stream = torch.cuda.Stream(device=self.dev) if self._dp else None
+        self._comm_stream = torch.cuda.Stream(device=self.dev) if self._dp else None          # gradient buckets
+        self._small_stream = torch.cuda.Stream(device=self.dev) if self._dp else None         # BatchNorm-backward sums whose reader is not the next op (dp.py)
 
     # ------------------------------------------------------------------ plans / buffers
     def _create_plan(self, n, replicated=False):
@@ -120,7 +121,7 @@ class HipUNet:
                 cnt = self.lib.unet_model_sync_points(p["m"], prog, None, 0)
                 arr = (_lib.SyncPoint * max(cnt, 1))()
                 self.lib.unet_model_sync_points(p["m"], prog, arr, cnt)
-                p["sync"][prog] = [(arr[i].after_op, arr[i].kind, arr[i].ptr, arr[i].count) for i in range(cnt)]
+                p["sync"][prog] = [(arr[i].after_op, arr[i].kind, arr[i].ptr, arr[i].count, arr[i].use_op) for i in range(cnt)]
         return p
 
     def _stream(self):
@@ -198,9 +199,19 @@ class HipUNet:
                 self._comm_stream.wait_event(ev)
                 self._all_reduce(self.grads[off:off + count], self.pg_grad)
 
+        def reduce_small_async(ptr, count):
+            # the reduction runs on its own stream behind everything launched so far; the compute stream goes on with the independent op(s) the program
+            # placed behind the producer and waits for `done` right before the reader (dp.run_program)
+            ev = torch.cuda.Event(); ev.record(cur)
+            with torch.cuda.stream(self._small_stream):
+                self._small_stream.wait_event(ev)
+                self._all_reduce(self._ws_view_f64(ptr, count))
+                done = torch.cuda.Event(); done.record(self._small_stream)
+            return done
+
         kinds = (0, 1, 2, 3) if self.sync_bn else (3,)
         dp.run_program(run_range, nops, plan["sync"][prog], reduce_small, reduce_bucket,
-                       lambda: cur.wait_stream(self._comm_stream), kinds)
+                       lambda: cur.wait_stream(self._comm_stream), kinds, reduce_small_async, lambda done: cur.wait_event(done))
 
     def _loss_tensor(self, plan):
         torch = _torch()

@@ -90,3 +90,23 @@ def test_run_program_slicing_and_kind_filter():
     dp.run_program(lambda b, e: calls.append(("run", b, e)), 8, sync, lambda h, c: calls.append(("small", h)),
                    lambda h, c: calls.append(("bucket", h)), lambda: calls.append(("finish",)), enabled_kinds=(3,))
     assert calls == [("run", 0, 4), ("bucket", "g0"), ("run", 4, 6), ("bucket", "g1"), ("run", 6, 8), ("finish",)]
+
+
+def test_deferred_small_reduction_waits_right_before_its_reader():
+    """A small reduction whose first reader is not the next op (use_op > after_op + 1: the backward programs put an independent weight gradient behind the op
+    that produces BatchNorm-backward sums) is started on a side stream and waited for just before the reader; inline ones (use_op == after_op + 1) and the
+    gradient buckets keep their order; without the async hooks every small reduction stays inline."""
+    sync = [(1, 2, "a", 4, 4),        # produced by op 1, read by op 4: ops 2, 3 may run beside it
+            (2, 2, "b", 4, 3),        # produced by op 2, read by op 3: inline
+            (5, 3, "g", 8, 8),        # bucket after op 5
+            (6, 2, "c", 4, 9)]        # reader beyond the end of the program: waited for at the end
+    log = []
+    dp.run_program(lambda b, e: log.append(("run", b, e)), 8, sync, lambda h, c: log.append(("inline", h)), lambda h, c: log.append(("bucket", h)),
+                   lambda: log.append(("finish",)), (0, 1, 2, 3), lambda h, c: (log.append(("async", h)), h)[1], lambda tok: log.append(("wait", tok)))
+    assert log == [("run", 0, 2), ("async", "a"), ("run", 2, 3), ("inline", "b"), ("run", 3, 4), ("wait", "a"), ("run", 4, 6), ("bucket", "g"), ("run", 6, 7),
+                   ("async", "c"), ("run", 7, 8), ("wait", "c"), ("finish",)], log
+    log2 = []
+    dp.run_program(lambda b, e: log2.append(("run", b, e)), 8, sync, lambda h, c: log2.append(("inline", h)), lambda h, c: log2.append(("bucket", h)),
+                   lambda: log2.append(("finish",)))
+    assert [t for t in log2 if t[0] != "run"] == [("inline", "a"), ("inline", "b"), ("bucket", "g"), ("inline", "c"), ("finish",)]
+    assert [t for t in log2 if t[0] == "run"] == [("run", 0, 2), ("run", 2, 3), ("run", 3, 6), ("run", 6, 7), ("run", 7, 8)]

@@ -217,3 +217,24 @@ def test_runner_on_two_ranks_equals_the_single_process_runner(tmp_path, monkeypa
         assert d.max() < 1.5e-2 and np.median(d) < 1e-3, k
     from covidseg_amd import hdf5_min as H5
     assert H5.is_hdf5(str(d2 / "unet_covid_weights_dice_coeff.hdf5"))                               # rank 0 wrote the reference's checkpoint files
+
+
+def test_backward_program_leaves_a_weight_gradient_beside_every_bn_backward_reduction():
+    """Data parallelism: the 8 BatchNorm-backward sums of the U-Net are batch-global (kind-2 sync points).  The backward program places an independent weight
+    gradient behind each op that produces such sums, and the sync point names the first op that reads the reduced values (use_op): the engine reduces on a
+    side stream beside the weight gradient and waits right before the reader (dp.run_program) instead of stalling the compute stream 8 times per step."""
+    from covidseg_amd.engine import HipUNet
+    eng = HipUNet(64, 64, 1, dropout_rate=0.0)
+    plan = eng._plan(2)
+    names = [o[0] for o in eng.op_profile(2, 1)]
+    k2 = [s for s in plan["sync"][1] if s[1] == 2]
+    assert len(k2) == 8
+    for after, _, _, _, use in k2:
+        assert use > after + 1, (names[after], use - after)
+        assert all(names[i].startswith("conv3x3_wgrad:") for i in range(after + 1, use)), names[after:use + 1]
+        assert names[use].startswith("conv3x3_dgrad_bn_bwd:") or names[use].startswith("bn_pool_bwd_apply:"), names[use]
+    buckets = [s for s in plan["sync"][1] if s[1] == 3]
+    assert len(buckets) == 4 and all(b[4] == len(names) for b in buckets)
+    # every weight gradient of a bucket is launched before the bucket is handed to the reducer
+    order = {n: i for i, n in enumerate(names)}
+    assert order["conv3x3_wgrad:c5a"] <= buckets[2][0] and order["conv3x3_wgrad:c6b"] <= buckets[1][0] and order["conv3x3_wgrad:c2a"] <= buckets[3][0]

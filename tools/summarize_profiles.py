@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Post-process tools/collect_profiles.sh output: kernel_stats.csv (per-kernel time table of the bench run) and pmc_traffic.json
+"""Post-process tools/collect_r03_profiles.sh output: kernel_stats.csv (per-kernel time table of the bench run) and pmc_traffic.json
 (HBM bytes per launch of the dominant kernel family = conv3x3 forward / data-gradient launches, calibrated on kernels whose byte
 counts are known exactly: bn_apply and adam).  MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> x2."""
 import collections
@@ -37,9 +37,7 @@ def collect(counter):
 
 
 def family(name):
-    if "conv_wino2d_kernel" in name or "conv_wino2d4_kernel" in name or "conv_wino_kernel" in name:
-        return "dom"
-    if "conv_mfma_kernel<0" in name or "conv_bf16_kernel<0" in name or "conv_h2_kernel<0" in name or "conv_x3_kernel" in name:
+    if "conv_mfma_kernel<0" in name or "conv_bf16_kernel<0" in name or "conv_h2_kernel<0" in name:
         return "dom"
     if "bn_apply_kernel" in name:
         return "bn_apply"          # fp32: 8 B per element, bf16 storage: 4 B
@@ -62,7 +60,7 @@ if "dom" in fam and fam["dom"]["launches"]:
     d = fam["dom"]
     steps = 4
     res = {
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/profile_ops.py --reps 1 --warm 3 (4 training steps, 512x512x1, batch 16); tools/collect_profiles.sh",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/profile_ops.py --reps 1 --warm 3 (4 training steps, 512x512x1, batch 16); tools/collect_r03_profiles.sh",
         "correction": "FETCH_SIZE (KB) x 1024 x 2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE (KB) x 1024; calibrated on bn_apply / adam whose byte counts are known",
         "calibration": {k: {"fetch_x2_GB": fam[k]["fetch_kb"] * 2048 / 1e9, "write_GB": fam[k]["write_kb"] * 1024 / 1e9} for k in ("bn_apply", "adam") if k in fam},
         "dominant_kernel": "conv3x3 fwd + data-gradient launches: " + ", ".join(sorted(d["names"])),
