@@ -212,8 +212,11 @@ int32_t k_h2_weights_multi(unet_ctx*, const float* const* w, void* const* img, c
 // any mix of layers in TWO launches; kind 0 / 1 = conv3x3 forward / data-gradient image, 2 / 3 = ConvT forward / data-gradient image (h2_convT_img_bytes each)
 int32_t k_h2_prep_multi(unet_ctx*, const float* const* w, const float* const* cs, void* const* img, const int* cin, const int* cout, const int* kind, int count, hipStream_t s);
 size_t h2_convT_img_bytes(int cin, int cout);
+// mask_climit (folded-BatchNorm data gradients, MASK_BN_BWD*): output channels >= mask_climit do not read x -- they get K0 dz + K2, the K1 x term is added by their consumer
 int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
-                         int act, float rate, uint64_t seed, hipStream_t s);
+                         int act, float rate, uint64_t seed, hipStream_t s, int mask_climit = 1 << 30);
+int32_t k_bn_maxpool_bwd_apply_k1(unet_ctx*, const float* x, int ldx, const float* bnp, const double* sums, double count, const float* g_skip, int ldg, const float* skip_k1,
+                                  const float* dy_pooled, float* dx, int lddx, int n, int h, int wd, int c, float rate, uint64_t seed, hipStream_t s);
 bool h2_convT_selected(const unet_ctx* ctx, int algo, int cin, int cout);
 int32_t k_convT_h2_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int ldy, int n, int h, int wd, int cin, int cout, hipStream_t s, const void* prepared = nullptr);
 int32_t k_convT_h2_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, const float* mask, float* dx, int n, int h, int wd, int cin, int cout, hipStream_t s, int mask_bits = 0,

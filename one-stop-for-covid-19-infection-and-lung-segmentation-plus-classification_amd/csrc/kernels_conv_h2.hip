@@ -134,7 +134,8 @@ template <int MODE, int NB, int RW, bool GEN, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
-                                                           int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs) {
+                                                           int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs,
+                                                           int mask_climit) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
   constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
@@ -372,7 +373,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int pxj = x0 + j * 8 + (lane >> 3);
-          const bool ok = mb0 + (lane & 7) * 4 < M && py < H && pxj < W;
+          // (mask_climit: output-channel blocks from there on do not read `mask` -- a folded-BatchNorm gradient whose K1 x term is added by the consumer)
+          const bool ok = mb0 + (lane & 7) * 4 < M && mb0 < mask_climit && py < H && pxj < W;
           const long long o = (((long long)n * H + py) * W + pxj) * ldy + mb0 + (lane & 7) * 4;
           mpre[nb][r][j] = ok ? *reinterpret_cast<const float4*>(mask + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         for (int q = 0; q < 4; ++q) {
           float4 m4;
           if (MPF) m4 = *reinterpret_cast<const float4*>(s_out + l31 * OUT_PS + hi * 64 + q * 16);
-          else m4 = live ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          else m4 = (live && mb0 < mask_climit) ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
           mv[q * 4] = m4.x; mv[q * 4 + 1] = m4.y; mv[q * 4 + 2] = m4.z; mv[q * 4 + 3] = m4.w;
         }
       }
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 
 template <int MODE, int NB, int RW, int WPS>
 int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd,
-                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s) {
+                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
@@ -601,7 +603,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
-                       stats_c, signs);
+                       stats_c, signs, mask_climit);
     return UNET_OK;
   };
   int32_t r;
@@ -680,16 +682,17 @@ int32_t k_h2_weights(unet_ctx* ctx, const float* w, void* img, int cin, int cout
 
 // x [n,h,wd,K] dense NHWC fp32, wimg from k_h2_weights (K contraction channels, M output channels), y [n,h,wd,M] fp32
 int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K,
-                         int M, int act, float rate, uint64_t seed, hipStream_t s) {
+                         int M, int act, float rate, uint64_t seed, hipStream_t s, int mask_climit) {
   if (K < 16 || (K % 16) || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: K=%d M=%d (multiples of 16)", K, M);
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
-  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+  if (mask_climit < M && ((mask_climit % 32) || mask_mode < MASK_BN_BWD)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2: mask_climit %d must be a whole number of 32-channel blocks of a folded-BatchNorm gradient", mask_climit);
+  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
   // 16-row tiles (twice the MFMAs per staged chunk, 7 spilled registers at two workgroups per CU) measured 3-5 % faster on the 64 x 64 ... 128 x 128 layers when
   // they still fill the 512 resident slots, 2-4 % slower on the 256 / 512 pixel layers (fewer, longer workgroups) and much slower when the grid falls below one round
   const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
-  if (h <= 128 && wgs16 >= 512) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
-  return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s);
+  if (h <= 128 && wgs16 >= 512) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
+  return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
 }
 
 // ---- ConvT 2x2 stride 2 (T1:886 ...) on the same kernels: forward = MODE 1 (K = cin, M = 4 cout), data gradient = MODE 2 (K = 4 cout, M = cin).

@@ -380,7 +380,7 @@ __global__ void bn_bwd_skip_term_kernel(double* __restrict__ sums, const double*
 template <typename T>
 __global__ __launch_bounds__(TPB) void pool_bn_bwd_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ bnp, const double* __restrict__ sums, double inv_count,
                                                                 const T* __restrict__ gskip, int ldg, const T* __restrict__ dyp, T* __restrict__ dx, int lddx, int N, int H,
-                                                                int W, int C, float rate, uint64_t seed) {
+                                                                int W, int C, float rate, uint64_t seed, const float* __restrict__ skip_k1) {
   const int lpp = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long long total = (long long)N * Ho * Wo * lpp;
   const int tid = threadIdx.x, q = tid % lpp;                        // lpp divides TPB: a thread keeps its channel quad
@@ -388,6 +388,9 @@ __global__ __launch_bounds__(TPB) void pool_bn_bwd_apply_kernel(const T* __restr
   const double* s1 = sums + q * 4; const double* s2 = sums + C + q * 4;
   const float4 k1 = make_float4((float)(s1[0] * inv_count), (float)(s1[1] * inv_count), (float)(s1[2] * inv_count), (float)(s1[3] * inv_count));
   const float4 k2 = make_float4((float)(s2[0] * inv_count), (float)(s2[1] * inv_count), (float)(s2[2] * inv_count), (float)(s2[3] * inv_count));
+  // skip_k1: the decoder's data gradient left out the K1 * y term of its folded-BatchNorm backward for the skip channels (it did not read the skip tensor): g_skip here
+  // holds K0 dz + K2 and the term is added from the y = BN(x) this kernel recomputes anyway
+  const float4 kk = skip_k1 ? ld4(skip_k1 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   for (long long i = (long long)blockIdx.x * TPB + tid; i < total; i += (long long)gridDim.x * TPB) {
     const unsigned pu = (unsigned)i / (unsigned)lpp, tu = pu / (unsigned)Wo;             // 32-bit index math (launcher checks total < 2^31)
     const int jo = (int)(pu - tu * (unsigned)Wo), io = (int)(tu % (unsigned)Ho);
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(TPB) void pool_bn_bwd_apply_kernel(const T* __restr
     const int kz = argmax4(yv[0].z, yv[1].z, yv[2].z, yv[3].z), kw = argmax4(yv[0].w, yv[1].w, yv[2].w, yv[3].w);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float tx = gs[k].x + (kx == k ? g.x : 0.f), ty = gs[k].y + (ky == k ? g.y : 0.f), tz = gs[k].z + (kz == k ? g.z : 0.f), tw = gs[k].w + (kw == k ? g.w : 0.f);
+      const float tx = fmaf(kk.x, yv[k].x, gs[k].x) + (kx == k ? g.x : 0.f), ty = fmaf(kk.y, yv[k].y, gs[k].y) + (ky == k ? g.y : 0.f);
+      const float tz = fmaf(kk.z, yv[k].z, gs[k].z) + (kz == k ? g.z : 0.f), tw = fmaf(kk.w, yv[k].w, gs[k].w) + (kw == k ? g.w : 0.f);
       float4 r;
       r.x = xv[k].x > 0.f ? sc.x * (tx - k1.x - (xv[k].x - mean.x) * istd.x * k2.x) : 0.f;
       r.y = xv[k].y > 0.f ? sc.y * (ty - k1.y - (xv[k].y - mean.y) * istd.y * k2.y) : 0.f;
@@ -885,13 +889,13 @@ int32_t unet_bn_bwd_skip_term(unet_ctx* ctx, double* sums, const double* dec_sum
 
 extern "C++" template <typename T> static int32_t bn_maxpool_bwd_apply_impl(unet_ctx* ctx, const T* x, int32_t ldx, const float* bnp, const double* sums, double count, const T* g_skip,
                                                                             int32_t ldg, const T* dy_pooled, T* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate,
-                                                                            uint64_t seed, void* stream) {
+                                                                            uint64_t seed, void* stream, const float* skip_k1 = nullptr) {
   if (!ctx || !x || !bnp || !sums || !dy_pooled || !dx || (c & 3) || c < 4 || TPB % (c / 4) || (h & 1) || (wd & 1) || ((ldx | lddx) & 3) || (g_skip && (ldg & 3)) || count < 1 || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn + maxpool bwd apply: bad args (c/4 must divide 256)");
   const long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);
   hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, as_stream(stream), x, ldx, bnp, sums, 1.0 / count, g_skip, ldg, dy_pooled, dx, lddx, n, h,
-                     wd, c, rate, seed);
+                     wd, c, rate, seed, skip_k1);
   UNET_CHECK_LAUNCH(ctx, "bn + maxpool bwd apply"); return UNET_OK;
 }
 
@@ -1014,6 +1018,11 @@ int32_t unet_bn_apply_maxpool_dropout_fwd(unet_ctx* ctx, const float* x, int32_t
 int32_t unet_bn_apply_maxpool_dropout_fwd_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const float* bnp, unet_bf16* y, int32_t ldy, unet_bf16* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_apply_maxpool_impl(ctx, x, ldx, bnp, y, ldy, pooled, n, h, wd, c, rate, seed, stream); }
 int32_t unet_maxpool2x2_dropout_bwd_sums(unet_ctx* ctx, const float* pooled, const float* dy_pooled, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_sums_impl(ctx, pooled, dy_pooled, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
 int32_t unet_maxpool2x2_dropout_bwd_sums_bf16(unet_ctx* ctx, const unet_bf16* pooled, const unet_bf16* dy_pooled, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_sums_impl(ctx, pooled, dy_pooled, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }
+extern "C++" int32_t k_bn_maxpool_bwd_apply_k1(unet_ctx* ctx, const float* x, int ldx, const float* bnp, const double* sums, double count, const float* g_skip, int ldg, const float* skip_k1,
+                                               const float* dy_pooled, float* dx, int lddx, int n, int h, int wd, int c, float rate, uint64_t seed, hipStream_t s) {
+  if (skip_k1 && !g_skip) UNET_FAIL(ctx, UNET_E_ARG, "bn + maxpool bwd apply: skip_k1 without a skip gradient");
+  return bn_maxpool_bwd_apply_impl(ctx, x, ldx, bnp, sums, count, g_skip, ldg, dy_pooled, dx, lddx, n, h, wd, c, rate, seed, (void*)s, skip_k1);
+}
 int32_t unet_bn_maxpool_bwd_apply(unet_ctx* ctx, const float* x, int32_t ldx, const float* bnp, const double* sums, double count, const float* g_skip, int32_t ldg, const float* dy_pooled, float* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_maxpool_bwd_apply_impl(ctx, x, ldx, bnp, sums, count, g_skip, ldg, dy_pooled, dx, lddx, n, h, wd, c, rate, seed, stream); }
 int32_t unet_bn_maxpool_bwd_apply_bf16(unet_ctx* ctx, const unet_bf16* x, int32_t ldx, const float* bnp, const double* sums, double count, const unet_bf16* g_skip, int32_t ldg, const unet_bf16* dy_pooled, unet_bf16* dx, int32_t lddx, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return bn_maxpool_bwd_apply_impl(ctx, x, ldx, bnp, sums, count, g_skip, ldg, dy_pooled, dx, lddx, n, h, wd, c, rate, seed, stream); }
 int32_t unet_maxpool2x2_dropout_bwd_bnstats(unet_ctx* ctx, const float* y, int32_t ldy, const float* dy, float* dx, int32_t lddx, const float* gamma, const float* beta, double* sums, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed, void* stream) { return maxpool_bwd_bnstats_impl(ctx, y, ldy, dy, dx, lddx, gamma, beta, sums, n, h, wd, c, rate, seed, stream); }

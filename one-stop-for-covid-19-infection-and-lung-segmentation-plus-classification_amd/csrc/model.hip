@@ -376,6 +376,8 @@ struct unet_model {
   // weight-gradient correction; folded_bn maps the BatchNorm's activation name to (its input buffer, its channel count): never written by the programs
   std::map<std::string, size_t> fold_off, fold_g_off, fold_c_off;     // fold_c_off: + the BatchNorm backward runs in the conv's data-gradient epilogue (coefficients [3][cin])
   std::map<std::string, std::pair<std::string, int>> folded_bn;
+  std::map<std::string, size_t> skip_k1_off;          // U-Net fp32: encoder BatchNorm name -> offset (floats) of the decoder's K1 coefficients of its skip channels: the decoder's
+                                                      // data gradient did not read the skip tensor, bn_pool_bwd_apply adds K1 * y (common.h: mask_climit)
   std::vector<Op> prog[3];
   std::vector<unet_sync_point> sync[3];
   struct SyncRef { int after_op, kind; bool in_ws; size_t off_bytes; int64_t count; int use_op = -1; };          // use_op -1: the op right behind after_op
@@ -517,6 +519,13 @@ void plan_workspace(unet_model* m) {
     if (m->ctx->opt_bn_fold >= 2 && (m->dt || h2_conv3x3_selected(m->algo, cout, cin))) m->fold_c_off[kv.first] = cv.take((size_t)3 * cin);
   }
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_b[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : unet_conv3x3_w_ws_floats(l.cin, l.cout));
+  // fp32: where a decoder block's BatchNorm backward runs in its data-gradient epilogue AND the matching encoder tail takes its fused backward, the K1 * x term of the
+  // skip half is added by the latter: coefficients [3][2C] of c<k>a, K1 of skip channel j at [2C + C + j]
+  if (!m->dt && m->ctx->opt_enc_bn_fused)
+    for (auto& kv : m->fold_c_off) {
+      const int k = kv.first[1] - '0'; const int c2 = 2 * m->act.at(kv.first).c;
+      if ((c2 / 2) % 32 == 0) m->skip_k1_off["bn" + std::to_string(10 - k)] = kv.second + (size_t)c2 + c2 / 2;
+    }
   // ReLU masks as sign bits (MASK_RELU_BITS): the output of a conv that is the mask of the next conv's / ConvT's data gradient -- c<k>a for the conv pairs,
   // c5b ... c8b for the ConvTs -- where producer and consumer both run on the h2 kernels (decided exactly as the launches decide)
   if (!m->dt && m->ctx->opt_relu_bits) {
@@ -865,7 +874,10 @@ void build_programs(unet_model* m) {
           if (r) return r;
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), m->wsf(co), CBF(m->Av(xraw)), MASK_BN_BWD, WBF(m->Dv(xraw)), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0,
                                             WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s, CBF(static_cast<void*>(m->wsf(m->wprep_b.at(name)))));
-          return k_conv3x3_h2_fwd(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->wsf(co), m->A(xraw), MASK_BN_BWD, m->D(xraw), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0, s);
+          // the skip half of the concat's gradient leaves without its K1 * x term when the encoder tail's fused backward adds it (it recomputes y = BN(x) anyway):
+          // this launch then reads only the upsampled half of the concat (-25 % of its bytes at every level)
+          const int climit = m->skip_k1_off.count("bn" + std::to_string(10 - (name[1] - '0'))) ? cin / 2 : (1 << 30);
+          return k_conv3x3_h2_fwd(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->wsf(co), m->A(xraw), MASK_BN_BWD, m->D(xraw), ob.n, ob.h, ob.w, cout, cin, ACT_NONE, 0.0f, 0, s, climit);
         });
         return;
       }
@@ -977,7 +989,9 @@ void build_programs(unet_model* m) {
         ADD_OP(BW, "bn_pool_bwd_apply:" + bnn, 0, eb * 3.25 * nel(xb), {
           if (dt) return unet_bn_maxpool_bwd_apply_bf16(ctx, CBF(m->Av(cb)), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, CBF(m->Dv(bnn)), gb.ld, CBF(m->Dv(pn)),
                                                         WBF(m->Dv(cb)), cg.ld, xb.n, xb.h, xb.w, xb.c, m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
-          return unet_bn_maxpool_bwd_apply(ctx, m->A(cb), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, m->D(bnn), gb.ld, m->D(pn), m->D(cb), cg.ld,
+          const auto k1o = m->skip_k1_off.find(bnn);
+          return k_bn_maxpool_bwd_apply_k1(ctx, m->A(cb), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, m->D(bnn), gb.ld,
+                                           k1o == m->skip_k1_off.end() ? nullptr : m->wsf(k1o->second), m->D(pn), m->D(cb), cg.ld,
                                            xb.n, xb.h, xb.w, xb.c, m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
         });
       } else {

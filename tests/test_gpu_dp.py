@@ -65,7 +65,8 @@ def test_two_ranks_equal_single_process_full_batch(tmp_path, arch):
     assert np.abs(got["losses"] - ref_losses).max() < 2e-5            # batch-global loss / dice on every rank
     # after 2 Adam steps (sign-like updates while v is tiny) fp32 summation-order noise of the gradients shows up at ~4e-5 in
     # the classifier's small-batch loss and 1 - 3e-5 in the segmentation losses; the weights themselves are compared below
-    assert np.abs(got["ld"] - ld.cpu().numpy()).max() < (1e-4 if arch == "classifier" else 5e-5) and np.allclose(got["sums"], sums, rtol=1e-5)
+    # (thresholded pixel counts after two optimizer steps: a pixel whose probability sits within ~1e-5 of a threshold may fall on either side -> a few pixels)
+    assert np.abs(got["ld"] - ld.cpu().numpy()).max() < (1e-4 if arch == "classifier" else 5e-5) and np.abs(got["sums"] - sums).max() <= 6.0 + 1e-5 * np.abs(sums).max()
     wref = eng.get_weights()
     for k, v in wref.items():                                         # identical replicas after 2 optimizer steps
         a = got["w/" + k]
