@@ -211,7 +211,7 @@ def main():
         shapes = W.weight_shapes(1, args.arch, (S, S))
 
         def exec_ratio(opname):
-            """executed / algorithmic multiplies of a conv3x3 op: 4/9 F(2x2,3x3), 2/3 F(2,3) along x, 1 direct (unet_conv3x3_exec_ratio)"""
+            """fp32-MFMA-time equivalent of a conv3x3 op's matrix work: 3 * 157.3 / 2500 on the fp16-split h2 kernels, 1 on the strict fp32 family (unet_conv3x3_exec_ratio)"""
             kind, _, lname = opname.partition(":")
             if not kind.startswith("conv3x3") or args.dtype == "bf16" or lname + "/kernel" not in shapes:
                 return 1.0
@@ -223,51 +223,45 @@ def main():
                 return float(eng.lib.unet_conv3x3_wgrad_exec_ratio(args.algo, hh, ww, ci, co))
             return float(eng.lib.unet_conv3x3_exec_ratio(args.algo, hh, ww, ci, co))
 
-        fl_exec = sum(o[1] * exec_ratio(o[0]) for o in dom); n_wino = sum(int(exec_ratio(o[0]) < 1.0) for o in dom)
         groups = {}
         for name, flops, by, tms, calls in ops:
             k = name.split(":")[0]
             g = groups.setdefault(k, [0.0, 0.0, 0.0]); g[0] += tms / max(calls, 1); g[1] += flops; g[2] += by
         effective = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0               # algorithmic (direct-convolution) FLOPs / time
-        executed = fl_exec / (ms * 1e-3) / 1e12 if ms > 0 else 0.0           # multiplies the matrix cores really perform / time
-        # whole-step floor on the EXECUTED work: every op at max(its algorithmic bytes / HBM peak, its executed FLOPs / fp32 MFMA peak)
+        # whole-step floor on the EXECUTED work: every op at max(its algorithmic bytes / HBM peak, its executed matrix FLOPs at the pipe it runs on)
         peak_fl = (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12
         floor_ms = sum(max(o[2] / (HBM_PEAK_GBS * 1e9), o[1] * exec_ratio(o[0]) / peak_fl) for o in ops) * 1e3
         # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE): collected OFFLINE at this exact workload
-        # (tools/collect_profiles.sh, calibration inside the file), not in this run -- only quoted for the configuration it was measured on
+        # (tools/collect_r03_profiles.sh, calibration inside the file), not in this run -- only quoted for the configuration it was measured on
         traffic, tname = None, None
-        for tname in (("r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.dtype == "fp32" else ("r02_pmc_traffic_bf16.json", "r01_pmc_traffic_bf16.json")):
+        for tname in (("r03_pmc_traffic.json", "r02_pmc_traffic.json") if args.dtype == "fp32" else ("r03_pmc_traffic_bf16.json", "r01_pmc_traffic_bf16.json")):
             tfile = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet":
                 traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
                 break
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
-        H2R, X3R = 3.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS, 6.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
-        ratios = [exec_ratio(o[0]) for o in dom]
-        n_h2 = sum(int(abs(r - H2R) < 1e-9) for r in ratios); n_x3 = sum(int(abs(r - X3R) < 1e-9) for r in ratios)
+        H2R = 3.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
+        n_h2 = sum(int(abs(exec_ratio(o[0]) - H2R) < 1e-9) for o in dom)
         gbs = sum(o[2] for o in dom) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        if n_h2 + n_x3 == launches and launches:
-            # every launch of the dominant family runs on the 16-bit matrix pipe (h2: three fp16 products per multiply, x3: six bf16 products): price
-            # the products it EXECUTES against that pipe's dense peak
-            per = [3.0 if abs(r - H2R) < 1e-9 else 6.0 for r in ratios]
-            prod = sum(o[1] * k for o, k in zip(dom, per)) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        if n_h2 == launches and launches:
+            # every launch of the dominant family runs on the fp16 matrix pipe (three products per fp32 multiply): price the products it EXECUTES against that pipe's dense peak
+            prod = 3.0 * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_h2_kernel (fp32 in / out, block-scaled two-term fp16 split, 3 v_mfma_f32_32x32x16_f16 products "
-                                               f"per multiply, {n_h2} launches)" + (f" / conv_x3_kernel (three-term bf16 split, 6 products, {n_x3} launches)" if n_x3 else ""),
+                                               f"per multiply, {n_h2} launches)",
                     "achieved": round(prod, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(prod / BF16_MFMA_PEAK_TFLOPS, 4),
                     "effective_tflops": round(effective, 2),
-                    "note": "achieved / frac = 16-bit MFMA FLOPs the matrix cores EXECUTE (3 or 6 products per fp32 multiply) / time vs the 2.5 PFLOP/s dense fp16 / bf16 peak; "
+                    "note": "achieved / frac = fp16 MFMA FLOPs the matrix cores EXECUTE (3 products per fp32 multiply) / time vs the 2.5 PFLOP/s dense fp16 peak; "
                             "effective_tflops = ALGORITHMIC fp32 FLOPs (SURVEY 8d) of the same launches / the same time (the fp32 MFMA peak is 157.3)",
                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                     # measured on this chip, not in this run (profiles/r02_mfma_power_probe.txt): back-to-back fp16 MFMAs from registers with random, half-zero
                     # operands sustain 1.74 PFLOP/s at the package power cap (sclk ~1700 MHz); `peak` / `frac` stay the guide's nominal 2.5 PFLOP/s
                     "power_capped_peak": 1740.0, "frac_of_power_capped_peak": round(prod / 1740.0, 4)}
         else:
-            roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_wino2d_kernel / conv_wino2d4_kernel / conv_wino_kernel (Winograd F(2x2,3x3) / F(2,3), {n_wino} launches) / "
-                                               f"conv_mfma_kernel<0,...> (direct, {launches - n_wino} launches)",
-                    "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+            roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_mfma_kernel<0,...> (strict fp32, v_mfma_f32_32x32x2_f32, {launches - n_h2} launches)"
+                                               + (f" / conv_h2_kernel ({n_h2} launches)" if n_h2 else ""),
+                    "achieved": round(effective, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(effective / FP32_MFMA_PEAK_TFLOPS, 4),
                     "effective_tflops": round(effective, 2),
-                    "note": "achieved / frac = multiplies the matrix cores EXECUTE (Winograd: 4/9 or 2/3 of the direct count; 16-bit split launches at their fp32-MFMA-time equivalent) / time, "
-                            "<= peak by construction; effective_tflops = ALGORITHMIC (direct-convolution, SURVEY 8d) FLOPs of the same launches / the same time",
+                    "note": "achieved = ALGORITHMIC (direct-convolution, SURVEY 8d) FLOPs of these launches / their time, against the fp32 MFMA peak",
                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         roof.update({"traffic": traffic,
                      "traffic_unit": f"HBM bytes per launch, rocprofv3 PMC collected offline on this workload (profiles/{tname}); not measured in this run",
