@@ -690,8 +690,13 @@ __global__ void bn_slot_fold_kernel(double* __restrict__ slots, OUT* __restrict_
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n2c) return;
   double s = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < nslots; ++k) { double* p = slots + (size_t)k * UNET_BN_SLOT_DOUBLES + i; s += *p; *p = 0.0; }
+  for (int k0 = 0; k0 < nslots; k0 += 16) {                 // (nslots is a multiple of 16) sixteen independent loads in flight, summed in index order
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { double* p = slots + (size_t)(k0 + k) * UNET_BN_SLOT_DOUBLES + i; v[k] = *p; *p = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+  }
   sums[i] += (OUT)s;
 }
 
@@ -705,10 +710,12 @@ __global__ void bn_fold_concat_kernel(double* __restrict__ slots, double* __rest
   const int c2 = c_up + c_skip;
   if (i < c_up) {
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < nslots; ++k) {
-      double* p = slots + (size_t)k * UNET_BN_SLOT_DOUBLES + i;
-      s1 += p[0]; p[0] = 0.0; s2 += p[c_up]; p[c_up] = 0.0;
+    for (int k0 = 0; k0 < nslots; k0 += 8) {                // eight independent load pairs in flight, summed in index order
+      double v1[8], v2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { double* p = slots + (size_t)(k0 + k) * UNET_BN_SLOT_DOUBLES + i; v1[k] = p[0]; p[0] = 0.0; v2[k] = p[c_up]; p[c_up] = 0.0; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s1 += v1[k]; s2 += v2[k]; }
     }
     sums[i] += s1; sums[c2 + i] += s2;
   } else if (i < c2) {
