@@ -11,6 +11,7 @@ Prints ONE JSON line (rank 0).  Besides the driver contract it carries
                  hipEvent durations vs that pipe's dense peak; algorithmic bytes / FLOPs beside it
   fp32_strict_img_s : the same step with every product on v_mfma_f32_32x32x2_f32 (--algo 2: exact fp32 multiply-add, the
                  out-of-domain fallback family) -- what the fp16 split buys, and what the IEEE-fp32 path costs
+  predict_batch1_ms : median latency of model.predict at batch 1 (T1:1137), synchronised per call
   cpu_baseline : the CPU oracle (torch-CPU restatement, kind "port") timed on the host cores on a
                  bounded sample of the same workload (rank 0, N=1 only)
 Before the W warm-up steps the chip is run for SETTLE_S seconds of untimed steps: its clocks need >= 1 s of load to settle at the
@@ -76,6 +77,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (fp16-split h2 kernels where the shape allows), 1 direct VALU kernels, 2 strict fp32 MFMA kernels")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the untimed fp32_strict_img_s measurement (--algo 2 engine, 8 steps)")
+    ap.add_argument("--deterministic", action="store_true", help="UNET_OPT_DETERMINISTIC: fixed-order reductions, no floating-point atomics (bit-identical reruns)")
     ap.add_argument("--settle", type=float, default=2.0, help="seconds of untimed steps ahead of the warm-up (clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
@@ -137,7 +139,7 @@ def main():
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
-                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")))
+                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), options={"deterministic": 1} if args.deterministic else None)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     # ---- untimed setup 1 (rank 0, N=1): the CPU baseline first, so the GPU work of this command is one contiguous block at its end
@@ -174,6 +176,17 @@ def main():
         strict = round(8 * B / (time.perf_counter() - ts), 1)
         del e2
         torch.cuda.empty_cache()
+
+    # ---- untimed setup 4 (rank 0, N=1): latency of model.predict(x.reshape(1,H,W,1)) (T1:1137) -- inference forward at batch 1, synchronised per call
+    predict_ms = None
+    if rank == 0 and world == 1 and args.arch == "unet":
+        x1 = x[:1].contiguous()
+        for _ in range(3):
+            eng.predict_batch(x1)
+        torch.cuda.synchronize(); lat = []
+        for _ in range(20):
+            ts = time.perf_counter(); eng.predict_batch(x1); torch.cuda.synchronize(); lat.append((time.perf_counter() - ts) * 1e3)
+        predict_ms = round(sorted(lat)[len(lat) // 2], 3)
 
     # ---- untimed: clock settle.  The chip needs >= 1 s of this load before its clocks sit at the power-capped operating point
     ts = time.perf_counter()
@@ -303,11 +316,13 @@ def main():
                                    + {"unet": "configs[2]" if args.config == 2 else "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
                        "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: every conv3x3 / ConvT forward, data gradient and weight gradient as three v_mfma_f32_32x32x16_f16 products of a block-scaled two-term fp16 split (h2; fp32-class accuracy, DESIGN.md 4g); Cin=1 first layer and 1x1 head on fp32 VALU", 1: "direct fp32 VALU kernels", 2: "strict fp32: v_mfma_f32_32x32x2_f32 direct kernels"}[args.algo],
-                       "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
+                       "deterministic": bool(args.deterministic), "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
         if strict is not None:
             out["fp32_strict_img_s"] = strict
+        if predict_ms is not None:
+            out["predict_batch1_ms"] = predict_ms          # median of 20 synchronised model.predict calls at batch 1 (T1:1137): latency, not throughput
         if cpu is not None:
             out["cpu_baseline"] = cpu
     # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which sits in libc's buffer until exit and would
