@@ -1,8 +1,8 @@
 """A minimal HDF5 reader / writer: exactly the subset of the file format that Keras weight files use.
 
 The reference stores its checkpoints with Keras on top of h5py (``ModelCheckpoint(filepath_dice_coeff, ...)`` T1:1046-1047 ->
-``model.save``; ``model.save_weights('unet_0.8954_cosine_annealer.h5')`` T1:1079; ``model.load_weights`` T1:1073).  h5py / libhdf5 are
-not in this image, so the byte format is restated here from the published "HDF5 File Format Specification" (version 1.1 / 2.0
+``model.save``; ``model.save_weights('unet_0.8954_cosine_annealer.h5')`` T1:1079; ``model.load_weights`` T1:1073).  h5py is not in this
+image (and the product may not depend on a libhdf5 found by accident), so the byte format is restated here from the published "HDF5 File Format Specification" (version 1.1 / 2.0
 structures, the ones libhdf5 emits with its default ``libver='earliest'`` bounds, which is what h5py.File(path, 'w') uses):
 
   writer  superblock version 0, old-style groups (symbol-table message -> version-1 B-tree of SNOD symbol-table nodes + local heap),
@@ -10,13 +10,17 @@ structures, the ones libhdf5 emits with its default ``libver='earliest'`` bounds
           version-1 dataspaces, contiguous version-3 data layouts, version-2 fill-value messages.
   reader  the same, plus what other writers of the format produce for the same logical content: object-header continuation blocks,
           version-2 object headers ("OHDR" / "OCHK") with compact link messages, superblock versions 1-3, attribute messages
-          versions 2 / 3, version-2 dataspaces, compact data layouts, big-endian numbers, variable-length strings (global heap).
+          versions 2 / 3, version-2 dataspaces, version-4 layouts, compact data layouts, big-endian numbers, variable-length strings (global heap).
           Chunked / filtered datasets and "dense" new-style groups (fractal heap) are NOT read: a clear H5FormatError names the feature.
 
-PARITY STATUS: "parity unpinned" -- no libhdf5-written file exists in /root/reference or in this image to check the bytes against;
-the tests check (i) write -> read round trips, (ii) an independent structural walk of the written bytes against the specification's
-field tables (tests/test_hdf5_min.py), (iii) the Keras logical layout (`layer_names` / `weight_names` attributes, `model_weights/`
-group) that keras/engine/saving.py defines.  Host-side file I/O, not on the hot path.
+PARITY STATUS: pinned against the real libhdf5 (HDF5 1.10.6; the build image carries it under /opt/conda, without h5py), both ways
+(tests/test_hdf5_pinned.py): the reader on files libhdf5 itself wrote in h5py-2 / h5py-3 / Keras shapes (tests/golden/hdf5/, made by
+tests/golden/make_hdf5_fixtures.c: fixed and variable-length strings, continuation blocks, libver='latest' headers with layout v4,
+compact and big-endian data, tracked times, a two-level group B-tree), and the writer's files re-read by libhdf5 through ctypes
+(tests/h5ref.py) and walked by h5dump / h5ls, every dataset, type and attribute identical.  NOT checked against h5py / Keras
+themselves (absent here): the Keras logical layout (`layer_names` / `weight_names`, `model_weights/`) follows keras/engine/saving.py.
+tests/test_hdf5_min.py adds write -> read round trips and a structural walk against the specification.  Host-side file I/O, not on
+the hot path.
 """
 from __future__ import annotations
 
@@ -60,7 +64,7 @@ class Group:
     def create_dataset(self, name: str, data) -> None:
         parts = name.strip("/").split("/")
         g = self.create_group("/".join(parts[:-1])) if len(parts) > 1 else self
-        g.children[parts[-1]] = np.ascontiguousarray(data)
+        g.children[parts[-1]] = np.asarray(data, order="C")          # (ascontiguousarray would turn a scalar into shape (1,))
 
     def __getitem__(self, name: str):
         g = self
@@ -148,7 +152,7 @@ class _Writer:
         return struct.pack("<BxHHH", 1, len(nm), len(dt), len(ds)) + _pad8(nm) + _pad8(dt) + _pad8(ds) + raw
 
     def dataset(self, a: np.ndarray) -> int:
-        a = np.ascontiguousarray(a)
+        a = np.asarray(a, order="C")
         if a.dtype.kind in "fiu":
             a = a.astype(a.dtype.newbyteorder("<"))
         raw = a.tobytes()
@@ -453,8 +457,8 @@ class _Reader:
                 raise H5FormatError("dataset without datatype / dataspace")
             esz = 16 if isinstance(dt, tuple) else dt.itemsize
             nbytes = esz * (int(np.prod(shape)) if shape else 1)
-            if layout[0] != 3:
-                raise H5FormatError(f"data layout message version {layout[0]} is not supported (only version 3)")
+            if layout[0] not in (3, 4):                               # version 4 (libver='latest' in 1.10) keeps the compact / contiguous fields of 3
+                raise H5FormatError(f"data layout message version {layout[0]} is not supported (only versions 3 and 4)")
             if layout[1] == 1:
                 a = struct.unpack("<Q", layout[2:10])[0]
                 raw = self._at(a, nbytes) if nbytes and a != UNDEF else b"\0" * nbytes

@@ -1,5 +1,5 @@
-"""hdf5_min.py: the HDF5 subset behind Keras weight files (T1:1046-1047, 1073, 1079).  No libhdf5 / h5py exists in this image, so the
-checks are (1) write -> read round trips of arbitrary trees, (2) `walk()` below: an INDEPENDENT decoder written straight from the field
+"""hdf5_min.py: the HDF5 subset behind Keras weight files (T1:1046-1047, 1073, 1079).  The pin against the real libhdf5 is
+tests/test_hdf5_pinned.py; the checks here need no library: (1) write -> read round trips of arbitrary trees, (2) `walk()` below: an INDEPENDENT decoder written straight from the field
 tables of the HDF5 File Format Specification (superblock v0, v1 object headers, symbol-table groups: local heap / v1 B-tree / SNOD,
 dataspace v1, datatype classes 0 / 1 / 3, layout v3, attribute v1) that re-derives every address, size, alignment and B-tree key
 invariant libhdf5 relies on, (3) the Keras layout of keras/engine/saving.py, incl. files whose layer names carry other counters."""
