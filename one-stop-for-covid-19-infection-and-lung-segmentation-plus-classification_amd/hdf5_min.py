@@ -17,8 +17,9 @@ PARITY STATUS: pinned against the real libhdf5 (HDF5 1.10.6; the build image car
 (tests/test_hdf5_pinned.py): the reader on files libhdf5 itself wrote in h5py-2 / h5py-3 / Keras shapes (tests/golden/hdf5/, made by
 tests/golden/make_hdf5_fixtures.c: fixed and variable-length strings, continuation blocks, libver='latest' headers with layout v4,
 compact and big-endian data, tracked times, a two-level group B-tree), and the writer's files re-read by libhdf5 through ctypes
-(tests/h5ref.py) and walked by h5dump / h5ls, every dataset, type and attribute identical.  NOT checked against h5py / Keras
-themselves (absent here): the Keras logical layout (`layer_names` / `weight_names`, `model_weights/`) follows keras/engine/saving.py.
+(tests/h5ref.py) and walked by h5dump / h5ls, every dataset, type and attribute identical; the real h5py 3.3.0 (the image's
+Anaconda interpreter, /opt/conda/bin/python3.9) wrote three more reader fixtures with Keras' call sequence (make_h5py_fixtures.py) and loads
+the writer's files along Keras' load path (tests/h5py_check.py).  NOT checked against Keras itself (absent here): the Keras logical layout (`layer_names` / `weight_names`, `model_weights/`) follows keras/engine/saving.py.
 tests/test_hdf5_min.py adds write -> read round trips and a structural walk against the specification.  Host-side file I/O, not on
 the hot path.
 """

@@ -3,8 +3,10 @@
   reader <- tests/golden/hdf5/*.h5: files written by libhdf5 itself (tests/golden/make_hdf5_fixtures.c) in the shapes h5py 2 / h5py 3 /
             Keras give their weight and full-model files (fixed and variable-length strings, continuation blocks, libver='latest' headers,
             compact + big-endian data, tracked times, a two-level group B-tree) -- committed, so this half runs anywhere;
-  writer -> what save_weights writes for the three graphs is re-read by libhdf5 through ctypes (tests/h5ref.py) and walked by h5dump /
-            h5ls; every dataset, type and attribute must come back identical.  Skipped where no libhdf5 is installed.
+            plus three files the real h5py 3.3.0 wrote with Keras' own call sequence (tests/golden/make_h5py_fixtures.py);
+  writer -> what save_weights writes for the three graphs is re-read by libhdf5 through ctypes (tests/h5ref.py), walked by h5dump /
+            h5ls, and loaded by the real h5py along Keras' load path (tests/h5py_check.py under /opt/conda/bin/python3.9); every dataset,
+            type and attribute must come back identical.  Skipped where no libhdf5 / h5py is installed.
 """
 import glob
 import json
@@ -23,6 +25,7 @@ from covidseg_amd import hdf5_min as H5        # noqa: E402
 from covidseg_amd import weights as W          # noqa: E402
 
 FIX = os.path.join(ROOT, "tests", "golden", "hdf5")
+H5PY_PYTHON = os.environ.get("H5PY_PYTHON", "/opt/conda/bin/python3.9")
 needs_libhdf5 = pytest.mark.skipif(not h5ref.available(), reason="no libhdf5 in this image")
 
 
@@ -41,7 +44,8 @@ SHAPES = {"conv2d_1/kernel:0": (3, 3, 1, 4), "conv2d_1/bias:0": (4,), "batch_nor
 
 # ---- libhdf5 wrote it, hdf5_min reads it ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,version", [("weights_h5py2_earliest", "2.3.1"), ("weights_tracked_times", "2.3.1"),
-                                          ("weights_latest_compact_be", "2.3.1"), ("fullmodel_h5py3_vlen", "2.4.0")])
+                                          ("weights_latest_compact_be", "2.3.1"), ("fullmodel_h5py3_vlen", "2.4.0"),
+                                          ("h5py_keras_weights", "2.3.1"), ("h5py_keras_fullmodel", "2.4.0")])
 def test_reader_on_files_written_by_libhdf5(name, version):
     path = os.path.join(FIX, name + ".h5")
     assert H5.is_hdf5(path)
@@ -55,9 +59,10 @@ def test_reader_on_files_written_by_libhdf5(name, version):
             seen.append(wn)
     assert seen == list(SHAPES)
     root = H5.read_file(path)
-    g = root["model_weights"] if name.startswith("fullmodel") else root
+    full = "fullmodel" in name
+    g = root["model_weights"] if full else root
     assert H5._strs(g.attrs["backend"]) == ["tensorflow"] and H5._strs(g.attrs["keras_version"]) == [version]
-    if name.startswith("fullmodel"):                                  # variable-length UTF-8 strings through the global heap
+    if full:                                                          # variable-length UTF-8 strings through the global heap
         cfg = json.loads(H5._strs(attrs["model_config"])[0])
         assert cfg["class_name"] == "Model" and [l["name"] for l in cfg["config"]["layers"]] == ["input_1", "conv2d_1"]
         assert json.loads(H5._strs(attrs["training_config"])[0])["optimizer_config"]["config"]["lr"] == 0.0005
@@ -65,7 +70,8 @@ def test_reader_on_files_written_by_libhdf5(name, version):
         assert H5._strs(ow.attrs["weight_names"]) == ["Adam/iterations:0", "Adam/conv2d_1/kernel/m:0"]
         assert int(ow["Adam/iterations:0"]) == 1234567890123 and ow["Adam/iterations:0"].dtype == np.int64
         m = ow["Adam/conv2d_1/kernel/m:0"]
-        assert m.dtype == np.float64 and m.shape == (3, 3, 1, 4) and np.array_equal(m.reshape(-1), val(77, 36).astype(np.float64))
+        assert m.dtype == (np.float32 if name.startswith("h5py") else np.float64)                      # the C generator stores this one as float64
+        assert m.shape == (3, 3, 1, 4) and np.array_equal(m.reshape(-1), val(77, 36).astype(m.dtype))
 
 
 def test_reader_walks_a_two_level_group_btree_written_by_libhdf5():
@@ -81,10 +87,18 @@ def test_reader_names_the_feature_it_refuses(name, what):
         H5.read_file(os.path.join(FIX, name + ".h5"))
 
 
+def test_reader_joins_the_attribute_chunks_keras_writes_above_64k():
+    """save_attributes_to_hdf5_group splits `layer_names` into layer_names0, layer_names1, ... (h5py wrote this one)"""
+    root = H5.read_file(os.path.join(FIX, "h5py_keras_chunked_attrs.h5"))
+    names = H5._chunked_attr(root, "layer_names")
+    assert len(names) == 2000 and names[0] == "layer_0000".ljust(40, "x") and names[-1] == "layer_1999".ljust(40, "x")
+    assert "layer_names" not in root.attrs and len(root.children) == 5
+
+
 def test_fixture_set_is_the_generators():
     got = sorted(os.path.basename(p) for p in glob.glob(os.path.join(FIX, "*.h5")))
-    src = open(os.path.join(ROOT, "tests", "golden", "make_hdf5_fixtures.c")).read()
-    assert len(got) == 7 and all(g in src for g in got)
+    src = open(os.path.join(ROOT, "tests", "golden", "make_hdf5_fixtures.c")).read() + open(os.path.join(ROOT, "tests", "golden", "make_h5py_fixtures.py")).read()
+    assert len(got) == 10 and all(g in src for g in got)
 
 
 # ---- hdf5_min wrote it, libhdf5 reads it ----------------------------------------------------------------------------------------
@@ -124,6 +138,34 @@ def test_libhdf5_reads_back_every_weight_file_the_writer_produces(tmp_path, arch
                 assert sum(1 for line in r.stdout.splitlines() if " Dataset " in line) == len(w)
 
 
+@pytest.mark.skipif(not os.path.exists(H5PY_PYTHON), reason="no interpreter with h5py in this image")
+@pytest.mark.parametrize("arch,full_model", [("unet", False), ("unet", True), ("unetpp", True), ("classifier", False)])
+def test_h5py_loads_the_writers_files_the_way_keras_does(tmp_path, arch, full_model):
+    """the real h5py (3.3.0, the image's Anaconda interpreter; the system python has none) opens what save_weights wrote and follows
+    saving.py's load path: layer_names -> group -> weight_names -> datasets"""
+    hw = (32, 32)
+    w = W.init_weights(9, 1, arch, hw)
+    rng = np.random.default_rng(4)
+    w = {k: (v + rng.standard_normal(v.shape).astype(np.float32) * 0.01) for k, v in w.items()}
+    f, out = str(tmp_path / "m.h5"), str(tmp_path / "read.npz")
+    W.save_weights(f, w, 1, arch, hw, full_model=full_model)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([H5PY_PYTHON, os.path.join(ROOT, "tests", "h5py_check.py"), f, out], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(out)
+    layer_lists = W._layer_weight_lists(w, 1, arch, hw)
+    assert list(z["layer_names"]) == [ln for ln, _ in layer_lists]
+    assert str(z["group::backend"]) == "tensorflow" and str(z["group::keras_version"]) == "2.3.1"
+    for ln, ws in layer_lists:
+        assert list(z["weight_names::" + ln]) == [wn for wn, _ in ws]
+        for wn, a in ws:
+            got = z[f"w::{ln}::{wn}"]
+            assert str(z[f"dtype::{ln}::{wn}"]) == "<f4" and got.shape == a.shape and np.array_equal(got, np.asarray(a, np.float32)), (ln, wn)
+    if full_model:
+        cfg = json.loads(str(z["rootattr::model_config"]))
+        assert [l["config"]["name"] for l in cfg["config"]["layers"]] == [ln for ln, _ in layer_lists]
+
+
 @needs_libhdf5
 def test_libhdf5_reads_back_wide_groups_mixed_types_and_scalars(tmp_path):
     """generic trees: 300 links in one group (two-level B-tree, several local-heap growths), int64 / float64 / scalar datasets,
@@ -154,7 +196,8 @@ def test_libhdf5_reads_back_wide_groups_mixed_types_and_scalars(tmp_path):
 @needs_libhdf5
 def test_both_readers_agree_on_the_libhdf5_fixtures():
     """hdf5_min's reading of each readable fixture equals libhdf5's own reading of it"""
-    for name in ("weights_h5py2_earliest", "weights_tracked_times", "weights_latest_compact_be", "fullmodel_h5py3_vlen", "wide_group_two_level_btree"):
+    for name in ("weights_h5py2_earliest", "weights_tracked_times", "weights_latest_compact_be", "fullmodel_h5py3_vlen", "wide_group_two_level_btree",
+                 "h5py_keras_weights", "h5py_keras_fullmodel", "h5py_keras_chunked_attrs"):
         path = os.path.join(FIX, name + ".h5")
         dsets, _, attrs, _ = h5ref.read_tree(path)
         root = H5.read_file(path)
