@@ -624,8 +624,11 @@ bool h2_conv3x3_selected(int algo, int K, int M) { return algo == UNET_ALGO_AUTO
 // bytes of the split weight image: 256-B header + 36 * K * M' (M' = M rounded up to whole 32-channel blocks; fits unet_conv3x3_w_ws_floats)
 size_t h2_wimg_bytes(int K, int M) { return (size_t)H2_HEADER + (size_t)36 * K * ((M + 31) / 32 * 32); }
 
-static int h2_nb_convT_fwd() { return 2; }
-static int h2_nb_convT_dgrad(int cin) { return (cin % 64) == 0 ? 2 : 1; }
+// ConvT: one tap, so a staged pixel patch feeds only NB x 32 output columns per k-step (a conv3x3 patch feeds 9 x that): four blocks per workgroup over 8-row
+// tiles instead of two over 16 rows -- the same accumulators and MFMAs per chunk, half the pixels scaled, split and stored per MFMA
+// (eight blocks over 4-row tiles measured slower again: u6 / u7 forward 0.072 -> 0.079, 0.085 -> 0.093 ms)
+static int h2_nb_convT_fwd() { return 4; }
+static int h2_nb_convT_dgrad(int cin) { return (cin % 128) == 0 ? 4 : (cin % 64) == 0 ? 2 : 1; }
 
 // One item of a preparation batch.  kind 0: conv3x3 forward image (K = cin, M = cout), 1: conv3x3 data-gradient image (flipped taps, K = cout, M = cin),
 // 2: ConvT forward (K = cin, M = 4 cout; Keras kernel [2][2][cout][cin]), 3: ConvT data gradient (K = 4 cout, M = cin).  cs: per-INPUT-channel factor of a
@@ -714,7 +717,7 @@ int32_t k_convT_h2_fwd(unet_ctx* ctx, const float* x, const float* w, const floa
     prepared = ctx->convt_img;
   }
   const unet_bf16* img = static_cast<const unet_bf16*>(prepared);
-  return launch_h2<1, 2, 4, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
+  return launch_h2<1, 4, 2, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
 }
 
 // dx[n,i,j,c] = sum_{ab,o} dU[n,2i+a,2j+b,o] * K[ab,o,c]; dy = channel slice with pixel stride lddy; mask: ReLU of the producer of x
@@ -729,6 +732,7 @@ int32_t k_convT_h2_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float* 
   }
   const unet_bf16* img = static_cast<const unet_bf16*>(prepared);
   const int mm = mask ? (mask_bits ? MASK_RELU_BITS : MASK_RELU) : MASK_NONE;
+  if (NB == 4) return launch_h2<2, 4, 2, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
   if (NB == 2) return launch_h2<2, 2, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
   return launch_h2<2, 1, 4, 2>(ctx, dy, lddy, img, nullptr, mask, mm, dx, cin, n, h, wd, 4 * cout, cin, ACT_NONE, 0.0f, 0, s);
 }
