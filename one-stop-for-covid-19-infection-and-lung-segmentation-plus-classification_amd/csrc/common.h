@@ -226,6 +226,8 @@ size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);
 int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                             float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
+bool c1_relu_bits_supported(int wd, int cout);
+int32_t k_conv3x3_c1_fwd_bits(unet_ctx*, const float* x, const float* w, const float* bias, float* y, unsigned long long* signs, int n, int h, int wd, int cout, hipStream_t s);
 int32_t k_conv3x3_c1_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, int n, int h,
                          int wd, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 size_t c1_wgrad_ws_bytes(int cout);

@@ -122,6 +122,57 @@ __global__ __launch_bounds__(TPB) void conv3x3_c1x4_kernel(const float* __restri
   }
 }
 
+// The same layer also leaving the ReLU sign bits of what it stores (MASK_RELU_BITS, common.h: the mask of the next conv's data gradient in 1/32 of the bytes).
+// Cout = 32, W % 8 == 0, ReLU, no dropout.  A wave owns 8 pixels of a row x 4 rows; lane (g, sub) = (lane / 8, lane % 8) computes channel quad `sub` of pixel
+// column g, one row per step (the 6 x 3 input window of the four rows stays in registers) -- so the wave's ballot of "component q > 0" in step t IS word q of
+// the (8 pixels x 32 channels) cell of row t (bit = (pixel % 8) * 8 + quad), and each step's store is one contiguous KB.
+__global__ __launch_bounds__(TPB) void conv3x3_c1_bits_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                                              unsigned long long* __restrict__ signs, int N, int H, int W) {
+  const int lane = threadIdx.x & 63, sub = lane & 7, gl = lane >> 3;
+  float4 wr[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wr[t] = *reinterpret_cast<const float4*>(w + t * 32 + sub * 4);
+  const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + sub * 4) : make_float4(0, 0, 0, 0);
+  const unsigned W8 = (unsigned)W >> 3, H4 = ((unsigned)H + 3) >> 2;
+  const long long items = (long long)N * H4 * W8;
+  const long long s0 = ((long long)blockIdx.x * TPB + threadIdx.x) >> 6, ss = ((long long)gridDim.x * TPB) >> 6;
+  for (long long it = s0; it < items; it += ss) {
+    const unsigned iu = (unsigned)it, rq = iu / W8;                      // (n, row quad)
+    const int xc = (int)(iu - rq * W8), n = (int)(rq / H4), i0 = (int)(rq - (unsigned)n * H4) * 4;
+    const int j = xc * 8 + gl;
+    const float* img = x + (long long)n * H * W;
+    float v[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int ii = i0 + a - 1;
+      const bool rok = ii >= 0 && ii < H;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int jj = j + b - 1;
+        v[a][b] = (rok && jj >= 0 && jj < W) ? img[(long long)ii * W + jj] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (i0 + t >= H) break;                                            // (wave-uniform)
+      float4 acc = b4;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const float xv = v[t + a][b]; const float4 kk = wr[a * 3 + b];
+          acc.x = fmaf(xv, kk.x, acc.x); acc.y = fmaf(xv, kk.y, acc.y); acc.z = fmaf(xv, kk.z, acc.z); acc.w = fmaf(xv, kk.w, acc.w);
+        }
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+      const long long row = (long long)n * H + i0 + t;
+      st4(y + (row * W + j) * 32 + sub * 4, acc);
+      const unsigned long long q0 = __builtin_amdgcn_ballot_w64(acc.x > 0.f), q1 = __builtin_amdgcn_ballot_w64(acc.y > 0.f);
+      const unsigned long long q2 = __builtin_amdgcn_ballot_w64(acc.z > 0.f), q3 = __builtin_amdgcn_ballot_w64(acc.w > 0.f);
+      if (lane < 4) signs[(row * W8 + xc) * 4 + lane] = lane == 0 ? q0 : lane == 1 ? q1 : lane == 2 ? q2 : q3;
+    }
+  }
+}
+
 // wt[t'][co][ci] = w[8-t'][ci][co]: weights of the data-gradient convolution.
 __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin, int Cout) {
   const int total = 9 * Cin * Cout;
@@ -354,6 +405,14 @@ static int32_t c1_fwd_impl(unet_ctx* ctx, const float* x, const float* w, const 
 }
 int32_t k_conv3x3_c1_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int cout, int act, float rate,
                          uint64_t seed, hipStream_t s) { return c1_fwd_impl(ctx, x, w, bias, y, n, h, wd, cout, act, rate, seed, s); }
+bool c1_relu_bits_supported(int wd, int cout) { return cout == 32 && wd >= 8 && (wd & 7) == 0; }
+// ... + the ReLU sign bits of y (layout of MASK_RELU_BITS, M = 32): ReLU only
+int32_t k_conv3x3_c1_fwd_bits(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, unsigned long long* signs, int n, int h, int wd, int cout, hipStream_t s) {
+  if (!c1_relu_bits_supported(wd, cout) || !signs || (long long)n * h * wd >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_c1 + sign bits: cout=%d W=%d unsupported", cout, wd);
+  const long long items = (long long)n * ((h + 3) / 4) * (wd / 8);          // one wave per (8 pixels x 4 rows)
+  hipLaunchKernelGGL(conv3x3_c1_bits_kernel, dim3(grid_for(items * 64, 4096)), dim3(TPB), 0, s, x, w, bias, y, signs, n, h, wd);
+  UNET_CHECK_LAUNCH(ctx, "conv3x3_c1_bits_fwd"); return UNET_OK;
+}
 int32_t k_conv3x3_c1_fwd_bf16(unet_ctx* ctx, const float* x, const float* w, const float* bias, unet_bf16* y, int n, int h, int wd, int cout, int act,
                               float rate, uint64_t seed, hipStream_t s) { return c1_fwd_impl(ctx, x, w, bias, y, n, h, wd, cout, act, rate, seed, s); }
 

@@ -116,8 +116,15 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
     w = uws;
   }
   if (use_mfma(algo, cin, cout)) return k_conv3x3_mfma_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
-  if (cin == 1 && !mask && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0)
+  if (cin == 1 && !mask && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0) {
+    if (ctx->signs_req && act == ACT_RELU && rate == 0.0f && c1_relu_bits_supported(wd, cout)) {          // (armed: unet_request_relu_bits)
+      unsigned long long* q = ctx->signs_req; ctx->signs_req = nullptr;
+      int32_t r = k_conv3x3_c1_fwd_bits(ctx, x, w, bias, y, q, n, h, wd, cout, s);
+      if (!r) ctx->signs_done = q;
+      return r;
+    }
     return k_conv3x3_c1_fwd(ctx, x, w, bias, y, n, h, wd, cout, act, rate, seed, s);
+  }
   return k_conv3x3_naive_fwd(ctx, x, w, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
 }
 
@@ -145,6 +152,7 @@ int32_t unet_request_bn_stats(unet_ctx* ctx, int32_t c) {
 // ReLU masks as one bit per element (MASK_RELU_BITS, common.h): which (forward conv, data gradient) pairs can use them, how big the bit tensor is, arming
 int32_t unet_relu_bits_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout) {
   if (cin < 1 || cout < 1 || (cout & 31) || (wd & 7) || h < 1) return 0;
+  if (cin == 1) return algo == UNET_ALGO_AUTO && c1_relu_bits_supported(wd, cout) ? 1 : 0;          // the first layer's own kernel (T1:859)
   return h2_conv3x3_selected(algo, cin, cout) ? 1 : 0;
 }
 size_t unet_relu_bits_bytes(int32_t n, int32_t h, int32_t wd, int32_t c) { return n > 0 && h > 0 && wd > 0 && c > 0 ? (size_t)n * h * wd * c / 8 : 0; }
@@ -531,8 +539,12 @@ void plan_workspace(unet_model* m) {
   if (!m->dt && m->ctx->opt_relu_bits) {
     auto h2_conv = [&](int w, int K, int M) { (void)w; return h2_conv3x3_selected(m->algo, K, M); };
     for (auto& l : m->layers) {
-      if (l.kind != 0 || l.cin <= 1) continue;
+      if (l.kind != 0) continue;
       const Buf ob = m->act.at(l.name);
+      if (l.cin == 1) {                                                                             // c1a: the Cin = 1 kernel writes the bits of c1b's data-gradient mask
+        if (m->algo == UNET_ALGO_AUTO && c1_relu_bits_supported(ob.w, l.cout) && h2_conv(ob.w, l.cout, l.cout)) m->sign_off[l.name] = cv.take((size_t)ob.n * ob.h * ob.w * l.cout / 32);
+        continue;
+      }
       if ((l.cout & 31) || (ob.w & 7) || !h2_conv(ob.w, l.cin, l.cout)) continue;
       const char last = l.name.back();
       bool used = false;

@@ -744,7 +744,7 @@ def test_convT_epilogue_bn_statistics_of_the_up_half(ops, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 24, 40, 32, 32), (1, 16, 72, 64, 64), (2, 9, 16, 128, 32), (1, 33, 8, 32, 96)])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 32, 32), (1, 16, 72, 64, 64), (2, 9, 16, 128, 32), (1, 33, 8, 32, 96), (2, 9, 64, 1, 32), (1, 5, 32, 1, 32), (3, 14, 24, 1, 32)])          # (Cin = 1: the first layer's own kernel, T1:859)
 def test_relu_masks_as_one_bit_per_element(ops, shape):
     """The backward of a Conv(relu) -> Conv pair (T1:859-860) reads the first conv's output only as `> 0`: unet_request_relu_bits makes the forward conv
     write that as one bit per element, unet_conv3x3_bwd_data(mask_mode = UNET_MASK_RELU_BITS) reads 1/32 of the bytes.  The bits must be exactly
