@@ -77,11 +77,16 @@ def test_two_ranks_equal_single_process_full_batch(tmp_path, arch):
     top = max(rms.values())
     for k, v in wref.items():
         a = got["w/" + k]
-        if k in rms and rms[k] < 1e-5 * top:
-            assert np.abs(a - v).max() <= 2 * steps * lr * 1.01, k
+        if k not in grads0:                                           # BatchNorm moving statistics: the second step's batch statistics see the first step's weights
+            assert np.linalg.norm(a - v) <= 5e-4 * np.linalg.norm(v) + 1e-6 * np.sqrt(v.size), k
             continue
-        upd = np.linalg.norm(v - wts[k]) if k in wts else 0.0
-        assert np.linalg.norm(a - v) <= 0.02 * upd + 2e-3 * np.linalg.norm(v) * (k not in wts) + 1e-7 * np.sqrt(v.size), (k, float(np.linalg.norm(a - v)), float(upd))
+        # per element: where the full-batch gradient is well above its summation noise the two runs took the same steps (2 % of the largest possible update);
+        # where it is not (a bias in front of a BatchNorm has an exactly zero true gradient, a dead unit's weights too) only Adam's bound 2 steps x 2 x lr holds
+        noisy = np.abs(grads0[k]) < 1e-3 * rms[k] + 1e-5 * top
+        tol = 0.02 * steps * lr + np.where(noisy, 2 * steps * lr, 0.0)
+        bad = np.abs(a - v) > tol
+        assert not bad.any(), (k, int(bad.sum()), float(np.abs(a - v).max()))
+        assert noisy.mean() < 0.5 or rms[k] < 1e-4 * top, (k, float(noisy.mean()))          # (the loose bound must stay the exception)
 
 
 def test_two_ranks_bf16_storage_match_full_batch(tmp_path):
