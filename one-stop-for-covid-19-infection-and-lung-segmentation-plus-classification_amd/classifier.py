@@ -155,8 +155,11 @@ class ClassifierModel:
         W.save_weights(path, self.backend.get_weights(), self.in_ch, "classifier", self._hw)
 
     def save(self, path):
-        """model.save(path): what ModelCheckpoint(filepath_loss, ...) writes (T2:820) -- `model_weights/` + `model_config`."""
-        W.save_weights(path, self.backend.get_weights(), self.in_ch, "classifier", self._hw, full_model=True)
+        """model.save(path): what ModelCheckpoint(filepath_loss, ...) writes (T2:820) -- `model_weights/` + `model_config` and the optimizer of a compiled model."""
+        opt = self.backend.get_optimizer_state() if self.compiled and hasattr(self.backend, "get_optimizer_state") else None
+        if opt is not None:
+            opt = dict(opt, loss="binary_crossentropy", metrics=["f1"])
+        W.save_weights(path, self.backend.get_weights(), self.in_ch, "classifier", self._hw, full_model=True, optimizer=opt)
 
     def load_weights(self, path):
         self.backend.set_weights(W.load_weights(path, self.in_ch, "classifier", self._hw))

@@ -162,6 +162,26 @@ class HipUNet:
     def reset_optimizer(self):
         self.adam_m.zero_(); self.adam_v.zero_(); self.step = 0
 
+    def get_optimizer_state(self):
+        """Adam's iteration count and moment slots keyed by tensor name (what Keras keeps in optimizer.weights, saved by model.save T1:1046-1047)"""
+        m, v = self.adam_m.cpu().numpy(), self.adam_v.cpu().numpy()
+        sl = [(name, off, cnt, shape) for name, (st, off, cnt, shape) in self._tinfo.items() if not st]
+        return {"step": int(self.step), "lr": float(self.lr), "m": OrderedDict((n, m[o:o + c].reshape(s).copy()) for n, o, c, s in sl),
+                "v": OrderedDict((n, v[o:o + c].reshape(s).copy()) for n, o, c, s in sl)}
+
+    def set_optimizer_state(self, state):
+        torch = _torch()
+        for name, (st, off, cnt, shape) in self._tinfo.items():
+            if st:
+                continue
+            for buf, src in ((self.adam_m, state["m"]), (self.adam_v, state["v"])):
+                a = np.ascontiguousarray(np.asarray(src[name], np.float32).reshape(-1))
+                assert a.size == cnt, name
+                buf[off:off + cnt].copy_(torch.from_numpy(a))
+        self.step = int(state["step"])
+        if "lr" in state:
+            self.lr = float(state["lr"])
+
     # ------------------------------------------------------------------ running programs
     def _to_dev(self, a):
         torch = _torch()

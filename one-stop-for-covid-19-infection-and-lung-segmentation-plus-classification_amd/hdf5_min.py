@@ -543,18 +543,28 @@ def _chunked_attr(g: Group, name: str):
     return out
 
 
-def save_keras_weights(path, layers, full_model: bool = False, model_config: str | None = None, keras_version: str = "2.3.1", backend: str = "tensorflow") -> None:
+def save_keras_weights(path, layers, full_model: bool = False, model_config: str | None = None, keras_version: str = "2.3.1", backend: str = "tensorflow",
+                       optimizer_weights=None, training_config: str | None = None) -> None:
     """layers: [(layer_name, [(weight_name, array), ...])] in model.layers order, weight-less layers included with [].
     full_model=False: the layout of model.save_weights (attributes and layer groups at the root, T1:1079);
     full_model=True: the layout of model.save / ModelCheckpoint(save_weights_only=False) (T1:1046-1047): the same under `model_weights/`,
-    `model_config` (+ keras_version, backend) as root attributes; optimizer state is not written (Keras loads such a file with a
-    "No training configuration found" warning; load_weights ignores everything but `model_weights`)."""
+    `model_config` (+ keras_version, backend) as root attributes.  optimizer_weights ([(name, array)] in optimizer.weights order) and
+    training_config (JSON) add what saving.py `_serialize_model` writes for a compiled model: the `optimizer_weights/` group with its
+    `weight_names` attribute and the `training_config` root attribute; without them Keras loads the file with a "No training configuration
+    found" warning.  load_weights ignores everything but `model_weights`."""
     root = Group()
     g = root.create_group("model_weights") if full_model else root
     if full_model:
         root.attrs["keras_version"] = keras_version; root.attrs["backend"] = backend
         if model_config is not None:
             root.attrs["model_config"] = model_config
+        if training_config is not None:
+            root.attrs["training_config"] = training_config
+        if optimizer_weights:
+            og = root.create_group("optimizer_weights")
+            og.attrs["weight_names"] = [n for n, _ in optimizer_weights]
+            for n, a in optimizer_weights:
+                og.create_dataset(n, np.asarray(a))
     g.attrs["layer_names"] = [n for n, _ in layers] if layers else np.zeros((0,), "S1")
     g.attrs["backend"] = backend; g.attrs["keras_version"] = keras_version
     for lname, ws in layers:
@@ -587,3 +597,15 @@ def load_keras_weights(path):
             ws[wn] = np.asarray(a, np.float32)
         out[ln] = ws
     return out, dict(root.attrs)
+
+
+def load_keras_optimizer(path):
+    """-> ([(name, array)] in `weight_names` order, training_config JSON string) of a full-model file, or (None, None) where the file has none
+    (saving.py `_deserialize_model`: optimizer_weights_group.attrs['weight_names'] -> optimizer.set_weights)"""
+    root = read_file(path)
+    tc = root.attrs.get("training_config")
+    tc = _strs(tc)[0] if tc is not None else None
+    if "optimizer_weights" not in root:
+        return None, tc
+    og = root["optimizer_weights"]
+    return [(n, np.asarray(og[n])) for n in _chunked_attr(og, "weight_names")], tc

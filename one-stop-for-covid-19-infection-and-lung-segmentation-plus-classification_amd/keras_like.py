@@ -52,6 +52,40 @@ def dp_shard(idx, world, rank):
     return idx, {"replicated": True}
 
 
+def load_model(path, backend=None, custom_objects=None, compile=True, **backend_kw):
+    """keras.models.load_model(path) (imported by every script of the reference, T1:67): the graph named by the file's `model_config`, its weights, and -- when
+    the file carries them and compile is true -- the compiled state: Adam's learning rate, iteration count and moment slots, so a further fit() continues the
+    saved one.  custom_objects is accepted for signature compatibility (the losses / metrics of the path are built in)."""
+    import json
+    from . import hdf5_min as H5
+    from . import keras_graph as KG
+    root = H5.read_file(path)
+    if "model_config" not in root.attrs:
+        raise ValueError(f"{path}: no `model_config` attribute -- a weights-only file (use load_weights)")
+    cfg = json.loads(H5._strs(root.attrs["model_config"])[0])
+    layers = cfg["config"]["layers"] if isinstance(cfg["config"], dict) else cfg["config"]
+    shape = next((l["config"]["batch_input_shape"] for l in layers if "batch_input_shape" in l.get("config", {})), None)
+    if shape is None:
+        raise ValueError(f"{path}: model_config carries no batch_input_shape")
+    h, w, in_ch = int(shape[1]), int(shape[2]), int(shape[3])
+    names = [l["config"]["name"] for l in layers]
+    arch = next((a for a in (("classifier",) if cfg["class_name"] == "Sequential" else ("unet", "unetpp"))
+                 if [l["name"] for l in KG.keras_layers(in_ch, a, (h, w))] == names), None)
+    if arch is None or h != w:
+        raise ValueError(f"{path}: the saved graph ({cfg['class_name']}, {len(names)} layers, input {shape}) is none of the three this engine runs")
+    if arch == "classifier":
+        from .classifier import ClassifierModel
+        model = ClassifierModel(h, in_ch, backend=backend, **backend_kw)
+    else:
+        model = UNetModel(h, in_ch, backend=backend, arch=arch, **backend_kw)
+    model.load_weights(path)
+    opt = W.load_optimizer(path, in_ch, arch, (h, w)) if compile else None
+    if opt is not None:
+        model.compile(lr=opt["lr"])                                  # (the loss / metrics of the path are the model class's own: T1:1053, T2:829)
+        model.backend.set_optimizer_state(opt)
+    return model
+
+
 class History:
     def __init__(self):
         self.history = {"loss": [], "dice_coeff": [], "val_loss": [], "val_dice_coeff": []}
@@ -100,9 +134,10 @@ class UNetModel:
         W.save_weights(path, self.backend.get_weights(), self.in_ch, self.arch, (self.h, self.w))
 
     def save(self, path):
-        """model.save(path) -- what ModelCheckpoint(save_weights_only=False) calls (T1:1046-1047): `model_weights/` + `model_config`;
-        optimizer state is not written."""
-        W.save_weights(path, self.backend.get_weights(), self.in_ch, self.arch, (self.h, self.w), full_model=True)
+        """model.save(path) -- what ModelCheckpoint(save_weights_only=False) calls (T1:1046-1047): `model_weights/` + `model_config` and, for a compiled
+        model, the optimizer (`training_config`, `optimizer_weights/`: Adam's iteration count and moment slots) so that load_model resumes the fit."""
+        opt = self.backend.get_optimizer_state() if self.compiled and hasattr(self.backend, "get_optimizer_state") else None
+        W.save_weights(path, self.backend.get_weights(), self.in_ch, self.arch, (self.h, self.w), full_model=True, optimizer=opt)
 
     def load_weights(self, path):
         self.backend.set_weights(W.load_weights(path, self.in_ch, self.arch, (self.h, self.w)))

@@ -178,11 +178,63 @@ def _layer_weight_lists(weights, in_ch, arch, hw):
     return out
 
 
-def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet", hw=None, full_model: bool = False):
+ADAM_DEFAULTS = {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-7, "decay": 0.0, "amsgrad": False}          # Adam(lr=0.0005), T1:1053
+
+
+def trainable_names(in_ch: int = 1, arch: str = "unet", hw=None):
+    """engine tensor names in Keras' model.trainable_weights order (layer order; kernel, bias / gamma, beta)"""
+    order = []
+    for _, ws in _layer_weight_lists({k: np.zeros(0, np.float32) for k in weight_shapes(in_ch, arch, hw)}, in_ch, arch, hw):
+        order += [n for n, _ in ws if not (n.endswith("moving_mean:0") or n.endswith("moving_variance:0"))]
+    back = {v: k for k, v in keras_names(in_ch, arch, hw).items()}
+    return [back[n] for n in order]
+
+
+def _optimizer_lists(opt, in_ch, arch, hw):
+    """Keras 2.3 Adam: optimizer.weights = [iterations] + ms + vs + vhats (vhat_i = zeros(1) without amsgrad), created under the name scopes
+    Adam/ (iterations) and training/Adam/ (keras/optimizers.py Adam.get_updates)"""
+    names = trainable_names(in_ch, arch, hw)
+    out = [("Adam/iterations:0", np.asarray(int(opt["step"]), np.int64))]
+    out += [(f"training/Adam/m_{i}:0", np.asarray(opt["m"][k], np.float32)) for i, k in enumerate(names)]
+    out += [(f"training/Adam/v_{i}:0", np.asarray(opt["v"][k], np.float32)) for i, k in enumerate(names)]
+    out += [(f"training/Adam/vhat_{i}:0", np.zeros(1, np.float32)) for i in range(len(names))]
+    cfg = {"optimizer_config": {"class_name": "Adam", "config": dict(ADAM_DEFAULTS, learning_rate=float(opt["lr"]))},
+           "loss": opt.get("loss", "bce_dice_loss"), "metrics": list(opt.get("metrics", ["dice_coeff"])), "weighted_metrics": None, "sample_weight_mode": None,
+           "loss_weights": None}
+    return out, json.dumps(cfg)
+
+
+def load_optimizer(path: str, in_ch: int = 1, arch: str = "unet", hw=None):
+    """The optimizer state of a full-model file (model.save / ModelCheckpoint, T1:1046-1047) -> {"step", "lr", "m": {...}, "v": {...}, "loss", "metrics"} keyed by
+    engine tensor names, or None when the file carries none.  Keras restores by position (optimizer.set_weights); so does this."""
+    from . import hdf5_min as H5
+    ows, tc = H5.load_keras_optimizer(path)
+    if not ows:
+        return None
+    names = trainable_names(in_ch, arch, hw)
+    sh = weight_shapes(in_ch, arch, hw)
+    P = len(names)
+    if len(ows) not in (1 + 2 * P, 1 + 3 * P):
+        raise ValueError(f"{path}: {len(ows)} optimizer weights for {P} trainable tensors (expected iterations + m + v [+ vhat])")
+    vals = [a for _, a in ows]
+    m = OrderedDict(); v = OrderedDict()
+    for i, k in enumerate(names):
+        for dst, a in ((m, vals[1 + i]), (v, vals[1 + P + i])):
+            if tuple(a.shape) != tuple(sh[k]):
+                raise ValueError(f"{path}: optimizer slot of {k} has shape {a.shape}, the graph wants {sh[k]}")
+            dst[k] = np.asarray(a, np.float32)
+    cfg = json.loads(tc) if tc else {}
+    oc = cfg.get("optimizer_config", {}).get("config", {})
+    return {"step": int(np.asarray(vals[0]).reshape(-1)[0]), "lr": float(oc.get("learning_rate", oc.get("lr", 0.0005))), "m": m, "v": v,
+            "loss": cfg.get("loss", "bce_dice_loss"), "metrics": cfg.get("metrics", ["dice_coeff"])}
+
+
+def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet", hw=None, full_model: bool = False, optimizer=None):
     """model.save_weights(path) (T1:1079) / the file ModelCheckpoint writes (T1:1046-1047, `full_model=True`): a Keras HDF5 weight file --
     root (or `model_weights/`) attributes `layer_names`, `backend`, `keras_version`; one group per layer with `weight_names` and the
-    datasets `<layer>/<layer>/kernel:0` ... (hdf5_min.py).  A path ending in `.npz` writes a NumPy archive keyed by the same Keras
-    weight names instead."""
+    datasets `<layer>/<layer>/kernel:0` ... (hdf5_min.py).  optimizer ({"step", "lr", "m", "v"}: engine.get_optimizer_state) adds the
+    `optimizer_weights/` group and `training_config` of a compiled model's full-model file.  A path ending in `.npz` writes a NumPy archive
+    keyed by the same Keras weight names instead."""
     if str(path).endswith(".npz"):
         kn = keras_names(in_ch, arch, hw)
         with open(path, "wb") as f:
@@ -194,7 +246,10 @@ def save_weights(path: str, weights, in_ch: int = 1, arch: str = "unet", hw=None
         from . import keras_graph as KG
         h, w = hw or ((224, 224) if arch != "classifier" else CLS_HW)
         cfg = KG.to_json(h, w, in_ch, arch)
-    H5.save_keras_weights(path, _layer_weight_lists(weights, in_ch, arch, hw), full_model=full_model, model_config=cfg)
+    ow = tc = None
+    if full_model and optimizer is not None:
+        ow, tc = _optimizer_lists(optimizer, in_ch, arch, hw)
+    H5.save_keras_weights(path, _layer_weight_lists(weights, in_ch, arch, hw), full_model=full_model, model_config=cfg, optimizer_weights=ow, training_config=tc)
 
 
 def load_weights(path: str, in_ch: int = 1, arch: str = "unet", hw=None):

@@ -33,6 +33,13 @@ def main(path, out):
                 assert d.chunks is None and d.compression is None
                 res["w::" + ln + "::" + n] = np.asarray(d)
                 res["dtype::" + ln + "::" + n] = np.array(d.dtype.str)
+        if "optimizer_weights" in f:                                   # saving.py _deserialize_model: weight_names -> [group[n] for n in names] -> optimizer.set_weights
+            og = f["optimizer_weights"]
+            on = [s(n) for n in og.attrs["weight_names"]]
+            res["optimizer_weight_names"] = np.array(on)
+            for i, n in enumerate(on):
+                res["ow::%d" % i] = np.asarray(og[n])
+            res["training_config"] = np.array(s(f.attrs["training_config"]))
         n_obj = [0]
         f.visititems(lambda name, obj: n_obj.__setitem__(0, n_obj[0] + 1))
         res["n_objects"] = np.array(n_obj[0])

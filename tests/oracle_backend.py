@@ -28,6 +28,15 @@ class OracleBackend:
             self.tr.m[k][...] = 0; self.tr.v[k][...] = 0
         self.tr.t = 0
 
+    def get_optimizer_state(self):
+        return {"step": int(self.tr.t), "lr": float(self.lr), "m": {k: np.array(v, np.float32) for k, v in self.tr.m.items()},
+                "v": {k: np.array(v, np.float32) for k, v in self.tr.v.items()}}
+
+    def set_optimizer_state(self, st):
+        for k in self.tr.m:
+            self.tr.m[k][...] = st["m"][k]; self.tr.v[k][...] = st["v"][k]
+        self.tr.t = int(st["step"]); self.lr = float(st.get("lr", self.lr))
+
     def train_batch(self, x, y, training_dropout=True):
         assert abs(self.lr - O.ADAM_LR) < 1e-12
         return np.array(self.tr.train_step(x, y, None))

@@ -418,3 +418,34 @@ def test_context_options_select_the_graph_forms_in_one_process():
         for k in g:
             assert relerr(g[k], gref[k]) < 2e-5, (opts, k, relerr(g[k], gref[k]))
     assert ref.lib.unet_ctx_set_option(ref.ctx.handle, 99, 1) != 0 and ref.lib.unet_ctx_set_option(ref.ctx.handle, _lib.OPTIONS["bn_fold"], 3) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["unet", "classifier"])
+def test_load_model_resumes_a_fit_bit_for_bit(tmp_path, arch):
+    """model.save (ModelCheckpoint, T1:1046-1047 / T2:820) of a compiled model carries Adam's state; load_model (T1:67) puts it back: 2 + 3 steps through the
+    file == 5 steps in one go, every weight bit-identical (deterministic engines, dropout off: the dropout stream position is not part of a Keras file either)"""
+    from covidseg_amd.classifier import ClassifierModel
+    from covidseg_amd.data import synthetic_classification, synthetic_ct
+    from covidseg_amd.keras_like import UNetModel, load_model
+    kw = dict(options={"deterministic": 1}, dropout_rate=0.0)
+    if arch == "classifier":
+        x, y = synthetic_classification(8, 32, seed=2); y = y.astype(np.float32)
+        a = ClassifierModel(32, seed=3, options={"deterministic": 1}); a.backend.dropout_rate = 0.0
+    else:
+        x, y = synthetic_ct(4, 32, seed=2)
+        a = UNetModel(32, seed=3, arch=arch, **kw)
+    a.compile(lr=0.0005)
+    for _ in range(2):
+        a.backend.train_batch(x, y, False)
+    f = str(tmp_path / "ckpt.hdf5")
+    a.save(f)
+    b = load_model(f, **(dict(options={"deterministic": 1}) if arch == "classifier" else kw))
+    assert b.compiled and b.backend.step == 2 and type(b) is type(a)
+    for _ in range(3):
+        la = a.backend.train_batch(x, y, False); lb = b.backend.train_batch(x, y, False)
+    assert torch.equal(la, lb)
+    wa, wb = a.get_weights(), b.get_weights()
+    assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+    oa, ob = a.backend.get_optimizer_state(), b.backend.get_optimizer_state()
+    assert oa["step"] == ob["step"] == 5 and all(np.array_equal(oa["m"][k], ob["m"][k]) and np.array_equal(oa["v"][k], ob["v"][k]) for k in oa["m"])

@@ -166,6 +166,36 @@ def test_h5py_loads_the_writers_files_the_way_keras_does(tmp_path, arch, full_mo
         assert [l["config"]["name"] for l in cfg["config"]["layers"]] == [ln for ln, _ in layer_lists]
 
 
+@pytest.mark.skipif(not os.path.exists(H5PY_PYTHON), reason="no interpreter with h5py in this image")
+def test_h5py_reads_the_optimizer_of_a_compiled_models_file(tmp_path):
+    """model.save of a compiled model (T1:1046-1047): h5py follows saving.py's `_deserialize_model` -- training_config, optimizer_weights.attrs['weight_names'],
+    one dataset per name -- and gets Adam's iteration count (int64 scalar) and slots back, in optimizer.weights order (iterations, m, v, vhat placeholders)"""
+    hw = (32, 32)
+    w = W.init_weights(3, 1, "unet", hw)
+    names = W.trainable_names(1, "unet", hw)
+    rng = np.random.default_rng(6)
+    opt = {"step": 41, "lr": 5e-4, "m": {k: rng.standard_normal(w[k].shape).astype(np.float32) for k in names}, "v": {k: rng.random(w[k].shape).astype(np.float32) for k in names}}
+    f, out = str(tmp_path / "unet_covid_weights_val_loss.hdf5"), str(tmp_path / "read.npz")
+    W.save_weights(f, w, 1, "unet", hw, full_model=True, optimizer=opt)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([H5PY_PYTHON, os.path.join(ROOT, "tests", "h5py_check.py"), f, out], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(out)
+    P = len(names)
+    on = list(z["optimizer_weight_names"])
+    assert len(on) == 1 + 3 * P and on[0] == "Adam/iterations:0" and on[1] == "training/Adam/m_0:0" and on[1 + P] == "training/Adam/v_0:0"
+    assert z["ow::0"].dtype == np.int64 and z["ow::0"].shape == () and int(z["ow::0"]) == 41
+    for i, k in enumerate(names):
+        assert np.array_equal(z["ow::%d" % (1 + i)], opt["m"][k]) and np.array_equal(z["ow::%d" % (1 + P + i)], opt["v"][k]), k
+        assert z["ow::%d" % (1 + 2 * P + i)].shape == (1,)
+    tc = json.loads(str(z["training_config"]))
+    assert tc["optimizer_config"] == {"class_name": "Adam", "config": {"beta_1": 0.9, "beta_2": 0.999, "epsilon": 1e-07, "decay": 0.0, "amsgrad": False, "learning_rate": 0.0005}}
+    assert tc["loss"] == "bce_dice_loss" and tc["metrics"] == ["dice_coeff"]
+    if h5ref.H5DUMP:
+        r = subprocess.run([h5ref.H5DUMP, "-H", f], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "error" not in r.stderr.lower()
+
+
 @needs_libhdf5
 def test_libhdf5_reads_back_wide_groups_mixed_types_and_scalars(tmp_path):
     """generic trees: 300 links in one group (two-level B-tree, several local-heap growths), int64 / float64 / scalar datasets,

@@ -1,5 +1,6 @@
 """CPU tests of the HOST logic (fit / evaluate / checkpoints / runners / weight files) with the CPU oracle
 injected as the backend (tests/oracle_backend.py).  The product's default backend is the HIP engine."""
+import json
 import os
 
 import numpy as np
@@ -43,6 +44,39 @@ def test_fit_history_batches_and_checkpoints(tmp_path):
     vals = np.array(vals)
     assert h.history["loss"][0] == pytest.approx(np.average(vals[:, 0], weights=sizes), rel=1e-6)
     assert h.history["dice_coeff"][0] == pytest.approx(vals[:, 1].mean(), rel=1e-6)
+
+
+def test_model_save_carries_the_optimizer_and_load_model_resumes_the_fit(tmp_path):
+    """model.save / ModelCheckpoint write a compiled model's optimizer (T1:1046-1047: `training_config`, `optimizer_weights/` = Adam's iteration count and moment
+    slots in optimizer.weights order); keras.models.load_model (T1:67) restores it: 2 + 3 steps through a file == 5 steps in one go, bit for bit (oracle backend)."""
+    from covidseg_amd.keras_like import load_model
+    from covidseg_amd import hdf5_min as H5
+    x, y = synthetic_ct(4, 16, seed=1)
+    a = small_model(); a.compile(lr=0.0005)
+    for _ in range(2):
+        a.backend.train_batch(x, y)
+    f = str(tmp_path / "unet_covid_weights_dice_coeff.hdf5")
+    a.save(f)
+    root = H5.read_file(f)
+    tc = json.loads(H5._strs(root.attrs["training_config"])[0])
+    assert tc["optimizer_config"]["class_name"] == "Adam" and tc["optimizer_config"]["config"]["learning_rate"] == 0.0005 and tc["loss"] == "bce_dice_loss"
+    names = H5._strs(root["optimizer_weights"].attrs["weight_names"])
+    P = len(W.trainable_names(1, "unet", (16, 16)))
+    assert len(names) == 1 + 3 * P and names[0] == "Adam/iterations:0" and names[1] == "training/Adam/m_0:0" and names[1 + 2 * P] == "training/Adam/vhat_0:0"
+    assert int(root["optimizer_weights"]["Adam/iterations:0"]) == 2 and root["optimizer_weights"]["Adam/iterations:0"].dtype == np.int64
+    b = load_model(f, backend=OracleBackend(16, 16))
+    assert b.compiled and b.backend.tr.t == 2 and b.arch == "unet" and (b.h, b.w, b.in_ch) == (16, 16, 1)
+    for _ in range(3):
+        a.backend.train_batch(x, y); b.backend.train_batch(x, y)
+    wa, wb = a.get_weights(), b.get_weights()
+    assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+    # compile=False / a model saved before compile(): weights only, a fresh optimizer
+    c = load_model(f, backend=OracleBackend(16, 16), compile=False)
+    assert not c.compiled and c.backend.tr.t == 0
+    d = small_model(); d.save(f)
+    assert "optimizer_weights" not in H5.read_file(f) and not load_model(f, backend=OracleBackend(16, 16)).compiled
+    with pytest.raises(ValueError, match="model_config"):
+        d.save_weights(f); load_model(f, backend=OracleBackend(16, 16))
 
 
 def test_evaluate_is_mean_of_batch_metrics_and_weighted_loss():
