@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   };
   for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
     issue_loads(chunk + 1);
+    __builtin_amdgcn_s_setprio(2);                           // (the wave feeding the matrix pipe goes ahead of the co-resident workgroups' staging / epilogue: 0.3 % of the step)
     mfma_chunk();
+    __builtin_amdgcn_s_setprio(0);
     if (chunk == 0) H2_STAMP(3);
     issue_w_loads(chunk + 1);                              // (behind this wave's last MFMA issue: the operand registers are free)
     post_amax();
@@ -382,7 +384,9 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
     }
   }
+  __builtin_amdgcn_s_setprio(2);
   mfma_chunk();
+  __builtin_amdgcn_s_setprio(0);
   H2_STAMP(7);
   const float unscale = pow2f(max(-e_run, -126)) * w_unscale;            // 2^-(e_x + e_w)
   // Output rows leave through LDS: a lane holds 64 B of ONE pixel, so its four 16-B stores land 128+ B apart from its neighbours' and a store instruction
