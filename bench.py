@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (fp16-split h2 kernels where the shape allows), 1 direct VALU kernels, 2 strict fp32 MFMA kernels")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the untimed fp32_strict_img_s measurement (--algo 2 engine, 8 steps)")
+    ap.add_argument("--fold16", action="store_true", help="UNET_OPT_BN_FOLD = 3: the classifier's 16-channel first block folded too (+15 %% there; more ReLU flips at full size, include/unet_hip.h)")
     ap.add_argument("--deterministic", action="store_true", help="UNET_OPT_DETERMINISTIC: fixed-order reductions, no floating-point atomics (bit-identical reruns)")
     ap.add_argument("--settle", type=float, default=2.0, help="seconds of untimed steps ahead of the warm-up (clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,7 +140,7 @@ def main():
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
-                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), options={"deterministic": 1} if args.deterministic else None)
+                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) or None)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     # ---- untimed setup 1 (rank 0, N=1): the CPU baseline first, so the GPU work of this command is one contiguous block at its end
@@ -316,7 +317,7 @@ def main():
                                    + {"unet": "configs[2]" if args.config == 2 else "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
                        "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: every conv3x3 / ConvT forward, data gradient and weight gradient as three v_mfma_f32_32x32x16_f16 products of a block-scaled two-term fp16 split (h2; fp32-class accuracy, DESIGN.md 4g); Cin=1 first layer and 1x1 head on fp32 VALU", 1: "direct fp32 VALU kernels", 2: "strict fp32: v_mfma_f32_32x32x2_f32 direct kernels"}[args.algo],
-                       "deterministic": bool(args.deterministic), "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
+                       "deterministic": bool(args.deterministic), "bn_fold": 3 if args.fold16 else 2, "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
         if strict is not None:

@@ -58,12 +58,14 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  * so one process can hold models / contexts of different settings side by side.
  *   RELU_BITS (1)          ReLU masks of the data gradients as one bit per element, written by the producing conv (0: the fp32 activation is re-read)
  *   BN_FOLD (2)            decoder BatchNormalization folded into the conv behind it: 0 = explicit statistics / apply passes, 1 = forward + weight gradient +
- *                          backward sums folded, 2 = also the BatchNorm backward applied in the data-gradient epilogue
+ *                          backward sums folded, 2 = also the BatchNorm backward applied in the data-gradient epilogue, 3 = as 2 and the classifier's
+ *                          16-channel first block too (T2:748-751: +15 % on that step; its folded pre-activations carry more round-off -- the raw
+ *                          activations have a large mean -- so at 224 x 224 x 256 about twice as many ReLU decisions differ from a float64 evaluation)
  *   ENC_BN_FUSED (1)       encoder tail backward without a statistics pass (sums from the pooled tensors + closed-form skip term, one fused apply pass)
  *   BN_CONCAT_ANALYTIC (1) decoder BatchNorm statistics: skip half from the encoder layer's sums, only the upsampled half measured
  *   BN_FUSE_STATS (1)      BatchNorm statistics accumulated by the producing conv's epilogue (unet_request_bn_stats honoured)
  *   DETERMINISTIC (0)      1 = every reduction in a fixed order: no floating-point atomics anywhere (BatchNorm / loss / metric sums through per-workgroup
- *                          slots folded in index order; statistics by their own pass), so reruns are bit-identical; costs ~3 % of the step */
+ *                          slots folded in index order; statistics by their own pass), so reruns are bit-identical; costs ~6 % of the step */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
 int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */

@@ -22,7 +22,7 @@ struct unet_ctx {
   int profiling = 0;
   // unet_ctx_set_option (include/unet_hip.h: UNET_OPT_*): graph-level choices a model reads when it is created, op-level choices the launches read
   int opt_relu_bits = 1;            // ReLU masks of the data gradients as one bit per element (0: re-read the fp32 activation)
-  int opt_bn_fold = 2;              // decoder BatchNorm folded into the conv behind it: 0 explicit passes, 1 forward + weight gradient + sums, 2 + backward in the dgrad epilogue
+  int opt_bn_fold = 2;              // decoder BatchNorm folded into the conv behind it: 0 explicit passes, 1 forward + weight gradient + sums, 2 + backward in the dgrad epilogue, 3 + the classifier's 16-channel block
   int opt_enc_bn_fused = 1;         // encoder tail backward without a statistics pass
   int opt_bn_concat_analytic = 1;   // decoder BatchNorm statistics: skip half analytic
   int opt_bn_fuse_stats = 1;        // BatchNorm statistics from the producing conv's epilogue

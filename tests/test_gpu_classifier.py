@@ -109,18 +109,25 @@ def count_flips(eng, n, acts, names, thr=1e-5):
     return flips
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, "fold16"])          # fold16: UNET_OPT_BN_FOLD = 3, the 16-channel first block folded too (opt-in)
 @pytest.mark.parametrize("hw,n", [((32, 32), 4), ((24, 40), 5), ((96, 128), 24)])
 def test_model_fwd_bwd_all_grads(hw, n, algo):
     h, w_ = hw
+    opts = None
+    if algo == "fold16":
+        algo, opts = 0, {"bn_fold": 3}
     rng = np.random.default_rng(h + n)
     wts = rand_weights(h, hw)
     x = rng.random((n, h, w_, 1)).astype(np.float32); y = (rng.random(n) > 0.5).astype(np.float32)
     cw = (0.8, 1.4)
     r = O.cls_loss_and_grads(wts, x, y, class_weights=cw, dtype=torch.float64, want_acts=True)
-    eng = make(h, w_, conv_algo=algo)
+    eng = make(h, w_, conv_algo=algo, options=opts)
     eng.set_weights(wts); eng.set_class_weights(*cw)
     ld = eng.forward_backward(x, y).cpu().numpy()
+    if opts:
+        names = [o[0] for o in eng.op_profile(n, 0)] + [o[0] for o in eng.op_profile(n, 1)]
+        assert "bn_fold_prepare:c1b" in names and "conv3x3_dgrad_bn_bwd:c1b" in names and "bn_apply:bn1a" not in names, names
+        ld = eng.forward_backward(x, y).cpu().numpy()
     assert abs(ld[0] - r["loss"]) < 1e-5 and abs(ld[1] - r["f1"]) < 1e-6
     convs = [f"c{k}{ab}" for k in (1, 2, 3) for ab in "ab"]
     for name in convs + ["bn1a", "bn2b", "p1", "p3"]:

@@ -29,6 +29,8 @@ def _worker(rank, world, port, wfile, x, y, out, arch="unet", dtype="fp32"):
     xs, ys = x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
     eng.forward_backward(xs, ys)
     grads = eng.get_grads()                                            # SUM-reduced over ranks with the global normaliser
+    if dtype == "fp32" and arch != "unetpp":                           # ReLU sign pattern of this rank's half batch (see the flip note in the test)
+        np.savez(out + f".signs{rank}.npz", **{k[:-7]: np.packbits(eng.tap(n, k[:-7]) > 0) for k in wts if k.endswith("/kernel") and k[0] == "c"})
     losses = [eng.train_batch(xs, ys).cpu().numpy() for _ in range(2)]
     p, ld = eng.predict_batch(xs, ys)
     sums = eng.threshold_sums(p, ys, [0.3, 0.5]).cpu().numpy() if arch != "classifier" else np.zeros(1)
@@ -44,18 +46,32 @@ def test_two_ranks_equal_single_process_full_batch(tmp_path, arch):
     from covidseg_amd import weights as W
     from covidseg_amd.data import synthetic_classification, synthetic_ct
     from covidseg_amd.engine import HipUNet
-    if arch == "classifier":
-        x, y = synthetic_classification(8, 32, seed=5); y = y.astype(np.float32)
-    else:
-        x, y = synthetic_ct(4, 32, seed=5)
-    wts = W.init_weights(4, 1, arch, (32, 32))
-    wfile = str(tmp_path / "w.npz"); np.savez(wfile, **wts)
-    out = str(tmp_path / "dp.npz")
+    # A ReLU pre-activation within round-off of zero can land on different sides in the two runs (the BatchNorm sums are added in another order): that is a
+    # discontinuity of the gradient, not an arithmetic difference -- ONE flipped element of c2a moved every upstream gradient of the classifier case by 2.5e-3.
+    # The comparison therefore runs on the first data seed whose two runs agree on every ReLU sign (checked, not assumed).
     mp.get_context("spawn")
-    mp.spawn(_worker, args=(2, _free_port(), wfile, x, y, out, arch), nprocs=2, join=True)
-    got = np.load(out)
-    eng = HipUNet(32, 32, 1, dropout_rate=0.0, arch=arch); eng.set_weights(wts)
-    eng.forward_backward(x, y)
+    for seed in (5, 6, 7, 8):
+        if arch == "classifier":
+            x, y = synthetic_classification(8, 32, seed=seed); y = y.astype(np.float32)
+        else:
+            x, y = synthetic_ct(4, 32, seed=seed)
+        wts = W.init_weights(4, 1, arch, (32, 32))
+        wfile = str(tmp_path / "w.npz"); np.savez(wfile, **wts)
+        out = str(tmp_path / f"dp{seed}.npz")
+        mp.spawn(_worker, args=(2, _free_port(), wfile, x, y, out, arch), nprocs=2, join=True)
+        got = np.load(out)
+        eng = HipUNet(32, 32, 1, dropout_rate=0.0, arch=arch); eng.set_weights(wts)
+        eng.forward_backward(x, y)
+        flips = 0
+        if arch != "unetpp":                                         # (ELU has a continuous derivative: no such discontinuity in U-Net++)
+            s0, s1 = np.load(out + ".signs0.npz"), np.load(out + ".signs1.npz")
+            for k in s0.files:
+                mine = eng.tap(x.shape[0], k) > 0
+                half = mine.shape[0] // 2
+                flips += int((np.packbits(mine[:half]) != s0[k]).sum() + (np.packbits(mine[half:]) != s1[k]).sum())
+        if flips == 0:
+            break
+    assert flips == 0, "no flip-free seed among four"
     grads0 = {k: np.array(v) for k, v in eng.get_grads().items()}
     for k, v in grads0.items():                                       # the reduced gradient of 2 half batches == full-batch gradient
         a = got["g/" + k]

@@ -417,7 +417,7 @@ def test_context_options_select_the_graph_forms_in_one_process():
         g = eng.get_grads()
         for k in g:
             assert relerr(g[k], gref[k]) < 2e-5, (opts, k, relerr(g[k], gref[k]))
-    assert ref.lib.unet_ctx_set_option(ref.ctx.handle, 99, 1) != 0 and ref.lib.unet_ctx_set_option(ref.ctx.handle, _lib.OPTIONS["bn_fold"], 3) != 0
+    assert ref.lib.unet_ctx_set_option(ref.ctx.handle, 99, 1) != 0 and ref.lib.unet_ctx_set_option(ref.ctx.handle, _lib.OPTIONS["bn_fold"], 4) != 0
 
 
 @pytest.mark.gpu

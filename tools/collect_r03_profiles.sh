@@ -17,6 +17,8 @@ python bench.py --config 2 --no-cpu-baseline --no-strict-leg > $OUT/bench_cfg2.j
 python bench.py --algo 2 --no-cpu-baseline --steps 20 > $OUT/bench_strict_fp32.json 2>> $OUT/bench.err
 python bench.py --arch unetpp --size 256 --batch 32 --no-cpu-baseline --no-strict-leg > $OUT/bench_unetpp.json 2>> $OUT/bench.err
 python bench.py --arch classifier --size 224 --batch 256 --no-cpu-baseline --no-strict-leg > $OUT/bench_cls.json 2>> $OUT/bench.err
+python bench.py --arch classifier --size 224 --batch 256 --no-cpu-baseline --no-strict-leg --fold16 > $OUT/bench_cls_fold16.json 2>> $OUT/bench.err
+python bench.py --no-cpu-baseline --no-strict-leg --deterministic > $OUT/bench_deterministic.json 2>> $OUT/bench.err
 python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2>> $OUT/bench.err
 python tools/profile_ops.py > $OUT/ops.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict-leg > $OUT/trace.log 2>&1
