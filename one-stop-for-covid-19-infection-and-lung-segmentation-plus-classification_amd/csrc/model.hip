@@ -1121,6 +1121,19 @@ void plan_workspace_pp(unet_model* m) {
     m->grad[kv.first] = mk(cv, b.n, b.h, b.w, b.c); seen[b.off] = kv.first;
   }
   for (auto& nd : pp_nodes()) { std::string nm = nd.name; m->grad["u" + nm.substr(1)] = slice(m->grad.at("cat_" + nm), 0, nd.c); }
+  // A level-1 tensor that goes into several concats (c1, x1_2, x1_3: UPP:884-921) LIVES in the slice of its first consumer's concat -- the BatchNorm that produces it
+  // writes there -- and is copied (the gradient twins above stay dense) only into the later ones: 3 of the 10 copies per step, the three biggest, go.  (The deeper ones are also ConvT inputs, read densely.)
+  for (const char* t : {"c1", "x1_2", "x1_3"}) {
+    bool done = false;
+    for (auto& nd : pp_nodes()) {
+      int off = nd.c;
+      for (auto sk : nd.skips) {
+        if (!done && std::string(sk) == t) { m->act[t] = slice(m->act.at("cat_" + std::string(nd.name)), off, pp_width(sk)); done = true; }
+        off += pp_width(sk);
+      }
+    }
+    if (std::string(t) == "c1") m->act["bn1"] = m->act[t]; else m->act[std::string(t) + "bbn"] = m->act[t];
+  }
   for (auto& nd : pp_nodes()) {                                   // ConvT data-gradient staging buffer (largest source tensor)
     const Buf& sb = m->act.at(nd.src); tmp_up = std::max(tmp_up, (size_t)sb.n * sb.h * sb.w * sb.c);
   }
@@ -1226,6 +1239,7 @@ void build_programs_pp(unet_model* m) {
         int off = c;
         for (auto sk : nd->skips) {
           const std::string skn = sk; const Buf kb = m->act.at(skn); const int o = off, cw = kb.c;
+          if (kb.off == cb.off && kb.chan_off == cb.chan_off + (size_t)o) { off += cw; continue; }          // (the tensor lives in this slice: plan_workspace_pp)
           ADD_OP(F, "copy_slice:" + skn + ">" + it, 0, 2 * eb * nel(kb), {
             if (dt) return unet_copy_slice_bf16(ctx, CBF(m->Av(skn)), kb.ld, WBF(m->Av(cat)) + o, cb.ld, (int64_t)kb.n * kb.h * kb.w, cw, s);
             return unet_copy_slice(ctx, m->A(skn), kb.ld, m->Aw(cat) + o, cb.ld, (int64_t)kb.n * kb.h * kb.w, cw, s);
@@ -1342,11 +1356,36 @@ void build_programs_pp(unet_model* m) {
     const TInfo a = m->tinfo.at(first), b = m->tinfo.at(last_tensor);
     SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off});
   };
+  // The gradient of a tensor that went into several concats is the sum of those concats' gradient slices (each concat keeps its own gradient buffer): the slices
+  // are only NOTED as the consumers finish and summed by ONE launch (up to 4 sources) right before the tensor's own backward starts -- x1_4, x1_3, x1_2 -> c1
+  // as one read-modify-write of 268 MB instead of three
+  std::map<std::string, std::vector<std::pair<std::string, int>>> pend;          // tensor -> (concat, channel offset)
+  auto flush_pending = [&](const std::string& dstn) {
+    auto pi = pend.find(dstn);
+    if (pi == pend.end() || pi->second.empty()) return;
+    const std::vector<std::pair<std::string, int>> srcv = pi->second; pend.erase(pi);
+    const Buf kb = m->act.at(dstn);
+    const int cw = kb.c, accs = first_touch(dstn), ns = (int)srcv.size();
+    std::string tag;
+    for (auto& sv : srcv) tag += (tag.empty() ? "" : "+") + sv.first.substr(4);
+    ADD_OP(BW, "accum_slice:" + tag + ">" + dstn, 0, (ns + 1 + accs) * eb * nel(kb), {
+      int32_t lds[4];
+      if (dt) {
+        const unet_bf16* srcs[4];
+        for (int k = 0; k < ns; ++k) { srcs[k] = CBF(m->Dv(srcv[k].first)) + srcv[k].second; lds[k] = m->grad.at(srcv[k].first).ld; }
+        return unet_accum_slices_bf16(ctx, srcs, lds, ns, WBF(m->Dv(dstn)), m->grad.at(dstn).ld, (int64_t)kb.n * kb.h * kb.w, cw, accs, s);
+      }
+      const float* srcs[4];
+      for (int k = 0; k < ns; ++k) { srcs[k] = m->D(srcv[k].first) + srcv[k].second; lds[k] = m->grad.at(srcv[k].first).ld; }
+      return unet_accum_slices(ctx, srcs, lds, ns, m->D(dstn), m->grad.at(dstn).ld, (int64_t)kb.n * kb.h * kb.w, cw, accs, s);
+    });
+  };
   for (int oi = 9; oi >= 0; --oi) {
     std::string it = PP_ORDER[oi];
     if (it[0] == 'e') {
       int k = it[1] - '0', c = ENC[k - 1], cin = k == 1 ? m->in_ch : ENC[k - 2];
       std::string ks = std::to_string(k), ca = "c" + ks + "a", cb = "c" + ks + "b";
+      flush_pending("c" + ks);
       bn_bwd("bn" + ks, "c" + ks, cb, c, MASK_ELU, 0.0f, 0);
       conv_bwd(cb, ca, c, c, true, MASK_ELU_DROP, PP_ENC_DROP, seed_of(ca));
       conv_bwd(ca, k == 1 ? "" : "p" + std::to_string(k - 1), cin, c, k > 1, MASK_NONE, 0.0f, 0);
@@ -1355,8 +1394,9 @@ void build_programs_pp(unet_model* m) {
         const Buf xb = m->act.at(ck);
         const int accf = first_touch(ck);
         ADD_OP(BW, "pool_bwd:" + pk, 0, eb * 3.25 * nel(xb), {
-          if (dt) return unet_maxpool2x2_dropout_bwd_bf16(ctx, CBF(m->Av(ck)), xb.ld, CBF(m->Dv(pk)), WBF(m->Dv(ck)), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, accf, s);
-          return unet_maxpool2x2_dropout_bwd(ctx, m->A(ck), xb.ld, m->D(pk), m->D(ck), xb.ld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, accf, s);
+          const int gld = m->grad.at(ck).ld;                      // (c1 lives in a concat slice, its gradient twin is dense)
+          if (dt) return unet_maxpool2x2_dropout_bwd_bf16(ctx, CBF(m->Av(ck)), xb.ld, CBF(m->Dv(pk)), WBF(m->Dv(ck)), gld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, accf, s);
+          return unet_maxpool2x2_dropout_bwd(ctx, m->A(ck), xb.ld, m->D(pk), m->D(ck), gld, xb.n, xb.h, xb.w, xb.c, 0.0f, 0, accf, s);
         });
       }
       if (k == 4) bucket("c4a/kernel", "x2_3bbn/beta");
@@ -1368,6 +1408,7 @@ void build_programs_pp(unet_model* m) {
       const std::string un = "u" + it.substr(1), src = nd->src, cat = "cat_" + it;
       const Buf sb = m->act.at(src), cb = m->act.at(cat);
       const int c = nd->c, csrc = pp_width(src);
+      flush_pending(it);
       bn_bwd(it + "bbn", it, it + "b", c, MASK_ELU_DROP, PP_BLOCK_DROP, seed_of(it + "b"));
       if (m->fold_off.count(it + "b")) {
         // folded BatchNorm (abn -> conv b): weight gradient on the raw x, corrected; the BatchNorm's backward sums from W . dW_raw and S; its backward apply and the
@@ -1428,19 +1469,7 @@ void build_programs_pp(unet_model* m) {
         return unet_accum_slices(ctx, srcs, lds, 1, m->D(src), m->grad.at(src).ld, (int64_t)sb.n * sb.h * sb.w, csrc, accu, s);
       });
       int off = c;
-      for (auto sk : nd->skips) {
-        const std::string skn = sk; const Buf kb = m->act.at(skn); const int o = off, cw = kb.c;
-        const int accs = first_touch(skn);
-        ADD_OP(BW, "accum_slice:" + it + ">" + skn, 0, 3 * eb * nel(kb), {
-          if (dt) {
-            const unet_bf16* srcs[1] = {CBF(m->Dv(cat)) + o}; const int32_t lds[1] = {cb.ld};
-            return unet_accum_slices_bf16(ctx, srcs, lds, 1, WBF(m->Dv(skn)), m->grad.at(skn).ld, (int64_t)kb.n * kb.h * kb.w, cw, accs, s);
-          }
-          const float* srcs[1] = {m->D(cat) + o}; const int32_t lds[1] = {cb.ld};
-          return unet_accum_slices(ctx, srcs, lds, 1, m->D(skn), m->grad.at(skn).ld, (int64_t)kb.n * kb.h * kb.w, cw, accs, s);
-        });
-        off += cw;
-      }
+      for (auto sk : nd->skips) { pend[sk].push_back({cat, off}); off += m->act.at(sk).c; }
       if (it == "x1_4") bucket("u1_4/kernel", "out/bias");
     }
   }
