@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--algo", type=int, default=0); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--warm", type=int, default=25); ap.add_argument("--dtype", default="fp32"); ap.add_argument("--arch", default="unet")
+    ap.add_argument("--algo", type=int, default=0); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--warm", type=int, default=25); ap.add_argument("--dtype", default="fp32"); ap.add_argument("--arch", default="unet"); ap.add_argument("--options", default="", help='JSON of context options, e.g. {"deterministic": 1}')
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -25,7 +25,7 @@ def main():
         xs, ys = synthetic_ct(min(a.batch, 4), a.size, seed=0)
     r = (a.batch + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * r)[:a.batch]).cuda(); y = torch.from_numpy(np.concatenate([ys] * r)[:a.batch]).cuda()
-    eng = HipUNet(a.size, a.size, 1, conv_algo=a.algo, dtype=a.dtype, arch=a.arch, dropout_rate=0.25)
+    eng = HipUNet(a.size, a.size, 1, conv_algo=a.algo, dtype=a.dtype, arch=a.arch, dropout_rate=0.25, options=__import__("json").loads(a.options) if a.options else None)
     eng.set_weights(W.init_weights(0, 1, a.arch, (a.size, a.size)))
     for _ in range(a.warm):          # the chip needs ~1 s of load to reach its sustained clocks
         eng.train_batch(x, y)
