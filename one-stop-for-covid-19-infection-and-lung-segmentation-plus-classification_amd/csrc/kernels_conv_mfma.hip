@@ -601,7 +601,8 @@ int32_t k_convT_mfma_dgrad(unet_ctx* ctx, const float* dy, int lddy, const float
 size_t mfma_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {        // large enough for this family AND the h2 form
   if (!mfma_wgrad_supported(cin, cout)) return 0;
   const WgradPlan p = plan_wgrad(9, n, h, wd, cin, cout, cout);
-  return std::max((p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float), h2_wgrad_ws_bytes(n, h, wd, cin, cout));
+  return std::max(std::max((p.part_floats + p.bias_floats + p.part2_floats) * sizeof(float), h2_wgrad_ws_bytes(n, h, wd, cin, cout)),
+                  h2_wgrad_c16_selected(UNET_ALGO_AUTO, wd, cin, cout) ? h2_wgrad_c16_ws_bytes(n, h, wd) : (size_t)0);
 }
 
 int32_t k_conv3x3_mfma_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h,

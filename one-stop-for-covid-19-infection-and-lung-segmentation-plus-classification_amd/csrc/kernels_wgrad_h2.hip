@@ -617,6 +617,39 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
   return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
 }
 
+// ---- 16 -> 16 channels (the classifier's first block, T2:748-751 at 224 x 224 x 256): a 32 x 32 MFMA tile is three quarters padding there.  An NHWC tensor
+// [n, h, w, 16] with w even IS the tensor [n, h, w / 2, 32] (a pixel pair = 32 channels), and the 32 -> 32 weight gradient G of that half-width problem holds
+// every product the 16 -> 16 one needs -- with x column 2 (J + B) + p and dy column 2 J + q:
+//     dW[a][b][ci][co] = sum over q in {0, 1} of G[a][B + 1][p * 16 + ci][q * 16 + co],   t = q + b - 1,  B = floor(t / 2),  p = t - 2 B
+// (a pair is never half outside the image, so the zero padding agrees).  Half of the tile is useful instead of a quarter: 1.07 -> ~0.55 ms at that size.
+namespace {
+__global__ void wgrad_c16_gather_kernel(const float* __restrict__ G, const float* __restrict__ gb, float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 9 * 256) {
+    const int co = i & 15, ci = (i >> 4) & 15, tap = i >> 8, a = tap / 3, b = tap - a * 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = q + b - 1, B = t < 0 ? -1 : (t >> 1), p = t - 2 * B;
+      acc += G[((a * 3 + B + 1) * 32 + p * 16 + ci) * 32 + q * 16 + co];
+    }
+    dw[i] = acc;
+  } else if (i < 9 * 256 + 16) { const int co = i - 9 * 256; db[co] = gb[co] + gb[16 + co]; }
+}
+}  // namespace
+bool h2_wgrad_c16_selected(int algo, int wd, int cin, int cout) { return algo == UNET_ALGO_AUTO && cin == 16 && cout == 16 && wd >= 2 && (wd & 1) == 0; }
+size_t h2_wgrad_c16_ws_bytes(int n, int h, int wd) { return h2_wgrad_ws_bytes(n, h, wd / 2, 32, 32) + (9 * 32 * 32 + 32) * sizeof(float); }
+int32_t k_conv3x3_h2_wgrad_c16(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, hipStream_t s) {
+  if ((wd & 1) || !ws || ws_bytes < h2_wgrad_c16_ws_bytes(n, h, wd)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad h2 (16 channels as pixel pairs): W=%d, workspace %zu < %zu bytes", wd, ws_bytes, h2_wgrad_c16_ws_bytes(n, h, wd));
+  const size_t inner = h2_wgrad_ws_bytes(n, h, wd / 2, 32, 32);
+  float* G = reinterpret_cast<float*>(static_cast<char*>(ws) + inner);
+  int32_t r = k_conv3x3_h2_wgrad(ctx, x, dy, G, G + 9 * 32 * 32, ws, inner, n, h, wd / 2, 32, 32, s);
+  if (r) return r;
+  hipLaunchKernelGGL(wgrad_c16_gather_kernel, dim3((9 * 256 + 16 + 255) / 256), dim3(256), 0, s, G, G + 9 * 32 * 32, dw, db);
+  UNET_CHECK_LAUNCH(ctx, "wgrad_c16_gather");
+  return UNET_OK;
+}
+
 // ---- ConvT weight gradient on the h2 kernels: cout (the dU channels) a multiple of 32, cin a multiple of 64
 bool h2_convT_wgrad_selected(int algo, int cin, int cout) {
   return algo == UNET_ALGO_AUTO && cout >= 32 && (cout % 32) == 0 && cin >= 64 && (cin % 64) == 0;

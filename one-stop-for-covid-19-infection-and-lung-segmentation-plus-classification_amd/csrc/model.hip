@@ -131,6 +131,8 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
                                       size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
   if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout)) {
+    if (h2_wgrad_c16_selected(algo, wd, cin, cout) && ws_bytes >= h2_wgrad_c16_ws_bytes(n, h, wd))
+      return k_conv3x3_h2_wgrad_c16(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, s);      // pixel pairs as 32 channels: half of the MFMA tile useful instead of a quarter
     if (h2_wgrad_selected(algo, cin, cout) && ws_bytes >= h2_wgrad_ws_bytes(n, h, wd, cin, cout))
       return k_conv3x3_h2_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);      // three fp16 MFMA products of the block-scaled two-term split
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);

@@ -23,7 +23,7 @@ def T64(a):
 CONV_SHAPES = [(2, 9, 13, 3, 5), (1, 16, 16, 1, 32), (2, 16, 16, 32, 32), (2, 12, 20, 32, 64), (1, 8, 8, 64, 128),
                (2, 6, 10, 128, 64), (1, 4, 4, 256, 512), (3, 14, 14, 64, 64), (1, 34, 70, 32, 32), (2, 64, 48, 1, 32), (1, 9, 13, 1, 32), (2, 4, 3, 512, 512),
                # channel counts that are not multiples of 32 (the classifier's 16-wide layers, T2:748-750): tiles overhang
-               (2, 16, 16, 16, 16), (1, 12, 20, 16, 32), (2, 8, 8, 32, 16), (1, 10, 10, 24, 80), (1, 8, 8, 8, 48), (2, 16, 16, 1, 16), (1, 10, 10, 48, 48), (2, 12, 20, 16, 48), (1, 9, 33, 48, 16),
+               (2, 16, 16, 16, 16), (2, 12, 40, 16, 16), (1, 9, 13, 16, 16), (1, 12, 20, 16, 32), (2, 8, 8, 32, 16), (1, 10, 10, 24, 80), (1, 8, 8, 8, 48), (2, 16, 16, 1, 16), (1, 10, 10, 48, 48), (2, 12, 20, 16, 48), (1, 9, 33, 48, 16),
                # wide rows: several 32-column tiles, ragged right edge, odd width
                (1, 6, 128, 32, 64), (2, 5, 150, 16, 32), (1, 9, 67, 64, 128), (1, 3, 64, 8, 8),
                # narrow images: tiles that overhang the image on the right and below
