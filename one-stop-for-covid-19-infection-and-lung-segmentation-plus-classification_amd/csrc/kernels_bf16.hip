@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
                                                            const float* __restrict__ bias, const unet_bf16* __restrict__ mask,
                                                            unet_bf16* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y,
-                                                           int groups, int total_blocks) {
+                                                           int groups, int total_blocks, double* __restrict__ stats, int stats_c) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
   constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
       const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + oc + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
     }
+    float st1[8], st2[8];                                   // BatchNorm statistics of the bf16 values this lane stores (channel oct lane & 3): unet_request_bn_stats
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st1[i] = 0.f; st2[i] = 0.f; }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int py = y0 + wave * RW + r;
@@ -308,7 +311,45 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const unet_bf16* __re
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (abj >> 1)) * (2 * W) + 2 * pxj + (abj & 1)) * ldy + ocj;
         else oj = (((long long)n * H + py) * W + pxj) * ldy + mb0;
-        if (pxj < W && mb0 + cj * 8 < M) *reinterpret_cast<uint4*>(y + oj + cj * 8) = t4;
+        if (pxj < W && mb0 + cj * 8 < M) {
+          *reinterpret_cast<uint4*>(y + oj + cj * 8) = t4;
+          if (MODE != 2 && stats) {                          // (wave-uniform) sums of what is STORED: the statistics pass would read these bf16 values
+            const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float a = bf16_lo(tw[i]), b = bf16_hi(tw[i]);
+              st1[2 * i] += a; st1[2 * i + 1] += b; st2[2 * i] = fmaf(a, a, st2[2 * i]); st2[2 * i + 1] = fmaf(b, b, st2[2 * i + 1]);
+            }
+          }
+        }
+      }
+    }
+    if (MODE != 2 && stats) {                               // lanes L, L + 4, ... hold the same channel oct: fold them, lanes 0-3 post the wave's sums
+      float* const s_stat = reinterpret_cast<float*>(smem + 4 * 32 * 80);          // [wave][nb][sum | sum of squares][32 channels], behind the staging rows
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        st1[i] += __shfl_xor(st1[i], 4); st1[i] += __shfl_xor(st1[i], 8); st1[i] += __shfl_xor(st1[i], 16); st1[i] += __shfl_xor(st1[i], 32);
+        st2[i] += __shfl_xor(st2[i], 4); st2[i] += __shfl_xor(st2[i], 8); st2[i] += __shfl_xor(st2[i], 16); st2[i] += __shfl_xor(st2[i], 32);
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s_stat[((wave * NB + nb) * 2 + 0) * 32 + lane * 8 + i] = st1[i]; s_stat[((wave * NB + nb) * 2 + 1) * 32 + lane * 8 + i] = st2[i]; }
+      }
+    }
+  }
+  if (MODE != 2 && stats) {
+    float* const s_stat = reinterpret_cast<float*>(smem + 4 * 32 * 80);
+    __syncthreads();
+    if (tid < NB * 64) {
+      const int nb = tid >> 6, kind = (tid >> 5) & 1, c32 = tid & 31;
+      const int mb = (g * NB + nb) * 32;
+      if (mb + c32 < M) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) t += s_stat[((wv * NB + nb) * 2 + kind) * 32 + c32];
+        int ch = mb + c32;
+        if (MODE == 1) ch = ch % (M >> 2);                 // ConvT: the four (a, b) planes of a channel
+        atomicAdd(stats + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + (kind ? stats_c : 0) + ch, (double)t);
       }
     }
   }
@@ -329,9 +370,19 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
   if (total >= (1LL << 28)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv bf16: too many tiles");
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
   const bool gen = MODE == 0 && (act == ACT_ELU || rate > 0.0f || mask_mode == MASK_ELU || mask_mode == MASK_ELU_DROP || mask_mode == MASK_BN_BWD_ELU || mask_mode == MASK_BN_BWD_ELU_DROP);
+  // an armed statistics request (common.h: unet_ctx::stats_req_c), exactly as the fp32 launcher honours it (kernels_conv_h2.hip: launch_h2)
+  double* stats = nullptr; int stats_c = 0;
+  if (MODE != 2 && ctx->stats_req_c > 0) {
+    const int c = ctx->stats_req_c; ctx->stats_req_c = 0;
+    if ((mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots && smem >= 4 * 32 * 80 + 4 * NB * 64 * 4 &&
+        (M % 32) == 0) {          // (a half-padded 16-channel block pays more in this epilogue than its statistics pass costs: classifier c1b 0.28 -> 0.39 ms)
+      stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c;
+    }
+  }
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_bf16");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
+                       stats_c);
     return UNET_OK;
   };
   int32_t r;

@@ -613,10 +613,9 @@ double nel(const Buf& b) { return (double)b.n * b.h * b.w * b.c; }
     (vec).push_back(std::move(_o));                           \
   } while (0)
 
-// Conv2D -> BatchNormalization (T1:860-861; every block of UPP:858-950 and T2:747-776): where a training-mode statistics pass directly follows the fp32
-// conv3x3 that wrote its input, the conv is armed (unet_request_bn_stats) and its kernel, if it can, leaves the sums for that pass to fold
+// Conv2D -> BatchNormalization (T1:860-861; every block of UPP:858-950 and T2:747-776): where a training-mode statistics pass directly follows the
+// conv3x3 (fp32 or bf16 storage) that wrote its input, the conv is armed (unet_request_bn_stats) and its kernel, if it can, leaves the sums for that pass to fold
 void arm_bn_statistics(unet_model* m) {
-  if (m->dt) return;
   auto& F = m->prog[UNET_PROG_FWD_TRAIN];
   unet_ctx* ctx = m->ctx;
   for (size_t i = 1; i < F.size(); ++i) {
@@ -766,7 +765,7 @@ void build_programs(unet_model* m) {
       int c = dec[k - 6]; std::string ks = std::to_string(k);
       const Buf ib = m->act.at(prev), ub = m->act.at("u" + ks);
       const std::string uin = prev, un = "u" + ks; const int ci = cprev;
-      const bool arm_up = training && !dt && ctx->opt_bn_concat_analytic;          // (the statistics pass of the concat reads only this half then)
+      const bool arm_up = training && ctx->opt_bn_concat_analytic;          // (the statistics pass of the concat reads only this half then)
       ADD_OP(F, "convT_fwd:" + un, 2.0 * 4 * ci * c * nel(ib) / ib.c, eb * (nel(ib) + nel(ub)), {
         if (arm_up) unet_request_bn_stats(ctx, c);
         if (dt) return k_convT_bf16_fwd(ctx, CBF(m->Av(uin)), m->P(un + "/kernel"), m->P(un + "/bias"), WBF(m->Av(un)), ub.ld, ib.n, ib.h, ib.w, ci, c, WBF(static_cast<void*>(m->wsf(m->off_wt))), s);
