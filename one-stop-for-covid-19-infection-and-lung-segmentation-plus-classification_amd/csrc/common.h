@@ -224,6 +224,7 @@ int32_t k_convT_h2_dgrad(unet_ctx*, const float* dy, int lddy, const float* w, c
 bool h2_wgrad_selected(int algo, int cin, int cout);
 bool h2_wgrad_c16_selected(int algo, int wd, int cin, int cout);          // 16 -> 16 channels as pixel pairs (kernels_wgrad_h2.hip)
 size_t h2_wgrad_c16_ws_bytes(int n, int h, int wd);
+int32_t k_wgrad_c16_gather(unet_ctx*, const float* G, float* dw, float* db, hipStream_t s);
 int32_t k_conv3x3_h2_wgrad_c16(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, hipStream_t s);
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);

@@ -732,12 +732,25 @@ int32_t run_wgrad_bf16(unet_ctx* ctx, const unet_bf16* A, int ldA, const unet_bf
 }  // namespace
 
 bool bf16_wgrad_supported(int ca, int cb) { return ca >= 16 && (ca % 8) == 0 && cb >= 16 && (cb % 8) == 0; }      // 32-wide tiles, overhang masked per 8-channel piece
-size_t bf16_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return bf16_wgrad_supported(cin, cout) ? plan_wgrad_bf16(0, n, h, wd, cin, cout).floats * sizeof(float) : 0; }
+// 16 -> 16 channels with an even width: the 32 -> 32 problem on pixel pairs (kernels_wgrad_h2.hip: k_conv3x3_h2_wgrad_c16), its 9 x 32 x 32 + 32 results behind the slabs
+static bool bf16_wgrad_c16(int wd, int cin, int cout) { return cin == 16 && cout == 16 && wd >= 2 && (wd & 1) == 0; }
+static size_t bf16_wgrad_c16_inner(int n, int h, int wd) { return plan_wgrad_bf16(0, n, h, wd / 2, 32, 32).floats * sizeof(float); }
+size_t bf16_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) {
+  if (!bf16_wgrad_supported(cin, cout)) return 0;
+  const size_t plain = plan_wgrad_bf16(0, n, h, wd, cin, cout).floats * sizeof(float);
+  return bf16_wgrad_c16(wd, cin, cout) ? std::max(plain, bf16_wgrad_c16_inner(n, h, wd) + (9 * 32 * 32 + 32) * sizeof(float)) : plain;
+}
 size_t bf16_convT_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return bf16_convT_supported(cin, cout) ? plan_wgrad_bf16(1, n, h, wd, cout, cin).floats * sizeof(float) : 0; }
 
 int32_t k_conv3x3_bf16_wgrad(unet_ctx* ctx, const unet_bf16* x, const unet_bf16* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd,
                              int cin, int cout, hipStream_t s) {
   if (!bf16_wgrad_supported(cin, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad bf16: cin=%d cout=%d unsupported (multiples of 8, >= 16)", cin, cout);
+  if (bf16_wgrad_c16(wd, cin, cout) && ws && ws_bytes >= bf16_wgrad_c16_inner(n, h, wd) + (9 * 32 * 32 + 32) * sizeof(float)) {
+    const size_t inner = bf16_wgrad_c16_inner(n, h, wd);
+    float* G = reinterpret_cast<float*>(static_cast<char*>(ws) + inner);
+    int32_t r = run_wgrad_bf16<0>(ctx, x, 32, dy, 32, G, G + 9 * 32 * 32, ws, inner, n, h, wd / 2, 32, 32, s);
+    return r ? r : k_wgrad_c16_gather(ctx, G, dw, db, s);
+  }
   return run_wgrad_bf16<0>(ctx, x, cin, dy, cout, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
 }
 

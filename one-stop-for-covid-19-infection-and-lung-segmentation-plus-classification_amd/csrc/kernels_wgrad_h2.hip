@@ -637,6 +637,11 @@ __global__ void wgrad_c16_gather_kernel(const float* __restrict__ G, const float
   } else if (i < 9 * 256 + 16) { const int co = i - 9 * 256; db[co] = gb[co] + gb[16 + co]; }
 }
 }  // namespace
+int32_t k_wgrad_c16_gather(unet_ctx* ctx, const float* G, float* dw, float* db, hipStream_t s) {          // G: [9][32][32] + 32 bias sums of the pixel-pair problem
+  hipLaunchKernelGGL(wgrad_c16_gather_kernel, dim3((9 * 256 + 16 + 255) / 256), dim3(256), 0, s, G, G + 9 * 32 * 32, dw, db);
+  UNET_CHECK_LAUNCH(ctx, "wgrad_c16_gather");
+  return UNET_OK;
+}
 bool h2_wgrad_c16_selected(int algo, int wd, int cin, int cout) { return algo == UNET_ALGO_AUTO && cin == 16 && cout == 16 && wd >= 2 && (wd & 1) == 0; }
 size_t h2_wgrad_c16_ws_bytes(int n, int h, int wd) { return h2_wgrad_ws_bytes(n, h, wd / 2, 32, 32) + (9 * 32 * 32 + 32) * sizeof(float); }
 int32_t k_conv3x3_h2_wgrad_c16(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, hipStream_t s) {
@@ -645,9 +650,7 @@ int32_t k_conv3x3_h2_wgrad_c16(unet_ctx* ctx, const float* x, const float* dy, f
   float* G = reinterpret_cast<float*>(static_cast<char*>(ws) + inner);
   int32_t r = k_conv3x3_h2_wgrad(ctx, x, dy, G, G + 9 * 32 * 32, ws, inner, n, h, wd / 2, 32, 32, s);
   if (r) return r;
-  hipLaunchKernelGGL(wgrad_c16_gather_kernel, dim3((9 * 256 + 16 + 255) / 256), dim3(256), 0, s, G, G + 9 * 32 * 32, dw, db);
-  UNET_CHECK_LAUNCH(ctx, "wgrad_c16_gather");
-  return UNET_OK;
+  return k_wgrad_c16_gather(ctx, G, dw, db, s);
 }
 
 // ---- ConvT weight gradient on the h2 kernels: cout (the dU channels) a multiple of 32, cin a multiple of 64
