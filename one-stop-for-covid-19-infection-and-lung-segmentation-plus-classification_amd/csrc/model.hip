@@ -1527,9 +1527,9 @@ void plan_workspace_cls(unet_model* m) {
     for (int k = 1; k <= 3; ++k) {
       const int c = CLS_C[k - 1]; const std::string cn = "c" + std::to_string(k) + "b";
       if (!wgrad_bn_fold_supported(c)) continue;
-      // (bf16 storage has the epilogues too but measured 1 % slower here: these layers are short-K, the per-step weight image of
-      //  the scaled weights and the x read in the data-gradient epilogue cost what the two saved passes gain)
-      constexpr int bf16_too = 0;          // (measured 1 % slower on this graph in bf16 storage: short-K layers)
+      // (bf16 storage: all three blocks, the 16-channel one included -- its storage rounding is far above the fold's extra round-off; re-measured at the end of round 3
+      //  with the fused statistics and the pixel-pair weight gradient in place: 58.0 k -> 64.8 k images/s at 224 x 224 x 256, where round 2 had measured -1 %)
+      constexpr int bf16_too = 1;
       if (m->dt) { if (!bf16_too || !bf16_conv3x3_supported(c, c)) continue; }
       // 16-channel blocks (T2:748-751 at 224 x 224) only on request (UNET_OPT_BN_FOLD = 3): +15 % on the classifier step, but the raw first-block activations carry a
       // large mean, the folded pre-activations more round-off, and at 224 x 224 x 256 twice the ReLU flips: c1a/kernel 5.2e-3 from the fp64 answer instead of 2.8e-3
