@@ -101,3 +101,28 @@ def test_training_trajectory_and_runner(tmp_path, capsys):
     txt = capsys.readouterr().out
     assert "test loss, test dice coefficient:" in txt and "We just checked for" in txt and len(out["new_dices"]) == len(np.arange(0.40, 0.50, 0.001))
     assert out["model"].count_params() == 2_209_697 and os.path.exists(tmp_path / "unet_covid_weights_dice_coeff.hdf5")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_level_one_tensors_live_in_their_first_concat_and_gradient_slices_are_summed_once(dtype):
+    """UPP:884-921: c1 / x1_2 / x1_3 go into several concats.  The program writes each straight into the slice of its FIRST consumer (no copy op for that
+    pair, the later concats still get theirs) and sums the gradient slices of all consumers in ONE multi-source launch right before the tensor's own backward;
+    the taps through the aliased buffers still equal the oracle's tensors."""
+    n, h = 2, 32
+    eng = make(h, dtype=dtype, dropout_rate=0.0)
+    wts = rand_weights(3); eng.set_weights(wts)
+    rng = np.random.default_rng(5)
+    x = rng.random((n, h, h, 1)).astype(np.float32); y = (rng.random((n, h, h, 1)) > 0.7).astype(np.float32)
+    eng.forward_backward(x, y)
+    fwd = [o[0] for o in eng.op_profile(n, 0)]; bwd = [o[0] for o in eng.op_profile(n, 1)]
+    for gone in ("copy_slice:c1>x1_2", "copy_slice:x1_2>x1_3", "copy_slice:x1_3>x1_4"):
+        assert gone not in fwd, gone
+    for kept in ("copy_slice:c1>x1_3", "copy_slice:c1>x1_4", "copy_slice:x1_2>x1_4", "copy_slice:c2>x2_2"):
+        assert kept in fwd, kept
+    acc = [o for o in bwd if o.startswith("accum_slice:")]
+    assert "accum_slice:x1_4+x1_3+x1_2>c1" in acc and "accum_slice:x1_4+x1_3>x1_2" in acc and "accum_slice:x1_4>x1_3" in acc and len(acc) == 6, acc
+    assert bwd.index("accum_slice:x1_4+x1_3>x1_2") < bwd.index("bn_bwd_stats:x1_2bbn")
+    if dtype == "fp32":
+        r = O.pp_loss_and_grads(wts, x, y, dtype=torch.float64, want_acts=True)
+        for name, ref in (("c1", "bn1"), ("x1_2", "x1_2bbn"), ("x1_3", "x1_3bbn"), ("x1_4", "x1_4bbn")):          # (oracle names: the BatchNorm that produces the tensor)
+            assert relerr(eng.tap(n, name), r["acts"][ref]) < 2e-5, name
