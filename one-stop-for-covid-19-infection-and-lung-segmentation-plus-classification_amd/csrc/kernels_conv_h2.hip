@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void h2_wimg_kernel(h2_prep_list L, int maxb) 
 }
 
 __device__ __forceinline__ f16x8 lds_frag(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+// byte offset of 16-B cell c (0..7) of pixel p (0..31) in a wave's 4-KB epilogue staging row
+__device__ __forceinline__ int out_cell(int p, int c) { return p * 128 + ((c ^ (p & 7)) << 4); }
 
 // MODE 0: conv3x3 'same' (forward; data gradient with the flipped / transposed weight image)
 // MODE 1: convT2x2s2 forward = per-pixel GEMM [pixels, Cin] x [Cin, 4 Cout] with a scatter epilogue into the (2i+a, 2j+b) positions of a channel slice (pixel
@@ -139,11 +141,17 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
   constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
-  constexpr int PLANE = KS * NPIX * 32;                  // bytes of one fp16 plane of the pixel patch: [k-step][pixel][16 channels]
+  // one fp16 plane of the pixel patch: [k-step][channel half][pixel][8 channels] -- a fragment read (ds_read_b128, serviced in groups of 16 lanes out of
+  // lanes 0-31 / 32-63) then covers 256 consecutive bytes = all 64 banks; with the 16 channels of a pixel side by side (32 B per pixel) the 16 lanes of a
+  // group hit only every other 16-B bank quad: every fragment read paid two LDS cycles per group (tools/lds_banks.py; round 3 PMC: 16-25 % conflict cycles).
+  // (ConvT patches: NPIX is a multiple of 256 -> the two halves would sit on the same banks for the staging stores: 64 B of padding per half)
+  constexpr int HS = NPIX * 16 + (MODE == 0 ? 0 : 64);   // bytes of one channel half
+  constexpr int PLANE = KS * 2 * HS;
   constexpr int IN_BYTES = 2 * PLANE, W_BYTES = KS * T * NB * 2 * 2 * 32 * 16;
   constexpr int PPIECES = KS * NPIX * 4, WPIECES = W_BYTES / 16;     // 16-B fp32 pieces of the patch (k-step, pixel, channel quad); 16-B pieces of the weight slab
   constexpr int PL = (PPIECES + 255) / 256, WL = (WPIECES + 255) / 256;
-  constexpr int OUT_PS = 128 + 16;                       // epilogue staging: bytes per pixel of a (row, 32-channel block) + padding against bank conflicts
+  constexpr int OUT_PS = 128;                            // epilogue staging: bytes per pixel of a (row, 32-channel block); 16-B cell c of pixel p sits at cell c ^ (p & 7):
+                                                         // conflict-free for the accumulator-layout side (8 pixels x one cell) AND the line-layout side (8 cells of a pixel)
   // the slab's LDS region is rounded up to whole 256-piece rounds (every thread stores every piece it loaded) -- except for the 32-channel groups, where the
   // exact size is what lets a FOURTH workgroup fit a CU's 160 KB (40.2 KB each): those layers are the 512 x 512 ones, bound by the bytes a CU keeps in flight
   constexpr bool WPAD = NB != 1 || MODE != 0;
@@ -245,7 +253,9 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         unsigned h0, m0, h1, m1;
         split2(__uint_as_float(preg[k][0]) * sc, __uint_as_float(preg[k][1]) * sc, h0, m0);
         split2(__uint_as_float(preg[k][2]) * sc, __uint_as_float(preg[k][3]) * sc, h1, m1);
-        char* p = s_in + idx * 8;                                       // plane-local layout [pixel][16 channels] fp16: piece (pixel, quad) -> 8 bytes
+        const int q = tid & 3, pp = (tid >> 2) + k * 64;                // (k * 64 / NPIX is a compile-time constant in the ConvT modes: NPIX % 64 == 0 there)
+        const int ks = MODE == 0 ? 0 : (k * 64) / NPIX;
+        char* p = s_in + ((ks * 2 + (q >> 1)) * HS + (pp - ks * NPIX) * 16 + (q & 1) * 8);          // piece (pixel, quad) -> 8 bytes of its channel half
         *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0, m1);
       }
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int rr = 0; rr < RW + 2; ++rr) px[p][rr] = lds_frag(s_in + p * PLANE + (((wave * RW + rr) * PWD + l31 + kx) * 32 + hi * 16));
+        for (int rr = 0; rr < RW + 2; ++rr) px[p][rr] = lds_frag(s_in + p * PLANE + hi * HS + ((wave * RW + rr) * PWD + l31 + kx) * 16);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         f16x8 wf[NB][2];
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int r = 0; r < RW; ++r) px[p][r] = lds_frag(s_in + p * PLANE + ks * NPIX * 32 + (((wave * RW + r) * 32 + l31) * 32 + hi * 16));
+          for (int r = 0; r < RW; ++r) px[p][r] = lds_frag(s_in + p * PLANE + (ks * 2 + hi) * HS + ((wave * RW + r) * 32 + l31) * 16);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -441,12 +451,12 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       } else if (want_m) {
         if (MPF) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(s_out + (j * 8 + (lane >> 3)) * OUT_PS + (lane & 7) * 16) = mpre[MPF ? nb : 0][MPF ? r : 0][j];
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(s_out + out_cell(j * 8 + (lane >> 3), lane & 7)) = mpre[MPF ? nb : 0][MPF ? r : 0][j];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float4 m4;
-          if (MPF) m4 = *reinterpret_cast<const float4*>(s_out + l31 * OUT_PS + hi * 64 + q * 16);
+          if (MPF) m4 = *reinterpret_cast<const float4*>(s_out + out_cell(l31, hi * 4 + q));
           else m4 = (live && mb0 < mask_climit) ? *reinterpret_cast<const float4*>(mask + o + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
           mv[q * 4] = m4.x; mv[q * 4 + 1] = m4.y; mv[q * 4 + 2] = m4.z; mv[q * 4 + 3] = m4.w;
         }
@@ -521,12 +531,12 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(s_out + l31 * OUT_PS + hi * 64 + q * 16) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+        *reinterpret_cast<float4*>(s_out + out_cell(l31, hi * 4 + q)) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
       // (LDS executes a wave's instructions in order: the reads below see the writes above, the next row's writes come after these reads)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pj = j * 8 + (lane >> 3), cj = lane & 7, pxj = x0 + pj;
-        const float4 t4 = *reinterpret_cast<const float4*>(s_out + pj * OUT_PS + cj * 16);
+        const float4 t4 = *reinterpret_cast<const float4*>(s_out + out_cell(pj, cj));
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
         else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
@@ -586,7 +596,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
-  constexpr size_t smem = (size_t)2 * KS * NPIX * 32 + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16 + 3 * NB * 32 * 4;
+  constexpr size_t smem = (size_t)2 * KS * 2 * (NPIX * 16 + (MODE == 0 ? 0 : 64)) + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16 + 3 * NB * 32 * 4;
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;

@@ -38,8 +38,8 @@ class _Builder:
         self.layers.append({"name": name, "class_name": cls, "config": cfg, "inbound": list(inbound), "engine": engine})
         return name
 
-    def conv(self, x, filters, k, act, init, engine):
-        return self.add("Conv2D", [x], engine, dtype="float32", filters=filters, kernel_size=[k, k], strides=[1, 1], padding="same", data_format="channels_last",
+    def conv(self, x, filters, k, act, init, engine, padding="same"):
+        return self.add("Conv2D", [x], engine, dtype="float32", filters=filters, kernel_size=[k, k], strides=[1, 1], padding=padding, data_format="channels_last",
                         dilation_rate=[1, 1], activation=act, use_bias=True, kernel_initializer=init, bias_initializer=_ZEROS, kernel_regularizer=None,
                         bias_regularizer=None, activity_regularizer=None, kernel_constraint=None, bias_constraint=None)
 
@@ -59,8 +59,8 @@ class _Builder:
     def drop(self, x, rate):
         return self.add("Dropout", [x], dtype="float32", rate=rate, noise_shape=None, seed=None)
 
-    def cat(self, xs):
-        return self.add("Concatenate", xs, dtype="float32", axis=3)
+    def cat(self, xs, axis=3):
+        return self.add("Concatenate", xs, dtype="float32", axis=axis)
 
 
 def _unet(b, hw, in_ch):
@@ -72,10 +72,10 @@ def _unet(b, hw, in_ch):
         x = b.drop(b.pool(x), 0.25)
     x = b.conv(x, 512, 3, "relu", _HE_NORMAL, "c5a"); x = b.conv(x, 512, 3, "relu", _HE_NORMAL, "c5b")      # T1:883-884
     for k, c, sk in zip((6, 7, 8, 9), DEC, (4, 3, 2, 1)):                                # T1:886-911
-        x = b.cat([b.convT(x, c, f"u{k}"), skips[sk]])
+        x = b.cat([b.convT(x, c, f"u{k}"), skips[sk]], 3 if k == 9 else -1)             # (only T1:908 passes axis=3; T1:887, 894, 901 take the default -1)
         x = b.bn(x, f"bn{k}")
         x = b.conv(x, c, 3, "relu", _HE_NORMAL, f"c{k}a"); x = b.conv(x, c, 3, "relu", _HE_NORMAL, f"c{k}b")
-    return b.conv(x, 1, 1, "sigmoid", _GLOROT, "out")                                    # T1:913
+    return b.conv(x, 1, 1, "sigmoid", _GLOROT, "out", padding="valid")                   # T1:913 (no padding argument: Keras' default)
 
 
 def _unetpp(b, hw, in_ch):
