@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="UNET_OPT_DETERMINISTIC: fixed-order reductions, no floating-point atomics (bit-identical reruns)")
     ap.add_argument("--settle", type=float, default=2.0, help="seconds of untimed steps ahead of the warm-up (clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fit-leg", action="store_true", help="skip the untimed fit_img_s measurement (UNetModel.fit on a host-resident set)")
+    ap.add_argument("--fit-steps", type=int, default=20, help="steps per epoch of the fit leg")
     ap.add_argument("--no-sync-bn", action="store_true")
     ap.add_argument("--arch", default="unet", choices=["unet", "unetpp", "classifier"], help="unetpp = the U-Net++ graph (BASELINE "
                     "configs[3], at fp32; --size 256 --batch 32); classifier = the task-2 CNN (configs[4] at the reference's 1-channel fp32; "
@@ -143,6 +145,13 @@ def main():
                   arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) or None)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
+    def settle(seconds):
+        ts = time.perf_counter()
+        while time.perf_counter() - ts < seconds:
+            for _ in range(5):
+                eng.train_batch(x, y)
+            torch.cuda.synchronize()
+
     # ---- untimed setup 1 (rank 0, N=1): the CPU baseline first, so the GPU work of this command is one contiguous block at its end
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -155,6 +164,7 @@ def main():
     roof = None
     for _ in range(2):
         eng.train_batch(x, y)                # first-touch: plans, workspace, weight images
+    settle(args.settle)                      # (a cold chip runs these launches ~40 % slower than the timed region does: the per-op times would not be the step's)
     eng.set_profiling(True, B)
     for _ in range(PROF_STEPS):
         eng.train_batch(x, y)
@@ -189,12 +199,28 @@ def main():
             ts = time.perf_counter(); eng.predict_batch(x1); torch.cuda.synchronize(); lat.append((time.perf_counter() - ts) * 1e3)
         predict_ms = round(sorted(lat)[len(lat) // 2], 3)
 
+    # ---- untimed setup 5 (rank 0, N=1, U-Net): the REAL model.fit path (T1:1059-1061) -- a host-resident float64 set, as the reference's runner holds it,
+    # through keras_like.UNetModel.fit: upload once (pinned staging), per step a device-side gather of the shuffled batch, per epoch one host sync
+    fit_stats = None
+    if rank == 0 and world == 1 and args.arch == "unet" and not args.no_fit_leg:
+        from covidseg_amd.keras_like import UNetModel
+        nfit = args.fit_steps * B
+        xh = np.concatenate([xs] * ((nfit + len(xs) - 1) // len(xs)))[:nfit].astype(np.float64)
+        yh = np.concatenate([ys] * ((nfit + len(ys) - 1) // len(ys)))[:nfit].astype(np.float64)
+        model = UNetModel(S, 1, backend=eng); model.verbose = 0
+        model.compile(lr=5e-4)
+        torch.cuda.synchronize(); ts = time.perf_counter()
+        hist = model.fit(xh, yh, batch_size=B, epochs=3, shuffle=True)
+        torch.cuda.synchronize(); wall = time.perf_counter() - ts
+        ep = sorted(hist.epoch_seconds[1:])[len(hist.epoch_seconds[1:]) // 2]
+        fit_stats = {"fit_img_s": round(3 * nfit / wall, 1), "fit_epoch_img_s": round(nfit / ep, 1),
+                     "fit_note": f"UNetModel.fit(x, y, batch_size={B}, epochs=3) on {nfit} host float64 slices ({args.fit_steps} steps per epoch, shuffled): fit_img_s = the whole call "
+                                 f"incl. the one-time upload; fit_epoch_img_s = a steady epoch (median of epochs 2-3) -- to be read against `value`"}
+        del xh, yh, model
+        eng.set_weights(W.init_weights(0, 1, args.arch, (S, S))); eng.reset_optimizer()
+
     # ---- untimed: clock settle.  The chip needs >= 1 s of this load before its clocks sit at the power-capped operating point
-    ts = time.perf_counter()
-    while time.perf_counter() - ts < args.settle:
-        for _ in range(5):
-            eng.train_batch(x, y)
-        torch.cuda.synchronize()
+    settle(args.settle)
 
     # ---- the measurement the contract defines: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize
     for _ in range(args.warmup):
@@ -248,11 +274,20 @@ def main():
         # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE): collected OFFLINE at this exact workload
         # (tools/collect_r03_profiles.sh, calibration inside the file), not in this run -- only quoted for the configuration it was measured on
         traffic, tname = None, None
-        for tname in (("r03_pmc_traffic.json", "r02_pmc_traffic.json") if args.dtype == "fp32" else ("r03_pmc_traffic_bf16.json", "r01_pmc_traffic_bf16.json")):
+        for tname in (("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if args.dtype == "fp32" else ("r03_pmc_traffic_bf16.json", "r01_pmc_traffic_bf16.json")):
             tfile = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet":
                 traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
                 break
+        step_traffic = None
+        tf4 = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        if os.path.exists(tf4) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet" and args.dtype == "fp32":
+            t4 = json.load(open(tf4))
+            if "hbm_bytes_per_step_all_kernels" in t4:
+                sb = float(t4["hbm_bytes_per_step_all_kernels"])
+                step_traffic = {"hbm_bytes_per_step_all_kernels": round(sb), "vs_survey_54.3GB": round(sb / 54.300299148e9, 3),
+                                "vs_op_model": round(sb / max(sum(o[2] for o in ops), 1.0), 3),
+                                "source": "profiles/r04_pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of one step, counter-only rocprofv3 passes; offline, this workload)"}
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
         H2R = 3.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
         n_h2 = sum(int(abs(exec_ratio(o[0]) - H2R) < 1e-9) for o in dom)
@@ -285,6 +320,7 @@ def main():
                      "step_floor_ms": round(floor_ms, 3), "step_frac": round(floor_ms / (dt / args.steps * 1e3), 4),
                      "step_note": "step_floor_ms = sum over the step's ops of max(algorithmic bytes / 8 TB/s, executed matrix FLOPs / that pipe's peak); step_frac = floor / measured ms_per_step",
                      "step_hbm_gbs": round(sum(o[2] for o in ops) / (dt / args.steps) / 1e9, 1), "step_hbm_frac": round(sum(o[2] for o in ops) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "step_traffic": step_traffic,
                      "profiled_steps": PROF_STEPS,
                      "op_ms_per_step": {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}})
         if args.dtype == "bf16":
@@ -322,6 +358,8 @@ def main():
         }
         if strict is not None:
             out["fp32_strict_img_s"] = strict
+        if fit_stats is not None:
+            out.update(fit_stats)
         if predict_ms is not None:
             out["predict_batch1_ms"] = predict_ms          # median of 20 synchronised model.predict calls at batch 1 (T1:1137): latency, not throughput
         if cpu is not None:

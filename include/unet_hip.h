@@ -265,6 +265,11 @@ int32_t unet_adam_keras(unet_ctx*, float* p, const float* g, float* m, float* v,
 int32_t unet_seg_metrics_sweep(unet_ctx*, const float* p, const float* gt, const float* thresholds,
                                int32_t nthr, double* out, int64_t count, void* stream);
 
+/* Replaces: the batch slicing of model.fit (T1:1059-1061; Keras takes `x[batch_ids]` of a shuffled index array per step) for a dataset that was
+ * uploaded ONCE: dst[i] = src[idx[i]], whole samples of sample_floats floats (a multiple of 4); idx = int64 sample numbers on the device. */
+int32_t unet_gather_samples(unet_ctx*, const float* src, const int64_t* idx, float* dst, int64_t n,
+                            int64_t sample_floats, void* stream);
+
 int32_t unet_zero(unet_ctx*, void* ptr, size_t bytes, void* stream);
 /* concatenate([...]) of a tensor that feeds SEVERAL concats (U-Net++ nested skips, task1_unet_plus_plus.py:891-923):
  * copy a dense/sliced tensor into a channel slice of a concat buffer; and the backward: dst (+)= sum of <= 4 gradient slices */

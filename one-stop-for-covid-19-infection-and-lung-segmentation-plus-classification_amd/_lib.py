@@ -107,6 +107,7 @@ _PROTOS = {
     "unet_head_bwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, i64, i32, i32, vp]),
     "unet_adam_keras": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     "unet_seg_metrics_sweep": (i32, [vp, vp, vp, vp, i32, vp, i64, vp]),
+    "unet_gather_samples": (i32, [vp, vp, vp, i64, i64, vp]),
     "unet_zero": (i32, [vp, vp, sz, vp]),
     "unet_copy_slice": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
     "unet_copy_slice_bf16": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),

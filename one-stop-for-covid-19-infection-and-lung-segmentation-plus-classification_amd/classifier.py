@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 from . import weights as W
-from .keras_like import dp_info, dp_shard
+from .keras_like import BatchSource, dp_info, dp_shard
 
 
 # ----------------------------------------------------------------------------------------- sklearn / plot-metric restatements
@@ -196,6 +196,7 @@ class ClassifierModel:
         best_loss = np.inf
         rng = np.random.RandomState(shuffle_seed)
         world, rank = dp_info(self.backend)
+        src = BatchSource(self.backend, x, y)                         # the training set goes to HBM once (keras_like.BatchSource)
         for ep in range(epochs):
             order = rng.permutation(n) if shuffle else np.arange(n)
             self.backend.set_class_weights(*cw)
@@ -203,7 +204,8 @@ class ClassifierModel:
             for i in range(0, n, batch_size):
                 idx = order[i:i + batch_size]
                 sel, kw = dp_shard(idx, world, rank)                  # data parallel: keras_like.dp_shard
-                outs.append(self.backend.train_batch(x[sel], y[sel], dropout, **kw)); sizes.append(len(idx))
+                xb, yb = src(sel)
+                outs.append(self.backend.train_batch(xb, yb, dropout, **kw)); sizes.append(len(idx))
             vals = np.stack([_host(o) for o in outs])
             hist.history["loss"].append(float(np.average(vals[:, 0], weights=sizes))); hist.history["f1"].append(float(vals[:, 1].mean()))
             line = f"Epoch {ep + 1}/{epochs} - loss: {hist.history['loss'][-1]:.4f} - f1: {hist.history['f1'][-1]:.4f}"

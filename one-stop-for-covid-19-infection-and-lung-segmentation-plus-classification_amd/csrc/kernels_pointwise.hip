@@ -1044,6 +1044,22 @@ int32_t unet_accum_slices(unet_ctx* ctx, const float* const* srcs, const int32_t
 int32_t unet_accum_slices_bf16(unet_ctx* ctx, const unet_bf16* const* srcs, const int32_t* lds, int32_t nsrc, unet_bf16* dst, int32_t ldd, int64_t pixels, int32_t c, int32_t accumulate, void* stream) { return accum_slices_impl(ctx, srcs, lds, nsrc, dst, ldd, pixels, c, accumulate, stream); }
 
 namespace {
+// dst[i] = src[idx[i]] for whole samples of `sf4` float4s: the mini-batch of a shuffled epoch, taken from a dataset that lives in HBM
+__global__ __launch_bounds__(TPB) void gather_samples_kernel(const float4* __restrict__ src, const long long* __restrict__ idx, float4* __restrict__ dst, long long n, long long sf4) {
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n * sf4; i += (long long)gridDim.x * TPB) {
+    const long long s = i / sf4, e = i - s * sf4;
+    dst[i] = src[idx[s] * sf4 + e];
+  }
+}
+}  // namespace
+int32_t unet_gather_samples(unet_ctx* ctx, const float* src, const int64_t* idx, float* dst, int64_t n, int64_t sample_floats, void* stream) {
+  if (!src || !idx || !dst || n < 1 || sample_floats < 4 || (sample_floats & 3)) UNET_FAIL(ctx, UNET_E_ARG, "gather_samples: bad args (sample_floats must be a multiple of 4)");
+  hipLaunchKernelGGL(gather_samples_kernel, dim3(grid_for(n * (sample_floats / 4))), dim3(TPB), 0, as_stream(stream), reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<const long long*>(idx), reinterpret_cast<float4*>(dst), (long long)n, (long long)(sample_floats / 4));
+  UNET_CHECK_LAUNCH(ctx, "gather_samples"); return UNET_OK;
+}
+
+namespace {
 __global__ __launch_bounds__(TPB) void cast_f32_bf16_kernel(const float* __restrict__ src, unet_bf16* __restrict__ dst, long long n4) {
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) st4(dst + i * 4, ld4(src + i * 4));
 }

@@ -71,6 +71,8 @@ class HipUNet:
         self._drop_calls = 0                   # dropout stream position: advances with every training forward, NOT reset by compile() / reset_optimizer()
         self._plans = {}
         self._ws = None
+        self._pinned = {}                      # _to_dev: pinned staging rings by element count
+        self._idx_pin, self._idx_i = [None] * 4, 0
         # flat buffers sized from a probe plan
         probe = self._create_plan(1)
         self.n_params = self.lib.unet_model_param_count(probe)
@@ -184,10 +186,60 @@ class HipUNet:
 
     # ------------------------------------------------------------------ running programs
     def _to_dev(self, a):
+        """Host array -> fp32 device tensor.  The copy goes through one of two PINNED staging buffers per size (the cast float64 -> float32 writes
+        straight into it) and is asynchronous on the current stream: the host runs ahead to the next batch while this one computes, and the buffer is
+        reused only after the copy that read it has finished (an event per buffer)."""
         torch = _torch()
         if isinstance(a, torch.Tensor):
             return a.to(self.dev, torch.float32).contiguous()
-        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)
+        a = np.asarray(a)
+        ring = self._pinned.setdefault(a.size, {"buf": [], "ev": [], "i": 0})
+        if len(ring["buf"]) < 2:
+            ring["buf"].append(torch.empty(a.size, dtype=torch.float32).pin_memory()); ring["ev"].append(None)
+        k = ring["i"] % len(ring["buf"]); ring["i"] += 1
+        if ring["ev"][k] is not None:
+            ring["ev"][k].synchronize()
+        np.copyto(ring["buf"][k].numpy().reshape(a.shape), a, casting="same_kind")
+        out = ring["buf"][k].to(self.dev, non_blocking=True).view(a.shape)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.dev)); ring["ev"][k] = ev
+        return out
+
+    # ------------------------------------------------------------------ datasets resident in HBM (model.fit's x_train / y_train, T1:1059-1061)
+    def resident(self, a, max_fraction: float = 0.4):
+        """Upload a whole dataset [N, ...] ONCE as fp32 (chunks through the pinned ring) and return the device tensor -- or None when 4 * a.size
+        exceeds max_fraction of the HBM that is free right now (the caller then feeds host batches through _to_dev).  The reference's sets are
+        1130 x 224 x 224 (227 MB); 288 GB of HBM hold any CT set this path is run on."""
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            return a.to(self.dev, torch.float32).contiguous()
+        a = np.asarray(a)
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        if a.size == 0 or 4 * a.size > max_fraction * free:
+            return None
+        out = torch.empty(a.shape, dtype=torch.float32, device=self.dev)
+        flat = out.view(a.shape[0], -1)
+        per = max(1, (64 << 20) // max(4 * flat.shape[1], 1))                    # 64-MB chunks
+        for i in range(0, a.shape[0], per):
+            flat[i:i + per].copy_(self._to_dev(a[i:i + per]).view(-1, flat.shape[1]), non_blocking=True)
+        return out
+
+    def take(self, ds, idx):
+        """ds[idx] on the device (unet_gather_samples): the mini-batch of a shuffled epoch out of a resident dataset; idx = host integers."""
+        torch = _torch()
+        idx = np.ascontiguousarray(idx, np.int64)
+        if len(idx) and np.all(np.diff(idx) == 1):
+            return ds[int(idx[0]):int(idx[0]) + len(idx)]                            # a contiguous range is a view
+        sf = int(np.prod(ds.shape[1:]))
+        if sf % 4:
+            return ds[torch.from_numpy(idx).to(self.dev)]
+        k = self._idx_i % 4; self._idx_i += 1                                        # four pinned index buffers in rotation (a step outlives the host by < 3 batches)
+        if self._idx_pin[k] is None or self._idx_pin[k].numel() < len(idx):
+            self._idx_pin[k] = torch.empty(max(len(idx), 256), dtype=torch.int64).pin_memory()
+        self._idx_pin[k][:len(idx)].copy_(torch.from_numpy(idx))
+        di = self._idx_pin[k][:len(idx)].to(self.dev, non_blocking=True)
+        out = torch.empty((len(idx),) + tuple(ds.shape[1:]), dtype=torch.float32, device=self.dev)
+        self.ctx.check(self.lib.unet_gather_samples(self.ctx.handle, ds.data_ptr(), di.data_ptr(), out.data_ptr(), len(idx), sf, self._stream()), "gather_samples")
+        return out
 
     def _all_reduce(self, t, group=None):
         """SUM all-reduce.  backend nccl (= RCCL) reduces device tensors in place; the gloo branch (used by the

@@ -9,6 +9,8 @@ explicit constructor argument so host logic can be unit-tested; there is no impl
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 
 from . import weights as W
@@ -86,9 +88,42 @@ def load_model(path, backend=None, custom_objects=None, compile=True, **backend_
     return model
 
 
+class BatchSource:
+    """x[idx] / y[idx] of model.fit / evaluate / predict (T1:1059-1061, 1101, 1137).  With a backend that can keep a dataset in HBM (engine.HipUNet.resident)
+    the arrays are uploaded ONCE and a mini-batch is a device-side gather (or a view, for a contiguous range); otherwise -- a set too large for the
+    device, or a backend without the hook (the CPU test backends) -- batches are cut on the host from an fp32 copy made once and travel through the
+    backend's staging (pinned, asynchronous in the engine).  device_resident: True / False / "auto" (upload when it fits)."""
+
+    def __init__(self, backend, *arrays, device_resident="auto"):
+        self.backend = backend
+        self.dev = []
+        for a in arrays:
+            d = None
+            if a is not None and device_resident and hasattr(backend, "resident") and hasattr(backend, "take"):
+                d = backend.resident(a) if device_resident == "auto" else backend.resident(a, max_fraction=1.0)
+            if d is None and a is not None and not hasattr(a, "detach"):
+                a = np.asarray(a)
+                if a.dtype != np.float32:
+                    a = a.astype(np.float32)                              # once, not per batch (the reference feeds float64, T1:520)
+            self.dev.append((d, a))
+
+    def __call__(self, idx):
+        out = []
+        for d, a in self.dev:
+            if a is None:
+                out.append(None)
+            elif d is not None:
+                out.append(self.backend.take(d, idx))
+            else:
+                idx = np.asarray(idx)
+                out.append(a[int(idx[0]):int(idx[0]) + len(idx)] if len(idx) and np.all(np.diff(idx) == 1) else a[idx])
+        return out
+
+
 class History:
     def __init__(self):
         self.history = {"loss": [], "dice_coeff": [], "val_loss": [], "val_dice_coeff": []}
+        self.epoch_seconds = []                       # wall time of every epoch incl. its validation pass (not a Keras field; bench.py reads it)
 
 
 class UNetModel:
@@ -146,7 +181,7 @@ class UNetModel:
         return W.to_json(self.h, self.w, self.in_ch, self.arch)
 
     def fit(self, x, y, batch_size=32, epochs=1, validation_data=None, checkpoint_dice=None, checkpoint_loss=None,
-            shuffle=True, shuffle_seed=0, dropout=True):
+            shuffle=True, shuffle_seed=0, dropout=True, device_resident="auto"):
         """model.fit(...) T1:1059-1061.  Per epoch: shuffle, bs-`batch_size` steps with a short
         last batch, loss = sample-weighted mean of batch losses, dice_coeff = mean of per-batch
         values; then a full validation pass; ModelCheckpoint(save_best_only) on val_dice_coeff
@@ -157,20 +192,24 @@ class UNetModel:
         best_dice, best_loss = -np.inf, np.inf
         rng = np.random.RandomState(shuffle_seed)
         world, rank = dp_info(self.backend)       # data parallel (T3:989-1009 on N GPUs): every rank walks the same shuffled batches, each takes its shard
+        src = BatchSource(self.backend, x, y, device_resident=device_resident)          # the training set goes to HBM once (when it fits), not batch by batch
+        val = BatchSource(self.backend, validation_data[0], validation_data[1], device_resident=device_resident) if validation_data is not None else None
         for ep in range(epochs):
+            t_ep = time.perf_counter()
             order = rng.permutation(n) if shuffle else np.arange(n)
             outs, sizes = [], []
             for i in range(0, n, batch_size):
                 idx = order[i:i + batch_size]
                 sel, kw = dp_shard(idx, world, rank)
-                outs.append(self.backend.train_batch(x[sel], y[sel], dropout, **kw))          # [loss, dice_coeff] of the WHOLE batch on every rank
+                xb, yb = src(sel)
+                outs.append(self.backend.train_batch(xb, yb, dropout, **kw))                  # [loss, dice_coeff] of the WHOLE batch on every rank
                 sizes.append(len(idx))
             vals = np.stack([_host(o) for o in outs])                     # one host sync per epoch
             hist.history["loss"].append(float(np.average(vals[:, 0], weights=sizes)))
             hist.history["dice_coeff"].append(float(vals[:, 1].mean()))
             line = f"Epoch {ep + 1}/{epochs} - loss: {hist.history['loss'][-1]:.4f} - dice_coeff: {hist.history['dice_coeff'][-1]:.4f}"
             if validation_data is not None:
-                ev = self.evaluate(validation_data[0], validation_data[1], batch_size=batch_size, verbose=0)
+                ev = self.evaluate(validation_data[0], validation_data[1], batch_size=batch_size, verbose=0, _source=val)
                 hist.history["val_loss"].append(ev["loss"]); hist.history["val_dice_coeff"].append(ev["dice_coeff"])
                 line += f" - val_loss: {ev['loss']:.4f} - val_dice_coeff: {ev['dice_coeff']:.4f}"
                 if checkpoint_dice and ev["dice_coeff"] > best_dice:
@@ -185,21 +224,23 @@ class UNetModel:
                     best_loss = ev["loss"]
                     if rank == 0:
                         self.save(checkpoint_loss)
+            hist.epoch_seconds.append(time.perf_counter() - t_ep)
             if self.verbose:
                 print(line)
         if world > 1:
             self.backend.barrier()                                    # the checkpoint files exist before any rank goes on to load_weights (T1:1073)
         return hist
 
-    def evaluate(self, x, y, batch_size=32, thresholds=None, verbose=0):
+    def evaluate(self, x, y, batch_size=32, thresholds=None, verbose=0, device_resident="auto", _source=None):
         """model.evaluate T1:1101: loss = sample-weighted mean over batches; every metric = mean of
         the per-batch values.  With `thresholds`, ONE forward pass per batch feeds all thresholds
         (the reference re-compiles and re-runs evaluate per threshold, T1:1205-1211)."""
         losses, dices, sizes, per_batch = [], [], [], []
         world, rank = dp_info(self.backend)
+        src = _source if _source is not None else BatchSource(self.backend, x, y, device_resident=device_resident)
         for i in range(0, len(x), batch_size):
             sel, kw = dp_shard(np.arange(i, min(i + batch_size, len(x))), world, rank)
-            xb, yb = x[sel], y[sel]
+            xb, yb = src(sel)
             p, ld = self.backend.predict_batch(xb, yb, **kw)          # loss / dice_coeff and the threshold sums are the whole batch's on every rank
             losses.append(ld); sizes.append(min(i + batch_size, len(x)) - i)
             if thresholds is not None and len(thresholds):
