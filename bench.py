@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the untimed fp32_strict_img_s measurement (--algo 2 engine, 8 steps)")
     ap.add_argument("--fold16", action="store_true", help="UNET_OPT_BN_FOLD = 3: the classifier's 16-channel first block folded too (+15 %% there; more ReLU flips at full size, include/unet_hip.h)")
     ap.add_argument("--deterministic", action="store_true", help="UNET_OPT_DETERMINISTIC: fixed-order reductions, no floating-point atomics (bit-identical reruns)")
+    ap.add_argument("--options", default="", help='context options as JSON, e.g. {"head_fused": 0} (same-box A/B of graph forms; _lib.OPTIONS)')
     ap.add_argument("--settle", type=float, default=2.0, help="seconds of untimed steps ahead of the warm-up (clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fit-leg", action="store_true", help="skip the untimed fit_img_s measurement (UNetModel.fit on a host-resident set)")
@@ -142,7 +143,7 @@ def main():
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
-                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) or None)
+                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) | (json.loads(args.options) if args.options else {}) or None)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     def settle(seconds):
@@ -245,7 +246,8 @@ def main():
     if rank == 0:
         # (conv3x3_dgrad_bn_bwd: the data gradient of a decoder block's first conv with the folded BatchNorm's backward in its epilogue -- the same
         #  kernel, same FLOPs; the op's time includes its 5 us coefficient launch)
-        dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_dgrad:") or o[0].startswith("conv3x3_dgrad_bn_bwd:")]
+        # (conv3x3_fwd_head: the last conv3x3 with the 1x1 sigmoid head and the loss sums in its epilogue -- the same kernel body and conv FLOPs)
+        dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_fwd_head:") or o[0].startswith("conv3x3_dgrad:") or o[0].startswith("conv3x3_dgrad_bn_bwd:")]
         dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel
         fl = sum(o[1] for o in dom); ms = sum(o[3] / max(o[4], 1) for o in dom); launches = len(dom)
         shapes = W.weight_shapes(1, args.arch, (S, S))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 10
+#define UNET_ABI_VERSION 11
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -65,8 +65,12 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   BN_CONCAT_ANALYTIC (1) decoder BatchNorm statistics: skip half from the encoder layer's sums, only the upsampled half measured
  *   BN_FUSE_STATS (1)      BatchNorm statistics accumulated by the producing conv's epilogue (unet_request_bn_stats honoured)
  *   DETERMINISTIC (0)      1 = every reduction in a fixed order: no floating-point atomics anywhere (BatchNorm / loss / metric sums through per-workgroup
- *                          slots folded in index order; statistics by their own pass), so reruns are bit-identical; costs ~6 % of the step */
-enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6 };
+ *                          slots folded in index order; statistics by their own pass), so reruns are bit-identical; costs ~6 % of the step
+ *   HEAD_FUSED (1)         fp32 U-Net, h2 kernels: the 1x1 sigmoid head (T1:913), the loss sums and the per-channel sums of the head's weight gradient come out of
+ *                          the epilogue of the last conv3x3 (no pass over its 32-channel output in forward; backward writes dL/d(conv output) from p, the labels
+ *                          and one bit per element); 0 = the separate head_fwd / head_bwd passes (always taken in deterministic mode) */
+enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,
+       UNET_OPT_HEAD_FUSED = 7 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
 int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */
 
@@ -253,6 +257,21 @@ int32_t unet_loss_finalize(unet_ctx*, const double* loss_sums, double count, flo
 int32_t unet_head_bwd(unet_ctx*, const float* x, const float* w, const float* p, const float* y_true,
                       const double* loss_sums, double count, float* dx, float* dw, float* db,
                       int64_t pixels, int32_t cin, int32_t relu_mask, void* stream);
+
+/* Replaces: `c9 = Conv2D(32, (3, 3), relu)(c9)` + `outputs = Conv2D(1, (1, 1), activation='sigmoid')(c9)` T1:911-913 and the loss sums of
+ * bce_dice_loss T1:784-799 in ONE launch (fp32, UNET_ALGO_AUTO kernels, 32 output channels, W % 8 == 0, not in deterministic mode:
+ * unet_conv3x3_head_supported): y = relu(conv3x3(x) + bias) [n,h,w,32], p = sigmoid(y . w_head + b_head) [n,h,w]; with y_true
+ *   loss_sums[4] += (sum bce, sum t p, sum t, sum p)   -- as unet_head_fwd
+ *   head_sums[99] += per channel c: sum a y_c | sum t q y_c | sum q y_c  (a = dBCE/dz = p_clipped - t inside the clip range, q = p (1 - p)), then sum a, sum t q, sum q
+ * The head's weight gradient is a combination of head_sums once the batch-global Dice sums are known (unet_head_dy), so the backward needs no pass
+ * over y.  ReLU sign bits of y can be requested as for unet_conv3x3_fwd (unet_request_relu_bits).  w_ws: unet_conv3x3_w_ws_floats(cin, 32) floats. */
+int32_t unet_conv3x3_head_supported(unet_ctx*, int32_t algo, int32_t w, int32_t cin, int32_t cout);
+int32_t unet_conv3x3_head_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, const float* w_head, const float* b_head, float* p,
+                              const float* y_true, double* loss_sums, double* head_sums, int32_t n, int32_t h, int32_t wd, int32_t cin, float* w_ws, void* stream);
+/* backward of that head: dy[n,h,w,32] = dz w_head [y > 0] (mask from relu_bits, or from y when relu_bits is NULL), dz as in unet_head_bwd from the
+ * GLOBAL loss sums; dw_head[32] / db_head[1] += the combination of head_sums. */
+int32_t unet_head_dy(unet_ctx*, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const float* w_head,
+                     const void* relu_bits, const float* y, float* dy, float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream);
 
 /* Replaces: Adam(lr=0.0005) step of model.fit T1:1053,1059 -- Keras-2.3 form:
  *   m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps), lr_t=lr*sqrt(1-b2^t)/(1-b1^t)

@@ -10,11 +10,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2          # fp16-split h2 kernels where the shape allows / VALU kernels / strict fp32 MFMA kernels
 # unet_ctx_set_option (include/unet_hip.h UNET_OPT_*)
-OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6}
+OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6, "head_fused": 7}
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
@@ -108,6 +108,9 @@ _PROTOS = {
     "unet_adam_keras": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     "unet_seg_metrics_sweep": (i32, [vp, vp, vp, vp, i32, vp, i64, vp]),
     "unet_gather_samples": (i32, [vp, vp, vp, i64, i64, vp]),
+    "unet_conv3x3_head_supported": (i32, [vp, i32, i32, i32, i32]),
+    "unet_conv3x3_head_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "unet_head_dy": (i32, [vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "unet_zero": (i32, [vp, vp, sz, vp]),
     "unet_copy_slice": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
     "unet_copy_slice_bf16": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
@@ -200,14 +203,21 @@ class Context:
     def get(cls, device: int, options: dict | None = None) -> "Context":
         """The shared default-option context of a device, or -- with options -- a private context carrying them
         (unet_ctx_set_option: a model reads the options when it is created, the op-level entry points when they launch)."""
-        if options:
+        key = (device, frozenset((k, int(v)) for k, v in options.items())) if options else device
+        if key not in cls._cache:                              # one context per (device, option set): engines with the same options share it (a context owns 24 MB of device scratch)
             ctx = cls(device)
-            for k, v in options.items():
+            for k, v in (options or {}).items():
                 ctx.check(ctx.lib.unet_ctx_set_option(ctx.handle, OPTIONS[k], int(v)), f"set_option({k})")
-            return ctx
-        if device not in cls._cache:
-            cls._cache[device] = cls(device)
-        return cls._cache[device]
+            cls._cache[key] = ctx
+        return cls._cache[key]
+
+    def close(self):
+        """unet_ctx_destroy: frees the context's device scratch (slot copies, ConvT image); the object must not be used afterwards"""
+        if self.handle is not None:
+            for k in [k for k, v in type(self)._cache.items() if v is self]:
+                del type(self)._cache[k]
+            self.lib.unet_ctx_destroy(self.handle)
+            self.handle = None
 
     def check(self, rc: int, what: str = ""):
         if rc != 0:

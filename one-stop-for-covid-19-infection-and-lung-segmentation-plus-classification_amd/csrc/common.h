@@ -16,6 +16,7 @@
 // Deterministic mode (UNET_OPT_DETERMINISTIC): UNET_BN_SLOTS_DET copies, every workgroup of a reduction kernel owns ONE copy (grids are capped at the copy
 // count), so each atomic lands on a zero it alone writes, and the fold kernel sums the copies in index order: bit-identical reruns.
 constexpr int UNET_BN_SLOTS = 64, UNET_BN_SLOTS_DET = 1024, UNET_BN_SLOT_DOUBLES = 2048;
+constexpr int UNET_HEAD_SUMS = 100;          // doubles behind the loss sums: the per-channel sums of a fused head's weight gradient (k_head_fold)
 struct unet_ctx {
   int device = 0;
   int num_cu = 256;
@@ -26,6 +27,7 @@ struct unet_ctx {
   int opt_enc_bn_fused = 1;         // encoder tail backward without a statistics pass
   int opt_bn_concat_analytic = 1;   // decoder BatchNorm statistics: skip half analytic
   int opt_bn_fuse_stats = 1;        // BatchNorm statistics from the producing conv's epilogue
+  int opt_head_fused = 1;           // the 1x1 sigmoid head + loss sums + the head's weight-gradient sums in the epilogue of the last conv3x3 (fp32 h2 kernels)
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
   int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
@@ -201,7 +203,7 @@ int32_t k_wgrad_bn_fold_fix(unet_ctx*, const float* dy, int n, int h, int wd, in
                             hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
 int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx*, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
                                  float* scratch, hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
-constexpr int UNET_WINO_PREP_MAX = 36;          // layers per batched weight-preparation launch (the list travels as a kernel argument: < 4 KiB)
+constexpr int UNET_PREP_MAX = 36;          // layers per batched weight-preparation launch (the list travels as a kernel argument: < 4 KiB)
 // fp32 conv3x3 / ConvT on the fp16 matrix cores through the block-scaled 2-term fp16 split (kernels_conv_h2.hip, kernels_wgrad_h2.hip): three fp16 MFMA products per
 // multiply.  The family of UNET_ALGO_AUTO wherever the channel counts allow; K = contraction channels, M = output channels of a launch
 bool h2_conv3x3_selected(int algo, int K, int M);
@@ -215,6 +217,16 @@ size_t h2_convT_img_bytes(int cin, int cout);
 // mask_climit (folded-BatchNorm data gradients, MASK_BN_BWD*): output channels >= mask_climit do not read x -- they get K0 dz + K2, the K1 x term is added by their consumer
 int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
                          int act, float rate, uint64_t seed, hipStream_t s, int mask_climit = 1 << 30);
+struct h2_head_args { const float* w = nullptr; const float* b = nullptr; float* p = nullptr; const float* t = nullptr; double* slots = nullptr; };
+bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int M);
+int32_t k_conv3x3_h2_head_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, float* y, const float* wh, const float* bh, float* p, const float* t,
+                              int n, int h, int wd, int K, hipStream_t s);
+// the sums k_conv3x3_h2_head_fwd left in the slot copies -> loss_sums[4] (+=) and head_sums[99] (+=): [32 x 3 per-channel sums][sum a, sum t q, sum q]
+int32_t k_head_fold(unet_ctx*, double* loss_sums, double* head_sums, hipStream_t s);
+// backward of the fused head: dy[p][c] = dz_p w_c [y_pc > 0] (mask from the sign bits `bits` or, if null, from y itself) and -- workgroup 0 -- the head's weight /
+// bias gradient out of head_sums and the batch-global loss sums (ACCUMULATED into dw[32], db[1])
+int32_t k_head_dy(unet_ctx*, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const float* w, const unsigned long long* bits,
+                  const float* y, float* dy, float* dw, float* db, int n, int h, int wd, hipStream_t s);
 int32_t k_bn_maxpool_bwd_apply_k1(unet_ctx*, const float* x, int ldx, const float* bnp, const double* sums, double count, const float* g_skip, int ldg, const float* skip_k1,
                                   const float* dy_pooled, float* dx, int lddx, int n, int h, int wd, int c, float rate, uint64_t seed, hipStream_t s);
 bool h2_convT_selected(const unet_ctx* ctx, int algo, int cin, int cout);
@@ -274,7 +286,7 @@ int32_t k_conv3x3_bf16_fwd(unet_ctx*, const unet_bf16* x, const float* w, const 
                            int wd, int cin, int cout, int act, float rate, uint64_t seed, unet_bf16* wimg, int flip, hipStream_t s,
                            const unet_bf16* prepared = nullptr);
 struct unet_wimg_prep { const float* w; unet_bf16* img; long long tap_stride, sk, sm, total8; int nb, nchunks, flip, m; };
-struct unet_wimg_prep_list { unet_wimg_prep item[UNET_WINO_PREP_MAX]; int n; };       // passed by value as a kernel argument (2.2 KiB)
+struct unet_wimg_prep_list { unet_wimg_prep item[UNET_PREP_MAX]; int n; };       // passed by value as a kernel argument (2.2 KiB)
 int32_t k_wimg_multi(unet_ctx*, unet_wimg_prep_list* L, const int* cin, const int* cout, hipStream_t s);
 int32_t k_convT_bf16_fwd(unet_ctx*, const unet_bf16* x, const float* w, const float* bias, unet_bf16* y, int ldy, int n, int h, int wd, int cin, int cout,
                          unet_bf16* wimg, hipStream_t s);

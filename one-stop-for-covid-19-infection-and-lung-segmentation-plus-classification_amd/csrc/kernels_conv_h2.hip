@@ -67,7 +67,7 @@ __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int H2_MAXB = 48;                                  // workgroups per layer of the max pass
 struct h2_prep { const float* w; const float* cs; unet_bf16* img; long long tap_stride, sk, sm, total, nw4; int T, KS, nb, nchunks, flip, m, cs_div, cs_mod; };
-struct h2_prep_list { h2_prep item[UNET_WINO_PREP_MAX]; int n; };          // passed by value as a kernel argument (3.4 KiB)
+struct h2_prep_list { h2_prep item[UNET_PREP_MAX]; int n; };          // passed by value as a kernel argument (3.4 KiB)
 
 __global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {          // grid (H2_MAXB, layers)
   const h2_prep& p = L.item[blockIdx.y];
@@ -132,12 +132,15 @@ __device__ __forceinline__ int out_cell(int p, int c) { return p * 128 + ((c ^ (
 //         stride ldy) of the concat buffer (T1:886-887)
 // MODE 2: convT2x2s2 data gradient = per-pixel GEMM over the virtual channels k = (ab, o): chunk -> (ab, o0) selects the parity plane (2i+a, 2j+b) of dU
 //         (pixel stride ldx) that is staged
-template <int MODE, int NB, int RW, bool GEN, int WPS>
+// HEAD (the network's last conv3x3, T1:911-913): the 1x1 sigmoid head, the four loss sums and the three per-channel sums the head's weight gradient is a
+// combination of are taken from the output tile while it is in registers / LDS (h2_head_args; one channel group of 32, ReLU, no mask)
+template <int MODE, int NB, int RW, bool GEN, int WPS, bool HEAD = false>
 __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
                                                            int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs,
-                                                           int mask_climit) {
+                                                           int mask_climit, h2_head_args hd) {
+  static_assert(!HEAD || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the fused head rides on the 32-channel forward kernel");
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
   constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
@@ -274,8 +277,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     s_bias[tid] = (bias && ok) ? bias[MODE == 1 ? ch % (M >> 2) : ch] : 0.f;
     const bool bn_bwd_mode = mask_mode >= MASK_BN_BWD && mask_mode <= MASK_BN_BWD_RELU;
     const bool coef = bn_bwd_mode && mask && ok;
-    s_bias[NB * 32 + tid] = coef ? bias[M + ch] : 0.f;
-    s_bias[2 * NB * 32 + tid] = coef ? bias[2 * M + ch] : 0.f;
+    s_bias[NB * 32 + tid] = HEAD ? hd.w[tid] : coef ? bias[M + ch] : 0.f;          // (HEAD: row 1 = the 32 weights of the 1x1 head, row 2 [0] = its bias)
+    s_bias[2 * NB * 32 + tid] = HEAD ? hd.b[0] : coef ? bias[2 * M + ch] : 0.f;
   }
   issue_loads(0);
   issue_w_loads(0);
@@ -394,6 +397,11 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
     }
   }
+  // HEAD: lane (l31, hi) does the sigmoid / loss arithmetic of pixel (row hi of its wave's two, column l31); its label travels under the last MFMAs
+  const int hpy = y0 + wave * RW + hi;
+  const bool hvalid = HEAD && hpy < H && px_ < W;
+  float hlabel = 0.f;
+  if (HEAD && hd.t && hvalid) hlabel = hd.t[((long long)n * H + hpy) * W + px_];
   __builtin_amdgcn_s_setprio(2);
   mfma_chunk();
   __builtin_amdgcn_s_setprio(0);
@@ -406,6 +414,99 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   char* const s_out = smem + wave * (32 * OUT_PS);
   float* const s_stat = reinterpret_cast<float*>(smem + 4 * 32 * OUT_PS);          // [wave][nb][sum | sum of squares][32 channels]
 
+  if constexpr (HEAD) {
+    // LDS (planes and slab are dead): [4 waves][32 pixels][128 B] staging rows | s_rec [4 waves][2 rows][32 pixels][8 floats] | s_hsum [4 waves][104 floats]
+    float* const s_rec = reinterpret_cast<float*>(smem + 4 * 32 * OUT_PS) + wave * (2 * 32 * 8);
+    float* const s_hsum = reinterpret_cast<float*>(smem + 4 * 32 * OUT_PS + 4 * 2 * 32 * 8 * 4);
+    float bv[16], wh[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(s_bias + hi * 16 + q * 4), w4 = *reinterpret_cast<const float4*>(s_bias + 32 + hi * 16 + q * 4);
+      bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
+      wh[q * 4] = w4.x; wh[q * 4 + 1] = w4.y; wh[q * 4 + 2] = w4.z; wh[q * 4 + 3] = w4.w;
+    }
+    float dpart[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {                         // y = relu(conv + bias) in place of the accumulators; this lane's 16 channels of the head's dot product
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float v = fmaxf(fmaf(acc[r][0][i], unscale, bv[i]), 0.f); acc[r][0][i] = v; d = fmaf(v, wh[i], d); }
+      dpart[r] = d;
+    }
+    // the partner lane (other channel half, same pixel column) holds the other 16 channels: each lane hands over the half-sum of the row it does NOT finish
+    const float z = (hi ? dpart[1] : dpart[0]) + __shfl_xor(hi ? dpart[0] : dpart[1], 32) + s_bias[64];
+    // sigmoid and the Keras loss terms of this pixel (T1:784-799; BCE in logit form on the clipped probability): inside the clip range the
+    // logit of the clipped p IS z; outside it is the logit of the fp32 clip bound as an fp32 evaluation has it (head_fwd_kernel, TF): 1 - 1e-7 is
+    // 1 - 2^-23 in fp32 -> logit 15.942385 (log term 2^-23), 1e-7 -> logit -16.118095 (log term 1.0000001e-7)
+    const float ez = expf(-fabsf(z)), rz = 1.0f / (1.0f + ez);
+    const float pr = z >= 0.f ? rz : ez * rz;
+    const float lo = 1e-7f, hi_ = 1.0f - 1e-7f;
+    const bool inr = pr >= lo && pr <= hi_;
+    const float pc = fminf(fmaxf(pr, lo), hi_);
+    const float zc = inr ? z : (z > 0.f ? 15.942385f : -16.118095f);
+    const float tl = hlabel;
+    const float bce = fmaxf(zc, 0.f) - zc * tl + (inr ? log1pf(ez) : (z > 0.f ? 1.1920929e-7f : 1.0000001e-7f));
+    const float qq = pr * (1.0f - pr);
+    if (hvalid) hd.p[((long long)n * H + hpy) * W + px_] = pr;
+    {
+      const bool on = hvalid && hd.t != nullptr;            // (inference: probabilities only)
+      float* rec = s_rec + (hi * 32 + l31) * 8;             // {bce, t p, t, p | a, t q, q, 0}: a = dBCE/dz inside the clip range, q = p (1 - p)
+      *reinterpret_cast<float4*>(rec) = on ? make_float4(bce, tl * pr, tl, pr) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(rec + 4) = on ? make_float4(inr ? pc - tl : 0.f, tl * qq, qq, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f), g2 = g1, g3 = g1; float gs = 0.f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int py = y0 + wave * RW + r;
+      if (py >= H) continue;                               // (wave-uniform)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(s_out + out_cell(l31, hi * 4 + q)) = make_float4(acc[r][0][q * 4], acc[r][0][q * 4 + 1], acc[r][0][q * 4 + 2], acc[r][0][q * 4 + 3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pj = j * 8 + (lane >> 3), cj = lane & 7, pxj = x0 + pj;
+        const float4 t4 = *reinterpret_cast<const float4*>(s_out + out_cell(pj, cj));
+        const long long oj = (((long long)n * H + py) * W + pxj) * ldy;
+        if (signs) {                                       // (wave-uniform) sign bits of the stored values: the mask of the head's own backward
+          const bool vld = pxj < W;
+          const unsigned long long b0 = __builtin_amdgcn_ballot_w64(vld && t4.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(vld && t4.y > 0.f);
+          const unsigned long long b2 = __builtin_amdgcn_ballot_w64(vld && t4.z > 0.f), b3 = __builtin_amdgcn_ballot_w64(vld && t4.w > 0.f);
+          if (lane < 4 && x0 + j * 8 < W)
+            signs[(((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        }
+        if (pxj < W) {
+          *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
+          if (hd.t) {
+            const float* rec = s_rec + (r * 32 + pj) * 8;
+            const float4 c4 = *reinterpret_cast<const float4*>(rec + 4);
+            g1.x = fmaf(c4.x, t4.x, g1.x); g1.y = fmaf(c4.x, t4.y, g1.y); g1.z = fmaf(c4.x, t4.z, g1.z); g1.w = fmaf(c4.x, t4.w, g1.w);
+            g2.x = fmaf(c4.y, t4.x, g2.x); g2.y = fmaf(c4.y, t4.y, g2.y); g2.z = fmaf(c4.y, t4.z, g2.z); g2.w = fmaf(c4.y, t4.w, g2.w);
+            g3.x = fmaf(c4.z, t4.x, g3.x); g3.y = fmaf(c4.z, t4.y, g3.y); g3.z = fmaf(c4.z, t4.z, g3.z); g3.w = fmaf(c4.z, t4.w, g3.w);
+            gs += rec[cj];                                 // scalar sum number cj (0..6) of this pixel; rec[7] = 0
+          }
+        }
+      }
+    }
+    if (hd.t) {                                            // (uniform) lanes L, L + 8, ... hold the same channel quad / scalar: fold, lanes 0-7 post the wave's sums
+      float sv[13] = {g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w, gs};
+#pragma unroll
+      for (int i = 0; i < 13; ++i) { sv[i] += __shfl_xor(sv[i], 8); sv[i] += __shfl_xor(sv[i], 16); sv[i] += __shfl_xor(sv[i], 32); }
+      if (lane < 8) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s_hsum[wave * 104 + k * 32 + lane * 4 + i] = sv[k * 4 + i];
+        s_hsum[wave * 104 + 96 + lane] = sv[12];
+      }
+      __syncthreads();
+      if (tid < 103) {                                     // [0, 96): the three per-channel sums; 96..99: bce, t p, t, p; 100..102: sum a, sum t q, sum q
+        const float t = (s_hsum[tid] + s_hsum[104 + tid]) + (s_hsum[208 + tid] + s_hsum[312 + tid]);
+        atomicAdd(hd.slots + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + tid, (double)t);
+      }
+    }
+    H2_STAMP(8);
+    return;
+  }
   // ---- epilogue: lane (l31, hi) holds, for pixel column l31 of each of its RW rows, channels mb + 0..15
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -590,9 +691,9 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #endif
 }
 
-template <int MODE, int NB, int RW, int WPS>
+template <int MODE, int NB, int RW, int WPS, bool HEAD = false>
 int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd,
-                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30) {
+                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30, h2_head_args hd = h2_head_args()) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
@@ -618,11 +719,14 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
-                       stats_c, signs, mask_climit);
+                       stats_c, signs, mask_climit, hd);
     return UNET_OK;
   };
   int32_t r;
-  if (gen) r = go(conv_h2_kernel<MODE, NB, RW, (MODE == 0), WPS>); else r = go(conv_h2_kernel<MODE, NB, RW, false, WPS>);
+  if (HEAD) {
+    if (gen || mask_mode != MASK_NONE || act != ACT_RELU || M != 32 || stats) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 + head: a plain 32-channel ReLU forward launch only");
+    r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, HEAD>);
+  } else if (gen) r = go(conv_h2_kernel<MODE, NB, RW, (MODE == 0), WPS>); else r = go(conv_h2_kernel<MODE, NB, RW, false, WPS>);
   if (r) return r;
   UNET_CHECK_LAUNCH(ctx, "conv_h2");
   return UNET_OK;
@@ -675,7 +779,7 @@ static void h2_fill_prep(h2_prep* p, const float* w, const float* cs, void* img,
 // count items (w, cs, img, cin, cout, kind) -> their split images, in TWO launches
 int32_t k_h2_prep_multi(unet_ctx* ctx, const float* const* w, const float* const* cs, void* const* img, const int* cin, const int* cout, const int* kind, int count, hipStream_t s) {
   if (count < 1) return UNET_OK;
-  if (count > UNET_WINO_PREP_MAX) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: too many layers");
+  if (count > UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: too many layers");
   h2_prep_list L; L.n = count;
   long long most = 1;
   for (int k = 0; k < count; ++k) {
@@ -711,6 +815,20 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
   if (h <= 128 && wgs16 >= 512) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
   return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
+}
+
+// The network's last conv3x3 + its 1x1 sigmoid head (T1:911-913) in one launch: y = relu(conv(x)) [n,h,wd,32], p = sigmoid(y . wh + bh) [n,h,wd]; with labels t:
+// the slot copies `ctx->bn_slots` receive [0,96) sum_p a y_c | sum_p t q y_c | sum_p q y_c, [96,100) sum bce, sum t p, sum t, sum p, [100,103) sum a, sum t q, sum q
+// (a = dBCE/dz, q = p (1 - p)): k_head_fold moves them out; the head's weight gradient is a combination of them once the batch-global Dice sums are known
+bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int M) {
+  return ctx && !ctx->opt_deterministic && ctx->opt_head_fused && ctx->bn_slots && h2_conv3x3_selected(algo, K, M) && M == 32 && (wd & 7) == 0;
+}
+int32_t k_conv3x3_h2_head_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, float* y, const float* wh, const float* bh, float* p, const float* t,
+                              int n, int h, int wd, int K, hipStream_t s) {
+  if (K < 16 || (K % 16) || !wh || !bh || !p) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2 + head: bad args");
+  if ((long long)h * wd * std::max(K, 32) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  h2_head_args hd; hd.w = wh; hd.b = bh; hd.p = p; hd.t = t; hd.slots = ctx->bn_slots;
+  return launch_h2<0, 1, 2, 4, true>(ctx, x, K, static_cast<const unet_bf16*>(wimg), bias, nullptr, MASK_NONE, y, 32, n, h, wd, K, 32, ACT_RELU, 0.0f, 0, s, 1 << 30, hd);
 }
 
 // ---- ConvT 2x2 stride 2 (T1:886 ...) on the same kernels: forward = MODE 1 (K = cin, M = 4 cout), data gradient = MODE 2 (K = 4 cout, M = cin).

@@ -589,6 +589,65 @@ __global__ __launch_bounds__(TPB) void head_bwd_kernel(const T* __restrict__ x, 
   }
 }
 
+// ---- the fused head (kernels_conv_h2.hip: conv_h2_kernel<..., HEAD>) -------------------------------------------------
+// fold of the 103 sums it left in the slot copies (cleared for the next launch): [96, 100) -> loss_sums, the rest -> head_sums[99]
+__global__ void head_fold_kernel(double* __restrict__ slots, double* __restrict__ loss_sums, double* __restrict__ head_sums, int nslots) {
+  const int i = threadIdx.x;
+  if (i >= 103) return;
+  double s = 0.0;
+  for (int k0 = 0; k0 < nslots; k0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { double* p = slots + (size_t)(k0 + k) * UNET_BN_SLOT_DOUBLES + i; v[k] = *p; *p = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+  }
+  if (i < 96) head_sums[i] += s; else if (i < 100) loss_sums[i - 96] += s; else head_sums[96 + (i - 100)] += s;
+}
+
+// dz of pixel p from the stored probability, the label and the batch-global sums (the same expression as head_bwd_kernel)
+__device__ __forceinline__ float head_dz(float pr, float t, float hb, float dice, float invS) {
+  const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+  const float pc = fminf(fmaxf(pr, lo), hi);
+  const bool inr = (pr >= lo) && (pr <= hi);
+  return (inr ? hb * (pc - t) : 0.0f) - 0.5f * (2.0f * t - dice) * invS * pr * (1.0f - pr);
+}
+
+// dy[p][c] = dz_p w_c [y_pc > 0], 32 channels: a thread writes one 16-B quad; the mask is one bit per element (the layout conv_h2_kernel writes:
+// per (row, 8 pixels) four 64-bit words, bit (pixel % 8) * 8 + quad of word k = channel quad * 4 + k) or, without bits, y itself.
+// Workgroup 0 also finishes the head's own gradient: dz = hb a - invS t q + 0.5 invS dice q, so
+//   dw_c = hb S1_c - invS S2_c + 0.5 invS dice S3_c  with the three per-channel sums the forward epilogue took; db the same with the scalar sums
+__global__ __launch_bounds__(TPB) void head_dy_kernel(const float* __restrict__ pin, const float* __restrict__ yt, const double* __restrict__ sums, double inv_count,
+                                                      const double* __restrict__ hs, const float* __restrict__ w, const unsigned long long* __restrict__ bits,
+                                                      const float* __restrict__ y, float* __restrict__ dy, float* dw, float* db, long long pixels, int wd) {
+  const double S = sums[2] + sums[3] + 1.0;
+  const float dice = (float)((2.0 * sums[1] + 1.0) / S), invS = (float)(1.0 / S);
+  const float hb = (float)(0.5 * inv_count);
+  if (blockIdx.x == 0 && threadIdx.x < 33) {
+    const int c = threadIdx.x;
+    const double g = c < 32 ? (0.5 * inv_count) * hs[c] - (1.0 / S) * hs[32 + c] + 0.5 * (1.0 / S) * ((2.0 * sums[1] + 1.0) / S) * hs[64 + c]
+                            : (0.5 * inv_count) * hs[96] - (1.0 / S) * hs[97] + 0.5 * (1.0 / S) * ((2.0 * sums[1] + 1.0) / S) * hs[98];
+    if (c < 32) dw[c] += (float)g; else db[0] += (float)g;
+  }
+  const int q = threadIdx.x & 7;
+  const float4 wv = ld4(w + q * 4);
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < pixels * 8; i += (long long)gridDim.x * TPB) {
+    const long long p = i >> 3;
+    const float dz = head_dz(pin[p], yt[p], hb, dice, invS);
+    bool m0, m1, m2, m3;
+    if (bits) {
+      const long long row = p / wd; const int x = (int)(p - row * wd);
+      const unsigned long long* bw = bits + (row * (wd >> 3) + (x >> 3)) * 4;
+      const int sh = (x & 7) * 8 + q;
+      m0 = (bw[0] >> sh) & 1; m1 = (bw[1] >> sh) & 1; m2 = (bw[2] >> sh) & 1; m3 = (bw[3] >> sh) & 1;
+    } else {
+      const float4 v = ld4(y + i * 4);
+      m0 = v.x > 0.f; m1 = v.y > 0.f; m2 = v.z > 0.f; m3 = v.w > 0.f;
+    }
+    st4(dy + i * 4, make_float4(m0 ? dz * wv.x : 0.f, m1 ? dz * wv.y : 0.f, m2 ? dz * wv.z : 0.f, m3 ? dz * wv.w : 0.f));
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
@@ -942,6 +1001,21 @@ extern "C++" template <typename T> static int32_t head_bwd_impl(unet_ctx* ctx, c
     hipLaunchKernelGGL(bn_slot_fold_kernel<float>, dim3(1), dim3(128), 0, as_stream(stream), ctx->bn_slots + cin, db, 1, nslots);
   }
   UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
+}
+
+extern "C++" int32_t k_head_fold(unet_ctx* ctx, double* loss_sums, double* head_sums, hipStream_t s) {
+  if (!loss_sums || !head_sums || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "head_fold: bad args");
+  hipLaunchKernelGGL(head_fold_kernel, dim3(1), dim3(128), 0, s, ctx->bn_slots, loss_sums, head_sums, UNET_BN_SLOTS);
+  UNET_CHECK_LAUNCH(ctx, "head_fold"); return UNET_OK;
+}
+
+extern "C++" int32_t k_head_dy(unet_ctx* ctx, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const float* w, const unsigned long long* bits,
+                  const float* y, float* dy, float* dw, float* db, int n, int h, int wd, hipStream_t s) {
+  if (!p || !t || !loss_sums || !head_sums || !w || (!bits && !y) || !dy || !dw || !db || count < 1 || (bits && (wd & 7))) UNET_FAIL(ctx, UNET_E_ARG, "head_dy: bad args");
+  const long long pixels = (long long)n * h * wd;
+  const int head_dy_blocks = 16384;          // (a thread: 8 iterations at 512 x 512 x 16)
+  hipLaunchKernelGGL(head_dy_kernel, dim3(std::min(grid_for(pixels * 8 / 4), head_dy_blocks)), dim3(TPB), 0, s, p, t, loss_sums, 1.0 / count, head_sums, w, bits, y, dy, dw, db, pixels, wd);
+  UNET_CHECK_LAUNCH(ctx, "head_dy"); return UNET_OK;
 }
 
 int32_t unet_adam_keras(unet_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr_t, float b1,

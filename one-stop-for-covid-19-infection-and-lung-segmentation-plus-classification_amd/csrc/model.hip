@@ -64,6 +64,7 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_BN_CONCAT_ANALYTIC: return &ctx->opt_bn_concat_analytic;
     case UNET_OPT_BN_FUSE_STATS: return &ctx->opt_bn_fuse_stats;
     case UNET_OPT_DETERMINISTIC: return &ctx->opt_deterministic;
+    case UNET_OPT_HEAD_FUSED: return &ctx->opt_head_fused;
     default: return nullptr;
   }
 }
@@ -174,6 +175,27 @@ int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const fl
   ctx->signs_req = nullptr;
   if (!r && armed && ctx->signs_done != armed) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_fwd: armed with unet_request_relu_bits but this launch cannot write them (unet_relu_bits_supported, act = ReLU, no dropout)");
   return r;
+}
+
+// T1:911-913 in one launch (include/unet_hip.h): the last conv3x3 + the 1x1 sigmoid head + loss sums + the sums of the head's weight gradient
+int32_t unet_conv3x3_head_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cin, int32_t cout) { return ctx && h2_conv3x3_head_selected(ctx, algo, wd, cin, cout) ? 1 : 0; }
+int32_t unet_conv3x3_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, const float* w_head, const float* b_head, float* p, const float* y_true,
+                              double* loss_sums, double* head_sums, int32_t n, int32_t h, int32_t wd, int32_t cin, float* w_ws, void* stream) {
+  if (!ctx || !x || !w || !bias || !y || !w_head || !b_head || !p || !w_ws || n < 1 || h < 1 || wd < 1 || (y_true && (!loss_sums || !head_sums)))
+    UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_head_fwd: bad args");
+  if (!h2_conv3x3_head_selected(ctx, UNET_ALGO_AUTO, wd, cin, 32)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_head_fwd: not supported here (unet_conv3x3_head_supported)");
+  unsigned long long* armed = ctx->signs_req;
+  int32_t r = k_h2_weights(ctx, w, w_ws, cin, 32, 0, as_stream(stream));
+  if (!r) r = k_conv3x3_h2_head_fwd(ctx, x, w_ws, bias, y, w_head, b_head, p, y_true, n, h, wd, cin, as_stream(stream));
+  ctx->signs_req = nullptr;
+  if (!r && armed && ctx->signs_done != armed) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_head_fwd: armed with unet_request_relu_bits but the launch did not write them");
+  if (!r && y_true) r = k_head_fold(ctx, loss_sums, head_sums, as_stream(stream));
+  return r;
+}
+int32_t unet_head_dy(unet_ctx* ctx, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const float* w_head, const void* relu_bits,
+                     const float* y, float* dy, float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream) {
+  if (!ctx) return UNET_E_ARG;
+  return k_head_dy(ctx, p, y_true, loss_sums, count, head_sums, w_head, static_cast<const unsigned long long*>(relu_bits), y, dy, dw_head, db_head, n, h, wd, as_stream(stream));
 }
 
 int32_t unet_conv3x3_pick_algo(int32_t algo, int32_t wd, int32_t cin, int32_t cout) {
@@ -379,8 +401,10 @@ struct unet_model {
   size_t off_bn_bsums = 0;                            // all bwd BN sums (double)
   std::map<std::string, size_t> bn_sum_off, bn_bsum_off, bnp_off;   // per-BN offsets (doubles / floats)
   size_t off_loss_sums = 0, off_loss_out = 0, off_wt = 0, off_wgrad_ws = 0; size_t wgrad_ws_bytes = 0;
+  size_t off_first_tmp = 0;                // bf16 storage with a multi-channel image (configs[4] as written: 224 x 224 x 3): fp32 staging of the first conv's output / output gradient
+  size_t off_head_sums = 0; bool head_fused = false;          // U-Net, fp32 h2 kernels: c9b + 1x1 head + loss sums in one launch (kernels_conv_h2.hip, HEAD)
   std::map<std::string, size_t> sign_off;            // U-Net fp32 training: activation name -> its one-bit-per-element ReLU mask (MASK_RELU_BITS), offset in floats
-  std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the Winograd-transformed weights (forward / data-gradient form),
+  std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the prepared weights: the split fp16 image of the h2 kernels (forward / data-gradient form),
                                                       // filled by ONE batched launch at the start of a program
   // U-Net fp32: convs whose input BatchNorm is folded into them: conv name -> scratch of (scaled weights, bias table) / of the
   // weight-gradient correction; folded_bn maps the BatchNorm's activation name to (its input buffer, its channel count): never written by the programs
@@ -466,19 +490,22 @@ void plan_scratch(unet_model* m, Carver& cv) {          // BN sums / params, los
   size_t nd = 0;
   for (auto& l : m->layers) if (l.kind == 2) { m->bn_sum_off[l.name] = nd; nd += 2 * (size_t)l.cout; }
   m->bn_sums_doubles = nd;
-  m->off_bn_sums = cv.take((nd + 4) * 2);                 // doubles -> 2 floats each; +4 loss sums
+  m->off_bn_sums = cv.take((nd + 4 + UNET_HEAD_SUMS) * 2);          // doubles -> 2 floats each; +4 loss sums, + the sums of a fused head (zeroed with them)
   m->off_loss_sums = m->off_bn_sums + nd * 2;
+  m->off_head_sums = m->off_loss_sums + 4 * 2;
   size_t nb = 0;
   for (auto& l : m->layers) if (l.kind == 2) { m->bn_bsum_off[l.name] = nb; nb += 2 * (size_t)l.cout; }
   m->off_bn_bsums = cv.take(nb * 2);
   for (auto& l : m->layers) if (l.kind == 2) m->bnp_off[l.name] = cv.take(4 * (size_t)l.cout);
   m->off_loss_out = cv.take(64);
+  if (m->dt && m->in_ch != 1) m->off_first_tmp = cv.take((size_t)m->N * m->H * m->W * 32);          // (first conv: 32 channels in the U-Nets, 16 in the classifier)
 }
 
 void plan_workspace(unet_model* m) {
   Carver cv; cv.dt = m->dt;
   const int N = m->N;
   plan_scratch(m, cv);
+  m->head_fused = !m->dt && h2_conv3x3_head_selected(m->ctx, m->algo, m->W, 32, 32);
   // --- activations ---
   int S = m->H, T = m->W;
   for (int k = 1; k <= 4; ++k) {
@@ -504,7 +531,7 @@ void plan_workspace(unet_model* m) {
     m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
   }
   { size_t wt = 0; for (auto& l : m->layers) if (l.kind == 0) wt = std::max(wt, unet_conv3x3_w_ws_floats(l.cin, l.cout)); m->off_wt = cv.take(wt); }   // transformed-weight scratch
-  // per-layer scratch of the prepared weights: 16 Winograd taps (fp32) or the 9-tap bf16 image
+  // per-layer scratch of the prepared weights: the split fp16 image (fp32 storage) or the 9-tap bf16 image
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) m->wprep_f[l.name] = cv.take(m->dt ? ((size_t)9 * l.cin * l.cout + 1) / 2 : unet_conv3x3_w_ws_floats(l.cin, l.cout));
   // decoder BatchNorm folded into the conv that consumes it: whenever that conv runs on the F(2x2,3x3) kernels (the only ones with the border-class bias)
   if (m->ctx->opt_bn_fold) {
@@ -552,6 +579,7 @@ void plan_workspace(unet_model* m) {
       bool used = false;
       if (last == 'a') used = h2_conv(ob.w, l.cout, l.cout);                                      // mask of c<k>b's data gradient (K = M = cout)
       else if (l.name == "c5b" || l.name == "c6b" || l.name == "c7b" || l.name == "c8b") used = h2_convT_selected(m->ctx, m->algo, l.cout, l.cout / 2);
+      else if (l.name == "c9b") used = m->head_fused;                                             // mask of the fused head's backward (k_head_dy)
       if (used) m->sign_off[l.name] = cv.take((size_t)ob.n * ob.h * ob.w * l.cout / 32);
     }
   }
@@ -629,6 +657,24 @@ void arm_bn_statistics(unet_model* m) {
   }
 }
 
+// First conv of a graph in bf16 storage (the image stays fp32): the Cin = 1 kernels (the reference feeds 1-channel slices, T1:853, T2:748) or, for a multi-channel
+// image (BASELINE configs[4] names 224 x 224 x 3), the fp32 VALU kernels through an fp32 staging tensor that is rounded to bf16 / widened from it
+static int32_t first_conv_fwd_bf16(unet_ctx* ctx, unet_model* m, const std::string& name, const Buf& ob, int cout, int act, float rate, uint64_t seed, hipStream_t s) {
+  if (m->in_ch == 1) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), static_cast<unet_bf16*>(m->Av(name)), ob.n, ob.h, ob.w, cout, act, rate, seed, s);
+  float* tmp = m->wsf(m->off_first_tmp);
+  int32_t r = k_conv3x3_naive_fwd(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, tmp, ob.n, ob.h, ob.w, m->in_ch, cout, act, rate, seed, s);
+  if (r) return r;
+  return unet_cast_f32_to_bf16(ctx, tmp, static_cast<unet_bf16*>(m->Av(name)), (int64_t)ob.n * ob.h * ob.w * cout, s);
+}
+static int32_t first_conv_wgrad_bf16(unet_ctx* ctx, unet_model* m, const std::string& name, const Buf& ob, int cout, hipStream_t s) {
+  if (m->in_ch == 1) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, static_cast<const unet_bf16*>(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
+                                                    ob.n, ob.h, ob.w, cout, s);
+  float* tmp = m->wsf(m->off_first_tmp);
+  int32_t r = unet_cast_bf16_to_f32(ctx, static_cast<const unet_bf16*>(m->Dv(name)), tmp, (int64_t)ob.n * ob.h * ob.w * cout, s);
+  if (r) return r;
+  return k_conv3x3_naive_wgrad(ctx, m->x, tmp, m->G(name + "/kernel"), m->G(name + "/bias"), ob.n, ob.h, ob.w, m->in_ch, cout, s);
+}
+
 void build_programs(unet_model* m) {
   unet_ctx* ctx = m->ctx;
   const int algo = m->algo;
@@ -640,16 +686,16 @@ void build_programs(unet_model* m) {
   auto& FT = m->prog[UNET_PROG_FWD_TRAIN];
   auto& FI = m->prog[UNET_PROG_FWD_INFER];
   auto& BW = m->prog[UNET_PROG_BWD];
-  const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
+  const size_t sums_bytes = (m->bn_sums_doubles + 4 + UNET_HEAD_SUMS) * sizeof(double);
   // layers whose 3x3 weights are consumed as a prepared image (decided per layer exactly as the conv dispatch does)
   struct PrepItem { std::string name; int cin, cout, h, w; };
   std::vector<PrepItem> prep_items;
   for (auto& l : m->layers) if (l.kind == 0 && l.cin > 1) { const Buf& ob = m->act.at(l.name); prep_items.push_back({l.name, l.cin, l.cout, ob.h, ob.w}); }
   auto prep_weights_bf16 = [=](int flip, hipStream_t s) -> int32_t {          // bf16 storage: the MFMA weight images of all conv3x3 layers
-    unet_wimg_prep_list L; L.n = 0; int ci[UNET_WINO_PREP_MAX], co[UNET_WINO_PREP_MAX];
+    unet_wimg_prep_list L; L.n = 0; int ci[UNET_PREP_MAX], co[UNET_PREP_MAX];
     for (auto& it : prep_items) {
-      if (L.n >= UNET_WINO_PREP_MAX) break;
       if (!flip && m->fold_off.count(it.name)) continue;          // image built from the scaled weights after the BatchNorm's finalize
+      if (L.n >= UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images (bf16): too many layers for one batch");
       L.item[L.n] = unet_wimg_prep{m->P(it.name + "/kernel"), static_cast<unet_bf16*>(static_cast<void*>(m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)))), 0, 0, 0, 0, 0, 0, flip, 0};
       ci[L.n] = flip ? it.cout : it.cin; co[L.n] = flip ? it.cin : it.cout; ++L.n;
     }
@@ -658,16 +704,17 @@ void build_programs(unet_model* m) {
   std::vector<PrepItem> convt_items;
   for (auto& l : m->layers) if (l.kind == 1 && m->wprep_f.count(l.name)) convt_items.push_back({l.name, l.cin, l.cout, 0, 0});
   auto prep_weights = [=](int flip, hipStream_t s) -> int32_t {          // fp32: the split fp16 weight images of every conv3x3 / ConvT launch that runs on the h2 kernels: two launches
-    const float* ws_[UNET_WINO_PREP_MAX]; void* is_[UNET_WINO_PREP_MAX]; int ci_[UNET_WINO_PREP_MAX], co_[UNET_WINO_PREP_MAX], kd_[UNET_WINO_PREP_MAX], nx = 0;
+    const float* ws_[UNET_PREP_MAX]; void* is_[UNET_PREP_MAX]; int ci_[UNET_PREP_MAX], co_[UNET_PREP_MAX], kd_[UNET_PREP_MAX], nx = 0;
     for (auto& it : prep_items) {
       const int K = flip ? it.cout : it.cin, M = flip ? it.cin : it.cout;          // channels the launch consumes / produces
       if (flip && it.name == "c1a") continue;
       if (!flip && m->fold_off.count(it.name)) continue;          // prepared after its BatchNorm's finalize (bn_fold_prepare)
-      if (!h2_conv3x3_selected(algo, K, M) || nx >= UNET_WINO_PREP_MAX) continue;
+      if (!h2_conv3x3_selected(algo, K, M)) continue;
+      if (nx >= UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch (a skipped layer would run on an image that was never written)");
       ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = flip; ++nx;
     }
     for (auto& it : convt_items) {
-      if (nx >= UNET_WINO_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch");
+      if (nx >= UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch");
       ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = flip ? 3 : 2; ++nx;
     }
     return k_h2_prep_multi(ctx, ws_, nullptr, is_, ci_, co_, kd_, nx, s);
@@ -686,7 +733,7 @@ void build_programs(unet_model* m) {
       double by = eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout;
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
         if (dt) {
-          if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_RELU, 0.0f, 0, s);
+          if (in.empty()) return first_conv_fwd_bf16(ctx, m, name, ob, cout, ACT_RELU, 0.0f, 0, s);
           return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU,
                                     0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s, CBF(static_cast<void*>(m->wsf(m->wprep_f.at(name)))));
         }
@@ -797,11 +844,31 @@ void build_programs(unet_model* m) {
         });
       } else
       conv("c" + ks + "a", "bn" + ks, 2 * c, c);
+      if (k == 9 && m->head_fused) {
+        // T1:911-913 in one launch: c9b, the 1x1 sigmoid head, the loss sums and the sums of the head's weight gradient (kernels_conv_h2.hip, HEAD)
+        const Buf ob = m->act.at("c9b"); const double px = (double)ob.n * ob.h * ob.w;
+        ADD_OP(F, "conv3x3_fwd_head:c9b", 2.0 * 9 * c * c * px + 2.0 * c * px, 4.0 * px * (c + c) + 4.0 * 9.0 * c * c + 8.0 * px, {
+          if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_fwd: p_out not set (unet_model_set_io)");
+          const auto so = training ? m->sign_off.find("c9b") : m->sign_off.end();
+          unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
+          ctx->signs_req = sg; ctx->signs_done = nullptr;
+          int32_t r = k_conv3x3_h2_head_fwd(ctx, m->A("c9a"), m->wsf(m->wprep_f.at("c9b")), m->P("c9b/bias"), m->Aw("c9b"), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt,
+                                            ob.n, ob.h, ob.w, c, s);
+          ctx->signs_req = nullptr;
+          if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd_head: the launch did not write the ReLU sign bits its backward was planned with");
+          return r;
+        });
+      } else
       conv("c" + ks + "b", "c" + ks + "a", c, c);
       prev = "c" + ks + "b"; cprev = c;
     }
     const Buf hb = m->act.at("c9b");
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
+    if (m->head_fused) ADD_OP(F, "head_fold", 0, 0, {
+      if (!m->yt) return UNET_OK;
+      return k_head_fold(ctx, m->wsd(m->off_loss_sums), m->wsd(m->off_head_sums), s);
+    });
+    else
     ADD_OP(F, "head_fwd", 2.0 * 32 * hp, hp * (eb * 32 + 8.0), {
       if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_fwd: p_out not set (unet_model_set_io)");
       if (dt) return unet_head_fwd_bf16(ctx, CBF(m->Av("c9b")), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt, m->yt ? m->wsd(m->off_loss_sums) : nullptr, hp, hb.c, s);
@@ -830,6 +897,14 @@ void build_programs(unet_model* m) {
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
     if (!dt) ADD_OP(BW, "weight_images:bwd", 0, 0, { return prep_weights(1, s); });
     else ADD_OP(BW, "weight_images:bwd", 0, 0, { return prep_weights_bf16(1, s); });
+    if (m->head_fused) ADD_OP(BW, "head_dy", 2.0 * 32 * hp, hp * (4.0 * 32 + 8.0 + 4.0), {
+      if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_dy: io not set");
+      const auto so = m->sign_off.find("c9b");
+      return k_head_dy(ctx, m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsd(m->off_head_sums), m->P("out/kernel"),
+                       so == m->sign_off.end() ? nullptr : reinterpret_cast<const unsigned long long*>(m->wsf(so->second)), m->A("c9b"), m->D("c9b"),
+                       m->G("out/kernel"), m->G("out/bias"), hb.n, hb.h, hb.w, s);
+    });
+    else
     ADD_OP(BW, "head_bwd", 4.0 * 32 * hp, hp * (eb * 64 + 8.0), {
       if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_bwd: io not set");
       if (dt) return unet_head_bwd_bf16(ctx, CBF(m->Av("c9b")), m->P("out/kernel"), m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, WBF(m->Dv("c9b")),
@@ -852,7 +927,7 @@ void build_programs(unet_model* m) {
       auto& WV = (defer_wgrad && xraw.empty()) ? DEF : BW;
       ADD_OP(WV, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
         if (dt) {
-          if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
+          if (in.empty()) return first_conv_wgrad_bf16(ctx, m, name, ob, cout, s);
           return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(xsrc)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w,
                                       cin, cout, s);
         }
@@ -1158,7 +1233,7 @@ void build_programs_pp(unet_model* m) {
 #define CBF(p) static_cast<const unet_bf16*>(p)
 #define WBF(p) static_cast<unet_bf16*>(p)
   auto& BW = m->prog[UNET_PROG_BWD];
-  const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
+  const size_t sums_bytes = (m->bn_sums_doubles + 4 + UNET_HEAD_SUMS) * sizeof(double);
   std::map<std::string, int> lidx;
   for (size_t i = 0; i < m->layers.size(); ++i) lidx[m->layers[i].name] = (int)i;
   auto seed_of = [=](const std::string& conv) { return (uint64_t)(lidx.at(conv) + 1) * 0x9E3779B97F4A7C15ull; };
@@ -1176,7 +1251,7 @@ void build_programs_pp(unet_model* m) {
       ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
         const float r = (tr && m->drop_rate > 0.0f) ? rate : 0.0f;
         if (dt) {
-          if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_ELU, r, m->drop_seed + sd, s);
+          if (in.empty()) return first_conv_fwd_bf16(ctx, m, name, ob, cout, ACT_ELU, r, m->drop_seed + sd, s);
           return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_ELU, r,
                                     m->drop_seed + sd, WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
         }
@@ -1335,7 +1410,7 @@ void build_programs_pp(unet_model* m) {
     const double px = (double)ob.n * ob.h * ob.w;
     ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
       if (dt) {
-        if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
+        if (in.empty()) return first_conv_wgrad_bf16(ctx, m, name, ob, cout, s);
         return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(in)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, cout, s);
       }
       const float* xin = in.empty() ? m->x : m->A(in);
@@ -1560,7 +1635,7 @@ void build_programs_cls(unet_model* m) {
   const double eb = dt ? 2.0 : 4.0;
 #define CBF(p) static_cast<const unet_bf16*>(p)
 #define WBF(p) static_cast<unet_bf16*>(p)
-  const size_t sums_bytes = (m->bn_sums_doubles + 4) * sizeof(double);
+  const size_t sums_bytes = (m->bn_sums_doubles + 4 + UNET_HEAD_SUMS) * sizeof(double);
   const Buf fb = m->act.at("p3");
   const int N = m->N, K = fb.h * fb.w * fb.c;
   const uint64_t fc_seed = 0xC2B2AE3D27D4EB4Full;
@@ -1575,7 +1650,7 @@ void build_programs_cls(unet_model* m) {
       double px = (double)ob.n * ob.h * ob.w;
       ADD_OP(F, "conv3x3_fwd:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
         if (dt) {
-          if (in.empty()) return k_conv3x3_c1_fwd_bf16(ctx, m->x, m->P(name + "/kernel"), m->P(name + "/bias"), WBF(m->Av(name)), ob.n, ob.h, ob.w, cout, ACT_RELU, 0.0f, 0, s);
+          if (in.empty()) return first_conv_fwd_bf16(ctx, m, name, ob, cout, ACT_RELU, 0.0f, 0, s);
           return k_conv3x3_bf16_fwd(ctx, CBF(m->Av(in)), m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, WBF(m->Av(name)), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0,
                                     WBF(static_cast<void*>(m->wsf(m->off_wt))), 0, s);
         }
@@ -1700,7 +1775,7 @@ void build_programs_cls(unet_model* m) {
     const double px = (double)ob.n * ob.h * ob.w;
     ADD_OP(BW, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
       if (dt) {
-        if (in.empty()) return k_conv3x3_c1_wgrad_bf16(ctx, m->x, CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cout, s);
+        if (in.empty()) return first_conv_wgrad_bf16(ctx, m, name, ob, cout, s);
         return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(in)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, cout, s);
       }
       const float* xin = in.empty() ? m->x : m->A(in);
@@ -1807,8 +1882,6 @@ int32_t unet_model_create(unet_ctx* ctx, int32_t arch, int32_t in_ch, int32_t n,
   if (!ctx || !out) return UNET_E_ARG;
   *out = nullptr;
   if (dtype != UNET_DTYPE_F32 && dtype != UNET_DTYPE_BF16) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown dtype %d", dtype);
-  if (dtype == UNET_DTYPE_BF16 && in_ch != 1)
-    UNET_FAIL(ctx, UNET_E_ARG, "model_create: bf16 storage needs a 1-channel image (the first-layer kernel keeps the image fp32); in_ch %d asked", in_ch);
   if (arch != UNET_ARCH_UNET && arch != UNET_ARCH_UNETPP && arch != UNET_ARCH_CLASSIFIER) UNET_FAIL(ctx, UNET_E_ARG, "model_create: unknown arch %d", arch);
   const int mult = arch == UNET_ARCH_UNET ? 16 : 8;      // 4 pool levels (T1:862-880) / 3 used pool levels (UPP: p4 is dead)
   if (in_ch < 1 || n < 1 || h < mult || w < mult || (h % mult) || (w % mult) || world_size < 1)

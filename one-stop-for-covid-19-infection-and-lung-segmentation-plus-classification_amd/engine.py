@@ -362,6 +362,10 @@ class HipUNet:
 
     def tap(self, n, name, grad=False, replicated=False):
         """Copy of an intermediate activation / gradient of the last run (tests)."""
+        return self.tap_device(n, name, grad, replicated).float().cpu().numpy()
+
+    def tap_device(self, n, name, grad=False, replicated=False):
+        """The same tensor as a strided VIEW of the workspace on the device [n, h, w, c] (valid until the next run overwrites it)."""
         torch = _torch()
         plan = self._plan(n, replicated)
         ptr, ld, nn, hh, ww, cc = _lib.vp(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -372,8 +376,7 @@ class HipUNet:
         esz = self.lib.unet_model_tap_elem_bytes(plan["m"], name.encode(), int(grad))
         tdt = torch.bfloat16 if esz == 2 else torch.float32
         flat = self._ws[off:off + esz * ((pix - 1) * ld.value + cc.value)].view(tdt)
-        v = torch.as_strided(flat, (pix, cc.value), (ld.value, 1))
-        return v.reshape(nn.value, hh.value, ww.value, cc.value).float().cpu().numpy()
+        return torch.as_strided(flat, (nn.value, hh.value, ww.value, cc.value), (hh.value * ww.value * ld.value, ww.value * ld.value, ld.value, 1))
 
     def op_profile(self, n, prog):
         """[(name, flops, bytes, ms, calls)] accumulated while ctx profiling was on."""

@@ -404,7 +404,10 @@ def test_context_options_select_the_graph_forms_in_one_process():
         return [o[0] for o in eng.op_profile(2, prog)]
     ref = make(64, 96, dropout_rate=0.0); ref.set_weights(wts); ref.forward_backward(x, y); gref = ref.get_grads()
     assert not any(n.startswith("bn_apply:bn9") for n in ops_of(ref, 0)) and any(n.startswith("conv3x3_dgrad_bn_bwd:c9a") for n in ops_of(ref, 1))
-    for opts, expect_fwd, expect_bwd in (({"bn_fold": 0}, "bn_apply:bn9", "bn_bwd_apply:bn9"), ({"bn_fold": 1}, None, "bn_bwd_apply:bn9"),
+    assert "conv3x3_fwd_head:c9b" in ops_of(ref, 0) and "head_fwd" not in ops_of(ref, 0) and "head_dy" in ops_of(ref, 1) and "conv3x3_fwd_head:c9b" in ops_of(ref, 2)
+    lref = ref.forward_backward(x, y).cpu().numpy()
+    for opts, expect_fwd, expect_bwd in (({"bn_fold": 0}, "bn_apply:bn9", "bn_bwd_apply:bn9"), ({"bn_fold": 1}, None, "bn_bwd_apply:bn9"), ({"head_fused": 0}, "head_fwd", "head_bwd"),
+                                         ({"head_fused": 1, "relu_bits": 0}, "conv3x3_fwd_head:c9b", "head_dy"),
                                          ({"enc_bn_fused": 0}, None, "pool_bwd_bnstats:p1"), ({"relu_bits": 0}, None, None),
                                          ({"bn_concat_analytic": 0, "bn_fuse_stats": 0}, None, None), ({"deterministic": 1}, None, None)):
         eng = make(64, 96, dropout_rate=0.0, options=opts); eng.set_weights(wts); eng.forward_backward(x, y)
@@ -417,6 +420,7 @@ def test_context_options_select_the_graph_forms_in_one_process():
         g = eng.get_grads()
         for k in g:
             assert relerr(g[k], gref[k]) < 2e-5, (opts, k, relerr(g[k], gref[k]))
+        assert np.abs(eng.forward_backward(x, y).cpu().numpy() - lref).max() < 2e-6, opts          # loss, dice_coeff
     assert ref.lib.unet_ctx_set_option(ref.ctx.handle, 99, 1) != 0 and ref.lib.unet_ctx_set_option(ref.ctx.handle, _lib.OPTIONS["bn_fold"], 4) != 0
 
 

@@ -316,6 +316,67 @@ def test_head_loss_fwd_bwd(ops):
     assert (p2.cpu().numpy() == p.cpu().numpy()).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 24, 32), (1, 40, 72, 32), (3, 9, 8, 64), (2, 8, 16, 16)])
+def test_conv3x3_head_fused_fwd_and_dy(ops, shape):
+    """T1:911-913 + bce_dice_loss in one launch (unet_conv3x3_head_fwd) and the head's backward from bits (unet_head_dy), against the float64 oracle:
+    the conv output, the probabilities, the four loss sums, the head's weight / bias gradient (a combination of the 99 sums the epilogue took) and
+    dL/d(conv output)."""
+    from gpu_util import relerr
+    n, h, w, cin = shape
+    c = 32
+    assert ops.lib.unet_conv3x3_head_supported(ops.h, 0, w, cin, c) == 1 and ops.lib.unet_conv3x3_head_supported(ops.h, 0, w + 4, cin, c) == 0
+    pixels = n * h * w
+    rng = np.random.default_rng(21)
+    x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
+    k3 = (rng.standard_normal((3, 3, cin, c)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32); b3 = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    k = (rng.standard_normal((1, 1, c, 1)) * 0.8).astype(np.float32); b = np.array([-0.2], np.float32)
+    x[0, 0, 0, :] = 400.0                                            # one pixel far into saturation: the clip path of the BCE (p == 1 or 0 in fp32)
+    t = (np.round(rng.random((n, h, w, 1)) ** 2 * 255) / 255).astype(np.float32)
+    y = ops.z(n, h, w, c); p = ops.z(n, h, w, 1); sums = ops.z(4, dtype=torch.float64); hs = ops.z(99, dtype=torch.float64); out = ops.z(2)
+    bits = torch.zeros(pixels * c // 8, dtype=torch.uint8, device="cuda")
+    ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits.data_ptr()), "arm")
+    ops.ck(ops.lib.unet_conv3x3_head_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k3).data_ptr(), ops.d(b3).data_ptr(), y.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p.data_ptr(),
+                                         ops.d(t).data_ptr(), sums.data_ptr(), hs.data_ptr(), n, h, w, cin, ops.wws(cin, c), ops.s), "conv + head fwd")
+    ops.ck(ops.lib.unet_loss_finalize(ops.h, sums.data_ptr(), float(pixels), out.data_ptr(), ops.s), "loss fin")
+    x3, k3t, b3t = T64(x), T64(k3), T64(b3)
+    yt = O.conv3x3_bias_relu(x3, k3t, b3t).detach().requires_grad_(True)
+    kt, bt = T64(k).requires_grad_(True), T64(b).requires_grad_(True)
+    pt = O.conv1x1_sigmoid(yt, kt, bt)
+    loss = O.bce_dice_loss(T64(t), pt)
+    yn = y.cpu().numpy()
+    assert relerr(yn, yt.detach().numpy()) < 2e-6
+    assert np.abs(p.cpu().numpy() - pt.detach().numpy()).max() < 2e-6
+    sn = sums.cpu().numpy(); tn = t.astype(np.float64); pn = pt.detach().numpy()
+    assert abs(sn[1] - (tn * pn).sum()) < 1e-5 * pixels ** 0.5 and abs(sn[2] - tn.sum()) < 1e-6 * pixels and abs(sn[3] - pn.sum()) < 1e-5 * pixels ** 0.5
+    lo = out.cpu().numpy()
+    # loss VALUE: the fused epilogue takes the BCE from the logit z it has (inside the clip range the logit of the clipped p IS z -- what float64 gives; an fp32
+    # evaluation that goes through p, as TF does, is off by up to 0.4 (1 - t) on a pixel with 15.2 < z < 15.9) and clips at the bounds an fp32 evaluation has:
+    # logit(1 - 2^-23) = 15.942385 above, logit(1e-7) = -16.118095 below.  Reference = exactly that, in float64
+    z64 = (yt.detach().reshape(-1, c) @ kt.detach().reshape(c, 1) + bt.detach()).reshape(-1).numpy()
+    zc = np.clip(z64, -16.118095, 15.942385); t64 = t.reshape(-1).astype(np.float64)
+    bce = (np.maximum(zc, 0) - zc * t64 + np.log1p(np.exp(-np.abs(zc)))).mean()
+    dice = float(O.dice_coeff(T64(t), pt))
+    assert abs(lo[0] - (0.5 * bce + 0.5 * (1.0 - dice))) < 1e-5 and abs(lo[1] - dice) < 2e-6
+    assert abs(sn[0] - bce * pixels) < 1e-5 * pixels
+    loss.backward()
+    dy = ops.z(n, h, w, c); dw = ops.z(c); db = ops.z(1)
+    for use_bits in (1, 0):
+        dy.zero_(); dw.zero_(); db.zero_()
+        ops.ck(ops.lib.unet_head_dy(ops.h, p.data_ptr(), ops.d(t).data_ptr(), sums.data_ptr(), float(pixels), hs.data_ptr(), ops.d(k).data_ptr(), bits.data_ptr() if use_bits else None,
+                                    y.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), n, h, w, ops.s), "head dy")
+        assert relerr(dy.cpu().numpy(), yt.grad.numpy() * (yn > 0)) < 2e-5
+        assert relerr(dw.cpu().numpy(), kt.grad.numpy().ravel()) < 3e-5 and relerr(db.cpu().numpy(), bt.grad.numpy()) < 3e-5
+    # inference form: no labels -> probabilities only, nothing lands in the sums
+    p2 = ops.z(n, h, w, 1); y2 = ops.z(n, h, w, c)
+    ops.ck(ops.lib.unet_conv3x3_head_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k3).data_ptr(), ops.d(b3).data_ptr(), y2.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p2.data_ptr(),
+                                         None, None, None, n, h, w, cin, ops.wws(cin, c), ops.s), "conv + head fwd (predict)")
+    assert (p2.cpu().numpy() == p.cpu().numpy()).all() and (y2.cpu().numpy() == yn).all()
+    # and against the separate kernels on the same y: same probabilities to the last bits, same gradient of the head
+    p3 = ops.z(n, h, w, 1); s3 = ops.z(4, dtype=torch.float64)
+    ops.ck(ops.lib.unet_head_fwd(ops.h, y.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p3.data_ptr(), ops.d(t).data_ptr(), s3.data_ptr(), pixels, c, ops.s), "head fwd")
+    assert np.abs(p3.cpu().numpy() - p.cpu().numpy()).max() < 5e-7 and np.abs(s3.cpu().numpy() - sn).max() < 1e-4 * max(1.0, np.abs(sn).max()) * 1e-1
+
+
 def test_adam_and_metrics(ops):
     from gpu_util import relerr
     rng = np.random.default_rng(4)

@@ -180,7 +180,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in unet_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert _lib.load().unet_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.load().unet_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_product_fails_loudly_without_gpu():
@@ -192,3 +192,24 @@ def test_product_fails_loudly_without_gpu():
         UNetModel(16)
     h = ctypes.c_void_p()
     assert _lib.load().unet_ctx_create(0, ctypes.byref(h)) == -5      # UNET_E_NODEV, no CPU fallback
+
+
+def test_fullsize_measured_errors_stay_inside_the_independent_bound():
+    """tests/golden/fullsize_measured.json (what the engine measured on an MI355X) only tightens the full-size gradient bounds of tests/test_gpu_fullsize.py;
+    here, without a GPU: every figure in it lies inside the independent bound max(3e-4, 4 x E_k) of its fixture (E_k = the fp32-CPU evaluation's distance
+    from fp64, capped at 2.5e-3), so the file cannot drift above it unnoticed."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    meas = json.load(open(os.path.join(here, "golden", "fullsize_measured.json")))
+    seen = 0
+    for name, tensors in meas.items():
+        if name.startswith("_"):
+            continue
+        z = np.load(os.path.join(here, "golden", f"fullsize_{name}.npz"))
+        for k, v in tensors.items():
+            if k.startswith("_"):
+                continue
+            bound = max(3e-4, 4.0 * min(float(z["fp32ref_relerr/" + k]), 2.5e-3))
+            assert max(v.get("norm_rel", 0.0), v.get("relerr", 0.0)) <= bound, (name, k, v, bound)
+            seen += 1
+    assert seen > 150

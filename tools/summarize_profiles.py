@@ -69,6 +69,23 @@ if "dom" in fam and fam["dom"]["launches"]:
     }
     res["hbm_bytes_per_launch"] = res["read_bytes_per_launch"] + res["write_bytes_per_launch"]
     res["hbm_bytes_per_step"] = res["hbm_bytes_per_launch"] * res["launches_per_step"]
+    # ---- every kernel of the step: FETCH_SIZE x 2 + WRITE_SIZE summed over ALL dispatches of the profiled process / its training steps
+    def short(name):
+        return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0][:48]
+    per = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for name, (v, n) in fetch.items():
+        per[short(name)][0] += v * 2048; per[short(name)][2] += n
+    for name, (v, n) in write.items():
+        per[short(name)][1] += v * 1024
+    tot_r = sum(v[0] for v in per.values()); tot_w = sum(v[1] for v in per.values())
+    res["hbm_bytes_per_step_all_kernels"] = (tot_r + tot_w) / steps
+    res["hbm_read_bytes_per_step_all_kernels"] = tot_r / steps
+    res["hbm_write_bytes_per_step_all_kernels"] = tot_w / steps
+    res["vs_survey_8d_model_54.3GB"] = res["hbm_bytes_per_step_all_kernels"] / 54.300299148e9
+    res["per_kernel_GB_per_step"] = {k: {"read": round(v[0] / steps / 1e9, 3), "write": round(v[1] / steps / 1e9, 3), "launches_per_step": v[2] / steps}
+                                     for k, v in sorted(per.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))}
+    res["all_kernels_note"] = ("FETCH_SIZE is doubled for every kernel (the calibration holds for wide streaming reads -- adam / bn_apply above; narrow or L2-resident reads may be "
+                               "over-counted by up to 2x), WRITE_SIZE taken as reported; Infinity-Cache hits are counted (MI355X_MICROARCH.md)")
     json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(res, indent=1)[:1500])
 else:
