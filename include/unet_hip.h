@@ -68,7 +68,8 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *                          slots folded in index order; statistics by their own pass), so reruns are bit-identical; costs ~6 % of the step
  *   HEAD_FUSED (1)         fp32 U-Net, h2 kernels: the 1x1 sigmoid head (T1:913), the loss sums and the per-channel sums of the head's weight gradient come out of
  *                          the epilogue of the last conv3x3 (no pass over its 32-channel output in forward; backward writes dL/d(conv output) from p, the labels
- *                          and one bit per element); 0 = the separate head_fwd / head_bwd passes (always taken in deterministic mode) */
+ *                          and one bit per element); 0 = the separate head_fwd / head_bwd passes (always taken in deterministic mode)
+ */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,
        UNET_OPT_HEAD_FUSED = 7 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);

@@ -1969,7 +1969,8 @@ int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profiling) { UNET_HIP(ctx, hipEventCreate(&e0)); UNET_HIP(ctx, hipEventCreate(&e1)); }
   // (weight gradients on a second stream beside the data-gradient chain were measured 1-3 % SLOWER on this chip -- two matrix kernels sharing the CUs
-  //  cost each other more than their gaps are worth -- and are not built: every launch of a model stays on the caller's stream)
+  //  cost each other more than their gaps are worth; round 4: even the ~25 tiny launches of the split weight images, forked onto a side stream beside the
+  //  HBM-bound first-layer kernel, cost 0.05 ms per step (same-box A/B 16.56 -> 16.61 ms) -- so every launch of a model stays on the caller's stream)
   if (begin == 0 && prog != UNET_PROG_BWD) { ctx->stats_req_c = 0; ctx->stats_in_slots = nullptr; ctx->stats_in_slots_c = 0; ctx->signs_req = nullptr; }   // a program starts clean whatever an aborted run left armed
   for (int i = begin; i < end; ++i) {
     if (ctx->profiling) UNET_HIP(ctx, hipEventRecord(e0, s));

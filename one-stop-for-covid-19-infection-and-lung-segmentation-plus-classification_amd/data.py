@@ -46,8 +46,9 @@ def synthetic_ct(n: int, size: int = 512, seed: int = 0):
     return xs, ys
 
 
-def synthetic_classification(n: int, size: int = 224, seed: int = 0):
-    """x float32 [n,size,size,1], y int [n]: the synthetic CT slices above; label 1 = the slice has an infection mask, and then the
+def synthetic_classification(n: int, size: int = 224, seed: int = 0, channels: int = 1):
+    """x float32 [n,size,size,channels], y int [n]: the synthetic CT slices above (channels > 1 -- BASELINE.json configs[4] names 224 x 224 x 3 -- : channel k is the
+    slice under its own intensity window, k / 255-quantised like the first); label 1 = the slice has an infection mask, and then the
     lesion is also painted into the image (+0.25 inside the soft mask) so the classes are separable.  Mirrors how the reference
     derives its labels: y = 1 iff the infection mask of the slice is not uniform (task2_covid19_classifcation.py:413-418)."""
     xs, ms = synthetic_ct(n, size, seed)
@@ -56,6 +57,8 @@ def synthetic_classification(n: int, size: int = 224, seed: int = 0):
     if n >= 4:
         y[:2] = (0, 1); y[2:4] = (0, 1)                           # both classes present at least twice (stratified split needs it)
     xs = np.clip(xs + 0.25 * ms * y[:, None, None, None], 0, 1).astype(np.float32)
+    if channels > 1:
+        xs = np.concatenate([np.clip((xs - 0.08 * k) * (1.0 + 0.15 * k), 0, 1) for k in range(channels)], axis=3).astype(np.float32)
     return np.round(xs * 255).astype(np.float32) / 255, y
 
 

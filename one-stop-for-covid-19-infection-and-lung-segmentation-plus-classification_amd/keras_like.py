@@ -10,6 +10,7 @@ explicit constructor argument so host logic can be unit-tested; there is no impl
 from __future__ import annotations
 
 import time
+import warnings
 
 import numpy as np
 
@@ -73,18 +74,32 @@ def load_model(path, backend=None, custom_objects=None, compile=True, **backend_
     names = [l["config"]["name"] for l in layers]
     arch = next((a for a in (("classifier",) if cfg["class_name"] == "Sequential" else ("unet", "unetpp"))
                  if [l["name"] for l in KG.keras_layers(in_ch, a, (h, w))] == names), None)
-    if arch is None or h != w:
+    if arch is None:
         raise ValueError(f"{path}: the saved graph ({cfg['class_name']}, {len(names)} layers, input {shape}) is none of the three this engine runs")
+    if h != w:
+        raise ValueError(f"{path}: the saved graph is {h} x {w}; the Keras-shaped model classes of this package take ONE input_size (new_dim, T1:479) -- "
+                         f"non-square inputs are supported by the engine (HipUNet(h, w)) but not by load_model")
     if arch == "classifier":
         from .classifier import ClassifierModel
         model = ClassifierModel(h, in_ch, backend=backend, **backend_kw)
+        own_loss, own_metrics = "binary_crossentropy", ["f1"]
     else:
         model = UNetModel(h, in_ch, backend=backend, arch=arch, **backend_kw)
+        own_loss, own_metrics = "bce_dice_loss", ["dice_coeff"]
     model.load_weights(path)
     opt = W.load_optimizer(path, in_ch, arch, (h, w)) if compile else None
     if opt is not None:
-        model.compile(lr=opt["lr"])                                  # (the loss / metrics of the path are the model class's own: T1:1053, T2:829)
-        model.backend.set_optimizer_state(opt)
+        # the compiled state names its loss / metrics: this package implements exactly one pair per graph (T1:1053, T2:829) -- a file trained on another loss must
+        # not silently continue on ours
+        if opt.get("loss") not in (None, own_loss):
+            raise ValueError(f"{path}: compiled with loss {opt['loss']!r}; this engine implements {own_loss!r} for the {arch} graph (load with compile=False for the weights only)")
+        if opt.get("metrics") and [m_ for m_ in opt["metrics"] if m_ not in own_metrics]:
+            warnings.warn(f"{path}: saved metrics {opt['metrics']} -- only {own_metrics} are computed here")
+        model.compile(lr=opt["lr"])
+        if hasattr(model.backend, "set_optimizer_state"):
+            model.backend.set_optimizer_state(opt)
+        else:
+            warnings.warn(f"{path}: the backend keeps no optimizer state -- weights loaded, Adam starts fresh")
     return model
 
 

@@ -133,20 +133,20 @@ def test_two_ranks_bf16_storage_match_full_batch(tmp_path):
     assert np.abs(got["losses"] - ref_losses).max() < 5e-3            # batch-global loss / Dice on every rank
 
 
-def _nccl_world1_worker(rank, port, wfile, x, y, out):
+def _nccl_world1_worker(rank, port, wfile, x, y, out, options=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from covidseg_amd.engine import HipUNet
     wts = dict(np.load(wfile))
-    eng = HipUNet(x.shape[1], x.shape[2], 1, device=0, process_group=dist.group.WORLD, dropout_rate=0.0, force_dp=True)
+    eng = HipUNet(x.shape[1], x.shape[2], 1, device=0, process_group=dist.group.WORLD, dropout_rate=0.0, force_dp=True, options=options)
     assert eng._dp and eng._comm_stream is not None and eng.pg_grad is not eng.pg          # the production multi-GPU objects exist
     eng.set_weights(wts)
     losses = [eng.train_batch(x, y).cpu().numpy() for _ in range(3)]
     p, ld = eng.predict_batch(x, y)
     sums = eng.threshold_sums(p, y, [0.3, 0.5]).cpu().numpy()
-    np.savez(out, losses=np.array(losses), ld=ld.cpu().numpy(), sums=sums, **{"w/" + k: v for k, v in eng.get_weights().items()})
+    np.savez(out, losses=np.array(losses), ld=ld.cpu().numpy(), sums=sums, **{"w/" + k: v for k, v in eng.get_weights().items()}, **{"g/" + k: v for k, v in eng.get_grads().items()})
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -219,6 +219,30 @@ def test_rccl_code_path_at_world_size_one_equals_the_plain_step(tmp_path):
     assert np.abs(got["ld"] - ld.cpu().numpy()).max() < 5e-6 and np.allclose(got["sums"], eng.threshold_sums(p, y, [0.3, 0.5]).cpu().numpy(), rtol=1e-6)
     for k, v in eng.get_weights().items():
         assert np.linalg.norm(got["w/" + k] - v) <= 2e-3 * np.linalg.norm(v) + 1e-6 * np.sqrt(v.size), k      # (Adam's first steps are sign-like: last-bit noise in a gradient becomes O(lr))
+
+
+def test_rccl_code_path_at_world_size_one_is_bit_identical_in_deterministic_mode(tmp_path):
+    """The same production path with options={"deterministic": 1} (no floating-point atomics anywhere): with one rank every all-reduce is the identity, so losses,
+    gradients and weights after three optimizer steps equal the plain deterministic engine IN EVERY BIT.  A stream / event ordering defect of the data-parallel
+    program -- a reader launched before its deferred reduction is done (reduce_small_async), a bucket reduced before its last producer -- changes bits here, where
+    the 2e-3 band of the atomics build above would hide it."""
+    import torch.multiprocessing as mp
+    from covidseg_amd import weights as W
+    from covidseg_amd.data import synthetic_ct
+    from covidseg_amd.engine import HipUNet
+    x, y = synthetic_ct(4, 64, seed=8)
+    wts = W.init_weights(6, 1, "unet", (64, 64))
+    wfile = str(tmp_path / "w.npz"); np.savez(wfile, **wts)
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_nccl_world1_worker, args=(_free_port(), wfile, x, y, out, {"deterministic": 1}), nprocs=1, join=True)
+    got = np.load(out)
+    eng = HipUNet(64, 64, 1, dropout_rate=0.0, options={"deterministic": 1}); eng.set_weights(wts)
+    ref = np.array([eng.train_batch(x, y).cpu().numpy() for _ in range(3)])
+    assert np.array_equal(got["losses"], ref)
+    for k, v in eng.get_grads().items():
+        assert np.array_equal(got["g/" + k], v), k
+    for k, v in eng.get_weights().items():
+        assert np.array_equal(got["w/" + k], v), k
 
 
 @pytest.mark.parametrize("runner,batch", [("runner_lung_segmentation", 8), ("holdout_runner_unet_infection_segmentation", 6)])

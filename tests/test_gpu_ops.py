@@ -374,7 +374,9 @@ def test_conv3x3_head_fused_fwd_and_dy(ops, shape):
     # and against the separate kernels on the same y: same probabilities to the last bits, same gradient of the head
     p3 = ops.z(n, h, w, 1); s3 = ops.z(4, dtype=torch.float64)
     ops.ck(ops.lib.unet_head_fwd(ops.h, y.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p3.data_ptr(), ops.d(t).data_ptr(), s3.data_ptr(), pixels, c, ops.s), "head fwd")
-    assert np.abs(p3.cpu().numpy() - p.cpu().numpy()).max() < 5e-7 and np.abs(s3.cpu().numpy() - sn).max() < 1e-4 * max(1.0, np.abs(sn).max()) * 1e-1
+    s3n = s3.cpu().numpy()
+    assert np.abs(p3.cpu().numpy() - p.cpu().numpy()).max() < 5e-7 and np.abs(s3n[1:] - sn[1:]).max() < 1e-5 * max(1.0, np.abs(sn[1:]).max())
+    assert abs(s3n[0] - sn[0]) < 0.5                                # (the BCE sum: the separate kernel takes the logit from p -- 0.39 (1 - t) off on the one pixel with z = 15.55, above)
 
 
 def test_adam_and_metrics(ops):

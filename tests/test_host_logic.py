@@ -77,6 +77,20 @@ def test_model_save_carries_the_optimizer_and_load_model_resumes_the_fit(tmp_pat
     assert "optimizer_weights" not in H5.read_file(f) and not load_model(f, backend=OracleBackend(16, 16)).compiled
     with pytest.raises(ValueError, match="model_config"):
         d.save_weights(f); load_model(f, backend=OracleBackend(16, 16))
+    # a file compiled with another loss does not silently continue on bce_dice_loss; its weights alone still load
+    opt = a.backend.get_optimizer_state()
+    W.save_weights(f, a.get_weights(), 1, "unet", (16, 16), full_model=True, optimizer=dict(opt, loss="mean_squared_error"))
+    with pytest.raises(ValueError, match="mean_squared_error"):
+        load_model(f, backend=OracleBackend(16, 16))
+    assert not load_model(f, backend=OracleBackend(16, 16), compile=False).compiled
+    # a backend without optimizer-state support: weights load, a warning says Adam starts fresh
+    a.save(f)
+
+    class NoOptState(OracleBackend):
+        set_optimizer_state = property()                                       # hasattr(...) is False
+    with pytest.warns(UserWarning, match="starts fresh"):
+        e = load_model(f, backend=NoOptState(16, 16))
+    assert e.compiled and all(np.array_equal(e.get_weights()[k], a.get_weights()[k]) for k in wa)
 
 
 def test_evaluate_is_mean_of_batch_metrics_and_weighted_loss():
