@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Phase timeline of conv_h2_kernel from s_memtime stamps (measurement build: `make -C <package>/csrc timeline` -> build/exp/libunet_exp5.so; the library
 path is given explicitly, the product library has no such symbol).
-    python tools/h2_timeline.py build/exp/libunet_exp5.so N H W CIN COUT [dgrad]"""
+    python tools/h2_timeline.py build/exp/libunet_exp5.so N H W CIN COUT [dgrad | convT | convT_dgrad]     (convT: H x W = the ConvT's input size)"""
 import ctypes
 import os
 import sys
@@ -12,7 +12,7 @@ import torch
 
 
 def main():
-    libp = sys.argv[1]; n, h, w, ci, co = map(int, sys.argv[2:7]); dgrad = len(sys.argv) > 7
+    libp = sys.argv[1]; n, h, w, ci, co = map(int, sys.argv[2:7]); mode = sys.argv[7] if len(sys.argv) > 7 else "fwd"; dgrad = mode == "dgrad"
     from covidseg_amd import _lib
     _lib.LIB_PATH = os.path.abspath(libp)
     lib = _lib.load(); ctx = _lib.Context.get(0)
@@ -24,7 +24,12 @@ def main():
     dy = torch.randn(n, h, w, co, device="cuda", generator=g); dx = torch.empty(n, h, w, ci, device="cuda")
     ws = torch.empty(max(int(lib.unet_conv3x3_w_ws_floats(ci, co)), 4), device="cuda")
     s = torch.cuda.current_stream().cuda_stream
+    if mode.startswith("convT"):
+        kT = torch.randn(2, 2, co, ci, device="cuda", generator=g) * (1.0 / ci) ** 0.5
+        u = torch.empty(n, 2 * h, 2 * w, 2 * co, device="cuda"); du = torch.randn(n, 2 * h, 2 * w, 2 * co, device="cuda", generator=g)
     def run():
+        if mode == "convT": return lib.unet_convT2x2_fwd(ctx.handle, x.data_ptr(), kT.data_ptr(), b.data_ptr(), u.data_ptr(), 2 * co, n, h, w, ci, co, 0, s)
+        if mode == "convT_dgrad": return lib.unet_convT2x2_bwd_data(ctx.handle, du.data_ptr(), 2 * co, kT.data_ptr(), None, dx.data_ptr(), n, h, w, ci, co, 0, s)
         if dgrad: return lib.unet_conv3x3_bwd_data(ctx.handle, dy.data_ptr(), k.data_ptr(), x.data_ptr(), 1, 0.0, 0, dx.data_ptr(), ws.data_ptr(), n, h, w, ci, co, 0, s)
         return lib.unet_conv3x3_fwd(ctx.handle, x.data_ptr(), k.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, ws.data_ptr(), s)
     for _ in range(300): ctx.check(run(), "conv")
@@ -33,8 +38,10 @@ def main():
     e0.record()
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
-    print(f"shape n={n} {h}x{w} {ci}->{co} {'dgrad' if dgrad else 'fwd'}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call (incl. weight image prep)")
+    print(f"shape n={n} {h}x{w} {ci}->{co} {mode}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call (incl. weight image prep)")
     nwg = min(16384, ((w + 31) // 32) * ((h + 7) // 8) * n * max(1, co // 64 if not dgrad else ci // 64))
+    if mode == "convT": nwg = min(16384, ((w + 31) // 32) * ((h + 7) // 8) * n * max(1, 4 * co // 128))
+    if mode == "convT_dgrad": nwg = min(16384, ((w + 31) // 32) * ((h + 7) // 8) * n * max(1, ci // 128))
     buf = np.zeros(16384 * 16, np.uint64)
     assert dbg(buf.ctypes.data, buf.size) == 0
     t = buf.reshape(16384, 16)[:nwg].astype(np.int64)
