@@ -69,9 +69,12 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   HEAD_FUSED (1)         fp32 U-Net, h2 kernels: the 1x1 sigmoid head (T1:913), the loss sums and the per-channel sums of the head's weight gradient come out of
  *                          the epilogue of the last conv3x3 (no pass over its 32-channel output in forward; backward writes dL/d(conv output) from p, the labels
  *                          and one bit per element); 0 = the separate head_fwd / head_bwd passes (always taken in deterministic mode)
+ *   SKIP_RAW (1)           fp32 U-Net with BN_FOLD >= 2, ENC_BN_FUSED and BN_CONCAT_ANALYTIC: the second conv of an encoder block (T1:860) writes straight into the skip half
+ *                          of its concat (T1:908) and the encoder BatchNorm's output is never stored: max-pool reads the raw tensor, the folded decoder BatchNorm is
+ *                          composed with the encoder one (two affine maps in a row are one).  -1 GB of writes per step at 512 x 512 x 16.  0 = the normalised copy is stored
  */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,
-       UNET_OPT_HEAD_FUSED = 7 };
+       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
 int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */
 

@@ -27,6 +27,7 @@ struct unet_ctx {
   int opt_enc_bn_fused = 1;         // encoder tail backward without a statistics pass
   int opt_bn_concat_analytic = 1;   // decoder BatchNorm statistics: skip half analytic
   int opt_bn_fuse_stats = 1;        // BatchNorm statistics from the producing conv's epilogue
+  int opt_skip_raw = 1;             // fp32 U-Net: an encoder block's second conv writes straight into the skip half of its concat; the encoder BatchNorm is composed into the folded decoder one
   int opt_head_fused = 1;           // the 1x1 sigmoid head + loss sums + the head's weight-gradient sums in the epilogue of the last conv3x3 (fp32 h2 kernels)
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
@@ -200,7 +201,8 @@ int32_t k_bn_fold_prepare(unet_ctx*, const float* w, const float* bias, const fl
 size_t wgrad_bn_fold_scratch_floats(int n, int cout);
 bool wgrad_bn_fold_supported(int cout);
 int32_t k_wgrad_bn_fold_fix(unet_ctx*, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db, float* scratch,
-                            hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
+                            hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr,
+                            const float* pre_s = nullptr, const float* pre_t = nullptr);          // (pre: the BatchNorm saw pre_s x + pre_t of the tensor the weight gradient ran on)
 int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx*, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
                                  float* scratch, hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
 constexpr int UNET_PREP_MAX = 36;          // layers per batched weight-preparation launch (the list travels as a kernel argument: < 4 KiB)
@@ -216,7 +218,11 @@ int32_t k_h2_prep_multi(unet_ctx*, const float* const* w, const float* const* cs
 size_t h2_convT_img_bytes(int cin, int cout);
 // mask_climit (folded-BatchNorm data gradients, MASK_BN_BWD*): output channels >= mask_climit do not read x -- they get K0 dz + K2, the K1 x term is added by their consumer
 int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K, int M,
-                         int act, float rate, uint64_t seed, hipStream_t s, int mask_climit = 1 << 30);
+                         int act, float rate, uint64_t seed, hipStream_t s, int mask_climit = 1 << 30, int ldy = 0);
+// Encoder BatchNorm whose output is the skip half of a decoder concat that is itself normalised and folded into the conv behind it (T1:861 -> 908-910): two affine maps
+// in a row are one.  comp = [scale' 2C][shift' 2C][pre_s 2C][pre_t 2C] with, for the skip channels j = C..2C-1, scale' = s_dec s_enc, shift' = s_dec t_enc + t_dec,
+// pre = (s_enc, t_enc) (x_dec = pre_s x_raw + pre_t: what the decoder BatchNorm's backward sums are taken over); the upsampled half keeps (s_dec, t_dec), pre = (1, 0)
+int32_t k_bn_compose(unet_ctx*, const float* bnp_dec, const float* bnp_enc, float* comp, int c, hipStream_t s);
 struct h2_head_args { const float* w = nullptr; const float* b = nullptr; float* p = nullptr; const float* t = nullptr; double* slots = nullptr; };
 bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int M);
 int32_t k_conv3x3_h2_head_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, float* y, const float* wh, const float* bh, float* p, const float* t,

@@ -69,6 +69,25 @@ __global__ void bn_bwd_coef_kernel(const float* __restrict__ bnp, const double* 
 }
 }  // namespace
 
+namespace {
+__global__ void bn_compose_kernel(const float* __restrict__ dec, const float* __restrict__ enc, float* __restrict__ comp, int C) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, C2 = 2 * C;
+  if (j >= C2) return;
+  const float sd = dec[j], td = dec[C2 + j];
+  if (j < C) { comp[j] = sd; comp[C2 + j] = td; comp[2 * C2 + j] = 1.0f; comp[3 * C2 + j] = 0.0f; }
+  else {
+    const float se = enc[j - C], te = enc[C + (j - C)];
+    comp[j] = sd * se; comp[C2 + j] = fmaf(sd, te, td); comp[2 * C2 + j] = se; comp[3 * C2 + j] = te;
+  }
+}
+}  // namespace
+int32_t k_bn_compose(unet_ctx* ctx, const float* bnp_dec, const float* bnp_enc, float* comp, int c, hipStream_t s) {
+  if (!bnp_dec || !bnp_enc || !comp || c < 1) UNET_FAIL(ctx, UNET_E_ARG, "bn_compose: bad args");
+  hipLaunchKernelGGL(bn_compose_kernel, dim3((unsigned)((2 * c + 127) / 128)), dim3(128), 0, s, bnp_dec, bnp_enc, comp, c);
+  UNET_CHECK_LAUNCH(ctx, "bn_compose");
+  return UNET_OK;
+}
+
 int32_t k_bn_bwd_coef(unet_ctx* ctx, const float* bnp, const double* sums, double count, float* coef, int c, hipStream_t s) {
   if (!bnp || !sums || !coef || c < 1 || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "bn_bwd_coef: bad args");
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((unsigned)((c + 127) / 128)), dim3(128), 0, s, bnp, sums, 1.0 / count, coef, c);
@@ -145,8 +164,10 @@ __global__ __launch_bounds__(1024) void fold_tap_sums_kernel(const float* __rest
 //   sum_p dz_c(p)        = sum_{tap,o} W[tap][c][o] * S[tap][o]
 //   sum_p dz_c(p) x_c(p) = sum_{tap,o} W[tap][c][o] * dW_raw[tap][c][o]        (dW_raw = the weight gradient on the raw x, before the correction)
 // and sum dz * xhat = istd * (sum dz x - mean * sum dz).  grid cin, 256 threads over the 9 * cout (tap, o) pairs; added into sums[2 * cin] (doubles).
+// pre_s / pre_t (or null): the BatchNorm's input was x = pre_s x_raw + pre_t of the tensor the weight gradient ran on, so sum dz x = pre_s sum dz x_raw + pre_t sum dz
 __global__ __launch_bounds__(256) void fold_bn_bwd_sums_kernel(const float* __restrict__ w, const float* __restrict__ dw_raw, const float* __restrict__ S,
-                                                               const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ sums, int cin, int cout) {
+                                                               const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ sums, int cin, int cout,
+                                                               const float* __restrict__ pre_s, const float* __restrict__ pre_t) {
   __shared__ double s_a[256], s_b[256];
   const int c = blockIdx.x;
   float a = 0.f, b = 0.f;
@@ -162,7 +183,10 @@ __global__ __launch_bounds__(256) void fold_bn_bwd_sums_kernel(const float* __re
     if ((int)threadIdx.x < st) { s_a[threadIdx.x] += s_a[threadIdx.x + st]; s_b[threadIdx.x] += s_b[threadIdx.x + st]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { sums[c] += s_b[0]; sums[cin + c] += (double)istd[c] * (s_a[0] - (double)mean[c] * s_b[0]); }
+  if (threadIdx.x == 0) {
+    const double dzx = pre_s ? (double)pre_s[c] * s_a[0] + (double)pre_t[c] * s_b[0] : s_a[0];
+    sums[c] += s_b[0]; sums[cin + c] += (double)istd[c] * (dzx - (double)mean[c] * s_b[0]);
+  }
 }
 __global__ void fold_fix_kernel(float* __restrict__ dw, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ S, int cin, int cout4,
                                 long long total4) {
@@ -182,14 +206,15 @@ size_t wgrad_bn_fold_scratch_floats(int n, int cout) { return (size_t)(n > 0 ? n
 // w / mean / istd / bn_bwd_sums (all or none): also accumulate the folded BatchNorm's backward sums (sum dz, sum dz * xhat) -- from W, the raw dw and S
 template <typename T>
 static int32_t wgrad_bn_fold_fix_impl(unet_ctx* ctx, const T* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                                      float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
+                                      float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums, const float* pre_s = nullptr,
+                                      const float* pre_t = nullptr) {
   if (!dy || !scale || !shift || !dw || !db || !scratch || !wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: bad args (cout=%d)", cout);
   float* border = scratch; float* S = scratch + (size_t)n * BORDER_SEG * 8 * cout;
   hipLaunchKernelGGL(border_sums_kernel<T>, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
   hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(1024), 0, s, border, db, S, n * BORDER_SEG, cout);
   if (bn_bwd_sums) {
     if (!w || !mean || !istd) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: the BatchNorm backward sums need w, mean, istd");
-    hipLaunchKernelGGL(fold_bn_bwd_sums_kernel, dim3((unsigned)cin), dim3(256), 0, s, w, dw, S, mean, istd, bn_bwd_sums, cin, cout);
+    hipLaunchKernelGGL(fold_bn_bwd_sums_kernel, dim3((unsigned)cin), dim3(256), 0, s, w, dw, S, mean, istd, bn_bwd_sums, cin, cout, pre_s, pre_t);
   }
   const long long total4 = 9LL * cin * cout / 4;
   hipLaunchKernelGGL(fold_fix_kernel, dim3((unsigned)std::min<long long>((total4 + 255) / 256, 2048)), dim3(256), 0, s, dw, scale, shift, S, cin, cout / 4, total4);
@@ -197,8 +222,9 @@ static int32_t wgrad_bn_fold_fix_impl(unet_ctx* ctx, const T* dy, int n, int h, 
   return UNET_OK;
 }
 int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {
-  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums);
+                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums, const float* pre_s, const float* pre_t) {
+  if ((pre_s == nullptr) != (pre_t == nullptr)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: pre_s and pre_t go together");
+  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums, pre_s, pre_t);
 }
 int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx* ctx, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
                                  float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {

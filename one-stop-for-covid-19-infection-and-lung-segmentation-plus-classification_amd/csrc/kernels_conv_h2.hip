@@ -804,17 +804,19 @@ int32_t k_h2_weights(unet_ctx* ctx, const float* w, void* img, int cin, int cout
 
 // x [n,h,wd,K] dense NHWC fp32, wimg from k_h2_weights (K contraction channels, M output channels), y [n,h,wd,M] fp32
 int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int n, int h, int wd, int K,
-                         int M, int act, float rate, uint64_t seed, hipStream_t s, int mask_climit) {
+                         int M, int act, float rate, uint64_t seed, hipStream_t s, int mask_climit, int ldy) {
+  if (ldy == 0) ldy = M;                                   // (ldy > M: the output is a channel slice of a wider NHWC buffer -- an encoder conv writing into its concat's skip half)
+  if (ldy < M || (ldy & 3) || (ldy != M && mask && mask_mode != MASK_BIAS_TAB)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2: ldy %d (M = %d; a strided output goes with a plain forward launch)", ldy, M);
   if (K < 16 || (K % 16) || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: K=%d M=%d (multiples of 16)", K, M);
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
   if (mask_climit < M && ((mask_climit % 32) || mask_mode < MASK_BN_BWD)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2: mask_climit %d must be a whole number of 32-channel blocks of a folded-BatchNorm gradient", mask_climit);
-  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
+  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
   // 16-row tiles (twice the MFMAs per staged chunk, 7 spilled registers at two workgroups per CU) measured 3-5 % faster on the 64 x 64 ... 128 x 128 layers when
   // they still fill the 512 resident slots, 2-4 % slower on the 256 / 512 pixel layers (fewer, longer workgroups) and much slower when the grid falls below one round
   const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
-  if (h <= 128 && wgs16 >= 512) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
-  return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, M, n, h, wd, K, M, act, rate, seed, s, mask_climit);
+  if (h <= 128 && wgs16 >= 512) return launch_h2<0, 2, 4, 2>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
+  return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
 }
 
 // The network's last conv3x3 + its 1x1 sigmoid head (T1:911-913) in one launch: y = relu(conv(x)) [n,h,wd,32], p = sigmoid(y . wh + bh) [n,h,wd]; with labels t:

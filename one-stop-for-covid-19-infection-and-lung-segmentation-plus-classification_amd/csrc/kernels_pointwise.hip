@@ -270,7 +270,7 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const T* __restrict__ 
     for (int k = 0; k < 4; ++k) {
       const float4 v = ld4(b + offs[k] * ldx);
       const float4 r = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-      st4(y + (pix + offs[k]) * ldy + q * 4, r);
+      if (y) st4(y + (pix + offs[k]) * ldy + q * 4, r);          // (y null: only the pooled tensor is wanted -- the normalised one is folded into its consumers)
       if (k == 0) m = r;
       else { m.x = fmaxf(m.x, r.x); m.y = fmaxf(m.y, r.y); m.z = fmaxf(m.z, r.z); m.w = fmaxf(m.w, r.w); }
     }
@@ -913,7 +913,7 @@ extern "C++" template <typename T> static int32_t maxpool_bwd_impl(unet_ctx* ctx
 extern "C++" template <typename T> static int32_t bn_apply_maxpool_impl(unet_ctx* ctx, const T* x, int32_t ldx, const float* bnp, T* y, int32_t ldy,
                                           T* pooled, int32_t n, int32_t h, int32_t wd, int32_t c, float rate, uint64_t seed,
                                           void* stream) {
-  if (!x || !bnp || !y || !pooled || !bn_c_ok(c) || (h & 1) || (wd & 1) || ldx < c || ldy < c || ((ldx | ldy) & 3) || rate < 0 || rate >= 1)
+  if (!x || !bnp || !pooled || !bn_c_ok(c) || (h & 1) || (wd & 1) || ldx < c || (y && (ldy < c || (ldy & 3))) || (ldx & 3) || rate < 0 || rate >= 1)
     UNET_FAIL(ctx, UNET_E_ARG, "bn_apply_maxpool fwd: bad args (h,w even; c%%4==0)");
   long long total = (long long)n * (h / 2) * (wd / 2) * (c / 4);
   if (total >= (1LL << 31)) UNET_FAIL(ctx, UNET_E_SHAPE, "pooling kernels index with 32 bits: %lld element quads is too many", total);

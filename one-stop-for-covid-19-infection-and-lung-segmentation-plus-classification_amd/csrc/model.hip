@@ -65,6 +65,7 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_BN_FUSE_STATS: return &ctx->opt_bn_fuse_stats;
     case UNET_OPT_DETERMINISTIC: return &ctx->opt_deterministic;
     case UNET_OPT_HEAD_FUSED: return &ctx->opt_head_fused;
+    case UNET_OPT_SKIP_RAW: return &ctx->opt_skip_raw;
     default: return nullptr;
   }
 }
@@ -102,9 +103,10 @@ static bool use_h2(int algo, int cin, int cout, const void* uws) { return uws &&
 // weights [3][3][cout][cin] of the layer and the roles of cin/cout below are already swapped (cin = channels of dy).
 static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                                     float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, int algo,
-                                    hipStream_t s, float* uws = nullptr, int flip = 0, const float* prepared = nullptr) {
+                                    hipStream_t s, float* uws = nullptr, int flip = 0, const float* prepared = nullptr, int ldy = 0) {
+  if (ldy && ldy != cout && !(use_h2(algo, cin, cout, uws) && prepared)) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3: a strided output (ldy %d) exists on the h2 kernels with a prepared image only", ldy);
   if (use_h2(algo, cin, cout, uws)) {
-    if (prepared) return k_conv3x3_h2_fwd(ctx, x, prepared, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);     // image built by the program's batch launch
+    if (prepared) return k_conv3x3_h2_fwd(ctx, x, prepared, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s, 1 << 30, ldy);     // image built by the program's batch launch
     int32_t r = flip ? k_h2_weights(ctx, w, uws, cout, cin, 1, s) : k_h2_weights(ctx, w, uws, cin, cout, 0, s);
     if (r) return r;
     return k_conv3x3_h2_fwd(ctx, x, uws, bias, mask, mask_mode, y, n, h, wd, cin, cout, act, rate, seed, s);
@@ -402,6 +404,9 @@ struct unet_model {
   std::map<std::string, size_t> bn_sum_off, bn_bsum_off, bnp_off;   // per-BN offsets (doubles / floats)
   size_t off_loss_sums = 0, off_loss_out = 0, off_wt = 0, off_wgrad_ws = 0; size_t wgrad_ws_bytes = 0;
   size_t off_first_tmp = 0;                // bf16 storage with a multi-channel image (configs[4] as written: 224 x 224 x 3): fp32 staging of the first conv's output / output gradient
+  // U-Net fp32, every decoder BatchNorm folded both ways: c<k>b (k = 1..4) IS the skip half of cat<10-k> -- the encoder conv writes there (ldy = 2C), the encoder BatchNorm's
+  // output is never stored (pool reads the raw tensor; the decoder fold composes the two BatchNorms: bn_comp_off = [scale'][shift'][pre_s][pre_t] x 2C per decoder level)
+  bool skip_raw = false; std::map<std::string, size_t> bn_comp_off; size_t off_tap_tmp = 0;
   size_t off_head_sums = 0; bool head_fused = false;          // U-Net, fp32 h2 kernels: c9b + 1x1 head + loss sums in one launch (kernels_conv_h2.hip, HEAD)
   std::map<std::string, size_t> sign_off;            // U-Net fp32 training: activation name -> its one-bit-per-element ReLU mask (MASK_RELU_BITS), offset in floats
   std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the prepared weights: the split fp16 image of the h2 kernels (forward / data-gradient form),
@@ -506,16 +511,28 @@ void plan_workspace(unet_model* m) {
   const int N = m->N;
   plan_scratch(m, cv);
   m->head_fused = !m->dt && h2_conv3x3_head_selected(m->ctx, m->algo, m->W, 32, 32);
+  m->skip_raw = !m->dt && m->ctx->opt_skip_raw && m->ctx->opt_bn_fold >= 2 && m->ctx->opt_enc_bn_fused && m->ctx->opt_bn_concat_analytic;
+  for (int k = 1; k <= 4 && m->skip_raw; ++k) {
+    const int c = ENC[k - 1];          // (exactly the conditions under which plan_workspace folds the decoder BatchNorm forward and backward, and the encoder conv runs on the h2 kernels)
+    m->skip_raw = wgrad_bn_fold_supported(c) && h2_conv3x3_selected(m->algo, 2 * c, c) && h2_conv3x3_selected(m->algo, c, 2 * c) && h2_conv3x3_selected(m->algo, c, c);
+  }
   // --- activations ---
   int S = m->H, T = m->W;
   for (int k = 1; k <= 4; ++k) {
     int c = ENC[k - 1];
     std::string ks = std::to_string(k), dk = std::to_string(10 - k);
     m->act["c" + ks + "a"] = mk(cv, N, S, T, c);
-    m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
+    if (!m->skip_raw) m->act["c" + ks + "b"] = mk(cv, N, S, T, c);
     Buf cat = mk(cv, N, S, T, 2 * c);
     m->act["cat" + dk] = cat;
     m->act["u" + dk] = slice(cat, 0, c);
+    if (m->skip_raw) {
+      m->act["c" + ks + "b"] = slice(cat, c, c);          // the raw conv output lives in the concat
+      if (k == 1) m->off_tap_tmp = cv.take((size_t)N * S * T * c);          // where a tap of bn<k> (tests, intermediate_output) is materialised on demand
+      Buf tb; tb.off = m->off_tap_tmp; tb.ld = c; tb.n = N; tb.h = S; tb.w = T; tb.c = c;
+      m->act["bn" + ks] = tb;
+      m->bn_comp_off["bn" + dk] = cv.take((size_t)4 * 2 * c);
+    } else
     m->act["bn" + ks] = slice(cat, c, c);
     m->act["p" + ks] = mk(cv, N, S / 2, T / 2, c);
     S /= 2; T /= 2;
@@ -594,6 +611,12 @@ void plan_workspace(unet_model* m) {
   for (auto& kv : m->act) {
     const std::string& nm = kv.first; const Buf& b = kv.second;
     if (nm.rfind("cat", 0) == 0) continue;
+    if (m->skip_raw && nm.size() == 3 && nm[0] == 'b' && nm[2] >= '1' && nm[2] <= '4') {          // bn<1..4>: the activation is only a tap scratch, the gradient IS the skip half of the concat's
+      const Buf g = m->grad.at("cat" + std::to_string(10 - (nm[2] - '0')));
+      m->grad[nm] = slice(g, g.c / 2, g.c / 2);
+    } else if (m->skip_raw && nm.size() == 3 && nm[0] == 'c' && nm[2] == 'b' && nm[1] >= '1' && nm[1] <= '4') {          // c<1..4>b lives in the concat, its gradient is a tensor of its own
+      m->grad[nm] = mk(cv, b.n, b.h, b.w, b.c);
+    } else
     if (b.chan_off != 0 || b.ld != b.c) {                       // slices of a cat buffer: u<k>, bn<1..4>
       std::string catname;
       if (nm[0] == 'u') catname = "cat" + nm.substr(1);
@@ -743,7 +766,7 @@ void build_programs(unet_model* m) {
         unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
         ctx->signs_req = sg; ctx->signs_done = nullptr;
         int32_t r = conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
-                                         ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second));
+                                         ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second), ob.ld);          // (ob.ld > cout: c<k>b inside its concat, skip_raw)
         ctx->signs_req = nullptr;
         if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd %s: the launch did not write the ReLU sign bits its data gradient was planned with", name.c_str());
         return r;
@@ -796,11 +819,11 @@ void build_programs(unet_model* m) {
       const std::string pin = "bn" + ks, pout = "p" + ks, xin = "c" + ks + "b";
       const int tr = training;
       const size_t bo = m->bnp_off.at("bn" + ks);
-      ADD_OP(F, "bn_apply_pool:" + pout, 0, eb * 2.25 * nel(ib), {
+      ADD_OP(F, "bn_apply_pool:" + pout, 0, eb * (m->skip_raw ? 1.25 : 2.25) * nel(ib), {
         if (dt) return unet_bn_apply_maxpool_dropout_fwd_bf16(ctx, CBF(m->Av(xin)), xb.ld, m->wsf(bo), WBF(m->Av(pin)), ib.ld, WBF(m->Av(pout)), ib.n, ib.h, ib.w, ib.c,
                                                               tr ? m->drop_rate : 0.0f, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
-        return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(xin), xb.ld, m->wsf(bo), m->Aw(pin), ib.ld, m->Aw(pout), ib.n, ib.h, ib.w, ib.c,
-                                                 tr ? m->drop_rate : 0.0f, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
+        return unet_bn_apply_maxpool_dropout_fwd(ctx, m->A(xin), xb.ld, m->wsf(bo), m->skip_raw ? nullptr : m->Aw(pin), ib.ld, m->Aw(pout), ib.n, ib.h, ib.w, ib.c,
+                                                 tr ? m->drop_rate : 0.0f, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);          // (skip_raw: the normalised tensor is never stored)
       });
       prev = pout; cprev = c;
     }
@@ -825,10 +848,17 @@ void build_programs(unet_model* m) {
         const std::string cn = "c" + ks + "a", xn = "cat" + ks, bnn = "bn" + ks;
         const Buf ob = m->act.at(cn); const int cin = 2 * c, cout = c;
         const size_t fo = m->fold_off.at(cn), bo = m->bnp_off.at(bnn), uo = m->wprep_f.at(cn);
+        const size_t co_ = m->skip_raw ? m->bn_comp_off.at(bnn) : 0, boe = m->skip_raw ? m->bnp_off.at("bn" + std::to_string(10 - k)) : 0;
         ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * cin * cout * 2, 4.0 * 9 * cin * cout * 4, {
-          int32_t r = k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), m->wsf(bo), m->wsf(bo) + cin, cin, cout, m->wsf(fo), s, dt != 0);
+          const float* sc_ = m->wsf(bo);                        // [scale 2C][shift 2C] of the folded map
+          if (m->skip_raw) {                                    // the skip half of the concat is the RAW encoder output: its BatchNorm and this one are one affine map (k_bn_compose)
+            int32_t rc = k_bn_compose(ctx, m->wsf(bo), m->wsf(boe), m->wsf(co_), cin / 2, s);
+            if (rc) return rc;
+            sc_ = m->wsf(co_);
+          }
+          int32_t r = k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), sc_, sc_ + cin, cin, cout, m->wsf(fo), s, dt != 0);
           if (r || dt) return r;                                // bf16 storage: the conv below builds its weight image from the scaled fp32 weights
-          return k_h2_weights(ctx, m->P(cn + "/kernel"), m->wsf(uo), cin, cout, 0, s, m->wsf(bo));          // fp32: the image kernel applies the scale per input channel
+          return k_h2_weights(ctx, m->P(cn + "/kernel"), m->wsf(uo), cin, cout, 0, s, sc_);          // fp32: the image kernel applies the scale per input channel
         });
         ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout, {
           const float* tab = m->wsf(fo) + (size_t)9 * cin * cout;
@@ -941,6 +971,11 @@ void build_programs(unet_model* m) {
           // ... and the BatchNorm's backward sums (sum dz, sum dz * xhat) come out of W, the raw dw and S: no pass over dz / x (bn_bwd below: stats_done)
           if (dt) return k_wgrad_bn_fold_fix_bf16(ctx, CBF(m->Dv(name)), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
                                                   m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in));
+          if (m->skip_raw) {                                    // the weight gradient ran on [up | RAW encoder output]: composite scale / shift, and the decoder BatchNorm saw pre_s x + pre_t
+            const float* comp = m->wsf(m->bn_comp_off.at(in));
+            return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, comp, comp + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
+                                       m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in), comp + 2 * cin, comp + 3 * cin);
+          }
           return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
                                      m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in));
         });
@@ -2003,13 +2038,23 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
     if (m->arch == UNET_ARCH_CLASSIFIER) conv = "c" + nm.substr(2, 1) + "b";                                             // classifier: bnKa -> cKb
     if (m->fold_c_off.count(conv)) return UNET_E_STATE;
   }
+  const std::string nm_ = name;
+  if (!grad && m->skip_raw && nm_.size() == 3 && nm_[0] == 'b' && nm_[2] >= '1' && nm_[2] <= '4') {
+    // skip_raw: an encoder BatchNorm's output is never stored -- a tap materialises it from the raw conv output (inside the concat) into the tap scratch
+    const std::string cb = std::string("c") + nm_[2] + "b";
+    const Buf& xb = m->act.at(cb);
+    int32_t r = unet_bn_apply(m->ctx, m->A(cb), xb.ld, m->wsf(m->bnp_off.at(name)), const_cast<float*>(m->A(name)), b.ld, (int64_t)b.n * b.h * b.w, b.c, nullptr);
+    if (r) return r;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return UNET_E_HIP;
+  }
   if (!grad && fb != m->folded_bn.end()) {
     // the programs never write this tensor (its BatchNorm is folded into the next conv): a tap materialises it from the layer's input and the
-    // scale / shift of the last forward, on the null stream, and waits for it
+    // scale / shift of the last forward, on the null stream, and waits for it (skip_raw: the composite map -- the concat holds the raw encoder output)
     const Buf& xb = m->act.at(fb->second.first);
+    const float* bnp_ = m->skip_raw && m->bn_comp_off.count(name) ? m->wsf(m->bn_comp_off.at(name)) : m->wsf(m->bnp_off.at(name));
     int32_t r = m->dt ? unet_bn_apply_bf16(m->ctx, static_cast<const unet_bf16*>(m->Av(fb->second.first)), xb.ld, m->wsf(m->bnp_off.at(name)), static_cast<unet_bf16*>(m->Av(name)), b.ld,
                                            (int64_t)b.n * b.h * b.w, fb->second.second, nullptr)
-                      : unet_bn_apply(m->ctx, m->A(fb->second.first), xb.ld, m->wsf(m->bnp_off.at(name)), const_cast<float*>(m->A(name)), b.ld, (int64_t)b.n * b.h * b.w, fb->second.second, nullptr);
+                      : unet_bn_apply(m->ctx, m->A(fb->second.first), xb.ld, bnp_, const_cast<float*>(m->A(name)), b.ld, (int64_t)b.n * b.h * b.w, fb->second.second, nullptr);
     if (r) return r;
     if (hipStreamSynchronize(nullptr) != hipSuccess) return UNET_E_HIP;
   }
