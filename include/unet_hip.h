@@ -72,9 +72,11 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   SKIP_RAW (1)           fp32 U-Net with BN_FOLD >= 2, ENC_BN_FUSED and BN_CONCAT_ANALYTIC: the second conv of an encoder block (T1:860) writes straight into the skip half
  *                          of its concat (T1:908) and the encoder BatchNorm's output is never stored: max-pool reads the raw tensor, the folded decoder BatchNorm is
  *                          composed with the encoder one (two affine maps in a row are one).  -1 GB of writes per step at 512 x 512 x 16.  0 = the normalised copy is stored
+ *   POOL_SUMS_FUSED (1)    fp32 U-Net with ENC_BN_FUSED: the pooled-path sums of an encoder tail's BatchNorm backward come out of the epilogue of the data gradient that
+ *                          produces the pooled tensor's gradient (no pass over the pooled tensors); dropout-removed elements are recognised by the -0.0f the forward stored
  */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,
-       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8 };
+       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8, UNET_OPT_POOL_SUMS_FUSED = 9 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
 int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */
 
@@ -261,6 +263,16 @@ int32_t unet_loss_finalize(unet_ctx*, const double* loss_sums, double count, flo
 int32_t unet_head_bwd(unet_ctx*, const float* x, const float* w, const float* p, const float* y_true,
                       const double* loss_sums, double count, float* dx, float* dw, float* db,
                       int64_t pixels, int32_t cin, int32_t relu_mask, void* stream);
+
+/* The data gradient of the conv BEHIND `MaxPooling2D((2, 2))` + `Dropout(0.25)` (T1:862-865: c2 = Conv2D(64)(p1) ...) together with the pooled-path sums the
+ * BatchNorm in front of that pool needs for its backward (what unet_maxpool2x2_dropout_bwd_sums computes in a pass of its own):
+ *   dx = conv3x3(dy, flipped w) [n,h,w,cin]  (= the gradient of the pooled tensor);  sums[2 cin] += (sum dx ks, sum dx ks (p (1 - rate) - beta) / gamma)
+ * with p = `pooled`, the OUTPUT of unet_bn_apply_maxpool_dropout_fwd at the same rate: that kernel stores a dropout-removed element as -0.0f (a kept zero as
+ * +0.0f), which is how ks = 1 / (1 - rate) | 0 is read back without replaying the random stream.  fp32 UNET_ALGO_AUTO kernels, cin % 32 == 0, not in
+ * deterministic mode (unet_conv3x3_bwd_data_pool_sums_supported).  wt_ws as for unet_conv3x3_bwd_data. */
+int32_t unet_conv3x3_bwd_data_pool_sums_supported(unet_ctx*, int32_t algo, int32_t wd, int32_t cin, int32_t cout);
+int32_t unet_conv3x3_bwd_data_pool_sums(unet_ctx*, const float* dy, const float* w, const float* pooled, const float* gamma, const float* beta, float rate,
+                                        float* dx, double* sums, float* wt_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream);
 
 /* Replaces: `c9 = Conv2D(32, (3, 3), relu)(c9)` + `outputs = Conv2D(1, (1, 1), activation='sigmoid')(c9)` T1:911-913 and the loss sums of
  * bce_dice_loss T1:784-799 in ONE launch (fp32, UNET_ALGO_AUTO kernels, 32 output channels, W % 8 == 0, not in deterministic mode:

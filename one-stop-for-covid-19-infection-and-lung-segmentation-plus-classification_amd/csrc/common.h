@@ -27,6 +27,7 @@ struct unet_ctx {
   int opt_enc_bn_fused = 1;         // encoder tail backward without a statistics pass
   int opt_bn_concat_analytic = 1;   // decoder BatchNorm statistics: skip half analytic
   int opt_bn_fuse_stats = 1;        // BatchNorm statistics from the producing conv's epilogue
+  int opt_pool_sums_fused = 1;      // fp32 U-Net: the pooled-path sums of the encoder tail's BatchNorm backward from the epilogue of the data gradient that produces the pooled gradient
   int opt_skip_raw = 1;             // fp32 U-Net: an encoder block's second conv writes straight into the skip half of its concat; the encoder BatchNorm is composed into the folded decoder one
   int opt_head_fused = 1;           // the 1x1 sigmoid head + loss sums + the head's weight-gradient sums in the epilogue of the last conv3x3 (fp32 h2 kernels)
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
@@ -180,6 +181,11 @@ enum { MASK_BN_BWD_RELU = 8 };
 // h2 kernels only: the ReLU mask as ONE BIT per element, written by the forward launch that produced the tensor (unet_ctx::signs_req):
 // u64 words [n][y][x / 8][c / 32][4]; word k of an (8 pixels x 32 channels) cell holds bit (pixel % 8) * 8 + (channel % 32) / 4 for channel % 4 == k
 enum { MASK_RELU_BITS = 9 };
+// h2 kernels only, data-gradient launches whose output is the gradient of a max-pool + dropout output p (U-Net encoder, T1:862-863): `mask` = p; besides the plain data
+// gradient g the epilogue adds the two per-channel sums of the encoder tail's BatchNorm backward to the context's slot copies (pool_bwd_sums_kernel's definition):
+//   sum g ks,  sum g ks (p (1 - rate) - beta) / gamma,   ks = 1 / (1 - rate) where the element was kept, 0 where dropout removed it
+// -- a removed element is stored as -0.0f by the forward (bn_pool_fwd_kernel), a kept zero as +0.0f, so no random stream is replayed here.  h2_head_args carries gamma / beta / rate
+enum { MASK_POOL_SUMS = 10 };
 int32_t k_bn_bwd_coef(unet_ctx*, const float* bnp, const double* sums, double count, float* coef, int c, hipStream_t s);
 __device__ __forceinline__ float mask_factor(float m, int mode, float ks /* keep_scale component */, float rate) {
   if (mode == MASK_RELU) return m > 0.0f ? 1.0f : 0.0f;
@@ -222,8 +228,14 @@ int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const floa
 // Encoder BatchNorm whose output is the skip half of a decoder concat that is itself normalised and folded into the conv behind it (T1:861 -> 908-910): two affine maps
 // in a row are one.  comp = [scale' 2C][shift' 2C][pre_s 2C][pre_t 2C] with, for the skip channels j = C..2C-1, scale' = s_dec s_enc, shift' = s_dec t_enc + t_dec,
 // pre = (s_enc, t_enc) (x_dec = pre_s x_raw + pre_t: what the decoder BatchNorm's backward sums are taken over); the upsampled half keeps (s_dec, t_dec), pre = (1, 0)
+// the data gradient of the conv behind an encoder tail with the tail's BatchNorm-backward sums in its epilogue (MASK_POOL_SUMS): dy [n,h,wd,K] -> dx [n,h,wd,M], pooled = the
+// forward's max-pool + dropout output [n,h,wd,M]; sums[2 M] += (folded out of the slot copies behind the launch)
+int32_t k_slot_fold(unet_ctx*, double* sums, int count, hipStream_t s);          // sums[i] += the slot copies' entries i (cleared), in index order (kernels_pointwise.hip)
+bool h2_pool_sums_selected(const unet_ctx* ctx, int algo, int wd, int K, int M);
+int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx*, const float* dy, const void* wimg, const float* pooled, const float* gamma, const float* beta, float rate, float* dx, double* sums,
+                                     int n, int h, int wd, int K, int M, hipStream_t s);
 int32_t k_bn_compose(unet_ctx*, const float* bnp_dec, const float* bnp_enc, float* comp, int c, hipStream_t s);
-struct h2_head_args { const float* w = nullptr; const float* b = nullptr; float* p = nullptr; const float* t = nullptr; double* slots = nullptr; };
+struct h2_head_args { const float* w = nullptr; const float* b = nullptr; float* p = nullptr; const float* t = nullptr; double* slots = nullptr; float aux = 0.0f; };          // (MASK_POOL_SUMS: w = gamma, b = beta, aux = dropout rate)
 bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int M);
 int32_t k_conv3x3_h2_head_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, float* y, const float* wh, const float* bh, float* p, const float* t,
                               int n, int h, int wd, int K, hipStream_t s);

@@ -134,13 +134,17 @@ __device__ __forceinline__ int out_cell(int p, int c) { return p * 128 + ((c ^ (
 //         (pixel stride ldx) that is staged
 // HEAD (the network's last conv3x3, T1:911-913): the 1x1 sigmoid head, the four loss sums and the three per-channel sums the head's weight gradient is a
 // combination of are taken from the output tile while it is in registers / LDS (h2_head_args; one channel group of 32, ReLU, no mask)
-template <int MODE, int NB, int RW, bool GEN, int WPS, bool HEAD = false>
+template <int MODE, int NB, int RW, bool GEN, int WPS, int EPI = 0>
 __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
                                                            int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs,
                                                            int mask_climit, h2_head_args hd) {
+  constexpr bool HEAD = EPI == 1, POOLS = EPI == 2;          // EPI: 0 the general epilogue, 1 + the 1x1 sigmoid head (below), 2 + the pooled-path sums of an encoder tail (MASK_POOL_SUMS)
   static_assert(!HEAD || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the fused head rides on the 32-channel forward kernel");
+  static_assert(!POOLS || (MODE == 0 && !GEN), "the pooled sums ride on a plain conv3x3 data-gradient launch");
+  if (POOLS) { mask_mode = MASK_POOL_SUMS; act = ACT_NONE; signs = nullptr; }          // (compile-time facts of this instance: the other epilogue forms fall away)
+  if (HEAD) { mask_mode = MASK_NONE; act = ACT_RELU; stats = nullptr; }
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
   constexpr int TH = 4 * RW;                             // tile rows: RW per wave
   constexpr int PR = MODE == 0 ? TH + 2 : TH, PWD = MODE == 0 ? 34 : 32, NPIX = PR * PWD;
@@ -277,8 +281,13 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     s_bias[tid] = (bias && ok) ? bias[MODE == 1 ? ch % (M >> 2) : ch] : 0.f;
     const bool bn_bwd_mode = mask_mode >= MASK_BN_BWD && mask_mode <= MASK_BN_BWD_RELU;
     const bool coef = bn_bwd_mode && mask && ok;
+    if (POOLS) {                                           // row 1 = 1 / gamma (0 where gamma is 0), row 2 = beta of the encoder BatchNorm in front of the pooled tensor
+      const float gm = ok ? hd.w[ch] : 0.f;
+      s_bias[NB * 32 + tid] = gm != 0.f ? 1.0f / gm : 0.f; s_bias[2 * NB * 32 + tid] = ok ? hd.b[ch] : 0.f;
+    } else {
     s_bias[NB * 32 + tid] = HEAD ? hd.w[tid] : coef ? bias[M + ch] : 0.f;          // (HEAD: row 1 = the 32 weights of the 1x1 head, row 2 [0] = its bias)
     s_bias[2 * NB * 32 + tid] = HEAD ? hd.b[0] : coef ? bias[2 * M + ch] : 0.f;
+    }
   }
   issue_loads(0);
   issue_w_loads(0);
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int k = 0; k < 4; ++k) mv[q * 4 + k] = ((d[k] >> (sh + q)) & 1u) ? 1.0f : 0.0f;
-      } else if (want_m) {
+      } else if (want_m && !POOLS) {
         if (MPF) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(s_out + out_cell(j * 8 + (lane >> 3), lane & 7)) = mpre[MPF ? nb : 0][MPF ? r : 0][j];
@@ -650,6 +659,19 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         }
         if (pxj < W && mb0 + cj * 4 < M) {
           *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
+          if (POOLS) {
+            // the stored gradient g and the pooled activation p of the same elements (line layout both): st1 += g ks, st2 += g ks (p (1 - rate) - beta) / gamma
+            const float4 pv = MPF ? mpre[MPF ? nb : 0][MPF ? r : 0][j] : *reinterpret_cast<const float4*>(mask + oj + cj * 4);
+            const float4 ig = *reinterpret_cast<const float4*>(s_bias + (NB + nb) * 32 + cj * 4), be = *reinterpret_cast<const float4*>(s_bias + (2 * NB + nb) * 32 + cj * 4);
+            const float unkeep = 1.0f - hd.aux, inv = 1.0f / unkeep;
+            const bool drop = hd.aux > 0.0f;
+            const float kx = drop && __float_as_uint(pv.x) == 0x80000000u ? 0.f : inv, ky = drop && __float_as_uint(pv.y) == 0x80000000u ? 0.f : inv;
+            const float kz = drop && __float_as_uint(pv.z) == 0x80000000u ? 0.f : inv, kw = drop && __float_as_uint(pv.w) == 0x80000000u ? 0.f : inv;
+            const float gx = t4.x * kx, gy = t4.y * ky, gz = t4.z * kz, gw = t4.w * kw;
+            st1.x += gx; st1.y += gy; st1.z += gz; st1.w += gw;
+            st2.x = fmaf(gx, (pv.x * unkeep - be.x) * ig.x, st2.x); st2.y = fmaf(gy, (pv.y * unkeep - be.y) * ig.y, st2.y);
+            st2.z = fmaf(gz, (pv.z * unkeep - be.z) * ig.z, st2.z); st2.w = fmaf(gw, (pv.w * unkeep - be.w) * ig.w, st2.w);
+          } else
           if (MODE != 2 && stats) {
             st1.x += t4.x; st1.y += t4.y; st1.z += t4.z; st1.w += t4.w;
             st2.x = fmaf(t4.x, t4.x, st2.x); st2.y = fmaf(t4.y, t4.y, st2.y); st2.z = fmaf(t4.z, t4.z, st2.z); st2.w = fmaf(t4.w, t4.w, st2.w);
@@ -691,7 +713,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #endif
 }
 
-template <int MODE, int NB, int RW, int WPS, bool HEAD = false>
+template <int MODE, int NB, int RW, int WPS, int EPI = 0>
 int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd,
                   int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30, h2_head_args hd = h2_head_args()) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
@@ -710,6 +732,10 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
     const int c = ctx->stats_req_c; ctx->stats_req_c = 0;
     if ((mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots) { stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; }
   }
+  if (mask_mode == MASK_POOL_SUMS) {
+    if (MODE != 0 || !ctx->bn_slots || 2 * M > UNET_BN_SLOT_DOUBLES || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "conv h2: the pooled-sums epilogue is a conv3x3 data-gradient launch (M = %d)", M);
+    stats = ctx->bn_slots; stats_c = M;
+  }
   if (mask_mode == MASK_RELU_BITS && ((M & 31) || (wd & 7))) UNET_FAIL(ctx, UNET_E_SHAPE, "conv h2: the bit mask needs M %% 32 == 0 and W %% 8 == 0 (M=%d W=%d)", M, wd);
   unsigned long long* signs = nullptr;
   if (MODE == 0 && ctx->signs_req) {
@@ -723,9 +749,13 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
     return UNET_OK;
   };
   int32_t r;
-  if (HEAD) {
+  if (EPI == 1) {
     if (gen || mask_mode != MASK_NONE || act != ACT_RELU || M != 32 || stats) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 + head: a plain 32-channel ReLU forward launch only");
-    r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, HEAD>);
+    r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
+  } else if (EPI == 2) {
+    if (gen || mask_mode != MASK_POOL_SUMS || act != ACT_NONE) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 + pooled sums: a plain data-gradient launch only");
+    r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
+  } else if (mask_mode == MASK_POOL_SUMS) { UNET_FAIL(ctx, UNET_E_ARG, "conv h2: MASK_POOL_SUMS goes with its own kernel instance");
   } else if (gen) r = go(conv_h2_kernel<MODE, NB, RW, (MODE == 0), WPS>); else r = go(conv_h2_kernel<MODE, NB, RW, false, WPS>);
   if (r) return r;
   UNET_CHECK_LAUNCH(ctx, "conv_h2");
@@ -819,6 +849,25 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   return launch_h2<0, 2, 2, 2>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
 }
 
+bool h2_pool_sums_selected(const unet_ctx* ctx, int algo, int wd, int K, int M) {
+  (void)wd;
+  return ctx && ctx->opt_pool_sums_fused && !ctx->opt_deterministic && ctx->bn_slots && h2_conv3x3_selected(algo, K, M) && (M % 32) == 0 && 2 * M <= UNET_BN_SLOT_DOUBLES;
+}
+int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx* ctx, const float* dy, const void* wimg, const float* pooled, const float* gamma, const float* beta, float rate, float* dx, double* sums,
+                                     int n, int h, int wd, int K, int M, hipStream_t s) {
+  if (!dy || !wimg || !pooled || !gamma || !beta || !dx || !sums || rate < 0.f || rate >= 1.f) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 dgrad + pooled sums: bad args");
+  if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  h2_head_args hd; hd.w = gamma; hd.b = beta; hd.aux = rate;
+  const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
+  int32_t r;
+  const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
+  if (h2_nb(M) == 1) r = launch_h2<0, 1, 2, 4, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
+  else if (h <= 128 && wgs16 >= 512) r = launch_h2<0, 2, 4, 2, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
+  else r = launch_h2<0, 2, 2, 2, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
+  if (r) return r;
+  return k_slot_fold(ctx, sums, 2 * M, s);
+}
+
 // The network's last conv3x3 + its 1x1 sigmoid head (T1:911-913) in one launch: y = relu(conv(x)) [n,h,wd,32], p = sigmoid(y . wh + bh) [n,h,wd]; with labels t:
 // the slot copies `ctx->bn_slots` receive [0,96) sum_p a y_c | sum_p t q y_c | sum_p q y_c, [96,100) sum bce, sum t p, sum t, sum p, [100,103) sum a, sum t q, sum q
 // (a = dBCE/dz, q = p (1 - p)): k_head_fold moves them out; the head's weight gradient is a combination of them once the batch-global Dice sums are known
@@ -830,7 +879,7 @@ int32_t k_conv3x3_h2_head_fwd(unet_ctx* ctx, const float* x, const void* wimg, c
   if (K < 16 || (K % 16) || !wh || !bh || !p) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2 + head: bad args");
   if ((long long)h * wd * std::max(K, 32) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   h2_head_args hd; hd.w = wh; hd.b = bh; hd.p = p; hd.t = t; hd.slots = ctx->bn_slots;
-  return launch_h2<0, 1, 2, 4, true>(ctx, x, K, static_cast<const unet_bf16*>(wimg), bias, nullptr, MASK_NONE, y, 32, n, h, wd, K, 32, ACT_RELU, 0.0f, 0, s, 1 << 30, hd);
+  return launch_h2<0, 1, 2, 4, 1>(ctx, x, K, static_cast<const unet_bf16*>(wimg), bias, nullptr, MASK_NONE, y, 32, n, h, wd, K, 32, ACT_RELU, 0.0f, 0, s, 1 << 30, hd);
 }
 
 // ---- ConvT 2x2 stride 2 (T1:886 ...) on the same kernels: forward = MODE 1 (K = cin, M = 4 cout), data gradient = MODE 2 (K = 4 cout, M = cin).

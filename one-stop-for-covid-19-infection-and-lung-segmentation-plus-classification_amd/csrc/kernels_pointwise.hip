@@ -274,7 +274,10 @@ __global__ __launch_bounds__(TPB) void bn_pool_fwd_kernel(const T* __restrict__ 
       if (k == 0) m = r;
       else { m.x = fmaxf(m.x, r.x); m.y = fmaxf(m.y, r.y); m.z = fmaxf(m.z, r.z); m.w = fmaxf(m.w, r.w); }
     }
-    if (rate > 0.0f) { float4 kk = keep_scale(i, rate, seed); m.x *= kk.x; m.y *= kk.y; m.z *= kk.z; m.w *= kk.w; }
+    // (an element dropout removes is stored as -0.0f, a kept one that happens to be zero as +0.0f: the data gradient behind this tensor reads the keep mask off the
+    //  stored value, MASK_POOL_SUMS in kernels_conv_h2.hip; every other reader sees a zero either way)
+    if (rate > 0.0f) { float4 kk = keep_scale(i, rate, seed); m.x = kk.x == 0.f ? -0.0f : m.x * kk.x + 0.0f; m.y = kk.y == 0.f ? -0.0f : m.y * kk.y + 0.0f;
+                       m.z = kk.z == 0.f ? -0.0f : m.z * kk.z + 0.0f; m.w = kk.w == 0.f ? -0.0f : m.w * kk.w + 0.0f; }
     st4(pooled + p * C + q * 4, m);
   }
 }
@@ -1003,6 +1006,10 @@ extern "C++" template <typename T> static int32_t head_bwd_impl(unet_ctx* ctx, c
   UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
 }
 
+extern "C++" int32_t k_slot_fold(unet_ctx* ctx, double* sums, int count, hipStream_t s) {
+  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((count + 127) / 128), dim3(128), 0, s, ctx->bn_slots, sums, count, ctx->bn_nslots());
+  UNET_CHECK_LAUNCH(ctx, "slot_fold"); return UNET_OK;
+}
 extern "C++" int32_t k_head_fold(unet_ctx* ctx, double* loss_sums, double* head_sums, hipStream_t s) {
   if (!loss_sums || !head_sums || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "head_fold: bad args");
   hipLaunchKernelGGL(head_fold_kernel, dim3(1), dim3(128), 0, s, ctx->bn_slots, loss_sums, head_sums, UNET_BN_SLOTS);

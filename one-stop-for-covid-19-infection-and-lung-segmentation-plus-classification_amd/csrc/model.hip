@@ -66,6 +66,7 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_DETERMINISTIC: return &ctx->opt_deterministic;
     case UNET_OPT_HEAD_FUSED: return &ctx->opt_head_fused;
     case UNET_OPT_SKIP_RAW: return &ctx->opt_skip_raw;
+    case UNET_OPT_POOL_SUMS_FUSED: return &ctx->opt_pool_sums_fused;
     default: return nullptr;
   }
 }
@@ -235,6 +236,17 @@ int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, co
   // data gradient = 3x3 convolution of dy (cout channels) with the flipped/transposed kernel -> cin channels
   return conv3x3_fwd_dispatch(ctx, dy, w, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
                               as_stream(stream), wt_ws, 1);
+}
+
+// the data gradient behind an encoder tail (MaxPooling2D + Dropout, T1:862-863) with that tail's pooled-path BatchNorm-backward sums in the epilogue (include/unet_hip.h)
+int32_t unet_conv3x3_bwd_data_pool_sums_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cin, int32_t cout) { return ctx && h2_pool_sums_selected(ctx, algo, wd, cout, cin) ? 1 : 0; }
+int32_t unet_conv3x3_bwd_data_pool_sums(unet_ctx* ctx, const float* dy, const float* w, const float* pooled, const float* gamma, const float* beta, float rate, float* dx, double* sums,
+                                        float* wt_ws, int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout, void* stream) {
+  if (!ctx || !dy || !w || !pooled || !gamma || !beta || !dx || !sums || !wt_ws || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data_pool_sums: bad args");
+  if (!h2_pool_sums_selected(ctx, UNET_ALGO_AUTO, wd, cout, cin)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bwd_data_pool_sums: not supported here (unet_conv3x3_bwd_data_pool_sums_supported)");
+  int32_t r = k_h2_weights(ctx, w, wt_ws, cin, cout, 1, as_stream(stream));
+  if (r) return r;
+  return k_conv3x3_h2_dgrad_pool_sums(ctx, dy, wt_ws, pooled, gamma, beta, rate, dx, sums, n, h, wd, cout, cin, as_stream(stream));
 }
 
 /* ---- conv3x3 over a BatchNorm-affine input without the normalised tensor (the decoder blocks BN -> Conv, T1:888-889 ...) ---- */
@@ -407,6 +419,7 @@ struct unet_model {
   // U-Net fp32, every decoder BatchNorm folded both ways: c<k>b (k = 1..4) IS the skip half of cat<10-k> -- the encoder conv writes there (ldy = 2C), the encoder BatchNorm's
   // output is never stored (pool reads the raw tensor; the decoder fold composes the two BatchNorms: bn_comp_off = [scale'][shift'][pre_s][pre_t] x 2C per decoder level)
   bool skip_raw = false; std::map<std::string, size_t> bn_comp_off; size_t off_tap_tmp = 0;
+  std::set<std::string> pool_sums_fused;          // pooled tensors whose backward sums come out of the data-gradient epilogue (MASK_POOL_SUMS)
   size_t off_head_sums = 0; bool head_fused = false;          // U-Net, fp32 h2 kernels: c9b + 1x1 head + loss sums in one launch (kernels_conv_h2.hip, HEAD)
   std::map<std::string, size_t> sign_off;            // U-Net fp32 training: activation name -> its one-bit-per-element ReLU mask (MASK_RELU_BITS), offset in floats
   std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the prepared weights: the split fp16 image of the h2 kernels (forward / data-gradient form),
@@ -1004,6 +1017,17 @@ void build_programs(unet_model* m) {
         });
         return;
       }
+      if (want_dx && !dt && !mask_in && in.size() == 2 && in[0] == 'p' && ctx->opt_enc_bn_fused && m->wprep_b.count(name) && h2_pool_sums_selected(ctx, algo, ob.w, cout, cin)) {
+        // the gradient of a pooled tensor p<k>: the pooled-path sums of the encoder tail's BatchNorm backward ride in this launch's epilogue (MASK_POOL_SUMS) --
+        // the pool_bwd_sums op below then only adds the closed-form skip term
+        const std::string bnn = "bn" + in.substr(1);
+        const size_t so = m->bn_bsum_off.at(bnn);
+        m->pool_sums_fused.insert(in);
+        ADD_OP(BW, "conv3x3_dgrad_pool_sums:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + 2 * cin) + 4.0 * 9.0 * cin * cout, {
+          return k_conv3x3_h2_dgrad_pool_sums(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->A(in), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->drop_rate, m->D(in),
+                                              m->wsd(m->off_bn_bsums) + so, ob.n, ob.h, ob.w, cout, cin, s);
+        });
+      } else
       if (want_dx) {
         const bool bits = mask_in && m->sign_off.count(in) != 0;
         ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? (bits ? cin / 32.0 : cin) : 0)) + 4.0 * 9.0 * cin * cout, {
@@ -1093,8 +1117,9 @@ void build_programs(unet_model* m) {
         const size_t sod = m->bn_bsum_off.at(dn), bod = m->bnp_off.at(dn), bo = m->bnp_off.at(bnn);
         const Buf cbuf = m->act.at(cb), cg = m->grad.at(cb);
         const int64_t pixels = (int64_t)xb.n * xb.h * xb.w;
-        ADD_OP(BW, "pool_bwd_sums:" + pn, 0, eb * 0.5 * nel(xb), {
-          int32_t r = dt ? unet_maxpool2x2_dropout_bwd_sums_bf16(ctx, CBF(m->Av(pn)), CBF(m->Dv(pn)), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h,
+        const bool sums_done = m->pool_sums_fused.count(pn) != 0;
+        ADD_OP(BW, sums_done ? "pool_bwd_skip_term:" + pn : "pool_bwd_sums:" + pn, 0, sums_done ? 0.0 : eb * 0.5 * nel(xb), {
+          int32_t r = sums_done ? UNET_OK : dt ? unet_maxpool2x2_dropout_bwd_sums_bf16(ctx, CBF(m->Av(pn)), CBF(m->Dv(pn)), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h,
                                                                  xb.w, xb.c, m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s)
                          : unet_maxpool2x2_dropout_bwd_sums(ctx, m->A(pn), m->D(pn), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c,
                                                             m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);

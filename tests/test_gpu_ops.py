@@ -379,6 +379,42 @@ def test_conv3x3_head_fused_fwd_and_dy(ops, shape):
     assert abs(s3n[0] - sn[0]) < 0.5                                # (the BCE sum: the separate kernel takes the logit from p -- 0.39 (1 - t) off on the one pixel with z = 15.55, above)
 
 
+@pytest.mark.parametrize("shape,rate", [((2, 16, 32, 64, 32), 0.25), ((1, 24, 40, 128, 64), 0.25), ((2, 8, 8, 256, 128), 0.0), ((3, 16, 16, 64, 64), 0.4)])
+def test_conv3x3_dgrad_with_pooled_sums_in_the_epilogue(ops, shape, rate):
+    """unet_conv3x3_bwd_data_pool_sums: the data gradient of the conv behind MaxPooling2D + Dropout (T1:862-865) with the pooled-path sums of the encoder tail's BatchNorm
+    backward in its epilogue.  dx == the plain data gradient bit for bit; the sums == unet_maxpool2x2_dropout_bwd_sums on (pooled, dx), which replays the random
+    stream -- here the keep mask is read off the -0.0f the forward stores for a removed element.  One channel has gamma = beta = 0 (every pooled value a kept +0.0 or a
+    removed -0.0), one has gamma < 0."""
+    n, h, w, cout, cin = shape                                       # the conv: cin -> cout channels at h x w; pooled tensor [n, h, w, cin]
+    assert ops.lib.unet_conv3x3_bwd_data_pool_sums_supported(ops.h, 0, w, cin, cout) == 1
+    rng = np.random.default_rng(cin + h)
+    xe = np.maximum(rng.standard_normal((n, 2 * h, 2 * w, cin)) + 0.2, 0).astype(np.float32)
+    ge = rng.uniform(0.5, 1.5, cin).astype(np.float32); be = (rng.standard_normal(cin) * 0.3).astype(np.float32)
+    ge[3] = 0.0; be[3] = 0.0; ge[5] = -0.7
+    es = ops.z(2 * cin, dtype=torch.float64); bnp = ops.z(4 * cin); pooled = ops.z(n, h, w, cin); ybn = ops.z(n, 2 * h, 2 * w, cin)
+    xd = ops.d(xe); pix = n * 4 * h * w
+    ops.ck(ops.lib.unet_bn_stats(ops.h, xd.data_ptr(), cin, es.data_ptr(), pix, cin, ops.s), "stats")
+    ops.ck(ops.lib.unet_bn_finalize_train(ops.h, es.data_ptr(), float(pix), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), ops.z(cin).data_ptr(), ops.z(cin).data_ptr(), bnp.data_ptr(), cin, ops.s), "fin")
+    ops.ck(ops.lib.unet_bn_apply_maxpool_dropout_fwd(ops.h, xd.data_ptr(), cin, bnp.data_ptr(), ybn.data_ptr(), cin, pooled.data_ptr(), n, 2 * h, 2 * w, cin, rate, 77, ops.s), "pool fwd")
+    pn = pooled.cpu().numpy()
+    if rate > 0:
+        removed = np.signbit(pn) & (pn == 0)
+        assert abs(removed.mean() - rate) < 0.02 and (pn[..., 3] == 0).all() and 0.1 < np.signbit(pn[..., 3]).mean() < 0.9          # the markers are there, kept zeros are +0.0
+    k = (rng.standard_normal((3, 3, cin, cout)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+    dx0 = ops.z(n, h, w, cin); dx1 = ops.z(n, h, w, cin); s0 = ops.z(2 * cin, dtype=torch.float64); s1 = ops.z(2 * cin, dtype=torch.float64)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), None, 0, 0.0, 0, dx0.data_ptr(), ops.wws(cin, cout), n, h, w, cin, cout, 0, ops.s), "dgrad")
+    ops.ck(ops.lib.unet_maxpool2x2_dropout_bwd_sums(ops.h, pooled.data_ptr(), dx0.data_ptr(), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), s0.data_ptr(), n, 2 * h, 2 * w, cin, rate, 77, ops.s), "sums pass")
+    s1 += 1.0                                                        # the sums are ADDED to what is there
+    ops.ck(ops.lib.unet_conv3x3_bwd_data_pool_sums(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), pooled.data_ptr(), ops.d(ge).data_ptr(), ops.d(be).data_ptr(), rate, dx1.data_ptr(),
+                                                   s1.data_ptr(), ops.wws(cin, cout), n, h, w, cin, cout, ops.s), "dgrad + sums")
+    assert (dx1.cpu().numpy() == dx0.cpu().numpy()).all()
+    a, b = s0.cpu().numpy(), s1.cpu().numpy() - 1.0
+    scale = np.abs(a).max()
+    assert np.abs(a - b).max() < 2e-6 * scale + 1e-9, (np.abs(a - b).max(), scale)
+    assert b[cin + 3] == 0.0                                         # gamma = 0: no xhat term (as the separate pass)
+
+
 def test_adam_and_metrics(ops):
     from gpu_util import relerr
     rng = np.random.default_rng(4)
