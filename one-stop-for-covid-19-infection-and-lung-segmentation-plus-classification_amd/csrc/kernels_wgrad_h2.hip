@@ -314,14 +314,15 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
 // The same machine with A = dU (cout channels, pixel stride ldA inside the concat gradient, 2H x 2W: 2R rows x 64 pixels staged per step) and B = x
 // (cin channels, H x W: R rows x 32 pixels); the four taps are the four parity planes of the staged dU rows -- a lane's eight consecutive K pixels sit two
 // pixel slots apart -- and the bias gradient is the sum over A.
-template <int WA, int WB, int WR, int R>
+// BW: x channel tiles per wave (the dU fragments of a k-step feed BW x 12 MFMAs: half the staging, LDS reads and barriers per MFMA at BW = 2)
+template <int WA, int WB, int WR, int R, int BW = 1>
 __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restrict__ A, int ldA, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
                                                            int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
                                                            int npairs, long long pstride, int units, int upb) {
   static_assert(WA * WB * WR == 4 && WR <= R, "4 waves");
   constexpr int TAPS = 4, AROWS = 2 * R, AW = 64;
   constexpr int ASUB = AROWS * AW * 64, BSUB = R * 32 * 64;       // bytes of one 32-channel sub-plane of one fp16 plane
-  constexpr int STAGE1 = WA * ASUB + WB * BSUB;
+  constexpr int STAGE1 = WA * ASUB + WB * BW * BSUB;
   constexpr int RED = WR > 1 ? 2 * TAPS * 16 * 64 * 4 : 0;
   constexpr int STAGE = 2 * STAGE1;
   __shared__ __attribute__((aligned(16))) char smem[STAGE > RED ? STAGE : RED];
@@ -335,24 +336,26 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
   const int pair = sq % npairs, split = (sq / npairs) * 8 + (blockIdx.x & 7);
   if (split >= nsplit) return;
   const int ta = pair / tiles_b, tb = pair % tiles_b;
-  const int a0 = ta * 32 * WA, b0 = tb * 32 * WB;
+  const int a0 = ta * 32 * WA, b0 = tb * 32 * WB * BW;
   const int chunk = split % chunks_per_strip; const int ublk = split / chunks_per_strip;
   const int ya = chunk * rows_per_chunk;
   const int yb = ya + rows_per_chunk < H ? ya + rows_per_chunk : H;
   const int HA = 2 * H, WAI = 2 * W;
 
-  f32x16 acc[TAPS];
+  f32x16 acc[BW][TAPS];
+#pragma unroll
+  for (int j = 0; j < BW; ++j)
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.0f;
   float bsum = 0.0f;
   int e_a = 120, e_b = 120;
 
   const int i16 = lane & 15, g4 = lane >> 4;
   const int tr_px = (g4 >> 1) * 8 + (i16 >> 2), tr_ch = ((g4 & 1) * 16 + (i16 & 3) * 4) * 2;
   const char* const pa = s_a + wa * ASUB + tr_ch;
-  const char* const pb = s_b + wb * BSUB + tr_ch;
+  const char* const pb = s_b + wb * BW * BSUB + tr_ch;
 
   const int u1 = (ublk + 1) * upb < units ? (ublk + 1) * upb : units;
   for (int unit = ublk * upb; unit < u1; ++unit) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + (long long)n * H * W * CB, (long long)H * W * CB * 4);
     // a thread fetches channel quad q8 of pixel column pc of a staged B row, and of pixel columns pc and 32 + pc of a staged A row
     const int q8 = tid & 7, pc = tid >> 3;
-    int abase_t[WA][2], bbase_t[WB];
+    int abase_t[WA][2], bbase_t[WB * BW];
 #pragma unroll
     for (int sub = 0; sub < WA; ++sub)
 #pragma unroll
@@ -371,11 +374,11 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
         abase_t[sub][half] = (gx < WAI && ch < CA) ? (gx * ldA + ch) * 4 : UNET_OOB;
       }
 #pragma unroll
-    for (int sub = 0; sub < WB; ++sub) {
+    for (int sub = 0; sub < WB * BW; ++sub) {
       const int gx = x0 + pc, ch = b0 + sub * 32 + q8 * 4;
       bbase_t[sub] = (gx < W && ch < CB) ? (gx * CB + ch) * 4 : UNET_OOB;
     }
-    constexpr int NA = WA * AROWS * 2, NB_ = WB * R;
+    constexpr int NA = WA * AROWS * 2, NB_ = WB * BW * R;
     unet_u32x4 areg[NA], breg[NB_];
     auto issue_loads = [&](int ys) __attribute__((always_inline)) {        // ys = first x row of the step
 #pragma unroll
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
             areg[(sub * AROWS + row) * 2 + half] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? abase_t[sub][half] : UNET_OOB, ok ? gy * WAI * ldA * 4 : 0, 0);
         }
 #pragma unroll
-      for (int sub = 0; sub < WB; ++sub)
+      for (int sub = 0; sub < WB * BW; ++sub)
 #pragma unroll
         for (int row = 0; row < R; ++row) {
           const int gy = ys + row;
@@ -426,9 +429,11 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
       if (d != 0) {
         const float f = pow2f(max(d, -126));
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int j = 0; j < BW; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+          for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] *= f;
       }
       const float sa = pow2f(e_a), sb = pow2f(e_b);
       auto put = [&](char* dst, const unet_u32x4& v, float sc) __attribute__((always_inline)) {
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
 #pragma unroll
           for (int half = 0; half < 2; ++half) put(s_a + ((sub * AROWS + row) * AW + half * 32 + pc) * 64 + q8 * 8, areg[(sub * AROWS + row) * 2 + half], sa);
 #pragma unroll
-      for (int sub = 0; sub < WB; ++sub)
+      for (int sub = 0; sub < WB * BW; ++sub)
 #pragma unroll
         for (int row = 0; row < R; ++row) put(s_b + ((sub * R + row) * 32 + pc) * 64 + q8 * 8, breg[sub * R + row], sb);
     };
@@ -462,8 +467,6 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
       for (int r = wr; r < R; r += WR) {
 #pragma unroll
         for (int kst = 0; kst < 2; ++kst) {
-          const char* bp = pb + (r * 32 + kst * 16 + tr_px) * 64;
-          const f16x8 bh = lds_tr_frag(bp, bp + 4 * 64), bm = lds_tr_frag(bp + STAGE1, bp + STAGE1 + 4 * 64);
           f16x8 ah[4], am[4];
 #pragma unroll
           for (int ab = 0; ab < 4; ++ab) {
@@ -476,11 +479,16 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
           }
           // product-major: a dependent MFMA never directly follows its producer
 #pragma unroll
-          for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ab], bm, acc[ab], 0, 0, 0);
+          for (int j = 0; j < BW; ++j) {
+            const char* bp = pb + j * BSUB + (r * 32 + kst * 16 + tr_px) * 64;
+            const f16x8 bh = lds_tr_frag(bp, bp + 4 * 64), bm = lds_tr_frag(bp + STAGE1, bp + STAGE1 + 4 * 64);
 #pragma unroll
-          for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ab], bh, acc[ab], 0, 0, 0);
+            for (int ab = 0; ab < 4; ++ab) acc[j][ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ab], bm, acc[j][ab], 0, 0, 0);
 #pragma unroll
-          for (int ab = 0; ab < 4; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ab], bh, acc[ab], 0, 0, 0);
+            for (int ab = 0; ab < 4; ++ab) acc[j][ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[ab], bh, acc[j][ab], 0, 0, 0);
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) acc[j][ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ab], bh, acc[j][ab], 0, 0, 0);
+          }
         }
       }
       if (more) post_amax();
@@ -491,12 +499,15 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
   const float un_a = pow2f(max(-e_a, -126));
   const float un = un_a * pow2f(max(-e_b, -126));
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int j = 0; j < BW; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] *= un;
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] *= un;
   bsum *= un_a;
 
   bsum += __shfl_xor(bsum, 32, 64);
+  static_assert(BW == 1 || WR == 1, "several x tiles per wave go with one row phase");
   if (WR > 1) {
     float* red = reinterpret_cast<float*>(smem);
     const int grp = wave / WR;
@@ -508,14 +519,14 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) img[(t * 16 + r) * 64 + lane] = acc[t][r];
+          for (int r = 0; r < 16; ++r) img[(t * 16 + r) * 64 + lane] = acc[0][t][r];
       }
       __syncthreads();
       if (wr < stride) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][r] += img[(t * 16 + r) * 64 + lane];
+          for (int r = 0; r < 16; ++r) acc[0][t][r] += img[(t * 16 + r) * 64 + lane];
       }
       __syncthreads();
     }
@@ -523,18 +534,22 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
   }
   if (wr != 0) return;
   float* P = part + (long long)split * pstride;
-  const int ar = a0 + wa * 32, bc = b0 + wb * 32 + l31;
+  const int ar = a0 + wa * 32;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int j = 0; j < BW; ++j) {
+    const int bc = b0 + (wb * BW + j) * 32 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = acc[t][r];
-    }
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = acc[j][t][r];
+      }
+  }
   if (wb == 0 && tb == 0 && lane < 32 && ar + l31 < CA) P[(long long)TAPS * CA * CB + ar + l31] = bsum;
 }
 
-struct WgPlanT { int WA, WB, WR, R, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs, units, upb; size_t floats; };
+struct WgPlanT { int WA, WB, WR, R, BW, tiles_a, tiles_b, strips, rows_per_chunk, chunks_per_strip, nsplit, nslabs, units, upb; size_t floats; };
 
 // ca = cout (dU channels), cb = cin (x channels); h, w = the ConvT's INPUT size
 WgPlanT plan_wgradT_h2(int n, int h, int w, int ca, int cb) {
@@ -542,7 +557,9 @@ WgPlanT plan_wgradT_h2(int n, int h, int w, int ca, int cb) {
   p.WA = (ca % 64) == 0 ? 2 : 1; p.WB = 2;                      // (cb is a multiple of 64: h2_convT_wgrad_selected)
   p.WR = 4 / (p.WA * p.WB);
   p.R = p.WA == 2 ? 1 : 2;                                       // 64 dU channels: one x row per step keeps the two fp16 planes at 40 KB (two rows: 80 KB, one workgroup per CU)
-  p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB - 1) / (32 * p.WB); p.strips = (w + 31) / 32;
+  // two x channel tiles per wave (64 x 128 workgroup tile, 48 KB) where the tile pairs still fill the chip: u6 / u7 / u8 of the U-Net (cin 512 / 256 / 128)
+  p.BW = (p.WA == 2 && (cb % 128) == 0 && (long long)(ca / 64) * (cb / 128) * n * ((w + 31) / 32) * std::max(1, h / 4) >= 512) ? 2 : 1;
+  p.tiles_a = (ca + 32 * p.WA - 1) / (32 * p.WA); p.tiles_b = (cb + 32 * p.WB * p.BW - 1) / (32 * p.WB * p.BW); p.strips = (w + 31) / 32;
   const long long pairs = (long long)p.tiles_a * p.tiles_b, per = 4LL * ca * cb;
   const long long units = (long long)n * p.strips;
   long long want = std::max<long long>(1, 512 / pairs);
@@ -670,7 +687,9 @@ int32_t k_convT_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, int ldd
   const long long S = 4LL * cout * cin + cout;
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
-  if (p.WA == 2) hipLaunchKernelGGL((wgradT_h2_kernel<2, 2, 1, 1>), grid, dim3(256), 0, s, dy, lddy, x, part, n, h, wd, cout, cin, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip,
+  if (p.WA == 2 && p.BW == 2) hipLaunchKernelGGL((wgradT_h2_kernel<2, 2, 1, 1, 2>), grid, dim3(256), 0, s, dy, lddy, x, part, n, h, wd, cout, cin, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip,
+                                    p.nsplit, npairs, S, p.units, p.upb);
+  else if (p.WA == 2) hipLaunchKernelGGL((wgradT_h2_kernel<2, 2, 1, 1>), grid, dim3(256), 0, s, dy, lddy, x, part, n, h, wd, cout, cin, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip,
                                     p.nsplit, npairs, S, p.units, p.upb);
   else hipLaunchKernelGGL((wgradT_h2_kernel<1, 2, 2, 2>), grid, dim3(256), 0, s, dy, lddy, x, part, n, h, wd, cout, cin, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit,
                           npairs, S, p.units, p.upb);

@@ -171,7 +171,7 @@ def test_h2_block_scaling_keeps_fp32_accuracy_over_any_range(ops, case):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 5, 8, 4), (1, 4, 4, 512, 256), (2, 8, 8, 64, 32), (1, 7, 9, 128, 64), (2, 5, 37, 64, 64), (1, 33, 34, 32, 32), (2, 40, 48, 64, 32),
-                                   (3, 17, 33, 128, 64), (2, 21, 70, 192, 96)])
+                                   (3, 17, 33, 128, 64), (2, 21, 70, 192, 96), (10, 30, 64, 256, 128), (16, 48, 96, 128, 64)])          # (the last two: two x tiles per wave in the weight gradient, BW = 2)
 def test_convT(ops, shape):
     from gpu_util import relerr
     n, h, w, ci, co = shape
