@@ -320,8 +320,11 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
                                                            int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
                                                            int npairs, long long pstride, int units, int upb) {
   static_assert(WA * WB * WR == 4 && WR <= R, "4 waves");
-  constexpr int TAPS = 4, AROWS = 2 * R, AW = 64;
-  constexpr int ASUB = AROWS * AW * 64, BSUB = R * 32 * 64;       // bytes of one 32-channel sub-plane of one fp16 plane
+  constexpr int TAPS = 4, AROWS = 2 * R;
+  // a staged dU row: its 64 pixels de-interleaved by column parity (a tap reads ONE parity plane: consecutive 64-B slots, conflict-free transpose reads -- interleaved,
+  // the 128-B stride put two of a read group's four pixels on the same banks: 21-23 % of the LDS cycles in round 4's counters), 64 B of padding between the planes
+  constexpr int PPL = 32 * 64 + 64, ROWB = 2 * PPL;
+  constexpr int ASUB = AROWS * ROWB, BSUB = R * 32 * 64;       // bytes of one 32-channel sub-plane of one fp16 plane
   constexpr int STAGE1 = WA * ASUB + WB * BW * BSUB;
   constexpr int RED = WR > 1 ? 2 * TAPS * 16 * 64 * 4 : 0;
   constexpr int STAGE = 2 * STAGE1;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
 #pragma unroll
         for (int row = 0; row < AROWS; ++row)
 #pragma unroll
-          for (int half = 0; half < 2; ++half) put(s_a + ((sub * AROWS + row) * AW + half * 32 + pc) * 64 + q8 * 8, areg[(sub * AROWS + row) * 2 + half], sa);
+          for (int half = 0; half < 2; ++half) put(s_a + (sub * AROWS + row) * ROWB + (pc & 1) * PPL + (half * 16 + (pc >> 1)) * 64 + q8 * 8, areg[(sub * AROWS + row) * 2 + half], sa);
 #pragma unroll
       for (int sub = 0; sub < WB * BW; ++sub)
 #pragma unroll
@@ -470,8 +473,8 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
           f16x8 ah[4], am[4];
 #pragma unroll
           for (int ab = 0; ab < 4; ++ab) {
-            const char* ap = pa + ((2 * r + (ab >> 1)) * AW + 2 * (kst * 16 + tr_px) + (ab & 1)) * 64;
-            ah[ab] = lds_tr_frag(ap, ap + 8 * 64); am[ab] = lds_tr_frag(ap + STAGE1, ap + STAGE1 + 8 * 64);
+            const char* ap = pa + (2 * r + (ab >> 1)) * ROWB + (ab & 1) * PPL + (kst * 16 + tr_px) * 64;
+            ah[ab] = lds_tr_frag(ap, ap + 4 * 64); am[ab] = lds_tr_frag(ap + STAGE1, ap + STAGE1 + 4 * 64);
             if (wb == 0 && tb == 0) {                                // (wave-uniform) the bias gradient rides on dU: the first x channel tile's workgroups only
 #pragma unroll
               for (int j = 0; j < 8; ++j) bsum += (float)ah[ab][j] + (float)am[ab][j];
