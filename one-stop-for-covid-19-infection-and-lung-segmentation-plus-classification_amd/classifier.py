@@ -34,10 +34,17 @@ def _approximate_mode(class_counts, n_draws, rng):
     return floored.astype(int)
 
 
-def stratified_shuffle_split(y, test_size: float = 0.3, random_state: int = 42):
+def stratified_shuffle_split(y, test_size: float = 0.3, random_state: int = 42, use_sklearn: bool = True):
     """One split of sklearn.model_selection.StratifiedShuffleSplit(n_splits=1, test_size=.3, random_state=42).split(X, y) (T2:647-650):
-    returns (train_index, test_index)."""
+    returns (train_index, test_index).  scikit-learn itself where it is installed (the reference's own call); the restatement below is what runs where it is
+    not (tests/test_classifier_host.py holds the two together)."""
     y = np.asarray(y)
+    if use_sklearn:
+        try:
+            from sklearn.model_selection import StratifiedShuffleSplit
+            return next(StratifiedShuffleSplit(n_splits=1, test_size=test_size, random_state=random_state).split(np.zeros(len(y)), y))
+        except ImportError:
+            pass
     n = len(y)
     n_test = int(math.ceil(test_size * n)); n_train = n - n_test
     classes, y_idx = np.unique(y, return_inverse=True)
@@ -57,9 +64,15 @@ def stratified_shuffle_split(y, test_size: float = 0.3, random_state: int = 42):
     return rng.permutation(train), rng.permutation(test)
 
 
-def compute_class_weight_balanced(y):
-    """sklearn.utils.class_weight.compute_class_weight('balanced', np.unique(y), y) (T2:801-803): n / (n_classes * bincount)."""
+def compute_class_weight_balanced(y, use_sklearn: bool = True):
+    """sklearn.utils.class_weight.compute_class_weight('balanced', np.unique(y), y) (T2:801-803): n / (n_classes * bincount); scikit-learn's own where installed."""
     y = np.asarray(y)
+    if use_sklearn:
+        try:
+            from sklearn.utils.class_weight import compute_class_weight
+            return compute_class_weight(class_weight="balanced", classes=np.unique(y), y=y)
+        except ImportError:
+            pass
     classes, y_idx = np.unique(y, return_inverse=True)
     return len(y) / (len(classes) * np.bincount(y_idx).astype(np.float64))
 

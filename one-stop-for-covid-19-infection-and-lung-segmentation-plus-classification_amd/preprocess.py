@@ -58,8 +58,11 @@ def min_max_to_u8(img):
 def clahe_u8(img_u8, clip_limit=3.0, tile_grid_size=(8, 8)):
     """cv2.createCLAHE(clipLimit, tileGridSize).apply(img) for uint8 slice(s)."""
     torch = _torch(); lib, ctx = _ctx()
-    a, single = _as_batch(img_u8)
-    x = torch.from_numpy(np.ascontiguousarray(a, np.uint8)).cuda()
+    if isinstance(img_u8, torch.Tensor):                          # already on the device (clahe_enhancer): [n, h, w] uint8
+        x, single = img_u8, False
+    else:
+        a, single = _as_batch(img_u8)
+        x = torch.from_numpy(np.ascontiguousarray(a, np.uint8)).cuda()
     n, h, w = x.shape
     tx, ty = int(tile_grid_size[0]), int(tile_grid_size[1])
     out = torch.empty_like(x)
@@ -77,7 +80,7 @@ def clahe_enhancer(test_img, demo=0):
     x = torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
     u8 = torch.empty(x.shape, dtype=torch.uint8, device="cuda")
     ctx.check(lib.unet_pre_unit_to_u8(ctx.handle, x.data_ptr(), u8.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream), "pre_unit_to_u8")
-    r = clahe_u8(u8.cpu().numpy(), 3.0, (8, 8))
+    r = clahe_u8(u8, 3.0, (8, 8))                                 # (the uint8 image stays on the device between the two kernels)
     return r[0] if single else r
 
 

@@ -21,17 +21,18 @@ def test_split_class_weight_auc_match_sklearn():
     rng = np.random.default_rng(0)
     for n in (10, 33, 57, 64, 200, 1001, 3520):
         y = (rng.random(n) < rng.uniform(0.2, 0.8)).astype(int); y[:4] = (0, 1, 0, 1)
-        tr, te = C.stratified_shuffle_split(y, 0.3, 42)                                  # T2:647
+        tr, te = C.stratified_shuffle_split(y, 0.3, 42, use_sklearn=False)               # T2:647 -- the RESTATEMENT (what a box without scikit-learn runs) against the library
         a, b = next(StratifiedShuffleSplit(n_splits=1, test_size=0.3, random_state=42).split(np.zeros(n), y))
         assert np.array_equal(tr, a) and np.array_equal(te, b), n
-        assert np.allclose(C.compute_class_weight_balanced(y),
+        assert np.allclose(C.compute_class_weight_balanced(y, use_sklearn=False),
                            class_weight.compute_class_weight(class_weight="balanced", classes=np.unique(y), y=y), rtol=0, atol=1e-15)
         for s in (rng.random(n), np.round(rng.random(n), 1), np.zeros(n)):              # continuous, heavily tied, all tied
             assert abs(C.roc_auc_score(y, s) - roc_auc_score(y, s)) < 1e-12
     with pytest.raises(ValueError):
         C.roc_auc_score(np.ones(5), np.arange(5))
-    with pytest.raises(ValueError):
-        C.stratified_shuffle_split(np.array([0, 0, 0, 1]), 0.3, 42)
+    for use in (False, True):
+        with pytest.raises(ValueError):
+            C.stratified_shuffle_split(np.array([0, 0, 0, 1]), 0.3, 42, use_sklearn=use)
 
 
 def test_confusion_report_and_f1_closure():
