@@ -247,7 +247,8 @@ def main():
         # (conv3x3_dgrad_bn_bwd: the data gradient of a decoder block's first conv with the folded BatchNorm's backward in its epilogue -- the same
         #  kernel, same FLOPs; the op's time includes its 5 us coefficient launch)
         # (conv3x3_fwd_head: the last conv3x3 with the 1x1 sigmoid head and the loss sums in its epilogue -- the same kernel body and conv FLOPs)
-        dom = [o for o in ops if o[0].startswith("conv3x3_fwd:") or o[0].startswith("conv3x3_fwd_head:") or o[0].startswith("conv3x3_dgrad:") or o[0].startswith("conv3x3_dgrad_bn_bwd:")]
+        # (conv3x3_dgrad_pool_sums: a data gradient with the encoder tail's pooled sums in its epilogue -- likewise)
+        dom = [o for o in ops if o[0].startswith(("conv3x3_fwd:", "conv3x3_fwd_head:", "conv3x3_dgrad:", "conv3x3_dgrad_bn_bwd:", "conv3x3_dgrad_pool_sums:"))]
         dom = [o for o in dom if not o[0].endswith(":c1a")]                  # c1a (Cin=1) runs the direct HBM-bound kernel
         fl = sum(o[1] for o in dom); ms = sum(o[3] / max(o[4], 1) for o in dom); launches = len(dom)
         shapes = W.weight_shapes(1, args.arch, (S, S))
