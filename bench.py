@@ -11,6 +11,7 @@ Prints ONE JSON line (rank 0).  Besides the driver contract it carries
                  hipEvent durations vs that pipe's dense peak; algorithmic bytes / FLOPs beside it
   fp32_strict_img_s : the same step with every product on v_mfma_f32_32x32x2_f32 (--algo 2: exact fp32 multiply-add, the
                  out-of-domain fallback family) -- what the fp16 split buys, and what the IEEE-fp32 path costs
+  fit_img_s / fit_epoch_img_s : the REAL model.fit path (T1:1059-1061): UNetModel.fit on a host-resident float64 set, whole call incl. the one-time upload / a steady epoch
   predict_batch1_ms : median latency of model.predict at batch 1 (T1:1137), synchronised per call
   cpu_baseline : the CPU oracle (torch-CPU restatement, kind "port") timed on the host cores on a
                  bounded sample of the same workload (rank 0, N=1 only)
