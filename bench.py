@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-fit-leg", action="store_true", help="skip the untimed fit_img_s measurement (UNetModel.fit on a host-resident set)")
     ap.add_argument("--fit-steps", type=int, default=20, help="steps per epoch of the fit leg")
     ap.add_argument("--no-sync-bn", action="store_true")
+    ap.add_argument("--small-allreduce", default="device", choices=["device", "rccl"], help="N > 1: BatchNorm / loss sums through the device-side all-reduce (csrc/comm.hip) or through RCCL")
     ap.add_argument("--arch", default="unet", choices=["unet", "unetpp", "classifier"], help="unetpp = the U-Net++ graph (BASELINE "
                     "configs[3], at fp32; --size 256 --batch 32); classifier = the task-2 CNN (configs[4] at the reference's 1-channel fp32; "
                     "--size 224 --batch 256).  Neither is the headline metric")
@@ -144,7 +145,7 @@ def main():
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
-                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) | (json.loads(args.options) if args.options else {}) or None)
+                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), small_allreduce=args.small_allreduce, options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) | (json.loads(args.options) if args.options else {}) or None)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     def settle(seconds):
@@ -243,6 +244,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     loss_dice = last.cpu().numpy().tolist()
+    if eng.comm_status() != 0:                 # a device-side all-reduce that timed out: the step's numbers are not a step's
+        raise RuntimeError(f"rank {rank}: device-side all-reduce missed rank {eng.comm_status() - 1}")
 
     if rank == 0:
         # (conv3x3_dgrad_bn_bwd: the data gradient of a decoder block's first conv with the folded BatchNorm's backward in its epilogue -- the same
@@ -356,7 +359,7 @@ def main():
                                    + f"{', RCCL grad all-reduce + sync-BN/global-Dice' if world > 1 else ''}; BASELINE.json "
                                    + {"unet": "configs[2]" if args.config == 2 else "configs[1]", "unetpp": "configs[3] graph at the reference's fp32",
                                       "classifier": "configs[4] graph at the reference's 1-channel fp32"}[args.arch],
-                       "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: every conv3x3 / ConvT forward, data gradient and weight gradient as three v_mfma_f32_32x32x16_f16 products of a block-scaled two-term fp16 split (h2; fp32-class accuracy, DESIGN.md 4g); Cin=1 first layer and 1x1 head on fp32 VALU", 1: "direct fp32 VALU kernels", 2: "strict fp32: v_mfma_f32_32x32x2_f32 direct kernels"}[args.algo],
+                       "storage": args.dtype, "global_batch": B * world, "parallelism": f"dp{world}", "small_allreduce": (("device (comm.hip: IPC-mapped areas, one kernel per reduction)" if eng._comm is not None else "torch.distributed") if eng._dp else None), "conv_algo": "mfma_f32_32x32x16_bf16 direct" if args.dtype == "bf16" else {0: "auto: every conv3x3 / ConvT forward, data gradient and weight gradient as three v_mfma_f32_32x32x16_f16 products of a block-scaled two-term fp16 split (h2; fp32-class accuracy, DESIGN.md 4g); Cin=1 first layer and 1x1 head on fp32 VALU", 1: "direct fp32 VALU kernels", 2: "strict fp32: v_mfma_f32_32x32x2_f32 direct kernels"}[args.algo],
                        "deterministic": bool(args.deterministic), "bn_fold": 3 if args.fold16 else 2, "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 11
+#define UNET_ABI_VERSION 12
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -450,6 +450,29 @@ typedef struct unet_sync_point {
                          programs place an independent weight gradient there).  Kind 3: the number of ops of the program (the optimizer is the reader). */
   int32_t reserved;
 } unet_sync_point;
+
+/* The SUM all-reduce of a sync point of kinds 0-2, device side (data parallelism is new: the reference is single-process, T1:1053-1061 runs one
+ * model.fit).  Every rank of ONE node owns a receive area in fine-grained HBM that its peers map through HIP IPC; one kernel on `stream` pushes the rank's
+ * doubles into every peer's area (xGMI is point to point: the W - 1 copies travel on W - 1 links at once), polls its own area until all W contributions of
+ * this call have landed and adds them in rank order -- every rank ends with the same bits.  No host proxy, no ring: one fabric latency per reduction.
+ *   unet_comm_create   allocates the area and returns its 64-byte IPC handle in handle_out; the host exchanges the handles of all ranks by any means it has
+ *                      (torch.distributed.all_gather_object in engine.py) and passes them, in rank order, to
+ *   unet_comm_connect  (handles = world x UNET_COMM_HANDLE_BYTES bytes; the own entry is ignored).
+ *   unet_comm_allreduce_f64  buf[0..count) <- sum over ranks, in place (one launch per UNET_COMM_MAX_DOUBLES).  Every rank must issue the same calls in the same order.
+ *                      A contribution that does not arrive within the timeout (default 60 s) ends the kernel and latches the communicator's error word:
+ *   unet_comm_status   *err_out = 0, or 1 + the rank that was missing (sticky; the reduced values of that call are not valid).  Synchronises `stream`.
+ * Gradient buckets (kind 3) are bandwidth-bound and stay with RCCL.  A rank may destroy its communicator once its own last all-reduce has completed (by then every
+ * peer has written all it will ever write into this rank's area). */
+#define UNET_COMM_HANDLE_BYTES 64
+#define UNET_COMM_MAX_WORLD 8
+#define UNET_COMM_MAX_DOUBLES 2048
+typedef struct unet_comm unet_comm;
+int32_t unet_comm_create(unet_ctx*, int32_t rank, int32_t world, unet_comm** out, unsigned char* handle_out);
+int32_t unet_comm_connect(unet_comm*, const unsigned char* handles);
+int32_t unet_comm_set_timeout_ms(unet_comm*, int32_t ms);
+int32_t unet_comm_allreduce_f64(unet_comm*, double* buf, int32_t count, void* stream);
+int32_t unet_comm_status(unet_comm*, int32_t* err_out, void* stream);
+void unet_comm_destroy(unet_comm*);
 
 /* arch: UNET_ARCH_UNET (T1:853-916), UNET_ARCH_UNETPP (task1_unet_plus_plus.py:858-950) or UNET_ARCH_CLASSIFIER (the Sequential
  * CNN of task2_covid19_classifcation.py:747-776: y_true / p_out are [n] floats, loss_ptr = (binary cross-entropy, f1)) */

@@ -10,7 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
+COMM_HANDLE_BYTES, COMM_MAX_WORLD, COMM_MAX_DOUBLES = 64, 8, 2048          # include/unet_hip.h: UNET_COMM_*
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2          # fp16-split h2 kernels where the shape allows / VALU kernels / strict fp32 MFMA kernels
 # unet_ctx_set_option (include/unet_hip.h UNET_OPT_*)
@@ -114,6 +115,12 @@ _PROTOS = {
     "unet_conv3x3_bwd_data_pool_sums": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "unet_head_dy": (i32, [vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "unet_zero": (i32, [vp, vp, sz, vp]),
+    "unet_comm_create": (i32, [vp, i32, i32, vp, vp]),
+    "unet_comm_connect": (i32, [vp, vp]),
+    "unet_comm_set_timeout_ms": (i32, [vp, i32]),
+    "unet_comm_allreduce_f64": (i32, [vp, vp, i32, vp]),
+    "unet_comm_status": (i32, [vp, vp, vp]),
+    "unet_comm_destroy": (None, [vp]),
     "unet_copy_slice": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
     "unet_copy_slice_bf16": (i32, [vp, vp, i32, vp, i32, i64, i32, vp]),
     "unet_accum_slices": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, i64, i32, i32, vp]),
@@ -220,6 +227,10 @@ class Context:
                 del type(self)._cache[k]
             self.lib.unet_ctx_destroy(self.handle)
             self.handle = None
+
+    def last_error(self) -> str:
+        msg = self.lib.unet_last_error(self.handle)
+        return msg.decode() if msg else "?"
 
     def check(self, rc: int, what: str = ""):
         if rc != 0:

@@ -208,7 +208,8 @@ size_t wgrad_bn_fold_scratch_floats(int n, int cout);
 bool wgrad_bn_fold_supported(int cout);
 int32_t k_wgrad_bn_fold_fix(unet_ctx*, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db, float* scratch,
                             hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr,
-                            const float* pre_s = nullptr, const float* pre_t = nullptr);          // (pre: the BatchNorm saw pre_s x + pre_t of the tensor the weight gradient ran on)
+                            const float* pre_s = nullptr, const float* pre_t = nullptr,           // (pre: the BatchNorm saw pre_s x + pre_t of the tensor the weight gradient ran on)
+                            float* dgamma = nullptr, float* dbeta = nullptr);                     // (with bn_bwd_sums: also the BatchNorm's parameter gradients = the local sums)
 int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx*, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
                                  float* scratch, hipStream_t s, const float* w = nullptr, const float* mean = nullptr, const float* istd = nullptr, double* bn_bwd_sums = nullptr);
 constexpr int UNET_PREP_MAX = 36;          // layers per batched weight-preparation launch (the list travels as a kernel argument: < 4 KiB)
@@ -220,6 +221,8 @@ size_t h2_wimg_bytes(int K, int M);
 int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s, const float* cs = nullptr);
 int32_t k_h2_weights_multi(unet_ctx*, const float* const* w, void* const* img, const int* cin, const int* cout, const int* flip, int count, hipStream_t s);
 // any mix of layers in TWO launches; kind 0 / 1 = conv3x3 forward / data-gradient image, 2 / 3 = ConvT forward / data-gradient image (h2_convT_img_bytes each)
+// (kind 4 = a kind-0 layer of which only the raw-weight maxima are taken: its image is built later by k_h2_weights_bound, once the per-channel factor exists)
+int32_t k_h2_weights_bound(unet_ctx*, const float* w, const float* cs, void* img, int cin, int cout, hipStream_t s);
 int32_t k_h2_prep_multi(unet_ctx*, const float* const* w, const float* const* cs, void* const* img, const int* cin, const int* cout, const int* kind, int count, hipStream_t s);
 size_t h2_convT_img_bytes(int cin, int cout);
 // mask_climit (folded-BatchNorm data gradients, MASK_BN_BWD*): output channels >= mask_climit do not read x -- they get K0 dz + K2, the K1 x term is added by their consumer
@@ -231,9 +234,15 @@ int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const floa
 // the data gradient of the conv behind an encoder tail with the tail's BatchNorm-backward sums in its epilogue (MASK_POOL_SUMS): dy [n,h,wd,K] -> dx [n,h,wd,M], pooled = the
 // forward's max-pool + dropout output [n,h,wd,M]; sums[2 M] += (folded out of the slot copies behind the launch)
 int32_t k_slot_fold(unet_ctx*, double* sums, int count, hipStream_t s);          // sums[i] += the slot copies' entries i (cleared), in index order (kernels_pointwise.hip)
+// the pooled sums a MASK_POOL_SUMS launch left in the slot copies -> sums[2 c] (+=), + the closed-form skip term (unet_bn_bwd_skip_term) + the BatchNorm's parameter gradients: one launch
+int32_t k_enc_tail_finish(unet_ctx*, double* sums, const double* dec_sum_dyxhat, const float* dec_invstd, const float* dec_gamma, const float* gamma, float* dgamma, float* dbeta, int c,
+                          double frac, hipStream_t s);
 bool h2_pool_sums_selected(const unet_ctx* ctx, int algo, int wd, int K, int M);
 int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx*, const float* dy, const void* wimg, const float* pooled, const float* gamma, const float* beta, float rate, float* dx, double* sums,
                                      int n, int h, int wd, int K, int M, hipStream_t s);
+// unet_bn_finalize_train / _infer of a decoder BatchNorm (c = 2 C_enc channels) AND k_bn_compose in one launch
+int32_t k_bn_finalize_compose(unet_ctx*, int training, const double* sums, double count, const float* gamma, const float* beta, float* mm, float* mv, float* bnp, int c,
+                              const float* enc_bnp, float* comp, hipStream_t s);
 int32_t k_bn_compose(unet_ctx*, const float* bnp_dec, const float* bnp_enc, float* comp, int c, hipStream_t s);
 struct h2_head_args { const float* w = nullptr; const float* b = nullptr; float* p = nullptr; const float* t = nullptr; double* slots = nullptr; float aux = 0.0f; };          // (MASK_POOL_SUMS: w = gamma, b = beta, aux = dropout rate)
 bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int M);

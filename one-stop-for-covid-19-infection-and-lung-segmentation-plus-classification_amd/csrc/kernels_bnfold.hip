@@ -165,17 +165,22 @@ __global__ __launch_bounds__(1024) void fold_tap_sums_kernel(const float* __rest
 //   sum_p dz_c(p) x_c(p) = sum_{tap,o} W[tap][c][o] * dW_raw[tap][c][o]        (dW_raw = the weight gradient on the raw x, before the correction)
 // and sum dz * xhat = istd * (sum dz x - mean * sum dz).  grid cin, 256 threads over the 9 * cout (tap, o) pairs; added into sums[2 * cin] (doubles).
 // pre_s / pre_t (or null): the BatchNorm's input was x = pre_s x_raw + pre_t of the tensor the weight gradient ran on, so sum dz x = pre_s sum dz x_raw + pre_t sum dz
-__global__ __launch_bounds__(256) void fold_bn_bwd_sums_kernel(const float* __restrict__ w, const float* __restrict__ dw_raw, const float* __restrict__ S,
+__global__ __launch_bounds__(256) void fold_bn_bwd_sums_kernel(const float* __restrict__ w, const float* dw_raw /* may be dw_fix */, const float* __restrict__ S,
                                                                const float* __restrict__ mean, const float* __restrict__ istd, double* __restrict__ sums, int cin, int cout,
-                                                               const float* __restrict__ pre_s, const float* __restrict__ pre_t) {
+                                                               const float* __restrict__ pre_s, const float* __restrict__ pre_t,
+                                                               // round 4: the same sweep over channel c's (tap, o) pairs also applies the weight-gradient correction (fold_fix_kernel's
+                                                               // expression) and leaves the BatchNorm's parameter gradients -- two launches less per decoder level
+                                                               float* dw_fix, const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
   __shared__ double s_a[256], s_b[256];
   const int c = blockIdx.x;
   float a = 0.f, b = 0.f;
   for (int i = threadIdx.x; i < 9 * cout; i += 256) {
     const int tap = i / cout, o = i - tap * cout;
     const long long j = ((long long)tap * cin + c) * cout + o;
-    const float wv = w[j];
-    a = fmaf(wv, dw_raw[j], a); b = fmaf(wv, S[i], b);
+    const float wv = w[j], dr = dw_raw[j], sv = S[i];
+    a = fmaf(wv, dr, a); b = fmaf(wv, sv, b);
+    if (dw_fix) dw_fix[j] = fmaf(scale[c], dr, shift[c] * sv);
   }
   s_a[threadIdx.x] = (double)a; s_b[threadIdx.x] = (double)b;
   __syncthreads();
@@ -185,7 +190,9 @@ __global__ __launch_bounds__(256) void fold_bn_bwd_sums_kernel(const float* __re
   }
   if (threadIdx.x == 0) {
     const double dzx = pre_s ? (double)pre_s[c] * s_a[0] + (double)pre_t[c] * s_b[0] : s_a[0];
-    sums[c] += s_b[0]; sums[cin + c] += (double)istd[c] * (dzx - (double)mean[c] * s_b[0]);
+    const double t1 = sums[c] + s_b[0], t2 = sums[cin + c] + (double)istd[c] * (dzx - (double)mean[c] * s_b[0]);
+    sums[c] = t1; sums[cin + c] = t2;
+    if (dgamma) { dbeta[c] = (float)t1; dgamma[c] = (float)t2; }          // (bn_bwd_param_grads_kernel: the LOCAL sums -- gradients are summed over ranks with their bucket)
   }
 }
 __global__ void fold_fix_kernel(float* __restrict__ dw, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ S, int cin, int cout4,
@@ -207,14 +214,16 @@ size_t wgrad_bn_fold_scratch_floats(int n, int cout) { return (size_t)(n > 0 ? n
 template <typename T>
 static int32_t wgrad_bn_fold_fix_impl(unet_ctx* ctx, const T* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
                                       float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums, const float* pre_s = nullptr,
-                                      const float* pre_t = nullptr) {
+                                      const float* pre_t = nullptr, float* dgamma = nullptr, float* dbeta = nullptr) {
   if (!dy || !scale || !shift || !dw || !db || !scratch || !wgrad_bn_fold_supported(cout)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: bad args (cout=%d)", cout);
   float* border = scratch; float* S = scratch + (size_t)n * BORDER_SEG * 8 * cout;
   hipLaunchKernelGGL(border_sums_kernel<T>, dim3(8 * BORDER_SEG, (unsigned)n), dim3(256), 0, s, dy, border, h, wd, cout);
   hipLaunchKernelGGL(fold_tap_sums_kernel, dim3(9, (unsigned)((cout + 63) / 64)), dim3(1024), 0, s, border, db, S, n * BORDER_SEG, cout);
   if (bn_bwd_sums) {
     if (!w || !mean || !istd) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: the BatchNorm backward sums need w, mean, istd");
-    hipLaunchKernelGGL(fold_bn_bwd_sums_kernel, dim3((unsigned)cin), dim3(256), 0, s, w, dw, S, mean, istd, bn_bwd_sums, cin, cout, pre_s, pre_t);
+    hipLaunchKernelGGL(fold_bn_bwd_sums_kernel, dim3((unsigned)cin), dim3(256), 0, s, w, dw, S, mean, istd, bn_bwd_sums, cin, cout, pre_s, pre_t, dw, scale, shift, dgamma, dbeta);
+    UNET_CHECK_LAUNCH(ctx, "wgrad_bn_fold_fix");
+    return UNET_OK;                                          // (the correction rode along)
   }
   const long long total4 = 9LL * cin * cout / 4;
   hipLaunchKernelGGL(fold_fix_kernel, dim3((unsigned)std::min<long long>((total4 + 255) / 256, 2048)), dim3(256), 0, s, dw, scale, shift, S, cin, cout / 4, total4);
@@ -222,9 +231,10 @@ static int32_t wgrad_bn_fold_fix_impl(unet_ctx* ctx, const T* dy, int n, int h, 
   return UNET_OK;
 }
 int32_t k_wgrad_bn_fold_fix(unet_ctx* ctx, const float* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
-                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums, const float* pre_s, const float* pre_t) {
-  if ((pre_s == nullptr) != (pre_t == nullptr)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: pre_s and pre_t go together");
-  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums, pre_s, pre_t);
+                            float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums, const float* pre_s, const float* pre_t,
+                            float* dgamma, float* dbeta) {
+  if ((pre_s == nullptr) != (pre_t == nullptr) || (dgamma == nullptr) != (dbeta == nullptr) || (dgamma && !bn_bwd_sums)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad_bn_fold_fix: pre_s / pre_t and dgamma / dbeta go in pairs");
+  return wgrad_bn_fold_fix_impl(ctx, dy, n, h, wd, cin, cout, scale, shift, dw, db, scratch, s, w, mean, istd, bn_bwd_sums, pre_s, pre_t, dgamma, dbeta);
 }
 int32_t k_wgrad_bn_fold_fix_bf16(unet_ctx* ctx, const unet_bf16* dy, int n, int h, int wd, int cin, int cout, const float* scale, const float* shift, float* dw, const float* db,
                                  float* scratch, hipStream_t s, const float* w, const float* mean, const float* istd, double* bn_bwd_sums) {

@@ -66,7 +66,7 @@ __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned
 // Every block of the image kernel folds the partial maxima itself (same values, same order -> same exponent): no atomics, no zeroing, no third launch.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int H2_MAXB = 48;                                  // workgroups per layer of the max pass
-struct h2_prep { const float* w; const float* cs; unet_bf16* img; long long tap_stride, sk, sm, total, nw4; int T, KS, nb, nchunks, flip, m, cs_div, cs_mod; };
+struct h2_prep { const float* w; const float* cs; unet_bf16* img; long long tap_stride, sk, sm, total, nw4; int T, KS, nb, nchunks, flip, m, cs_div, cs_mod, max_only, cs_bound; };
 struct h2_prep_list { h2_prep item[UNET_PREP_MAX]; int n; };          // passed by value as a kernel argument (3.4 KiB)
 
 __global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {          // grid (H2_MAXB, layers)
@@ -88,11 +88,21 @@ __global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {         
 
 __global__ __launch_bounds__(256) void h2_wimg_kernel(h2_prep_list L, int maxb) {          // blockIdx.y = layer
   const h2_prep& p = L.item[blockIdx.y];
+  if (p.max_only) return;                                    // (kind 4: only the partial maxima of the raw weights were wanted -- the image follows once the folded BatchNorm's scale exists)
   const int NB = p.nb, nchunks = p.nchunks, M = p.m, T = p.T, KS = p.KS;
   float* const hdr = reinterpret_cast<float*>(p.img);
   float mx = (int)(threadIdx.x & 63) < maxb ? hdr[8 + (threadIdx.x & 63)] : 0.f;          // (every wave folds the partial maxima: no barrier)
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (p.cs_bound) {
+    // the partial maxima are those of the RAW weights (taken with the program's batch): max |w cs| <= max |w| max |cs| -- an exponent from the bound costs at most the
+    // ratio in dynamic range below the 2^-14 the split keeps, and saves this layer its own pass over the weights
+    float mc = 0.f;
+    for (int i = threadIdx.x & 63; i < p.cs_mod; i += 64) mc = fmaxf(mc, fabsf(p.cs[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mc = fmaxf(mc, __shfl_xor(mc, o));
+    mx *= mc;
+  }
   const int eb = (int)((__float_as_uint(mx) >> 23) & 0xFF);
   int e = eb >= 11 ? scale_exp_for(eb) : 0;
   e = min(max(e, -100), 100);
@@ -783,7 +793,8 @@ static int h2_nb_convT_dgrad(int cin) { return (cin % 128) == 0 ? 4 : (cin % 64)
 // 2: ConvT forward (K = cin, M = 4 cout; Keras kernel [2][2][cout][cin]), 3: ConvT data gradient (K = 4 cout, M = cin).  cs: per-INPUT-channel factor of a
 // kind-0 image (folded BatchNorm scale) or null
 static void h2_fill_prep(h2_prep* p, const float* w, const float* cs, void* img, int cin, int cout, int kind) {
-  p->w = w; p->cs = cs; p->img = static_cast<unet_bf16*>(img); p->flip = 0; p->cs_div = 4; p->cs_mod = 1;
+  p->w = w; p->cs = cs; p->img = static_cast<unet_bf16*>(img); p->flip = 0; p->cs_div = 4; p->cs_mod = 1; p->max_only = kind == 4; p->cs_bound = 0;
+  if (kind == 4) kind = 0;
   int K, M;
   if (kind <= 1) {
     const int flip = kind;
@@ -814,12 +825,24 @@ int32_t k_h2_prep_multi(unet_ctx* ctx, const float* const* w, const float* const
   long long most = 1;
   for (int k = 0; k < count; ++k) {
     if (cs && cs[k] && (kind[k] != 0 || (cout[k] & 3))) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: a channel factor goes with a conv3x3 forward image");
+    if (kind[k] < 0 || kind[k] > 4) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: kind %d", kind[k]);
     h2_fill_prep(&L.item[k], w[k], cs ? cs[k] : nullptr, img[k], cin[k], cout[k], kind[k]);
     most = std::max(most, L.item[k].total);
   }
   hipLaunchKernelGGL(h2_wmax_kernel, dim3(H2_MAXB, (unsigned)count), dim3(256), 0, s, L);
   hipLaunchKernelGGL(h2_wimg_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 256), (unsigned)count), dim3(256), 0, s, L, (int)H2_MAXB);
   UNET_CHECK_LAUNCH(ctx, "h2_prep_multi");
+  return UNET_OK;
+}
+
+// the image of a conv3x3 forward layer with a per-input-channel factor (a folded BatchNorm's scale) whose raw-weight maxima a kind-4 item of an earlier batch left in its header: ONE launch
+int32_t k_h2_weights_bound(unet_ctx* ctx, const float* w, const float* cs, void* img, int cin, int cout, hipStream_t s) {
+  if (!w || !cs || !img || (cout & 3)) UNET_FAIL(ctx, UNET_E_ARG, "h2_weights_bound: bad args");
+  h2_prep_list L; L.n = 1;
+  h2_fill_prep(&L.item[0], w, cs, img, cin, cout, 0);
+  L.item[0].cs_bound = 1;
+  hipLaunchKernelGGL(h2_wimg_kernel, dim3((unsigned)std::min<long long>((L.item[0].total + 255) / 256, 256), 1), dim3(256), 0, s, L, (int)H2_MAXB);
+  UNET_CHECK_LAUNCH(ctx, "h2_weights_bound");
   return UNET_OK;
 }
 
@@ -855,7 +878,7 @@ bool h2_pool_sums_selected(const unet_ctx* ctx, int algo, int wd, int K, int M) 
 }
 int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx* ctx, const float* dy, const void* wimg, const float* pooled, const float* gamma, const float* beta, float rate, float* dx, double* sums,
                                      int n, int h, int wd, int K, int M, hipStream_t s) {
-  if (!dy || !wimg || !pooled || !gamma || !beta || !dx || !sums || rate < 0.f || rate >= 1.f) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 dgrad + pooled sums: bad args");
+  if (!dy || !wimg || !pooled || !gamma || !beta || !dx || rate < 0.f || rate >= 1.f) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 dgrad + pooled sums: bad args");          // (sums null: the sums stay in the slot copies for k_enc_tail_finish)
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   h2_head_args hd; hd.w = gamma; hd.b = beta; hd.aux = rate;
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
@@ -864,7 +887,7 @@ int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx* ctx, const float* dy, const void*
   if (h2_nb(M) == 1) r = launch_h2<0, 1, 2, 4, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
   else if (h <= 128 && wgs16 >= 512) r = launch_h2<0, 2, 4, 2, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
   else r = launch_h2<0, 2, 2, 2, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
-  if (r) return r;
+  if (r || !sums) return r;
   return k_slot_fold(ctx, sums, 2 * M, s);
 }
 

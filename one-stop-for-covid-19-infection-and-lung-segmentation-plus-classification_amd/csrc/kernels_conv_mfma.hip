@@ -451,6 +451,8 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
   }
 }
 
+// (round 4: both levels in ONE launch -- the last workgroup of a column, by ticket, sums the group results -- measured +1.5 ms per step: the device-scope fences each
+//  workgroup needs around its ticket write back / invalidate the XCD's L2 on this 8-XCD part.  Two launches it stays.)
 // Last reduction level, weights and bias in ONE launch.  src = `count` slabs of `stride` floats, each [taps][ca*cb] weight partials
 // followed by the bias partials.
 __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ src, long long stride, int count, int n4 /* ca*cb/4 */, int taps,

@@ -83,9 +83,16 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(const T* __restrict__ a, 
   }
 }
 
+// enc / comp (or null): the layer is a decoder BatchNorm over concat([up, BN_enc(y)]) whose skip half holds the RAW y (k_bn_compose, kernels_bnfold.hip): the composite map
+// [scale' C][shift' C][pre_s C][pre_t C] of the fold is written in the same launch (C = 2 C_enc: channels C/2 .. C-1 are the skip half)
+__device__ __forceinline__ void bn_compose_one(const float* __restrict__ enc, float* __restrict__ comp, int C, int c, float sd, float td) {
+  const int ce = C >> 1;
+  if (c < ce) { comp[c] = sd; comp[C + c] = td; comp[2 * C + c] = 1.0f; comp[3 * C + c] = 0.0f; }
+  else { const float se = enc[c - ce], te = enc[ce + (c - ce)]; comp[c] = sd * se; comp[C + c] = fmaf(sd, te, td); comp[2 * C + c] = se; comp[3 * C + c] = te; }
+}
 __global__ void bn_finalize_train_kernel(const double* sums, double count, const float* gamma,
                                          const float* beta, float* mm, float* mv, float* bnp, int C,
-                                         float momentum, float eps) {
+                                         float momentum, float eps, const float* __restrict__ enc = nullptr, float* __restrict__ comp = nullptr) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double mean = sums[c] / count;
@@ -94,18 +101,20 @@ __global__ void bn_finalize_train_kernel(const double* sums, double count, const
   float istd = (float)(1.0 / sqrt(var + (double)eps));
   float sc = gamma[c] * istd;
   bnp[c] = sc; bnp[C + c] = beta[c] - (float)mean * sc; bnp[2 * C + c] = (float)mean; bnp[3 * C + c] = istd;
+  if (comp) bn_compose_one(enc, comp, C, c, sc, beta[c] - (float)mean * sc);
   double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
   mm[c] = mm[c] * momentum + (float)mean * (1.0f - momentum);
   mv[c] = mv[c] * momentum + (float)unbiased * (1.0f - momentum);
 }
 
 __global__ void bn_finalize_infer_kernel(const float* gamma, const float* beta, const float* mm,
-                                         const float* mv, float* bnp, int C, float eps) {
+                                         const float* mv, float* bnp, int C, float eps, const float* __restrict__ enc = nullptr, float* __restrict__ comp = nullptr) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float istd = 1.0f / sqrtf(mv[c] + eps);
   float sc = gamma[c] * istd;
   bnp[c] = sc; bnp[C + c] = beta[c] - mm[c] * sc; bnp[2 * C + c] = mm[c]; bnp[3 * C + c] = istd;
+  if (comp) bn_compose_one(enc, comp, C, c, sc, beta[c] - mm[c] * sc);
 }
 
 template <typename T>
@@ -378,6 +387,25 @@ __global__ void bn_bwd_skip_term_kernel(double* __restrict__ sums, const double*
   if (j >= C || gamma[j] == 0.f) return;
   const double is = dec_istd[j];
   sums[C + j] += frac * (double)dec_gamma[j] * dec_s2[j] * (double)eps * is * is / (double)gamma[j];
+}
+// bn_slot_fold + bn_bwd_skip_term + bn_bwd_param_grads of an encoder tail in ONE launch (the pooled sums sit in the slot copies, left there by a data-gradient epilogue)
+__global__ void enc_tail_finish_kernel(double* __restrict__ slots, double* __restrict__ sums, const double* __restrict__ dec_s2, const float* __restrict__ dec_istd,
+                                       const float* __restrict__ dec_gamma, const float* __restrict__ gamma, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, double frac,
+                                       float eps, int nslots) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k0 = 0; k0 < nslots; k0 += 8) {                  // eight independent load pairs in flight, summed in index order
+    double v1[8], v2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { double* p = slots + (size_t)(k0 + k) * UNET_BN_SLOT_DOUBLES + j; v1[k] = p[0]; p[0] = 0.0; v2[k] = p[C]; p[C] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += v1[k]; s2 += v2[k]; }
+  }
+  double t1 = sums[j] + s1, t2 = sums[C + j] + s2;
+  if (gamma[j] != 0.f) { const double is = dec_istd[j]; t2 += frac * (double)dec_gamma[j] * dec_s2[j] * (double)eps * is * is / (double)gamma[j]; }
+  sums[j] = t1; sums[C + j] = t2;
+  dbeta[j] = (float)t1; dgamma[j] = (float)t2;
 }
 // one thread = one pooled pixel x 4 channels: y = BN(x) recomputed exactly as the forward stored it (arg-max), total gradient, BatchNorm backward, ReLU mask
 template <typename T>
@@ -1009,6 +1037,19 @@ extern "C++" template <typename T> static int32_t head_bwd_impl(unet_ctx* ctx, c
 extern "C++" int32_t k_slot_fold(unet_ctx* ctx, double* sums, int count, hipStream_t s) {
   hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((count + 127) / 128), dim3(128), 0, s, ctx->bn_slots, sums, count, ctx->bn_nslots());
   UNET_CHECK_LAUNCH(ctx, "slot_fold"); return UNET_OK;
+}
+extern "C++" int32_t k_enc_tail_finish(unet_ctx* ctx, double* sums, const double* dec_sum_dyxhat, const float* dec_invstd, const float* dec_gamma, const float* gamma, float* dgamma,
+                                       float* dbeta, int c, double frac, hipStream_t s) {
+  if (!sums || !dec_sum_dyxhat || !dec_invstd || !dec_gamma || !gamma || !dgamma || !dbeta || c < 1 || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "enc_tail_finish: bad args");
+  hipLaunchKernelGGL(enc_tail_finish_kernel, dim3((c + 127) / 128), dim3(128), 0, s, ctx->bn_slots, sums, dec_sum_dyxhat, dec_invstd, dec_gamma, gamma, dgamma, dbeta, c, frac, 1e-3f, UNET_BN_SLOTS);
+  UNET_CHECK_LAUNCH(ctx, "enc_tail_finish"); return UNET_OK;
+}
+extern "C++" int32_t k_bn_finalize_compose(unet_ctx* ctx, int training, const double* sums, double count, const float* gamma, const float* beta, float* mm, float* mv, float* bnp, int c,
+                                           const float* enc_bnp, float* comp, hipStream_t s) {
+  if (!gamma || !beta || !mm || !mv || !bnp || !enc_bnp || !comp || c < 2 || (c & 1) || (training && (!sums || count < 1))) UNET_FAIL(ctx, UNET_E_ARG, "bn_finalize_compose: bad args");
+  if (training) hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((c + 127) / 128), dim3(128), 0, s, sums, count, gamma, beta, mm, mv, bnp, c, 0.99f, 1e-3f, enc_bnp, comp);
+  else hipLaunchKernelGGL(bn_finalize_infer_kernel, dim3((c + 127) / 128), dim3(128), 0, s, gamma, beta, mm, mv, bnp, c, 1e-3f, enc_bnp, comp);
+  UNET_CHECK_LAUNCH(ctx, "bn_finalize_compose"); return UNET_OK;
 }
 extern "C++" int32_t k_head_fold(unet_ctx* ctx, double* loss_sums, double* head_sums, hipStream_t s) {
   if (!loss_sums || !head_sums || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "head_fold: bad args");

@@ -744,10 +744,10 @@ void build_programs(unet_model* m) {
     for (auto& it : prep_items) {
       const int K = flip ? it.cout : it.cin, M = flip ? it.cin : it.cout;          // channels the launch consumes / produces
       if (flip && it.name == "c1a") continue;
-      if (!flip && m->fold_off.count(it.name)) continue;          // prepared after its BatchNorm's finalize (bn_fold_prepare)
+      const bool folded = !flip && m->fold_off.count(it.name) != 0;          // image prepared after its BatchNorm's finalize (bn_fold_prepare): only the raw-weight maxima here (kind 4)
       if (!h2_conv3x3_selected(algo, K, M)) continue;
       if (nx >= UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch (a skipped layer would run on an image that was never written)");
-      ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = flip; ++nx;
+      ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = folded ? 4 : flip; ++nx;
     }
     for (auto& it : convt_items) {
       if (nx >= UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch");
@@ -790,6 +790,7 @@ void build_programs(unet_model* m) {
       const Buf ib = m->act.at(in), ob = m->act.at(out);
       const int64_t pixels = (int64_t)ib.n * ib.h * ib.w;
       const size_t so = m->bn_sum_off.at(name), bo = m->bnp_off.at(name);
+      const bool composed = m->skip_raw && !skip_src.empty() && m->bn_comp_off.count(name) != 0;          // decoder BatchNorm over [up | RAW encoder output]: finalize + k_bn_compose in one launch
       if (training) {
         if (!skip_src.empty() && ctx->opt_bn_concat_analytic) {
           const size_t sso = m->bn_sum_off.at(skip_src);
@@ -808,11 +809,15 @@ void build_programs(unet_model* m) {
         }
         SY.push_back({(int)F.size() - 1, 0, true, (m->off_bn_sums * 4) + so * 8, 2 * (int64_t)c});
         ADD_OP(F, "bn_finalize:" + name, 0, 0, {
+          if (composed) return k_bn_finalize_compose(ctx, 1, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"),
+                                                     m->P(name + "/var"), m->wsf(bo), c, m->wsf(m->bnp_off.at(skip_src)), m->wsf(m->bn_comp_off.at(name)), s);
           return unet_bn_finalize_train(ctx, m->wsd(m->off_bn_sums) + so, (double)pixels * gcount, m->P(name + "/gamma"), m->P(name + "/beta"),
                                         m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
         });
       } else {
         ADD_OP(F, "bn_finalize_infer:" + name, 0, 0, {
+          if (composed) return k_bn_finalize_compose(ctx, 0, nullptr, 0.0, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c,
+                                                     m->wsf(m->bnp_off.at(skip_src)), m->wsf(m->bn_comp_off.at(name)), s);
           return unet_bn_finalize_infer(ctx, m->P(name + "/gamma"), m->P(name + "/beta"), m->P(name + "/mean"), m->P(name + "/var"), m->wsf(bo), c, s);
         });
       }
@@ -864,14 +869,11 @@ void build_programs(unet_model* m) {
         const size_t co_ = m->skip_raw ? m->bn_comp_off.at(bnn) : 0, boe = m->skip_raw ? m->bnp_off.at("bn" + std::to_string(10 - k)) : 0;
         ADD_OP(F, "bn_fold_prepare:" + cn, 2.0 * 9 * cin * cout * 2, 4.0 * 9 * cin * cout * 4, {
           const float* sc_ = m->wsf(bo);                        // [scale 2C][shift 2C] of the folded map
-          if (m->skip_raw) {                                    // the skip half of the concat is the RAW encoder output: its BatchNorm and this one are one affine map (k_bn_compose)
-            int32_t rc = k_bn_compose(ctx, m->wsf(bo), m->wsf(boe), m->wsf(co_), cin / 2, s);
-            if (rc) return rc;
-            sc_ = m->wsf(co_);
-          }
+          if (m->skip_raw) sc_ = m->wsf(co_);                  // the skip half of the concat is the RAW encoder output: the composite map bn_finalize left (k_bn_finalize_compose)
+          (void)boe;
           int32_t r = k_bn_fold_prepare(ctx, m->P(cn + "/kernel"), m->P(cn + "/bias"), sc_, sc_ + cin, cin, cout, m->wsf(fo), s, dt != 0);
           if (r || dt) return r;                                // bf16 storage: the conv below builds its weight image from the scaled fp32 weights
-          return k_h2_weights(ctx, m->P(cn + "/kernel"), m->wsf(uo), cin, cout, 0, s, sc_);          // fp32: the image kernel applies the scale per input channel
+          return k_h2_weights_bound(ctx, m->P(cn + "/kernel"), sc_, m->wsf(uo), cin, cout, s);          // fp32: the image kernel applies the scale per input channel (exponent from max |w| max |scale|)
         });
         ADD_OP(F, "conv3x3_fwd:" + cn, 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w, eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout, {
           const float* tab = m->wsf(fo) + (size_t)9 * cin * cout;
@@ -980,6 +982,7 @@ void build_programs(unet_model* m) {
       });
       if (!xraw.empty()) {
         const size_t go = m->fold_g_off.at(name), bo = m->bnp_off.at(in);
+        const bool pg = !dt && m->fold_c_off.count(name) != 0;          // the BatchNorm's parameter gradients ride in the same launch (the op below stays as the carrier of the sync point)
         ADD_OP(BW, "wgrad_bn_fold_fix:" + name, 2.0 * 9 * cin * cout, 8.0 * 9 * cin * cout, {
           // ... and the BatchNorm's backward sums (sum dz, sum dz * xhat) come out of W, the raw dw and S: no pass over dz / x (bn_bwd below: stats_done)
           if (dt) return k_wgrad_bn_fold_fix_bf16(ctx, CBF(m->Dv(name)), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
@@ -987,10 +990,12 @@ void build_programs(unet_model* m) {
           if (m->skip_raw) {                                    // the weight gradient ran on [up | RAW encoder output]: composite scale / shift, and the decoder BatchNorm saw pre_s x + pre_t
             const float* comp = m->wsf(m->bn_comp_off.at(in));
             return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, comp, comp + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
-                                       m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in), comp + 2 * cin, comp + 3 * cin);
+                                       m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in), comp + 2 * cin, comp + 3 * cin,
+                                       pg ? m->G(in + "/gamma") : nullptr, pg ? m->G(in + "/beta") : nullptr);
           }
           return k_wgrad_bn_fold_fix(ctx, m->D(name), ob.n, ob.h, ob.w, cin, cout, m->wsf(bo), m->wsf(bo) + cin, m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(go), s,
-                                     m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in));
+                                     m->P(name + "/kernel"), m->wsf(bo) + 2 * cin, m->wsf(bo) + 3 * cin, m->wsd(m->off_bn_bsums) + m->bn_bsum_off.at(in), nullptr, nullptr,
+                                     pg ? m->G(in + "/gamma") : nullptr, pg ? m->G(in + "/beta") : nullptr);
         });
       }
       if (!xraw.empty() && m->fold_c_off.count(name)) {
@@ -999,6 +1004,7 @@ void build_programs(unet_model* m) {
         const std::string bnn = in;
         const size_t so = m->bn_bsum_off.at(bnn), bo = m->bnp_off.at(bnn), co = m->fold_c_off.at(name);
         ADD_OP(BW, "bn_bwd_param_grads:" + bnn, 0, 0, {
+          if (!dt) return UNET_OK;                             // fp32: written by wgrad_bn_fold_fix above (one launch less; this op carries the cross-rank sync point)
           return unet_bn_bwd_param_grads(ctx, m->wsd(m->off_bn_bsums) + so, m->G(bnn + "/gamma"), m->G(bnn + "/beta"), cin, s);
         });
         SY.push_back({(int)BW.size() - 1, 2, true, m->off_bn_bsums * 4 + so * 8, 2 * (int64_t)cin});
@@ -1024,8 +1030,10 @@ void build_programs(unet_model* m) {
         const size_t so = m->bn_bsum_off.at(bnn);
         m->pool_sums_fused.insert(in);
         ADD_OP(BW, "conv3x3_dgrad_pool_sums:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + 2 * cin) + 4.0 * 9.0 * cin * cout, {
+          // (the sums stay in the slot copies: the pool_bwd_skip_term op right below folds them out together with the skip term -- nothing between the two uses the slots)
+          (void)so;
           return k_conv3x3_h2_dgrad_pool_sums(ctx, m->D(name), m->wsf(m->wprep_b.at(name)), m->A(in), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->drop_rate, m->D(in),
-                                              m->wsd(m->off_bn_bsums) + so, ob.n, ob.h, ob.w, cout, cin, s);
+                                              nullptr, ob.n, ob.h, ob.w, cout, cin, s);
         });
       } else
       if (want_dx) {
@@ -1124,6 +1132,9 @@ void build_programs(unet_model* m) {
                          : unet_maxpool2x2_dropout_bwd_sums(ctx, m->A(pn), m->D(pn), m->P(bnn + "/gamma"), m->P(bnn + "/beta"), m->wsd(m->off_bn_bsums) + so, xb.n, xb.h, xb.w, xb.c,
                                                             m->drop_rate, m->drop_seed + (uint64_t)k * 0x9E3779B97F4A7C15ull, s);
           if (r) return r;
+          if (sums_done)                                        // fold of the epilogue's sums + skip term + parameter gradients: one launch
+            return k_enc_tail_finish(ctx, m->wsd(m->off_bn_bsums) + so, m->wsd(m->off_bn_bsums) + sod + 3 * (size_t)c, m->wsf(bod) + 7 * (size_t)c, m->P(dn + "/gamma") + c,
+                                     m->P(bnn + "/gamma"), m->G(bnn + "/gamma"), m->G(bnn + "/beta"), c, 1.0 / gcount, s);
           r = unet_bn_bwd_skip_term(ctx, m->wsd(m->off_bn_bsums) + so, m->wsd(m->off_bn_bsums) + sod + 3 * (size_t)c, m->wsf(bod) + 7 * (size_t)c, m->P(dn + "/gamma") + c,
                                     m->P(bnn + "/gamma"), c, 1.0 / gcount, s);
           if (r) return r;

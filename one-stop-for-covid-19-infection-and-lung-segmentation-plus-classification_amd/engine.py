@@ -30,7 +30,7 @@ class HipUNet:
 
     def __init__(self, h: int, w: int, in_ch: int = 1, device: int | None = None, conv_algo: int = _lib.ALGO_AUTO,
                  process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR,
-                 arch: str = "unet", dtype: str = "fp32", force_dp: bool = False, options: dict | None = None):
+                 arch: str = "unet", dtype: str = "fp32", force_dp: bool = False, options: dict | None = None, small_allreduce: str = "device"):
         torch = _torch()
         self.lib = _lib.load()
         # dtype "bf16": activations / activation gradients stored as bf16 in the workspace (BASELINE.json configs[3], [4]); image,
@@ -91,6 +91,11 @@ class HipUNet:
         self.lib.unet_model_destroy(probe)
         self._comm_stream = torch.cuda.Stream(device=self.dev) if self._dp else None          # gradient buckets
         self._small_stream = torch.cuda.Stream(device=self.dev) if self._dp else None         # BatchNorm-backward sums whose reader is not the next op (dp.py)
+        # small_allreduce: "device" = the BatchNorm / loss sums go through unet_comm_* (csrc/comm.hip: one kernel on the compute stream that pushes into the
+        # peers' IPC-mapped receive areas; falls back to RCCL, loudly and on every rank together, if the areas cannot be mapped or a self-test fails);
+        # "rccl" = torch.distributed all-reduces, inline or on the side stream.  Gradient buckets are RCCL either way.
+        assert small_allreduce in ("device", "rccl"), small_allreduce
+        self._comm = self._make_comm() if (self._dp and small_allreduce == "device") else None
 
     # ------------------------------------------------------------------ plans / buffers
     def _create_plan(self, n, replicated=False):
@@ -241,6 +246,73 @@ class HipUNet:
         self.ctx.check(self.lib.unet_gather_samples(self.ctx.handle, ds.data_ptr(), di.data_ptr(), out.data_ptr(), len(idx), sf, self._stream()), "gather_samples")
         return out
 
+    def _make_comm(self):
+        """unet_comm_* communicator over the ranks of self.pg (one node, <= 8 ranks), verified by one all-reduce of known values; None (= RCCL) unless
+        EVERY rank got through."""
+        import socket
+        import warnings
+        import torch.distributed as dist
+        torch = _torch()
+        lib, world, rank = self.lib, self.world, self.rank
+        comm, why = _lib.vp(), ""
+        handle = (C.c_ubyte * _lib.COMM_HANDLE_BYTES)()
+        if world > _lib.COMM_MAX_WORLD:
+            why = f"{world} ranks (the device-side all-reduce serves one node: <= {_lib.COMM_MAX_WORLD})"
+        elif lib.unet_comm_create(self.ctx.handle, rank, world, C.byref(comm), handle) != 0:
+            why, comm = self.ctx.last_error(), _lib.vp()
+        mine = (socket.gethostname(), bytes(handle), why)
+        everyone = [None] * world
+        if world > 1:
+            dist.all_gather_object(everyone, mine, group=self.pg)
+        else:
+            everyone = [mine]
+        ok = not any(e[2] for e in everyone) and len({e[0] for e in everyone}) == 1
+        if not ok and not why:
+            why = next((f"rank {r}: {e[2]}" for r, e in enumerate(everyone) if e[2]), "ranks on different hosts")
+        if ok and lib.unet_comm_connect(comm, b"".join(e[1] for e in everyone)) != 0:
+            ok, why = False, self.ctx.last_error()
+        if ok:                                             # self-test: sum over ranks of (rank + 1) * (i + 1), short timeout
+            lib.unet_comm_set_timeout_ms(comm, 10000)
+            t = (torch.arange(1, 301, dtype=torch.float64, device=self.dev) * (rank + 1))
+            err = C.c_int32(0)
+            if lib.unet_comm_allreduce_f64(comm, t.data_ptr(), t.numel(), self._stream()) != 0 or lib.unet_comm_status(comm, C.byref(err), self._stream()) != 0:
+                ok, why = False, self.ctx.last_error()
+            elif err.value != 0:
+                ok, why = False, f"self-test: nothing from rank {err.value - 1} within 10 s"
+            elif not torch.equal(t.cpu(), torch.arange(1, 301, dtype=torch.float64) * (world * (world + 1) // 2)):
+                ok, why = False, "self-test: wrong sums"
+            lib.unet_comm_set_timeout_ms(comm, 60000)
+        if world > 1:                                      # all ranks or none
+            flags = [None] * world
+            dist.all_gather_object(flags, (ok, why), group=self.pg)
+            bad = [(r, f[1]) for r, f in enumerate(flags) if not f[0]]
+            if bad:
+                ok, why = False, why or f"rank {bad[0][0]}: {bad[0][1]}"
+        if not ok:
+            if comm:
+                lib.unet_comm_destroy(comm)
+            warnings.warn(f"covidseg_amd: device-side small all-reduce unavailable ({why}); BatchNorm / loss sums go through torch.distributed instead", RuntimeWarning)
+            return None
+        return comm
+
+    def comm_status(self):
+        """0, or 1 + the rank whose contribution to a device-side all-reduce did not arrive in time (sticky; synchronises the stream)"""
+        if self._comm is None:
+            return 0
+        err = C.c_int32(0)
+        self.ctx.check(self.lib.unet_comm_status(self._comm, C.byref(err), self._stream()), "comm_status")
+        return err.value
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self.lib.unet_comm_destroy(self._comm); self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _all_reduce(self, t, group=None):
         """SUM all-reduce.  backend nccl (= RCCL) reduces device tensors in place; the gloo branch (used by the
         single-GPU multi-process tests) stages through the host."""
@@ -262,7 +334,10 @@ class HipUNet:
         cur = torch.cuda.current_stream(self.dev)
 
         def reduce_small(ptr, count):
-            self._all_reduce(self._ws_view_f64(ptr, count))
+            if self._comm is not None:
+                self.ctx.check(lib.unet_comm_allreduce_f64(self._comm, ptr, count, self._stream()), "comm_allreduce")
+            else:
+                self._all_reduce(self._ws_view_f64(ptr, count))
 
         def reduce_bucket(ptr, count):
             off = (ptr - self.grads.data_ptr()) // 4
@@ -282,8 +357,9 @@ class HipUNet:
             return done
 
         kinds = (0, 1, 2, 3) if self.sync_bn else (3,)
+        # (device-side reductions cost one small kernel: they run inline even where the program leaves room for a side stream)
         dp.run_program(run_range, nops, plan["sync"][prog], reduce_small, reduce_bucket,
-                       lambda: cur.wait_stream(self._comm_stream), kinds, reduce_small_async, lambda done: cur.wait_event(done))
+                       lambda: cur.wait_stream(self._comm_stream), kinds, None if self._comm is not None else reduce_small_async, lambda done: cur.wait_event(done))
 
     def _loss_tensor(self, plan):
         torch = _torch()
