@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 12
+#define UNET_ABI_VERSION 13
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -74,9 +74,12 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *                          composed with the encoder one (two affine maps in a row are one).  -1 GB of writes per step at 512 x 512 x 16.  0 = the normalised copy is stored
  *   POOL_SUMS_FUSED (1)    fp32 U-Net with ENC_BN_FUSED: the pooled-path sums of an encoder tail's BatchNorm backward come out of the epilogue of the data gradient that
  *                          produces the pooled tensor's gradient (no pass over the pooled tensors); dropout-removed elements are recognised by the -0.0f the forward stored
+ *   HEAD_BWD_FUSED (1)     with HEAD_FUSED and RELU_BITS: dL/d(output of the last conv3x3) = dz_p w_c [y_pc > 0] is never written as a tensor -- unet_head_dzm leaves
+ *                          {dz_p, 32 mask bits} per pixel (8 bytes instead of 128) and the last conv's data gradient and weight gradient expand that stream while they
+ *                          stage it (-1.5 GB of traffic per step at 512 x 512 x 16); 0 = unet_head_dy writes the fp32 tensor
  */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,
-       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8, UNET_OPT_POOL_SUMS_FUSED = 9 };
+       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8, UNET_OPT_POOL_SUMS_FUSED = 9, UNET_OPT_HEAD_BWD_FUSED = 10 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
 int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */
 
@@ -288,6 +291,21 @@ int32_t unet_conv3x3_head_fwd(unet_ctx*, const float* x, const float* w, const f
  * GLOBAL loss sums; dw_head[32] / db_head[1] += the combination of head_sums. */
 int32_t unet_head_dy(unet_ctx*, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const float* w_head,
                      const void* relu_bits, const float* y, float* dy, float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream);
+/* The same backward without the fp32 tensor dy: it has ONE fp32 degree of freedom and 32 mask bits per pixel, so unet_head_dzm writes the stream
+ * dzm[n,h,w] = {float dz, uint32 mask (bit c = y_c > 0)} (8 bytes per pixel instead of 128; relu_bits required; dw_head / db_head += as unet_head_dy) and the two
+ * gradients of the conv in front of the head (`Conv2D(32, (3, 3), relu)`, T1:911) expand it while they stage it:
+ *   unet_conv3x3_bwd_data_dzm     dx[n,h,w,cin] = conv3x3_bwd_data(dy, w) with w_head folded into the weight image; relu_bits_in (or NULL) = the ReLU bits of the conv's INPUT
+ *                                 (unet_request_relu_bits on the launch that produced it); wt_ws as for unet_conv3x3_bwd_data
+ *   unet_conv3x3_bwd_weights_dzm  dw[3][3][cin][32], db[32] = conv3x3_bwd_weights(x, dy) (overwritten), the head's weights applied to the finished columns; ws as for
+ *                                 unet_conv3x3_bwd_weights(cin, 32)
+ * fp32 UNET_ALGO_AUTO kernels, cin = 32, W % 8 == 0 (unet_head_bwd_stream_supported). */
+int32_t unet_head_bwd_stream_supported(unet_ctx*, int32_t algo, int32_t wd, int32_t cin);
+int32_t unet_head_dzm(unet_ctx*, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const void* relu_bits, void* dzm,
+                      float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream);
+int32_t unet_conv3x3_bwd_data_dzm(unet_ctx*, const void* dzm, const float* w, const float* w_head, const void* relu_bits_in, float* dx, float* wt_ws, int32_t n, int32_t h,
+                                  int32_t wd, int32_t cin, void* stream);
+int32_t unet_conv3x3_bwd_weights_dzm(unet_ctx*, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int32_t n, int32_t h,
+                                     int32_t wd, int32_t cin, void* stream);
 
 /* Replaces: Adam(lr=0.0005) step of model.fit T1:1053,1059 -- Keras-2.3 form:
  *   m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t*m/(sqrt(v)+eps), lr_t=lr*sqrt(1-b2^t)/(1-b1^t)

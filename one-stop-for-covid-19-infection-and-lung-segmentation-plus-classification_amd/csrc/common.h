@@ -30,6 +30,7 @@ struct unet_ctx {
   int opt_pool_sums_fused = 1;      // fp32 U-Net: the pooled-path sums of the encoder tail's BatchNorm backward from the epilogue of the data gradient that produces the pooled gradient
   int opt_skip_raw = 1;             // fp32 U-Net: an encoder block's second conv writes straight into the skip half of its concat; the encoder BatchNorm is composed into the folded decoder one
   int opt_head_fused = 1;           // the 1x1 sigmoid head + loss sums + the head's weight-gradient sums in the epilogue of the last conv3x3 (fp32 h2 kernels)
+  int opt_head_bwd_fused = 1;       // the head's backward as an 8-byte-per-pixel {dz, mask} stream that the last conv's two gradients expand (no fp32 dY tensor)
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
   int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
@@ -94,6 +95,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // way must be smaller than 1 GiB (COL_OOB + a valid row offset must still be out of range).
 typedef float unet_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned unet_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned unet_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int UNET_OOB = (int)0x80000000u;        // invalid element (or row)
 constexpr int UNET_COL_OOB = 0x40000000;          // invalid column part, may be added to a valid or invalid row part
 // `soff` = wave-uniform byte offset (an SGPR operand of the instruction: no per-lane add; it does not bring an out-of-range lane
@@ -267,6 +269,14 @@ int32_t k_wgrad_c16_gather(unet_ctx*, const float* G, float* dw, float* db, hipS
 int32_t k_conv3x3_h2_wgrad_c16(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, hipStream_t s);
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
 int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);
+// the head's backward as a rank-1 stream: k_head_dzm writes dzm[n,h,wd] = {dz, 32 mask bits} (+ the head's own dw / db, accumulated), the two gradients of the
+// last conv3x3 expand it while staging
+int32_t k_head_dzm(unet_ctx*, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const unsigned long long* bits, void* dzm, float* dw,
+                   float* db, int n, int h, int wd, hipStream_t s);
+bool h2_head_bwd_selected(const unet_ctx* ctx, int algo, int wd, int cin);
+int32_t k_conv3x3_h2_dgrad_dzm(unet_ctx*, const void* dzm, const void* wimg, const float* mask, int mask_mode, float* dx, int n, int h, int wd, int M, hipStream_t s);
+int32_t k_conv3x3_h2_wgrad_dzm(unet_ctx*, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin,
+                               hipStream_t s);
 int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                             float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 bool c1_relu_bits_supported(int wd, int cout);

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {         
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.nw4; i += (long long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(p.w)[i];
     float m4 = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    if (p.cs) m4 *= fabsf(p.cs[(int)((i * 4 / p.cs_div) % p.cs_mod)]);          // (the four elements of a float4 share their input channel: cs_div is a multiple of 4)
+    if (p.cs && !p.cs_bound) m4 *= fabsf(p.cs[(int)((i * 4 / p.cs_div) % p.cs_mod)]);          // (the four elements of a float4 share their input channel: cs_div is a multiple of 4)
     mx = fmaxf(mx, m4);
   }
 #pragma unroll
@@ -151,6 +151,11 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
                                                            int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs,
                                                            int mask_climit, h2_head_args hd) {
   constexpr bool HEAD = EPI == 1, POOLS = EPI == 2;          // EPI: 0 the general epilogue, 1 + the 1x1 sigmoid head (below), 2 + the pooled-path sums of an encoder tail (MASK_POOL_SUMS)
+  // EPI 3 (VDY): the general epilogue behind a VIRTUAL input -- the gradient of the last conv3x3's output, dy[p][c] = dz_p w_c [y_pc > 0] (T1:911-913 backwards), staged from
+  // the 8-byte-per-pixel stream {dz_p, 32 mask bits} of head_dzm_kernel (x = that stream, ldx = 2): one value is scaled and split per staged piece, the mask bits pick
+  // the channels it goes to; w_c is a per-contraction-channel factor of the weight image (h2_prep::cs).  K = 32.
+  constexpr bool VDY = EPI == 3;
+  static_assert(!VDY || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the virtual head gradient feeds the 32-channel data-gradient launch");
   static_assert(!HEAD || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the fused head rides on the 32-channel forward kernel");
   static_assert(!POOLS || (MODE == 0 && !GEN), "the pooled sums ride on a plain conv3x3 data-gradient launch");
   if (POOLS) { mask_mode = MASK_POOL_SUMS; act = ACT_NONE; signs = nullptr; }          // (compile-time facts of this instance: the other epilogue forms fall away)
@@ -214,10 +219,18 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     else { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); }
     const bool ok = idx < PPIECES && gy >= 0 && gy < H && gx >= 0 && gx < W;
     if (MODE == 2) poff[k] = ok ? (((2 * gy) * WI + 2 * gx) * ldx + ks * 16 + q * 4) * 4 : UNET_OOB;
+    else if (VDY) poff[k] = ok ? (gy * WI + gx) * 8 : UNET_OOB;                            // (the four pieces of a pixel read the same 8 bytes)
     else poff[k] = ok ? ((gy * WI + gx) * ldx + ks * 16 + q * 4) * 4 : UNET_OOB;          // halo and overhang pieces read 0 (out-of-range buffer offset)
   }
   unet_u32x4 preg[PL], wreg[WL];
   auto issue_loads = [&](int chunk) __attribute__((always_inline)) {
+    if (VDY) {                                             // both chunks expand the same {dz, mask} words: fetched once
+      if (chunk == 0) {
+#pragma unroll
+        for (int k = 0; k < PL; ++k) { const unet_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, poff[k], 0, 0); preg[k][0] = v[0]; preg[k][1] = v[1]; }
+      }
+      return;
+    }
     int soff;
     if (MODE == 2) { const int ct = K >> 2, k0 = chunk * 32, ab = k0 / ct, o0 = k0 - ab * ct; soff = (((ab >> 1) * WI + (ab & 1)) * ldx + o0) * 4; }
     else soff = chunk * 16 * KS * 4;
@@ -238,14 +251,17 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   auto post_amax = [&]() __attribute__((always_inline)) {
     float mx = 0.f;
 #pragma unroll
-    for (int k = 0; k < PL; ++k)
+    for (int k = 0; k < PL; ++k) {
+      if (VDY) { mx = fmaxf(mx, preg[k][1] ? fabsf(__uint_as_float(preg[k][0])) : 0.f); continue; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(__uint_as_float(preg[k][j])));
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if (lane == 0) s_amax[wave] = mx;
   };
   int e_run = 120;                                           // running exponent of the activation operand: staged values are x * 2^e_run
+  int st_chunk = 0;                                          // (VDY) the chunk the next store_lds stages
   // after the barrier that follows post_amax: lower the running exponent if this chunk needs it (rescaling the accumulators), then scale, split and store
   auto store_lds = [&]() __attribute__((always_inline)) {
     const float mx = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
@@ -268,8 +284,17 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       const int idx = tid + k * 256;
       if (idx < PPIECES) {
         unsigned h0, m0, h1, m1;
+        if (VDY) {
+          const float v = __uint_as_float(preg[k][0]) * sc;
+          unsigned hh, mm;
+          split2(v, v, hh, mm);
+          const unsigned nib = preg[k][1] >> (st_chunk * 16 + (tid & 3) * 4);          // bits 0..3: this piece's four channels
+          const unsigned k01 = ((nib & 1u) ? 0xFFFFu : 0u) | ((nib & 2u) ? 0xFFFF0000u : 0u), k23 = ((nib & 4u) ? 0xFFFFu : 0u) | ((nib & 8u) ? 0xFFFF0000u : 0u);
+          h0 = hh & k01; h1 = hh & k23; m0 = mm & k01; m1 = mm & k23;
+        } else {
         split2(__uint_as_float(preg[k][0]) * sc, __uint_as_float(preg[k][1]) * sc, h0, m0);
         split2(__uint_as_float(preg[k][2]) * sc, __uint_as_float(preg[k][3]) * sc, h1, m1);
+        }
         const int q = tid & 3, pp = (tid >> 2) + k * 64;                // (k * 64 / NPIX is a compile-time constant in the ConvT modes: NPIX % 64 == 0 there)
         const int ks = MODE == 0 ? 0 : (k * 64) / NPIX;
         char* p = s_in + ((ks * 2 + (q >> 1)) * HS + (pp - ks * NPIX) * 16 + (q & 1) * 8);          // piece (pixel, quad) -> 8 bytes of its channel half
@@ -280,6 +305,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < WL; ++k)
       if (WPAD || tid + k * 256 < WPIECES) *reinterpret_cast<unet_u32x4*>(s_w + (tid + k * 256) * 16) = wreg[k];          // (pieces past the slab: zeros into the padding)
+    ++st_chunk;
   };
 
   H2_STAMP(0);
@@ -494,7 +520,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
             signs[(((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
         }
         if (pxj < W) {
-          *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
+          if (y) *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;          // (y null: nothing downstream reads the tensor -- p, the sums and the sign bits are all the backward takes)
           if (hd.t) {
             const float* rec = s_rec + (r * 32 + pj) * 8;
             const float4 c4 = *reinterpret_cast<const float4*>(rec + 4);
@@ -765,6 +791,9 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   } else if (EPI == 2) {
     if (gen || mask_mode != MASK_POOL_SUMS || act != ACT_NONE) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 + pooled sums: a plain data-gradient launch only");
     r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
+  } else if (EPI == 3) {
+    if (gen || K != 32 || ldx != 2 || act != ACT_NONE || mask_mode == MASK_POOL_SUMS) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 behind the head's {dz, mask} stream: a plain 32-channel data-gradient launch only");
+    r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
   } else if (mask_mode == MASK_POOL_SUMS) { UNET_FAIL(ctx, UNET_E_ARG, "conv h2: MASK_POOL_SUMS goes with its own kernel instance");
   } else if (gen) r = go(conv_h2_kernel<MODE, NB, RW, (MODE == 0), WPS>); else r = go(conv_h2_kernel<MODE, NB, RW, false, WPS>);
   if (r) return r;
@@ -824,9 +853,12 @@ int32_t k_h2_prep_multi(unet_ctx* ctx, const float* const* w, const float* const
   h2_prep_list L; L.n = count;
   long long most = 1;
   for (int k = 0; k < count; ++k) {
-    if (cs && cs[k] && (kind[k] != 0 || (cout[k] & 3))) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: a channel factor goes with a conv3x3 forward image");
+    if (cs && cs[k] && (kind[k] > 1 || (cout[k] & 3))) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: a channel factor goes with a conv3x3 image");
     if (kind[k] < 0 || kind[k] > 4) UNET_FAIL(ctx, UNET_E_ARG, "h2_prep_multi: kind %d", kind[k]);
     h2_fill_prep(&L.item[k], w[k], cs ? cs[k] : nullptr, img[k], cin[k], cout[k], kind[k]);
+    // a data-gradient image contracts over the conv's OUTPUT channels: its factor (the 1x1 head's weights behind the last conv3x3, EPI 3) varies inside a float4 of
+    // the weights, so the max pass takes the raw maxima and the exponent comes from the bound max |w| max |cs|
+    if (cs && cs[k] && kind[k] == 1) { L.item[k].cs_bound = 1; L.item[k].cs_mod = cout[k]; }
     most = std::max(most, L.item[k].total);
   }
   hipLaunchKernelGGL(h2_wmax_kernel, dim3(H2_MAXB, (unsigned)count), dim3(256), 0, s, L);
@@ -853,6 +885,17 @@ int32_t k_h2_weights_multi(unet_ctx* ctx, const float* const* w, void* const* im
 int32_t k_h2_weights(unet_ctx* ctx, const float* w, void* img, int cin, int cout, int flip, hipStream_t s, const float* cs) {
   const float* ws[1] = {w}; const float* css[1] = {cs}; void* is[1] = {img};
   return k_h2_prep_multi(ctx, ws, css, is, &cin, &cout, &flip, 1, s);
+}
+
+// The data gradient of the last conv3x3 (32 output channels, T1:911) from the head's rank-1 stream dzm[n,h,wd] = {dz, 32 mask bits} (k_head_dzm): dx[n,h,wd,M];
+// wimg = the kind-1 image of that conv with cs = the head's 32 weights; mask / mask_mode as for any data gradient (the ReLU of the conv in front)
+bool h2_head_bwd_selected(const unet_ctx* ctx, int algo, int wd, int cin) {
+  return ctx && ctx->opt_head_bwd_fused && h2_conv3x3_selected(algo, 32, cin) && h2_nb(cin) == 1 && (wd & 7) == 0;
+}
+int32_t k_conv3x3_h2_dgrad_dzm(unet_ctx* ctx, const void* dzm, const void* wimg, const float* mask, int mask_mode, float* dx, int n, int h, int wd, int M, hipStream_t s) {
+  if (!dzm || !wimg || !dx || h2_nb(M) != 1 || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 dgrad behind the head stream: bad args (M = %d)", M);
+  if ((long long)h * wd * std::max(32, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  return launch_h2<0, 1, 2, 4, 3>(ctx, static_cast<const float*>(dzm), 2, static_cast<const unet_bf16*>(wimg), nullptr, mask, mask_mode, dx, M, n, h, wd, 32, M, ACT_NONE, 0.0f, 0, s);
 }
 
 // x [n,h,wd,K] dense NHWC fp32, wimg from k_h2_weights (K contraction channels, M output channels), y [n,h,wd,M] fp32
@@ -899,7 +942,7 @@ bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int 
 }
 int32_t k_conv3x3_h2_head_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, float* y, const float* wh, const float* bh, float* p, const float* t,
                               int n, int h, int wd, int K, hipStream_t s) {
-  if (K < 16 || (K % 16) || !wh || !bh || !p) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2 + head: bad args");
+  if (K < 16 || (K % 16) || !wh || !bh || !p) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2 + head: bad args");          // (y may be null: the 32-channel tensor is then not stored)
   if ((long long)h * wd * std::max(K, 32) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   h2_head_args hd; hd.w = wh; hd.b = bh; hd.p = p; hd.t = t; hd.slots = ctx->bn_slots;
   return launch_h2<0, 1, 2, 4, 1>(ctx, x, K, static_cast<const unet_bf16*>(wimg), bias, nullptr, MASK_NONE, y, 32, n, h, wd, K, 32, ACT_RELU, 0.0f, 0, s, 1 << 30, hd);

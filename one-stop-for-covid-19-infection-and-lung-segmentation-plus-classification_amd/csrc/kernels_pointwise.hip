@@ -679,6 +679,38 @@ __global__ __launch_bounds__(TPB) void head_dy_kernel(const float* __restrict__ 
   }
 }
 
+// The same gradient as a rank-1 stream: dy[p][c] = dz_p w_c [y_pc > 0] has ONE fp32 degree of freedom and 32 mask bits per pixel.  out[p] = {dz_p, mask_p}
+// (bit c of mask_p = y_pc > 0; 8 bytes instead of the 128 head_dy_kernel writes): the data gradient and the weight gradient of the last conv3x3 expand it while they
+// stage it (kernels_conv_h2.hip EPI 3, kernels_wgrad_h2.hip VDY) -- w_c goes into the data gradient's weight image / the weight gradient's column scale.
+// A thread: one pixel.  The sign bits of 8 pixels x 32 channels are four 64-bit words (layout above): byte x % 8 of word k holds channels k, 4 + k, 8 + k, ...
+__global__ __launch_bounds__(TPB) void head_dzm_kernel(const float* __restrict__ pin, const float* __restrict__ yt, const double* __restrict__ sums, double inv_count,
+                                                       const double* __restrict__ hs, const unsigned long long* __restrict__ bits, uint2* __restrict__ out, float* dw, float* db,
+                                                       long long pixels, int wd) {
+  const double S = sums[2] + sums[3] + 1.0;
+  const float dice = (float)((2.0 * sums[1] + 1.0) / S), invS = (float)(1.0 / S);
+  const float hb = (float)(0.5 * inv_count);
+  if (blockIdx.x == 0 && threadIdx.x < 33) {
+    const int c = threadIdx.x;
+    const double g = c < 32 ? (0.5 * inv_count) * hs[c] - (1.0 / S) * hs[32 + c] + 0.5 * (1.0 / S) * ((2.0 * sums[1] + 1.0) / S) * hs[64 + c]
+                            : (0.5 * inv_count) * hs[96] - (1.0 / S) * hs[97] + 0.5 * (1.0 / S) * ((2.0 * sums[1] + 1.0) / S) * hs[98];
+    if (c < 32) dw[c] += (float)g; else db[0] += (float)g;
+  }
+  for (long long p = (long long)blockIdx.x * TPB + threadIdx.x; p < pixels; p += (long long)gridDim.x * TPB) {
+    const float dz = head_dz(pin[p], yt[p], hb, dice, invS);
+    const long long row = p / wd; const int x = (int)(p - row * wd);
+    const unsigned long long* bw = bits + (row * (wd >> 3) + (x >> 3)) * 4;
+    const int sh = (x & 7) * 8;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned b = (unsigned)(bw[k] >> sh) & 0xFFu;          // bit Q = channel 4 Q + k  ->  spread to every fourth bit
+      b = (b | (b << 12)) & 0x000F000Fu; b = (b | (b << 6)) & 0x03030303u; b = (b | (b << 3)) & 0x11111111u;
+      m |= b << k;
+    }
+    out[p] = make_uint2(__float_as_uint(dz), m);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
@@ -1055,6 +1087,14 @@ extern "C++" int32_t k_head_fold(unet_ctx* ctx, double* loss_sums, double* head_
   if (!loss_sums || !head_sums || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "head_fold: bad args");
   hipLaunchKernelGGL(head_fold_kernel, dim3(1), dim3(128), 0, s, ctx->bn_slots, loss_sums, head_sums, UNET_BN_SLOTS);
   UNET_CHECK_LAUNCH(ctx, "head_fold"); return UNET_OK;
+}
+
+extern "C++" int32_t k_head_dzm(unet_ctx* ctx, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const unsigned long long* bits,
+                               void* dzm, float* dw, float* db, int n, int h, int wd, hipStream_t s) {
+  if (!p || !t || !loss_sums || !head_sums || !bits || !dzm || !dw || !db || count < 1 || (wd & 7)) UNET_FAIL(ctx, UNET_E_ARG, "head_dzm: bad args");
+  const long long pixels = (long long)n * h * wd;
+  hipLaunchKernelGGL(head_dzm_kernel, dim3(std::min(grid_for(pixels), 4096)), dim3(TPB), 0, s, p, t, loss_sums, 1.0 / count, head_sums, bits, static_cast<uint2*>(dzm), dw, db, pixels, wd);
+  UNET_CHECK_LAUNCH(ctx, "head_dzm"); return UNET_OK;
 }
 
 extern "C++" int32_t k_head_dy(unet_ctx* ctx, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const float* w, const unsigned long long* bits,

@@ -46,11 +46,15 @@ constexpr int APX = 34;                                       // X pixels per st
 // piece; the kernel is instruction-issue bound: 4 - 5.6 VALU + ~2 LDS instructions per MFMA before the ring) falls by a third.  If a new row forces the
 // running exponent of the X operand down, the two kept rows are fetched again and re-split at the new scale (rare: the maximum has to grow 8x).
 // The bias gradient (column sums of the dY operand) is taken by the workgroups of the FIRST X channel tile only.
-template <int WA, int WB, int WR, int R>
+// VDY: the dY operand is VIRTUAL -- the gradient of the network's last conv3x3 output, dy[p][c] = dz_p w_c [y_pc > 0] (T1:911-913 backwards), staged from the
+// 8-byte-per-pixel stream {dz_p, 32 mask bits} of head_dzm_kernel (B = that stream, CB = 32): one value is scaled and split per staged piece, the mask bits pick the
+// channels; w_c (colscale) multiplies the finished columns.
+template <int WA, int WB, int WR, int R, bool VDY = false>
 __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
                                                           int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
-                                                          int npairs, long long pstride, int units, int upb) {
+                                                          int npairs, long long pstride, int units, int upb, const float* __restrict__ colscale) {
   static_assert(WA * WB * WR == 4 && WR <= R, "4 waves");
+  static_assert(!VDY || WB == 1, "the head stream carries one 32-channel tile");
   constexpr int TAPS = 9, AROWS = R + 2;
   constexpr int ASUB = AROWS * APX * 64, BSUB = R * 32 * 64;      // bytes of one 32-channel sub-plane of one fp16 plane
   constexpr int STAGE1 = WA * ASUB + WB * BSUB;                   // one fp16 plane of everything that is staged per step
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
     const int cs = unit % strips, n = unit / strips;
     const int x0 = cs * 32;
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A + (long long)n * H * W * CA, (long long)H * W * CA * 4);
-    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(B + (long long)n * H * W * CB, (long long)H * W * CB * 4);
+    const __amdgpu_buffer_rsrc_t rs_b = VDY ? make_rsrc(B + (long long)n * H * W * 2, (long long)H * W * 8) : make_rsrc(B + (long long)n * H * W * CB, (long long)H * W * CB * 4);
     // staging plan.  A thread always fetches channel quad q = tid & 7 of pixel column pc = tid >> 3 (0..31) of a staged row, so one byte offset per
     // operand (and per 32-channel sub-plane: its validity differs) is all it keeps; rows and sub-planes are wave-uniform immediates.  The X rows have
     // 34 pixels: columns 0..31 (image column x0 - 1 + pc) go with the main pieces, columns 32 / 33 with one extra piece of the first 16 * WA * AROWS threads.
@@ -106,7 +110,8 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
 #pragma unroll
     for (int sub = 0; sub < WB; ++sub) {
       const int gx = x0 + pc, ch = b0 + sub * 32 + q8 * 4;
-      bbase_t[sub] = (gx < W && ch < CB) ? (gx * CB + ch) * 4 : UNET_OOB;
+      if (VDY) bbase_t[sub] = gx < W ? gx * 8 : UNET_OOB;          // (the eight quads of a pixel read the same 8 bytes)
+      else bbase_t[sub] = (gx < W && ch < CB) ? (gx * CB + ch) * 4 : UNET_OOB;
     }
     // halo piece: thread t < 16 * WA * AROWS -> column 32 + ((t >> 3) & 1), (sub, row) = t >> 4
     constexpr int HALO_T = 16 * WA * AROWS;
@@ -151,7 +156,8 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
         for (int row = 0; row < R; ++row) {
           const int gy = ys + row;
           const bool ok = gy < yb;                                       // rows past the chunk contribute 0
-          breg[sub * R + row] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, ok ? bbase_t[sub] : UNET_OOB, ok ? gy * W * CB * 4 : 0, 0);
+          if (VDY) { const unet_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_b, ok ? bbase_t[sub] : UNET_OOB, ok ? gy * W * 8 : 0, 0); breg[sub * R + row][0] = v[0]; breg[sub * R + row][1] = v[1]; }
+          else breg[sub * R + row] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, ok ? bbase_t[sub] : UNET_OOB, ok ? gy * W * CB * 4 : 0, 0);
         }
     };
     auto post_amax = [&]() __attribute__((always_inline)) {
@@ -161,9 +167,11 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
 #pragma unroll
         for (int j = 0; j < 4; ++j) ma = fmaxf(ma, fabsf(__uint_as_float(areg[k][j])));
 #pragma unroll
-      for (int k = 0; k < NB_; ++k)
+      for (int k = 0; k < NB_; ++k) {
+        if (VDY) { mb = fmaxf(mb, breg[k][1] ? fabsf(__uint_as_float(breg[k][0])) : 0.f); continue; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) mb = fmaxf(mb, fabsf(__uint_as_float(breg[k][j])));
+      }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
       if (lane == 0) { s_amax[0][wave] = ma; s_amax[1][wave] = mb; }
@@ -212,7 +220,19 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
 #pragma unroll
       for (int sub = 0; sub < WB; ++sub)
 #pragma unroll
-        for (int row = 0; row < R; ++row) put(s_b + ((sub * R + row) * 32 + pc) * 64 + q8 * 8, breg[sub * R + row], sb);
+        for (int row = 0; row < R; ++row) {
+          char* dst = s_b + ((sub * R + row) * 32 + pc) * 64 + q8 * 8;
+          if (VDY) {
+            const unet_u32x4& v = breg[sub * R + row];
+            const float x = __uint_as_float(v[0]) * sb;
+            unsigned hh, mm;
+            split2(x, x, hh, mm);
+            const unsigned nib = v[1] >> (q8 * 4);                   // bits 0..3: this piece's four channels
+            const unsigned k01 = ((nib & 1u) ? 0xFFFFu : 0u) | ((nib & 2u) ? 0xFFFF0000u : 0u), k23 = ((nib & 4u) ? 0xFFFFu : 0u) | ((nib & 8u) ? 0xFFFF0000u : 0u);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(hh & k01, hh & k23);
+            *reinterpret_cast<uint2*>(dst + STAGE1) = make_uint2(mm & k01, mm & k23);
+          } else put(dst, breg[sub * R + row], sb);
+        }
     };
 
     issue_loads(ya, 0);
@@ -300,14 +320,15 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
   if (wr != 0) return;
   float* P = part + (long long)split * pstride;
   const int ar = a0 + wa * 32, bc = b0 + wb * 32 + l31;
+  const float cscale = VDY ? (bc < CB ? colscale[bc] : 0.f) : 1.0f;          // (VDY: the operand was dz [y > 0]; the column's head weight comes last)
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = acc[t][r];
+      if (ar + m < CA && bc < CB) P[((long long)t * CA + ar + m) * CB + bc] = VDY ? acc[t][r] * cscale : acc[t][r];
     }
-  if (wa == 0 && ta == 0 && lane < 32 && bc < CB) P[(long long)TAPS * CA * CB + bc] = bsum;
+  if (wa == 0 && ta == 0 && lane < 32 && bc < CB) P[(long long)TAPS * CA * CB + bc] = VDY ? bsum * cscale : bsum;
 }
 
 // ---- ConvT 2x2 stride 2 (T1:886 ...): dK[ab][o][c] = sum_{n,i,j} dU[n, 2i+a, 2j+b, o] * x[n, i, j, c],  db[o] = sum dU.
@@ -626,14 +647,33 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
 #define UNET_WG(WA_, WB_, WR_) hipLaunchKernelGGL((wgrad_h2_kernel<WA_, WB_, WR_, 2>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, \
-                                                  p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb)
+                                                  p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb, (const float*)nullptr)
   if (p.WA == 2 && p.WB == 2) UNET_WG(2, 2, 1);
   else if (p.WA == 2) UNET_WG(2, 1, 2);
   else if (p.WB == 2) UNET_WG(1, 2, 2);
   else hipLaunchKernelGGL((wgrad_h2_kernel<1, 1, 4, 4>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S,
-                          p.units, p.upb);
+                          p.units, p.upb, (const float*)nullptr);
 #undef UNET_WG
   UNET_CHECK_LAUNCH(ctx, "wgrad_h2");
+  return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
+}
+
+// The weight gradient of the last conv3x3 (cin -> 32, T1:911) from the head's rank-1 stream dzm[n,h,wd] = {dz, 32 mask bits} (k_head_dzm) and the head's weights w_head[32]:
+// dw[3][3][cin][32], db[32] (overwritten); cin = 32 (one channel tile: the kernel form with four row phases)
+int32_t k_conv3x3_h2_wgrad_dzm(unet_ctx* ctx, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin,
+                               hipStream_t s) {
+  const int cout = 32;
+  if (!x || !dzm || !w_head || cin != 32) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2 behind the head stream: cin=%d (32)", cin);
+  if ((long long)h * wd * 32 * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  const WgPlanH2 p = plan_wgrad_h2(n, h, wd, cin, cout);
+  if (!ws || ws_bytes < p.floats * sizeof(float)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad h2: workspace %zu < %zu bytes", ws_bytes, p.floats * sizeof(float));
+  float* part = static_cast<float*>(ws);
+  const long long S = 9LL * cin * cout + cout;
+  const int npairs = p.tiles_a * p.tiles_b;
+  const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
+  hipLaunchKernelGGL((wgrad_h2_kernel<1, 1, 4, 4, true>), grid, dim3(256), 0, s, x, static_cast<const float*>(dzm), part, n, h, wd, cin, cout, p.tiles_b, p.strips, p.rows_per_chunk,
+                     p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb, w_head);
+  UNET_CHECK_LAUNCH(ctx, "wgrad_h2_dzm");
   return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
 }
 

@@ -67,6 +67,7 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_HEAD_FUSED: return &ctx->opt_head_fused;
     case UNET_OPT_SKIP_RAW: return &ctx->opt_skip_raw;
     case UNET_OPT_POOL_SUMS_FUSED: return &ctx->opt_pool_sums_fused;
+    case UNET_OPT_HEAD_BWD_FUSED: return &ctx->opt_head_bwd_fused;
     default: return nullptr;
   }
 }
@@ -194,6 +195,28 @@ int32_t unet_conv3x3_head_fwd(unet_ctx* ctx, const float* x, const float* w, con
   if (!r && armed && ctx->signs_done != armed) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_head_fwd: armed with unet_request_relu_bits but the launch did not write them");
   if (!r && y_true) r = k_head_fold(ctx, loss_sums, head_sums, as_stream(stream));
   return r;
+}
+int32_t unet_head_bwd_stream_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cin) {
+  return ctx && cin == 32 && h2_head_bwd_selected(ctx, algo, wd, cin) && h2_wgrad_selected(algo, cin, 32) ? 1 : 0;
+}
+int32_t unet_head_dzm(unet_ctx* ctx, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const void* relu_bits, void* dzm,
+                      float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream) {
+  if (!ctx) return UNET_E_ARG;
+  return k_head_dzm(ctx, p, y_true, loss_sums, count, head_sums, static_cast<const unsigned long long*>(relu_bits), dzm, dw_head, db_head, n, h, wd, as_stream(stream));
+}
+int32_t unet_conv3x3_bwd_data_dzm(unet_ctx* ctx, const void* dzm, const float* w, const float* w_head, const void* relu_bits_in, float* dx, float* wt_ws, int32_t n, int32_t h,
+                                  int32_t wd, int32_t cin, void* stream) {
+  if (!ctx || !dzm || !w || !w_head || !dx || !wt_ws || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_data_dzm: bad args");
+  if (!unet_head_bwd_stream_supported(ctx, UNET_ALGO_AUTO, wd, cin)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bwd_data_dzm: not supported here (unet_head_bwd_stream_supported)");
+  int32_t r = k_h2_weights(ctx, w, wt_ws, cin, 32, 1, as_stream(stream), w_head);          // (the head's weights: a per-contraction-channel factor of the image)
+  if (r) return r;
+  return k_conv3x3_h2_dgrad_dzm(ctx, dzm, wt_ws, static_cast<const float*>(relu_bits_in), relu_bits_in ? MASK_RELU_BITS : MASK_NONE, dx, n, h, wd, cin, as_stream(stream));
+}
+int32_t unet_conv3x3_bwd_weights_dzm(unet_ctx* ctx, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int32_t n, int32_t h,
+                                     int32_t wd, int32_t cin, void* stream) {
+  if (!ctx || !x || !dzm || !w_head || !dw || !db || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_weights_dzm: bad args");
+  if (!unet_head_bwd_stream_supported(ctx, UNET_ALGO_AUTO, wd, cin)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bwd_weights_dzm: not supported here (unet_head_bwd_stream_supported)");
+  return k_conv3x3_h2_wgrad_dzm(ctx, x, dzm, w_head, dw, db, ws, ws_bytes, n, h, wd, cin, as_stream(stream));
 }
 int32_t unet_head_dy(unet_ctx* ctx, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const float* w_head, const void* relu_bits,
                      const float* y, float* dy, float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream) {
@@ -420,6 +443,8 @@ struct unet_model {
   // output is never stored (pool reads the raw tensor; the decoder fold composes the two BatchNorms: bn_comp_off = [scale'][shift'][pre_s][pre_t] x 2C per decoder level)
   bool skip_raw = false; std::map<std::string, size_t> bn_comp_off; size_t off_tap_tmp = 0;
   std::set<std::string> pool_sums_fused;          // pooled tensors whose backward sums come out of the data-gradient epilogue (MASK_POOL_SUMS)
+  bool c9b_virtual = false;               // HEAD_BWD_FUSED with sign bits: the fused head launch does not store c9b's output at all (a tap recomputes it)
+  bool head_bwd_fused = false;            // ... and its backward as the {dz, mask} stream the two gradients of c9b expand (HEAD_BWD_FUSED; the stream sits at the start of c9b's gradient buffer)
   size_t off_head_sums = 0; bool head_fused = false;          // U-Net, fp32 h2 kernels: c9b + 1x1 head + loss sums in one launch (kernels_conv_h2.hip, HEAD)
   std::map<std::string, size_t> sign_off;            // U-Net fp32 training: activation name -> its one-bit-per-element ReLU mask (MASK_RELU_BITS), offset in floats
   std::map<std::string, size_t> wprep_f, wprep_b;    // U-Net fp32: per-layer scratch of the prepared weights: the split fp16 image of the h2 kernels (forward / data-gradient form),
@@ -740,20 +765,23 @@ void build_programs(unet_model* m) {
   std::vector<PrepItem> convt_items;
   for (auto& l : m->layers) if (l.kind == 1 && m->wprep_f.count(l.name)) convt_items.push_back({l.name, l.cin, l.cout, 0, 0});
   auto prep_weights = [=](int flip, hipStream_t s) -> int32_t {          // fp32: the split fp16 weight images of every conv3x3 / ConvT launch that runs on the h2 kernels: two launches
-    const float* ws_[UNET_PREP_MAX]; void* is_[UNET_PREP_MAX]; int ci_[UNET_PREP_MAX], co_[UNET_PREP_MAX], kd_[UNET_PREP_MAX], nx = 0;
+    const float* ws_[UNET_PREP_MAX]; const float* cs_[UNET_PREP_MAX]; void* is_[UNET_PREP_MAX]; int ci_[UNET_PREP_MAX], co_[UNET_PREP_MAX], kd_[UNET_PREP_MAX], nx = 0;
+    for (int k = 0; k < UNET_PREP_MAX; ++k) cs_[k] = nullptr;
     for (auto& it : prep_items) {
       const int K = flip ? it.cout : it.cin, M = flip ? it.cin : it.cout;          // channels the launch consumes / produces
       if (flip && it.name == "c1a") continue;
       const bool folded = !flip && m->fold_off.count(it.name) != 0;          // image prepared after its BatchNorm's finalize (bn_fold_prepare): only the raw-weight maxima here (kind 4)
       if (!h2_conv3x3_selected(algo, K, M)) continue;
       if (nx >= UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch (a skipped layer would run on an image that was never written)");
-      ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = folded ? 4 : flip; ++nx;
+      ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = folded ? 4 : flip;
+      if (flip && it.name == "c9b" && m->head_bwd_fused) cs_[nx] = m->P("out/kernel");          // the data gradient contracts dz [y > 0] with w_head[c] W[c][.]: the head's weights ride in the image
+      ++nx;
     }
     for (auto& it : convt_items) {
       if (nx >= UNET_PREP_MAX) UNET_FAIL(ctx, UNET_E_STATE, "weight images: too many layers for one batch");
       ws_[nx] = m->P(it.name + "/kernel"); is_[nx] = m->wsf((flip ? m->wprep_b : m->wprep_f).at(it.name)); ci_[nx] = it.cin; co_[nx] = it.cout; kd_[nx] = flip ? 3 : 2; ++nx;
     }
-    return k_h2_prep_multi(ctx, ws_, nullptr, is_, ci_, co_, kd_, nx, s);
+    return k_h2_prep_multi(ctx, ws_, cs_, is_, ci_, co_, kd_, nx, s);
   };
 
   // ------------------------------------------------------------------ forward (train / infer)
@@ -890,6 +918,7 @@ void build_programs(unet_model* m) {
       } else
       conv("c" + ks + "a", "bn" + ks, 2 * c, c);
       if (k == 9 && m->head_fused) {
+        m->c9b_virtual = ctx->opt_head_bwd_fused && m->sign_off.count("c9b") != 0;
         // T1:911-913 in one launch: c9b, the 1x1 sigmoid head, the loss sums and the sums of the head's weight gradient (kernels_conv_h2.hip, HEAD)
         const Buf ob = m->act.at("c9b"); const double px = (double)ob.n * ob.h * ob.w;
         ADD_OP(F, "conv3x3_fwd_head:c9b", 2.0 * 9 * c * c * px + 2.0 * c * px, 4.0 * px * (c + c) + 4.0 * 9.0 * c * c + 8.0 * px, {
@@ -897,8 +926,9 @@ void build_programs(unet_model* m) {
           const auto so = training ? m->sign_off.find("c9b") : m->sign_off.end();
           unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
           ctx->signs_req = sg; ctx->signs_done = nullptr;
-          int32_t r = k_conv3x3_h2_head_fwd(ctx, m->A("c9a"), m->wsf(m->wprep_f.at("c9b")), m->P("c9b/bias"), m->Aw("c9b"), m->P("out/kernel"), m->P("out/bias"), m->pout, m->yt,
-                                            ob.n, ob.h, ob.w, c, s);
+          // (c9b_virtual: nothing reads the tensor -- the backward takes p, the sums and the sign bits, inference takes p -- so it is not written: -0.5 GB per step at 512 x 512 x 16)
+          int32_t r = k_conv3x3_h2_head_fwd(ctx, m->A("c9a"), m->wsf(m->wprep_f.at("c9b")), m->P("c9b/bias"), m->c9b_virtual ? nullptr : m->Aw("c9b"), m->P("out/kernel"), m->P("out/bias"),
+                                            m->pout, m->yt, ob.n, ob.h, ob.w, c, s);
           ctx->signs_req = nullptr;
           if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd_head: the launch did not write the ReLU sign bits its backward was planned with");
           return r;
@@ -942,6 +972,14 @@ void build_programs(unet_model* m) {
     const int64_t hp = (int64_t)hb.n * hb.h * hb.w;
     if (!dt) ADD_OP(BW, "weight_images:bwd", 0, 0, { return prep_weights(1, s); });
     else ADD_OP(BW, "weight_images:bwd", 0, 0, { return prep_weights_bf16(1, s); });
+    m->head_bwd_fused = m->head_fused && ctx->opt_head_bwd_fused && m->arch == UNET_ARCH_UNET && m->sign_off.count("c9b") && m->wprep_b.count("c9b") && h2_head_bwd_selected(ctx, algo, hb.w, 32) &&
+                        h2_wgrad_selected(algo, 32, 32);
+    if (m->head_bwd_fused) ADD_OP(BW, "head_dzm", 8.0 * hp, hp * (8.0 + 4.0 + 8.0), {
+      if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_dzm: io not set");
+      return k_head_dzm(ctx, m->pout, m->yt, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsd(m->off_head_sums), reinterpret_cast<const unsigned long long*>(m->wsf(m->sign_off.at("c9b"))),
+                        m->D("c9b"), m->G("out/kernel"), m->G("out/bias"), hb.n, hb.h, hb.w, s);
+    });
+    else
     if (m->head_fused) ADD_OP(BW, "head_dy", 2.0 * 32 * hp, hp * (4.0 * 32 + 8.0 + 4.0), {
       if (!m->yt || !m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_dy: io not set");
       const auto so = m->sign_off.find("c9b");
@@ -977,6 +1015,8 @@ void build_programs(unet_model* m) {
                                       cin, cout, s);
         }
         const float* xin = xsrc.empty() ? m->x : m->A(xsrc);
+        if (name == "c9b" && m->head_bwd_fused)               // dy = the head's {dz, mask} stream (head_dzm above)
+          return k_conv3x3_h2_wgrad_dzm(ctx, xin, m->D(name), m->P("out/kernel"), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, s);
         return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
                                       ob.n, ob.h, ob.w, cin, cout, algo, s);
       });
@@ -1043,6 +1083,9 @@ void build_programs(unet_model* m) {
                                             ob.w, cout, cin, ACT_NONE, 0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s, CBF(static_cast<void*>(m->wsf(m->wprep_b.at(name)))));
           const auto pb = m->wprep_b.find(name);
           const auto so = mask_in ? m->sign_off.find(in) : m->sign_off.end();
+          if (name == "c9b" && m->head_bwd_fused)
+            return k_conv3x3_h2_dgrad_dzm(ctx, m->D(name), m->wsf(pb->second), so != m->sign_off.end() ? m->wsf(so->second) : mask_in ? m->A(in) : nullptr,
+                                          so != m->sign_off.end() ? MASK_RELU_BITS : mask_in ? MASK_RELU : MASK_NONE, m->D(in), ob.n, ob.h, ob.w, cin, s);
           if (so != m->sign_off.end())                        // one bit per element instead of the fp32 activation (written by the forward conv that produced `in`)
             return conv3x3_fwd_dispatch(ctx, m->D(name), m->P(name + "/kernel"), nullptr, m->wsf(so->second), MASK_RELU_BITS, m->D(in), ob.n, ob.h,
                                         ob.w, cout, cin, ACT_NONE, 0.0f, 0, algo, s, m->wsf(m->off_wt), 1, pb == m->wprep_b.end() ? nullptr : m->wsf(pb->second));
@@ -2075,6 +2118,15 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
     if (m->fold_c_off.count(conv)) return UNET_E_STATE;
   }
   const std::string nm_ = name;
+  if (!grad && m->c9b_virtual && nm_ == "c9b") {
+    // the fused head launch did not store this tensor: a tap recomputes it from c9a with the weight image of the last forward (bias: the current parameter)
+    const Buf& xb = m->act.at("c9a");
+    int32_t r = k_conv3x3_h2_fwd(m->ctx, m->A("c9a"), m->wsf(m->wprep_f.at("c9b")), m->P("c9b/bias"), nullptr, MASK_NONE, const_cast<float*>(m->A("c9b")), xb.n, xb.h, xb.w, xb.c, b.c, ACT_RELU,
+                                 0.0f, 0, nullptr);
+    if (r) return r;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return UNET_E_HIP;
+  }
+  if (grad && m->head_bwd_fused && nm_ == "c9b") return UNET_E_STATE;          // the head's backward leaves the {dz, mask} stream there, not the tensor (HEAD_BWD_FUSED)
   if (!grad && m->skip_raw && nm_.size() == 3 && nm_[0] == 'b' && nm_[2] >= '1' && nm_[2] <= '4') {
     // skip_raw: an encoder BatchNorm's output is never stored -- a tap materialises it from the raw conv output (inside the concat) into the tap scratch
     const std::string cb = std::string("c") + nm_[2] + "b";

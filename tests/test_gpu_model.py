@@ -99,8 +99,9 @@ def test_live_oracle_all_grads_and_taps(hw, n):
     tol_a, tol_g = 2e-4, 3e-4
     # gradients wrt activations (ours are already ReLU-masked where the producer is a ReLU conv)
     for name, masked in (("c9b", True), ("c9a", True), ("bn9", False), ("u9", False), ("c5b", True), ("p4", False), ("c4b", True), ("c1a", True)):       # (bn4's total gradient is only formed inside the fused encoder-tail pass: c4b checks its result)
-        if name == "bn9":
-            # folded: the gradient w.r.t. bn9's output lives only in the data-gradient epilogue of c9a (which writes the gradient of the raw concat: "u9" below)
+        if name in ("bn9", "c9b"):
+            # folded: the gradient w.r.t. bn9's output lives only in the data-gradient epilogue of c9a (which writes the gradient of the raw concat: "u9" below);
+            # c9b's output gradient exists only as the head's {dz, mask} stream (head_bwd_fused; the tensor form is compared in test_gpu_ops.py and with the option off below)
             with pytest.raises(Exception):
                 eng.tap(n, name, grad=True)
             continue
@@ -410,7 +411,7 @@ def test_context_options_select_the_graph_forms_in_one_process():
     ref = make(64, 96, dropout_rate=0.0); ref.set_weights(wts); ref.forward_backward(x, y); gref = ref.get_grads()
     assert not any(n.startswith("bn_apply:bn9") for n in ops_of(ref, 0)) and any(n.startswith("conv3x3_dgrad_bn_bwd:c9a") for n in ops_of(ref, 1))
     assert "conv3x3_dgrad_pool_sums:c2a" in ops_of(ref, 1) and "pool_bwd_skip_term:p1" in ops_of(ref, 1) and "pool_bwd_sums:p1" not in ops_of(ref, 1)
-    assert "conv3x3_fwd_head:c9b" in ops_of(ref, 0) and "head_fwd" not in ops_of(ref, 0) and "head_dy" in ops_of(ref, 1) and "conv3x3_fwd_head:c9b" in ops_of(ref, 2)
+    assert "conv3x3_fwd_head:c9b" in ops_of(ref, 0) and "head_fwd" not in ops_of(ref, 0) and "head_dzm" in ops_of(ref, 1) and "head_dy" not in ops_of(ref, 1) and "conv3x3_fwd_head:c9b" in ops_of(ref, 2)
     lref = ref.forward_backward(x, y).cpu().numpy()
     # skip_raw (default): c<k>b IS the skip half of its concat (same memory, pixel stride 2C) and the encoder BatchNorm's output exists only as a tap
     a1, c9 = ref.tap_device(2, "c1b"), ref.tap_device(2, "cat9")
@@ -420,7 +421,7 @@ def test_context_options_select_the_graph_forms_in_one_process():
     for nm in ("bn1", "bn3", "c2b", "p2", "bn9", "c9a"):
         assert relerr(ref.tap(2, nm), off.tap(2, nm)) < 2e-6, nm
     for opts, expect_fwd, expect_bwd in (({"bn_fold": 0}, "bn_apply:bn9", "bn_bwd_apply:bn9"), ({"bn_fold": 1}, None, "bn_bwd_apply:bn9"), ({"head_fused": 0}, "head_fwd", "head_bwd"),
-                                         ({"head_fused": 1, "relu_bits": 0}, "conv3x3_fwd_head:c9b", "head_dy"), ({"skip_raw": 0}, None, None), ({"pool_sums_fused": 0}, None, "pool_bwd_sums:p1"),
+                                         ({"head_fused": 1, "relu_bits": 0}, "conv3x3_fwd_head:c9b", "head_dy"), ({"skip_raw": 0}, None, None), ({"pool_sums_fused": 0}, None, "pool_bwd_sums:p1"), ({"head_bwd_fused": 0}, None, "head_dy"),
                                          ({"enc_bn_fused": 0}, None, "pool_bwd_bnstats:p1"), ({"relu_bits": 0}, None, None),
                                          ({"bn_concat_analytic": 0, "bn_fuse_stats": 0}, None, None), ({"deterministic": 1}, None, None)):
         eng = make(64, 96, dropout_rate=0.0, options=opts); eng.set_weights(wts); eng.forward_backward(x, y)

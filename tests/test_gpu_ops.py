@@ -379,6 +379,69 @@ def test_conv3x3_head_fused_fwd_and_dy(ops, shape):
     assert abs(s3n[0] - sn[0]) < 0.5                                # (the BCE sum: the separate kernel takes the logit from p -- 0.39 (1 - t) off on the one pixel with z = 15.55, above)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 24), (1, 40, 72), (3, 9, 8), (1, 6, 104)])
+def test_head_backward_as_a_stream_expanded_by_the_last_convs_gradients(ops, shape):
+    """dL/d(output of the last conv3x3) = dz_p w_c [y_pc > 0] (T1:911-913 backwards) has one fp32 degree of freedom and 32 mask bits per pixel: unet_head_dzm writes that
+    stream (8 bytes per pixel) and unet_conv3x3_bwd_data_dzm / unet_conv3x3_bwd_weights_dzm expand it while staging.  Checked: the stream IS the tensor unet_head_dy writes
+    (dz w_c [bit c] equal in every bit), and both gradients against float64 (same masks) and against the launches that read the fp32 tensor."""
+    import torch.nn.functional as F
+    from gpu_util import relerr
+    n, h, w = shape
+    c = 32
+    assert ops.lib.unet_head_bwd_stream_supported(ops.h, 0, w, c) == 1 and ops.lib.unet_head_bwd_stream_supported(ops.h, 0, w, 64) == 0 and ops.lib.unet_head_bwd_stream_supported(ops.h, 0, w + 4, c) == 0
+    pixels = n * h * w
+    rng = np.random.default_rng(5 + w)
+    x0 = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    ka = (rng.standard_normal((3, 3, c, c)) * (2.0 / (9 * c)) ** 0.5).astype(np.float32); ba = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    k3 = (rng.standard_normal((3, 3, c, c)) * (2.0 / (9 * c)) ** 0.5).astype(np.float32); b3 = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    k = (rng.standard_normal((1, 1, c, 1)) * 0.8).astype(np.float32); b = np.array([-0.2], np.float32)
+    k[0, 0, 7, 0] = 0.0                                               # (a head weight of zero: its column of the weight gradient is zero)
+    t = (np.round(rng.random((n, h, w, 1)) ** 2 * 255) / 255).astype(np.float32)
+    # x = relu(conv(x0)) with its sign bits (the mask of the data gradient), then the fused last conv + head with the sign bits of y
+    x = ops.z(n, h, w, c); bits_in = torch.zeros(pixels * c // 64, dtype=torch.int64, device="cuda")
+    ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits_in.data_ptr()), "arm")
+    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x0).data_ptr(), ops.d(ka).data_ptr(), ops.d(ba).data_ptr(), x.data_ptr(), n, h, w, c, c, 1, 0.0, 0, 0, ops.wws(c, c), ops.s), "conv + bits")
+    y = ops.z(n, h, w, c); p = ops.z(n, h, w, 1); sums = ops.z(4, dtype=torch.float64); hs = ops.z(99, dtype=torch.float64)
+    bits = torch.zeros(pixels * c // 64, dtype=torch.int64, device="cuda")
+    ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits.data_ptr()), "arm")
+    ops.ck(ops.lib.unet_conv3x3_head_fwd(ops.h, x.data_ptr(), ops.d(k3).data_ptr(), ops.d(b3).data_ptr(), y.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p.data_ptr(),
+                                         ops.d(t).data_ptr(), sums.data_ptr(), hs.data_ptr(), n, h, w, c, ops.wws(c, c), ops.s), "conv + head fwd")
+    # the fp32 tensor and what reads it
+    dy = ops.z(n, h, w, c); dwh = ops.z(c); dbh = ops.z(1)
+    ops.ck(ops.lib.unet_head_dy(ops.h, p.data_ptr(), ops.d(t).data_ptr(), sums.data_ptr(), float(pixels), hs.data_ptr(), ops.d(k).data_ptr(), bits.data_ptr(), y.data_ptr(), dy.data_ptr(),
+                                dwh.data_ptr(), dbh.data_ptr(), n, h, w, ops.s), "head dy")
+    dx_t = ops.z(n, h, w, c)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, dy.data_ptr(), ops.d(k3).data_ptr(), bits_in.data_ptr(), 9, 0.0, 0, dx_t.data_ptr(), ops.wws(c, c), n, h, w, c, c, 0, ops.s), "dgrad of the tensor")
+    wsb = int(ops.lib.unet_conv3x3_bwd_weights_ws_bytes(n, h, w, c, c)); wsg = torch.zeros(wsb // 4 + 16, device="cuda")
+    dw_t = ops.z(3, 3, c, c); db_t = ops.z(c)
+    ops.ck(ops.lib.unet_conv3x3_bwd_weights(ops.h, x.data_ptr(), dy.data_ptr(), dw_t.data_ptr(), db_t.data_ptr(), wsg.data_ptr(), wsb, n, h, w, c, c, 0, ops.s), "wgrad of the tensor")
+    # the stream
+    dzm = torch.zeros(pixels, dtype=torch.int64, device="cuda"); dwh2 = ops.z(c); dbh2 = ops.z(1)
+    ops.ck(ops.lib.unet_head_dzm(ops.h, p.data_ptr(), ops.d(t).data_ptr(), sums.data_ptr(), float(pixels), hs.data_ptr(), bits.data_ptr(), dzm.data_ptr(), dwh2.data_ptr(), dbh2.data_ptr(),
+                                 n, h, w, ops.s), "head dzm")
+    assert torch.equal(dwh, dwh2) and torch.equal(dbh, dbh2)
+    st = dzm.cpu().numpy().view(np.uint32).reshape(pixels, 2)
+    dz = st[:, 0].copy().view(np.float32); mask = st[:, 1]
+    yn = y.cpu().numpy().reshape(pixels, c)
+    assert ((((mask[:, None] >> np.arange(c, dtype=np.uint32)) & 1) == 1) == (yn > 0)).all()
+    assert np.array_equal(np.where(yn > 0, dz[:, None] * k.reshape(1, c), np.float32(0)).astype(np.float32), dy.cpu().numpy().reshape(pixels, c))
+    dx = ops.z(n, h, w, c); dw = ops.z(3, 3, c, c); db = ops.z(c)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data_dzm(ops.h, dzm.data_ptr(), ops.d(k3).data_ptr(), ops.d(k).data_ptr(), bits_in.data_ptr(), dx.data_ptr(), ops.wws(c, c), n, h, w, c, ops.s), "dgrad of the stream")
+    ops.ck(ops.lib.unet_conv3x3_bwd_weights_dzm(ops.h, x.data_ptr(), dzm.data_ptr(), ops.d(k).data_ptr(), dw.data_ptr(), db.data_ptr(), wsg.data_ptr(), wsb, n, h, w, c, ops.s), "wgrad of the stream")
+    # float64 from the same stream and the same masks
+    xn = x.cpu().numpy()
+    dpre = T64(np.where(yn > 0, dz.astype(np.float64)[:, None] * k.reshape(1, c).astype(np.float64), 0.0).reshape(n, h, w, c)).permute(0, 3, 1, 2)
+    xt = T64(xn).permute(0, 3, 1, 2).requires_grad_(True); kt = T64(k3).permute(3, 2, 0, 1).requires_grad_(True)
+    F.conv2d(xt, kt, padding=1).backward(dpre)
+    dx64 = xt.grad.permute(0, 2, 3, 1).numpy() * (xn > 0); dw64 = kt.grad.permute(2, 3, 1, 0).numpy(); db64 = dpre.sum((0, 2, 3)).numpy()
+    assert relerr(dx.cpu().numpy(), dx64) < 5e-6 and relerr(dx_t.cpu().numpy(), dx64) < 5e-6
+    assert relerr(dw.cpu().numpy(), dw64) < 5e-6 and relerr(dw_t.cpu().numpy(), dw64) < 5e-6
+    assert relerr(db.cpu().numpy(), db64) < 5e-6 and float(np.abs(dw.cpu().numpy()[:, :, :, 7]).max()) == 0.0 and float(db.cpu().numpy()[7]) == 0.0
+    # no mask on the data gradient (relu_bits_in = NULL)
+    ops.ck(ops.lib.unet_conv3x3_bwd_data_dzm(ops.h, dzm.data_ptr(), ops.d(k3).data_ptr(), ops.d(k).data_ptr(), None, dx.data_ptr(), ops.wws(c, c), n, h, w, c, ops.s), "dgrad of the stream, no mask")
+    assert relerr(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy()) < 5e-6
+
+
 @pytest.mark.parametrize("shape,rate", [((2, 16, 32, 64, 32), 0.25), ((1, 24, 40, 128, 64), 0.25), ((2, 8, 8, 256, 128), 0.0), ((3, 16, 16, 64, 64), 0.4)])
 def test_conv3x3_dgrad_with_pooled_sums_in_the_epilogue(ops, shape, rate):
     """unet_conv3x3_bwd_data_pool_sums: the data gradient of the conv behind MaxPooling2D + Dropout (T1:862-865) with the pooled-path sums of the encoder tail's BatchNorm
