@@ -283,7 +283,8 @@ int32_t unet_conv3x3_bwd_data_pool_sums(unet_ctx*, const float* dy, const float*
  *   loss_sums[4] += (sum bce, sum t p, sum t, sum p)   -- as unet_head_fwd
  *   head_sums[99] += per channel c: sum a y_c | sum t q y_c | sum q y_c  (a = dBCE/dz = p_clipped - t inside the clip range, q = p (1 - p)), then sum a, sum t q, sum q
  * The head's weight gradient is a combination of head_sums once the batch-global Dice sums are known (unet_head_dy), so the backward needs no pass
- * over y.  ReLU sign bits of y can be requested as for unet_conv3x3_fwd (unet_request_relu_bits).  w_ws: unet_conv3x3_w_ws_floats(cin, 32) floats. */
+ * over y.  ReLU sign bits of y can be requested as for unet_conv3x3_fwd (unet_request_relu_bits).  w_ws: unet_conv3x3_w_ws_floats(cin, 32) floats.
+ * y may be NULL: the 32-channel tensor is then not stored (a backward through unet_head_dzm reads p, the sums and the sign bits only; inference reads p). */
 int32_t unet_conv3x3_head_supported(unet_ctx*, int32_t algo, int32_t w, int32_t cin, int32_t cout);
 int32_t unet_conv3x3_head_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y, const float* w_head, const float* b_head, float* p,
                               const float* y_true, double* loss_sums, double* head_sums, int32_t n, int32_t h, int32_t wd, int32_t cin, float* w_ws, void* stream);

@@ -185,7 +185,7 @@ int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const fl
 int32_t unet_conv3x3_head_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cin, int32_t cout) { return ctx && h2_conv3x3_head_selected(ctx, algo, wd, cin, cout) ? 1 : 0; }
 int32_t unet_conv3x3_head_fwd(unet_ctx* ctx, const float* x, const float* w, const float* bias, float* y, const float* w_head, const float* b_head, float* p, const float* y_true,
                               double* loss_sums, double* head_sums, int32_t n, int32_t h, int32_t wd, int32_t cin, float* w_ws, void* stream) {
-  if (!ctx || !x || !w || !bias || !y || !w_head || !b_head || !p || !w_ws || n < 1 || h < 1 || wd < 1 || (y_true && (!loss_sums || !head_sums)))
+  if (!ctx || !x || !w || !bias || !w_head || !b_head || !p || !w_ws || n < 1 || h < 1 || wd < 1 || (y_true && (!loss_sums || !head_sums)))          // (y null: the 32-channel tensor is not stored)
     UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_head_fwd: bad args");
   if (!h2_conv3x3_head_selected(ctx, UNET_ALGO_AUTO, wd, cin, 32)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_head_fwd: not supported here (unet_conv3x3_head_supported)");
   unsigned long long* armed = ctx->signs_req;

@@ -371,6 +371,12 @@ def test_conv3x3_head_fused_fwd_and_dy(ops, shape):
     ops.ck(ops.lib.unet_conv3x3_head_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k3).data_ptr(), ops.d(b3).data_ptr(), y2.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p2.data_ptr(),
                                          None, None, None, n, h, w, cin, ops.wws(cin, c), ops.s), "conv + head fwd (predict)")
     assert (p2.cpu().numpy() == p.cpu().numpy()).all() and (y2.cpu().numpy() == yn).all()
+    # y = NULL: nothing but the 32-channel store is left out -- same probabilities, same sums, same sign bits
+    p4 = ops.z(n, h, w, 1); s4 = ops.z(4, dtype=torch.float64); hs4 = ops.z(99, dtype=torch.float64); bits4 = torch.zeros_like(bits)
+    ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits4.data_ptr()), "arm")
+    ops.ck(ops.lib.unet_conv3x3_head_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k3).data_ptr(), ops.d(b3).data_ptr(), None, ops.d(k).data_ptr(), ops.d(b).data_ptr(), p4.data_ptr(),
+                                         ops.d(t).data_ptr(), s4.data_ptr(), hs4.data_ptr(), n, h, w, cin, ops.wws(cin, c), ops.s), "conv + head fwd (no y)")
+    assert torch.equal(p4, p) and torch.equal(bits4, bits) and np.allclose(s4.cpu().numpy(), sn, rtol=1e-12, atol=1e-9) and np.allclose(hs4.cpu().numpy(), hs.cpu().numpy(), rtol=1e-9, atol=1e-9)
     # and against the separate kernels on the same y: same probabilities to the last bits, same gradient of the head
     p3 = ops.z(n, h, w, 1); s3 = ops.z(4, dtype=torch.float64)
     ops.ck(ops.lib.unet_head_fwd(ops.h, y.data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), p3.data_ptr(), ops.d(t).data_ptr(), s3.data_ptr(), pixels, c, ops.s), "head fwd")
