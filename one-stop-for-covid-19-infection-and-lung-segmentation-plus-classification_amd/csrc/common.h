@@ -96,6 +96,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 typedef float unet_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned unet_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned unet_u32x2 __attribute__((ext_vector_type(2)));
+#ifdef __HIPCC__
+// bits (b, b + 1) of v -> 0xFFFF in the low / high half of a packed fp16 pair: two sign-extending one-bit field extracts and one bit-field insert
+__device__ __forceinline__ unsigned h2_pair_mask(unsigned v, int b) {
+  // (as instructions: written with & / | / ?: the compiler turns each bit into and + compare + select + or -- 11 operations per pair of masks instead of 3)
+  unsigned lo, hi, r;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(lo) : "v"(v), "n"(b));
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(hi) : "v"(v), "n"(b + 1));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xFFFFu), "v"(lo), "v"(hi));
+  return r;
+}
+#endif
 constexpr int UNET_OOB = (int)0x80000000u;        // invalid element (or row)
 constexpr int UNET_COL_OOB = 0x40000000;          // invalid column part, may be added to a valid or invalid row part
 // `soff` = wave-uniform byte offset (an SGPR operand of the instruction: no per-lane add; it does not bring an out-of-range lane

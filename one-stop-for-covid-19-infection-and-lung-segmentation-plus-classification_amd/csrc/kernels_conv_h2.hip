@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
           unsigned hh, mm;
           split2(v, v, hh, mm);
           const unsigned nib = preg[k][1] >> (st_chunk * 16 + (tid & 3) * 4);          // bits 0..3: this piece's four channels
-          const unsigned k01 = ((nib & 1u) ? 0xFFFFu : 0u) | ((nib & 2u) ? 0xFFFF0000u : 0u), k23 = ((nib & 4u) ? 0xFFFFu : 0u) | ((nib & 8u) ? 0xFFFF0000u : 0u);
+          const unsigned k01 = h2_pair_mask(nib, 0), k23 = h2_pair_mask(nib, 2);
           h0 = hh & k01; h1 = hh & k23; m0 = mm & k01; m1 = mm & k23;
         } else {
         split2(__uint_as_float(preg[k][0]) * sc, __uint_as_float(preg[k][1]) * sc, h0, m0);

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
             unsigned hh, mm;
             split2(x, x, hh, mm);
             const unsigned nib = v[1] >> (q8 * 4);                   // bits 0..3: this piece's four channels
-            const unsigned k01 = ((nib & 1u) ? 0xFFFFu : 0u) | ((nib & 2u) ? 0xFFFF0000u : 0u), k23 = ((nib & 4u) ? 0xFFFFu : 0u) | ((nib & 8u) ? 0xFFFF0000u : 0u);
+            const unsigned k01 = h2_pair_mask(nib, 0), k23 = h2_pair_mask(nib, 2);
             *reinterpret_cast<uint2*>(dst) = make_uint2(hh & k01, hh & k23);
             *reinterpret_cast<uint2*>(dst + STAGE1) = make_uint2(mm & k01, mm & k23);
           } else put(dst, breg[sub * R + row], sb);

@@ -921,7 +921,7 @@ void build_programs(unet_model* m) {
         m->c9b_virtual = ctx->opt_head_bwd_fused && m->sign_off.count("c9b") != 0;
         // T1:911-913 in one launch: c9b, the 1x1 sigmoid head, the loss sums and the sums of the head's weight gradient (kernels_conv_h2.hip, HEAD)
         const Buf ob = m->act.at("c9b"); const double px = (double)ob.n * ob.h * ob.w;
-        ADD_OP(F, "conv3x3_fwd_head:c9b", 2.0 * 9 * c * c * px + 2.0 * c * px, 4.0 * px * (c + c) + 4.0 * 9.0 * c * c + 8.0 * px, {
+        ADD_OP(F, "conv3x3_fwd_head:c9b", 2.0 * 9 * c * c * px + 2.0 * c * px, 4.0 * px * (c + (m->c9b_virtual ? 0 : c)) + 4.0 * 9.0 * c * c + 8.0 * px + (training ? px * c / 8.0 : 0.0), {
           if (!m->pout) UNET_FAIL(ctx, UNET_E_STATE, "head_fwd: p_out not set (unet_model_set_io)");
           const auto so = training ? m->sign_off.find("c9b") : m->sign_off.end();
           unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
@@ -1008,7 +1008,8 @@ void build_programs(unet_model* m) {
       const double px = (double)ob.n * ob.h * ob.w;
       const std::string xsrc = xraw.empty() ? in : xraw;
       auto& WV = (defer_wgrad && xraw.empty()) ? DEF : BW;
-      ADD_OP(WV, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cin + cout) + 4.0 * 9.0 * cin * cout, {
+      const bool hstream = name == "c9b" && m->head_bwd_fused;          // dy = the head's 8-byte-per-pixel stream
+      ADD_OP(WV, "conv3x3_wgrad:" + name, 2.0 * 9 * cin * cout * px, (hstream ? eb * px * cin + 8.0 * px : eb * px * (cin + cout)) + 4.0 * 9.0 * cin * cout, {
         if (dt) {
           if (in.empty()) return first_conv_wgrad_bf16(ctx, m, name, ob, cout, s);
           return k_conv3x3_bf16_wgrad(ctx, CBF(m->Av(xsrc)), CBF(m->Dv(name)), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w,
@@ -1078,7 +1079,7 @@ void build_programs(unet_model* m) {
       } else
       if (want_dx) {
         const bool bits = mask_in && m->sign_off.count(in) != 0;
-        ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, eb * px * (cout + cin + (mask_in ? (bits ? cin / 32.0 : cin) : 0)) + 4.0 * 9.0 * cin * cout, {
+        ADD_OP(BW, "conv3x3_dgrad:" + name, 2.0 * 9 * cin * cout * px, (hstream ? 8.0 * px + eb * px * (cin + (mask_in ? (bits ? cin / 32.0 : cin) : 0)) : eb * px * (cout + cin + (mask_in ? (bits ? cin / 32.0 : cin) : 0))) + 4.0 * 9.0 * cin * cout, {
           if (dt) return k_conv3x3_bf16_fwd(ctx, CBF(m->Dv(name)), m->P(name + "/kernel"), nullptr, mask_in ? CBF(m->Av(in)) : nullptr, mask_in ? MASK_RELU : MASK_NONE, WBF(m->Dv(in)), ob.n, ob.h,
                                             ob.w, cout, cin, ACT_NONE, 0.0f, 0, WBF(static_cast<void*>(m->wsf(m->off_wt))), 1, s, CBF(static_cast<void*>(m->wsf(m->wprep_b.at(name)))));
           const auto pb = m->wprep_b.find(name);
