@@ -77,9 +77,12 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   HEAD_BWD_FUSED (1)     with HEAD_FUSED and RELU_BITS: dL/d(output of the last conv3x3) = dz_p w_c [y_pc > 0] is never written as a tensor -- unet_head_dzm leaves
  *                          {dz_p, 32 mask bits} per pixel (8 bytes instead of 128) and the last conv's data gradient and weight gradient expand that stream while they
  *                          stage it (-1.5 GB of traffic per step at 512 x 512 x 16); 0 = unet_head_dy writes the fp32 tensor
+ *   WGRAD_ATOMIC (0)       fp32 conv3x3 weight gradients on the h2 kernels: 1 = the pixel splits of a layer add their tiles into dw / db with fp32 atomics instead of writing
+ *                          per-split slabs that two more launches reduce (75 MB of partial sums per layer, 34 launches per U-Net step); the summation order of the splits is
+ *                          then not fixed (never taken in deterministic mode).  Measured 0.04 ms per step SLOWER than the slabs on MI355X, hence opt-in
  */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,
-       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8, UNET_OPT_POOL_SUMS_FUSED = 9, UNET_OPT_HEAD_BWD_FUSED = 10 };
+       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8, UNET_OPT_POOL_SUMS_FUSED = 9, UNET_OPT_HEAD_BWD_FUSED = 10, UNET_OPT_WGRAD_ATOMIC = 11 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
 int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */
 

@@ -31,6 +31,8 @@ struct unet_ctx {
   int opt_skip_raw = 1;             // fp32 U-Net: an encoder block's second conv writes straight into the skip half of its concat; the encoder BatchNorm is composed into the folded decoder one
   int opt_head_fused = 1;           // the 1x1 sigmoid head + loss sums + the head's weight-gradient sums in the epilogue of the last conv3x3 (fp32 h2 kernels)
   int opt_head_bwd_fused = 1;       // the head's backward as an 8-byte-per-pixel {dz, mask} stream that the last conv's two gradients expand (no fp32 dY tensor)
+  int opt_wgrad_atomic = 0;         // conv3x3 weight gradients (h2 kernels): the pixel splits add their tiles into the gradient with fp32 atomics instead of writing slabs that two more launches
+                                    // reduce.  Measured +0.04 ms per step (the atomics execute at the memory side): off by default
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
   int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
@@ -279,7 +281,8 @@ size_t h2_wgrad_c16_ws_bytes(int n, int h, int wd);
 int32_t k_wgrad_c16_gather(unet_ctx*, const float* G, float* dw, float* db, hipStream_t s);
 int32_t k_conv3x3_h2_wgrad_c16(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, hipStream_t s);
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
-int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);
+int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s,
+                           int out_mode /* 0 slabs + reduction, 1 atomics into dw / db zeroed by the call, 2 atomics, the caller zeroed them */);
 // the head's backward as a rank-1 stream: k_head_dzm writes dzm[n,h,wd] = {dz, 32 mask bits} (+ the head's own dw / db, accumulated), the two gradients of the
 // last conv3x3 expand it while staging
 int32_t k_head_dzm(unet_ctx*, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const unsigned long long* bits, void* dzm, float* dw,
@@ -287,7 +290,7 @@ int32_t k_head_dzm(unet_ctx*, const float* p, const float* t, const double* loss
 bool h2_head_bwd_selected(const unet_ctx* ctx, int algo, int wd, int cin);
 int32_t k_conv3x3_h2_dgrad_dzm(unet_ctx*, const void* dzm, const void* wimg, const float* mask, int mask_mode, float* dx, int n, int h, int wd, int M, hipStream_t s);
 int32_t k_conv3x3_h2_wgrad_dzm(unet_ctx*, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin,
-                               hipStream_t s);
+                               hipStream_t s, int out_mode);
 int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                             float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 bool c1_relu_bits_supported(int wd, int cout);

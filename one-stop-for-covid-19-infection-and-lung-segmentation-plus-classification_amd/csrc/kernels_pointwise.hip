@@ -801,8 +801,9 @@ inline int grid_for(long long work_items) {
   long long b = cdiv64(work_items, TPB);
   return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
 }
-__global__ __launch_bounds__(TPB) void zero_kernel(float4* __restrict__ p, long long n4) {
+__global__ __launch_bounds__(TPB) void zero_kernel(float4* __restrict__ p, long long n4, int tail_words) {          // n4 16-byte pieces + up to three 4-byte words behind them
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail_words) reinterpret_cast<float*>(p + n4)[threadIdx.x] = 0.f;
 }
 
 // sums[i] += sum over the slot copies IN INDEX ORDER; the copies are cleared for the next launch.  OUT = double (statistics) or float (the head's
@@ -1150,9 +1151,9 @@ int32_t unet_zero(unet_ctx* ctx, void* ptr, size_t bytes, void* stream) {
   if (!ptr) UNET_FAIL(ctx, UNET_E_ARG, "zero: null");
   // a plain kernel instead of hipMemsetAsync: the runtime's fill path costs a ~22 us bubble in the stream at every call
   // (kernel trace), and the training step zeroes its reduction scratch several times
-  if ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bytes & 15) == 0 && bytes > 0) {
+  if ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bytes & 3) == 0 && bytes > 0) {
     const long long n4 = (long long)(bytes / 16);
-    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n4)), dim3(TPB), 0, as_stream(stream), static_cast<float4*>(ptr), n4);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(std::max<long long>(n4, 1))), dim3(TPB), 0, as_stream(stream), static_cast<float4*>(ptr), n4, (int)((bytes & 15) / 4));
     UNET_CHECK_LAUNCH(ctx, "zero");
     return UNET_OK;
   }

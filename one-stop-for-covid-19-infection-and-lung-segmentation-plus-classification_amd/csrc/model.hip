@@ -68,6 +68,7 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_SKIP_RAW: return &ctx->opt_skip_raw;
     case UNET_OPT_POOL_SUMS_FUSED: return &ctx->opt_pool_sums_fused;
     case UNET_OPT_HEAD_BWD_FUSED: return &ctx->opt_head_bwd_fused;
+    case UNET_OPT_WGRAD_ATOMIC: return &ctx->opt_wgrad_atomic;
     default: return nullptr;
   }
 }
@@ -134,12 +135,12 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
 }
 
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
-                                      size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
+                                      size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s, bool prezeroed = false) {
   if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout)) {
     if (h2_wgrad_c16_selected(algo, wd, cin, cout) && ws_bytes >= h2_wgrad_c16_ws_bytes(n, h, wd))
       return k_conv3x3_h2_wgrad_c16(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, s);      // pixel pairs as 32 channels: half of the MFMA tile useful instead of a quarter
     if (h2_wgrad_selected(algo, cin, cout) && ws_bytes >= h2_wgrad_ws_bytes(n, h, wd, cin, cout))
-      return k_conv3x3_h2_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);      // three fp16 MFMA products of the block-scaled two-term split
+      return k_conv3x3_h2_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s, ctx->opt_wgrad_atomic ? (prezeroed ? 2 : 1) : 0);      // three fp16 MFMA products of the block-scaled two-term split
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   }
   if (cin == 1 && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0 && cout <= 256 && ws && ws_bytes >= c1_wgrad_ws_bytes(cout))
@@ -216,7 +217,7 @@ int32_t unet_conv3x3_bwd_weights_dzm(unet_ctx* ctx, const float* x, const void* 
                                      int32_t wd, int32_t cin, void* stream) {
   if (!ctx || !x || !dzm || !w_head || !dw || !db || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_weights_dzm: bad args");
   if (!unet_head_bwd_stream_supported(ctx, UNET_ALGO_AUTO, wd, cin)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bwd_weights_dzm: not supported here (unet_head_bwd_stream_supported)");
-  return k_conv3x3_h2_wgrad_dzm(ctx, x, dzm, w_head, dw, db, ws, ws_bytes, n, h, wd, cin, as_stream(stream));
+  return k_conv3x3_h2_wgrad_dzm(ctx, x, dzm, w_head, dw, db, ws, ws_bytes, n, h, wd, cin, as_stream(stream), ctx->opt_wgrad_atomic ? 1 : 0);
 }
 int32_t unet_head_dy(unet_ctx* ctx, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const float* w_head, const void* relu_bits,
                      const float* y, float* dy, float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream) {
@@ -443,6 +444,7 @@ struct unet_model {
   // output is never stored (pool reads the raw tensor; the decoder fold composes the two BatchNorms: bn_comp_off = [scale'][shift'][pre_s][pre_t] x 2C per decoder level)
   bool skip_raw = false; std::map<std::string, size_t> bn_comp_off; size_t off_tap_tmp = 0;
   std::set<std::string> pool_sums_fused;          // pooled tensors whose backward sums come out of the data-gradient epilogue (MASK_POOL_SUMS)
+  bool grads_prezeroed = false;           // WGRAD_ATOMIC: zero_bwd_sums clears the whole gradient buffer
   bool c9b_virtual = false;               // HEAD_BWD_FUSED with sign bits: the fused head launch does not store c9b's output at all (a tap recomputes it)
   bool head_bwd_fused = false;            // ... and its backward as the {dz, mask} stream the two gradients of c9b expand (HEAD_BWD_FUSED; the stream sits at the start of c9b's gradient buffer)
   size_t off_head_sums = 0; bool head_fused = false;          // U-Net, fp32 h2 kernels: c9b + 1x1 head + loss sums in one launch (kernels_conv_h2.hip, HEAD)
@@ -963,9 +965,11 @@ void build_programs(unet_model* m) {
     for (auto& kv : m->bn_bsum_off) nb = std::max(nb, kv.second);
     size_t bs_bytes = 0;
     for (auto& l : m->layers) if (l.kind == 2) bs_bytes += 2 * (size_t)l.cout * sizeof(double);
+    m->grads_prezeroed = !dt && ctx->opt_wgrad_atomic && !ctx->opt_deterministic;          // WGRAD_ATOMIC: every gradient zeroed once, the conv3x3 weight gradients add into it
     ADD_OP(BW, "zero_bwd_sums", 0, 0, {
       int32_t r = unet_zero(ctx, m->wsf(m->off_bn_bsums), bs_bytes, s);
       if (r) return r;
+      if (m->grads_prezeroed) return unet_zero(ctx, m->grads, (size_t)m->n_params * sizeof(float), s);
       return unet_zero(ctx, m->G("out/kernel"), (size_t)(m->tinfo.at("out/kernel").count + 1) * sizeof(float), s);
     });
     const Buf hb = m->act.at("c9b");
@@ -1017,9 +1021,10 @@ void build_programs(unet_model* m) {
         }
         const float* xin = xsrc.empty() ? m->x : m->A(xsrc);
         if (name == "c9b" && m->head_bwd_fused)               // dy = the head's {dz, mask} stream (head_dzm above)
-          return k_conv3x3_h2_wgrad_dzm(ctx, xin, m->D(name), m->P("out/kernel"), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, s);
+          return k_conv3x3_h2_wgrad_dzm(ctx, xin, m->D(name), m->P("out/kernel"), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, s,
+                                        m->grads_prezeroed ? 2 : 0);
         return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
-                                      ob.n, ob.h, ob.w, cin, cout, algo, s);
+                                      ob.n, ob.h, ob.w, cin, cout, algo, s, m->grads_prezeroed);
       });
       if (!xraw.empty()) {
         const size_t go = m->fold_g_off.at(name), bo = m->bnp_off.at(in);
