@@ -472,3 +472,46 @@ def test_load_model_resumes_a_fit_bit_for_bit(tmp_path, arch):
     assert all(np.array_equal(wa[k], wb[k]) for k in wa)
     oa, ob = a.backend.get_optimizer_state(), b.backend.get_optimizer_state()
     assert oa["step"] == ob["step"] == 5 and all(np.array_equal(oa["m"][k], ob["m"][k]) and np.array_equal(oa["v"][k], ob["v"][k]) for k in oa["m"])
+
+
+@pytest.mark.parametrize("arch", ["unet", "unetpp", "classifier"])
+def test_repeated_predict_reuses_the_weight_preparation_and_stays_exact(arch):
+    """Serving: predict on unchanged weights skips the ops that only re-derive per-weight data (split weight images, inference BatchNorm scale / shift, folded tables).
+    Whatever could have changed that data -- another batch size (all plans share one workspace), a training step, set_weights -- must bring the full program back:
+    every prediction below equals, in every bit, what a fresh engine holding the same weights predicts."""
+    from covidseg_amd import weights as W
+    from covidseg_amd.data import synthetic_classification, synthetic_ct
+    from covidseg_amd.engine import HipUNet
+    hw = (64, 96) if arch == "unet" else (64, 64)
+    mk = lambda: HipUNet(hw[0], hw[1], 1, dropout_rate=0.0, arch=arch, options={"deterministic": 1})
+    if arch == "classifier":
+        x, y = synthetic_classification(4, 64, seed=3); y = y.astype(np.float32)
+    else:
+        x, y = synthetic_ct(4, 64, seed=3)
+        if arch == "unet":
+            x = np.concatenate([x, x[:, :, :32]], axis=2); y = np.concatenate([y, y[:, :, :32]], axis=2)
+    w0 = W.init_weights(9, 1, arch, hw)
+
+    def fresh(wts, xs):
+        e = mk(); e.set_weights(wts)
+        return e.predict_batch(xs)[0].cpu().numpy()
+    eng = mk(); eng.set_weights(w0)
+    pa = eng.predict_batch(x[:1])[0].cpu().numpy()
+    plan1 = eng._plan(1)
+    assert eng._infer_ready is plan1 and len(plan1["infer_prep_ops"]) >= 2
+    assert np.array_equal(pa, fresh(w0, x[:1]))
+    assert np.array_equal(eng.predict_batch(x[:1])[0].cpu().numpy(), pa) and eng._infer_ready is plan1           # the short program
+    p2 = eng.predict_batch(x[:2])[0].cpu().numpy()                                                                # another plan: its own preparation, same workspace
+    assert eng._infer_ready is eng._plan(2) and np.array_equal(p2, fresh(w0, x[:2]))
+    assert np.array_equal(eng.predict_batch(x[:1])[0].cpu().numpy(), pa)
+    eng.train_batch(x, y)                                                                                         # weights and moving statistics move
+    assert eng._infer_ready is None
+    w1 = eng.get_weights()
+    pb = eng.predict_batch(x[:1])[0].cpu().numpy()
+    assert np.array_equal(pb, fresh(w1, x[:1])) and not np.array_equal(pb, pa)
+    assert np.array_equal(eng.predict_batch(x[:1], y[:1])[0].cpu().numpy(), pb)                                   # (with labels: same ops + the loss)
+    eng.forward_backward(x[:1], y[:1])                                      # a training forward: folded images from the batch statistics in the same buffers, moving statistics move
+    assert eng._infer_ready is None
+    assert np.array_equal(eng.predict_batch(x[:1])[0].cpu().numpy(), fresh(eng.get_weights(), x[:1]))
+    eng.set_weights(w0)
+    assert eng._infer_ready is None and np.array_equal(eng.predict_batch(x[:1])[0].cpu().numpy(), pa)
