@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void small_allreduce_kernel(double* __restrict
 
 struct unet_comm {
   unet_ctx* ctx = nullptr;
+  int device = 0;                            // (kept here: destroy may run after the context is gone)
   int rank = 0, world = 1;
   unsigned seq = 0;
   int timeout_ms = 60000;
@@ -81,7 +82,7 @@ int32_t unet_comm_create(unet_ctx* ctx, int32_t rank, int32_t world, unet_comm**
   static_assert(sizeof(hipIpcMemHandle_t) <= UNET_COMM_HANDLE_BYTES, "handle size");
   (void)hipSetDevice(ctx->device);
   unet_comm* c = new unet_comm;
-  c->ctx = ctx; c->rank = rank; c->world = world;
+  c->ctx = ctx; c->device = ctx->device; c->rank = rank; c->world = world;
   // uncached: a peer's store must be visible to the polling loads of a RUNNING kernel (plain device memory is only coherent at kernel boundaries)
   hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->area), AREA_BYTES, hipDeviceMallocUncached);
   if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->area), AREA_BYTES, hipDeviceMallocFinegrained); }
@@ -151,7 +152,7 @@ int32_t unet_comm_status(unet_comm* c, int32_t* err_out, void* stream) {
 
 void unet_comm_destroy(unet_comm* c) {
   if (!c) return;
-  (void)hipSetDevice(c->ctx->device);
+  (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (int r = 0; r < c->world; ++r)
     if (c->mapped[r]) (void)hipIpcCloseMemHandle(c->peers.p[r]);
