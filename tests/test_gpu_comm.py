@@ -1,6 +1,6 @@
 """-m gpu: the device-side small all-reduce (include/unet_hip.h unet_comm_*, csrc/comm.hip) through the C ABI.
 
-The GPU box has ONE device: two ranks are two processes on it, each mapping the other's receive area through HIP IPC -- the same code path the ranks of an
+The GPU box has ONE device: two (and four) ranks are as many processes on it, each mapping the others' receive areas through HIP IPC -- the same code path the ranks of an
 8-GPU node take (there the mapped area lives behind an xGMI link).  Checked: sums exact in fp64 and bit-identical on both ranks, vectors longer than one
 launch, many back-to-back calls of changing length (the two alternating areas), a missing peer ends the kernel with the error word set instead of hanging."""
 import ctypes as C
@@ -84,14 +84,15 @@ def _worker(rank, world, port, out):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu(tmp_path, world):
     import torch.multiprocessing as mp
     out = str(tmp_path / "comm")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
-    assert bool(r0["ok"]) and bool(r1["ok"])
-    assert np.array_equal(r0["last"], r1["last"])                     # the same bits on both ranks
-    assert int(r0["timed_out"]) == 2                                  # 1 + the rank that was missing
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = [np.load(out + f".{r}.npz") for r in range(world)]
+    assert all(bool(r["ok"]) for r in res)
+    assert all(np.array_equal(res[0]["last"], r["last"]) for r in res[1:])          # the same bits on every rank
+    assert int(res[0]["timed_out"]) == 2                              # 1 + the first rank that was missing
 
 
 def _engine_worker(rank, world, port, out, mode):
