@@ -10,12 +10,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 COMM_HANDLE_BYTES, COMM_MAX_WORLD, COMM_MAX_DOUBLES = 64, 8, 2048          # include/unet_hip.h: UNET_COMM_*
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2          # fp16-split h2 kernels where the shape allows / VALU kernels / strict fp32 MFMA kernels
 # unet_ctx_set_option (include/unet_hip.h UNET_OPT_*)
-OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6, "head_fused": 7, "skip_raw": 8, "pool_sums_fused": 9, "head_bwd_fused": 10, "wgrad_atomic": 11}
+OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6, "head_fused": 7, "skip_raw": 8, "pool_sums_fused": 9, "head_bwd_fused": 10, "wgrad_atomic": 11, "c1a_recompute": 12}
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
@@ -115,6 +115,8 @@ _PROTOS = {
     "unet_conv3x3_bwd_data_pool_sums": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "unet_head_dy": (i32, [vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "unet_head_bwd_stream_supported": (i32, [vp, i32, i32, i32]),
+    "unet_conv3x3_fwd_c1a_supported": (i32, [vp, i32, i32, i32]),
+    "unet_conv3x3_fwd_c1a": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "unet_head_dzm": (i32, [vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_data_dzm": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_dzm": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),

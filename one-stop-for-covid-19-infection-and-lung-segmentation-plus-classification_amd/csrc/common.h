@@ -33,6 +33,8 @@ struct unet_ctx {
   int opt_head_bwd_fused = 1;       // the head's backward as an 8-byte-per-pixel {dz, mask} stream that the last conv's two gradients expand (no fp32 dY tensor)
   int opt_wgrad_atomic = 0;         // conv3x3 weight gradients (h2 kernels): the pixel splits add their tiles into the gradient with fp32 atomics instead of writing slabs that two more launches
                                     // reduce.  Measured +0.04 ms per step (the atomics execute at the memory side): off by default
+  int opt_c1a_recompute = 0;        // fp32 U-Net: the second conv of the first block recomputes the first layer's output (one input channel) while staging instead of reading it.
+                                    // Measured: that launch 0.286 -> 0.433 ms (the step +0.23 ms) -- more than the first layer's own 0.133 ms: opt-in, off by default
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
   int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
@@ -288,6 +290,9 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw
 int32_t k_head_dzm(unet_ctx*, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const unsigned long long* bits, void* dzm, float* dw,
                    float* db, int n, int h, int wd, hipStream_t s);
 bool h2_head_bwd_selected(const unet_ctx* ctx, int algo, int wd, int cin);
+bool h2_c1a_recompute_selected(const unet_ctx* ctx, int algo, int wd, int M);
+int32_t k_conv3x3_h2_fwd_c1a(unet_ctx*, const float* img, const float* w1, const float* b1, const void* wimg, const float* bias, float* y, int ldy, int n, int h, int wd, int M, int act,
+                             hipStream_t s);
 int32_t k_conv3x3_h2_dgrad_dzm(unet_ctx*, const void* dzm, const void* wimg, const float* mask, int mask_mode, float* dx, int n, int h, int wd, int M, hipStream_t s);
 int32_t k_conv3x3_h2_wgrad_dzm(unet_ctx*, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin,
                                hipStream_t s, int out_mode);

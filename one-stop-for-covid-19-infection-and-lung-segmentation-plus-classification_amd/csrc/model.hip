@@ -69,6 +69,7 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_POOL_SUMS_FUSED: return &ctx->opt_pool_sums_fused;
     case UNET_OPT_HEAD_BWD_FUSED: return &ctx->opt_head_bwd_fused;
     case UNET_OPT_WGRAD_ATOMIC: return &ctx->opt_wgrad_atomic;
+    case UNET_OPT_C1A_RECOMPUTE: return &ctx->opt_c1a_recompute;
     default: return nullptr;
   }
 }
@@ -196,6 +197,15 @@ int32_t unet_conv3x3_head_fwd(unet_ctx* ctx, const float* x, const float* w, con
   if (!r && armed && ctx->signs_done != armed) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_head_fwd: armed with unet_request_relu_bits but the launch did not write them");
   if (!r && y_true) r = k_head_fold(ctx, loss_sums, head_sums, as_stream(stream));
   return r;
+}
+int32_t unet_conv3x3_fwd_c1a_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cout) { return h2_c1a_recompute_selected(ctx, algo, wd, cout) ? 1 : 0; }
+int32_t unet_conv3x3_fwd_c1a(unet_ctx* ctx, const float* img, const float* w1, const float* b1, const float* w, const float* bias, float* y, int32_t n, int32_t h, int32_t wd, int32_t cout,
+                             int32_t act, float* w_ws, void* stream) {
+  if (!ctx || !img || !w1 || !b1 || !w || !y || !w_ws || n < 1 || h < 1 || wd < 1 || act < 0 || act > ACT_RELU) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd_c1a: bad args");
+  if (!h2_c1a_recompute_selected(ctx, UNET_ALGO_AUTO, wd, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_fwd_c1a: not supported here (unet_conv3x3_fwd_c1a_supported)");
+  int32_t r = k_h2_weights(ctx, w, w_ws, 32, cout, 0, as_stream(stream));
+  if (r) return r;
+  return k_conv3x3_h2_fwd_c1a(ctx, img, w1, b1, w_ws, bias, y, cout, n, h, wd, cout, act, as_stream(stream));
 }
 int32_t unet_head_bwd_stream_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cin) {
   return ctx && cin == 32 && h2_head_bwd_selected(ctx, algo, wd, cin) && h2_wgrad_selected(algo, cin, 32) ? 1 : 0;
@@ -444,6 +454,7 @@ struct unet_model {
   // output is never stored (pool reads the raw tensor; the decoder fold composes the two BatchNorms: bn_comp_off = [scale'][shift'][pre_s][pre_t] x 2C per decoder level)
   bool skip_raw = false; std::map<std::string, size_t> bn_comp_off; size_t off_tap_tmp = 0;
   std::set<std::string> pool_sums_fused;          // pooled tensors whose backward sums come out of the data-gradient epilogue (MASK_POOL_SUMS)
+  bool c1a_recompute = false;             // C1A_RECOMPUTE: c1b's forward recomputes c1a's output from the image; the inference program has no c1a op
   bool grads_prezeroed = false;           // WGRAD_ATOMIC: zero_bwd_sums clears the whole gradient buffer
   bool c9b_virtual = false;               // HEAD_BWD_FUSED with sign bits: the fused head launch does not store c9b's output at all (a tap recomputes it)
   bool head_bwd_fused = false;            // ... and its backward as the {dz, mask} stream the two gradients of c9b expand (HEAD_BWD_FUSED; the stream sits at the start of c9b's gradient buffer)
@@ -797,6 +808,9 @@ void build_programs(unet_model* m) {
       const Buf ob = m->act.at(name);
       double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
       double by = eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout;
+      if (name == "c1a") m->c1a_recompute = !dt && m->in_ch == 1 && m->wprep_f.count("c1b") != 0 && h2_c1a_recompute_selected(ctx, algo, ob.w, 32);
+      if (name == "c1a" && m->c1a_recompute && !training) return;          // inference: nothing reads the first layer's output any more (a tap recomputes it)
+      if (name == "c1b" && m->c1a_recompute) by = eb * (double)ob.n * ob.h * ob.w * (cin / 32.0 + cout) + 4.0 * 9.0 * cin * cout;
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
         if (dt) {
           if (in.empty()) return first_conv_fwd_bf16(ctx, m, name, ob, cout, ACT_RELU, 0.0f, 0, s);
@@ -808,7 +822,11 @@ void build_programs(unet_model* m) {
         const auto so = training ? m->sign_off.find(name) : m->sign_off.end();
         unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
         ctx->signs_req = sg; ctx->signs_done = nullptr;
-        int32_t r = conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
+        int32_t r;
+        if (name == "c1b" && m->c1a_recompute)                // the first layer's output is recomputed from the image while it is staged (kernels_conv_h2.hip, EPI 4): not read
+          r = k_conv3x3_h2_fwd_c1a(ctx, m->x, m->P("c1a/kernel"), m->P("c1a/bias"), m->wsf(pf->second), m->P(name + "/bias"), m->Aw(name), ob.ld, ob.n, ob.h, ob.w, cout, ACT_RELU, s);
+        else
+        r = conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
                                          ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second), ob.ld);          // (ob.ld > cout: c<k>b inside its concat, skip_raw)
         ctx->signs_req = nullptr;
         if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd %s: the launch did not write the ReLU sign bits its data gradient was planned with", name.c_str());
@@ -2124,6 +2142,12 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
     if (m->fold_c_off.count(conv)) return UNET_E_STATE;
   }
   const std::string nm_ = name;
+  if (!grad && m->c1a_recompute && nm_ == "c1a") {
+    // the inference program does not run the first layer (its consumer recomputes it): a tap does
+    int32_t r = k_conv3x3_c1_fwd(m->ctx, m->x, m->P("c1a/kernel"), m->P("c1a/bias"), const_cast<float*>(m->A("c1a")), b.n, b.h, b.w, b.c, ACT_RELU, 0.0f, 0, nullptr);
+    if (r) return r;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return UNET_E_HIP;
+  }
   if (!grad && m->c9b_virtual && nm_ == "c9b") {
     // the fused head launch did not store this tensor: a tap recomputes it from c9a with the weight image of the last forward (bias: the current parameter)
     const Buf& xb = m->act.at("c9a");
