@@ -1149,6 +1149,7 @@ void build_programs(unet_model* m) {
       const TInfo a = m->tinfo.at(first), b = m->tinfo.at(last_tensor);
       SY.push_back({(int)BW.size() - 1, 3, false, (size_t)a.off * 4, b.off + b.count - a.off});
     };
+    bool enc_split = false;
     const int dec[4] = {256, 128, 64, 32};
     for (int k = 9; k >= 6; --k) {
       int c = dec[k - 6]; std::string ks = std::to_string(k);
@@ -1211,6 +1212,9 @@ void build_programs(unet_model* m) {
         const size_t syi = SY.size() - 1;
         flush_def();                                          // (the weight gradient of the conv that consumed this level's pooled tensor runs while the sums are reduced)
         if (k == 4) bucket("c5a/kernel", "c5b/bias");
+        // levels 3 and 4 are complete once c3a's (deferred) weight gradient is out: their 4.4 MB go now, so that what is left for the end of the program -- the one
+        // all-reduce nothing can hide -- is the 0.3 MB of levels 1 and 2
+        if (k == 2) { bucket("c3a/kernel", "bn4/beta"); enc_split = true; }
         SY[syi].use_op = (int)BW.size();
         ADD_OP(BW, "bn_pool_bwd_apply:" + bnn, 0, eb * 3.25 * nel(xb), {
           if (dt) return unet_bn_maxpool_bwd_apply_bf16(ctx, CBF(m->Av(cb)), cbuf.ld, m->wsf(bo), m->wsd(m->off_bn_bsums) + so, (double)pixels * gcount, CBF(m->Dv(bnn)), gb.ld, CBF(m->Dv(pn)),
@@ -1236,7 +1240,7 @@ void build_programs(unet_model* m) {
       conv_bwd("c" + ks + "a", k == 1 ? "" : "p" + std::to_string(k - 1), cprev, c, k > 1, false, "", k > 1 && ctx->opt_enc_bn_fused != 0);
     }
     flush_def();
-    bucket("c1a/kernel", "bn4/beta");
+    bucket("c1a/kernel", enc_split ? "bn2/beta" : "bn4/beta");
   }
 #undef CBF
 #undef WBF

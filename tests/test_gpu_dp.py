@@ -297,7 +297,12 @@ def test_backward_program_leaves_a_weight_gradient_beside_every_bn_backward_redu
         assert all(names[i].startswith("conv3x3_wgrad:") for i in range(after + 1, use)), names[after:use + 1]
         assert names[use].startswith("conv3x3_dgrad_bn_bwd:") or names[use].startswith("bn_pool_bwd_apply:"), names[use]
     buckets = [s for s in plan["sync"][1] if s[1] == 3]
-    assert len(buckets) == 4 and all(b[4] == len(names) for b in buckets)
+    assert len(buckets) == 5 and all(b[4] == len(names) for b in buckets)
     # every weight gradient of a bucket is launched before the bucket is handed to the reducer
     order = {n: i for i, n in enumerate(names)}
-    assert order["conv3x3_wgrad:c5a"] <= buckets[2][0] and order["conv3x3_wgrad:c6b"] <= buckets[1][0] and order["conv3x3_wgrad:c2a"] <= buckets[3][0]
+    assert order["conv3x3_wgrad:c5a"] <= buckets[2][0] and order["conv3x3_wgrad:c6b"] <= buckets[1][0] and order["conv3x3_wgrad:c2a"] <= buckets[4][0]
+    assert max(order["conv3x3_wgrad:c3a"], order["conv3x3_wgrad:c4a"], order["conv3x3_wgrad:c3b"], order["pool_bwd_skip_term:p3"]) <= buckets[3][0] < order["conv3x3_wgrad:c2b"]
+    # the buckets tile the gradient buffer, and the one at the very end of the program (nothing hides its all-reduce) is the small one: levels 1 and 2
+    spans = sorted((b[2], b[3]) for b in buckets)
+    assert all(spans[i][0] + 4 * spans[i][1] == spans[i + 1][0] for i in range(4)) and sum(c for _, c in spans) == eng.n_params
+    assert buckets[4][0] == len(names) - 1 and buckets[4][3] < 100_000 < buckets[3][3]
