@@ -33,29 +33,72 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense v_mfma_f32_32x32x16_bf16
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(size, seconds_budget=25.0, arch="unet"):
-    """Time the oracle's identical training step on the host cores: bounded sample (batch 2)."""
-    import numpy as np
+def _physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs of the cpus in the affinity mask (hyper-thread siblings counted once)."""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", str(c)))
+    return max(1, len(seen))
+
+
+def cpu_baseline(size, seconds_budget=28.0, arch="unet"):
+    """Time the oracle's identical training step (fwd + loss + bwd + Keras-Adam, oneDNN convolutions on channels_last memory: the oracle's NHWC tensors viewed as
+    NCHW ARE torch's channels_last format) on the host cores: a bounded sample of the same workload -- batch 8 of the 16 where it fits the budget, one thread per
+    PHYSICAL core (the default thread count of a 256-cpu host put two threads on every core of one socket's worth and ran at a third of this), the better of the
+    full core count and half of it (one socket / less memory contention)."""
     import torch
     from covidseg_amd.data import synthetic_ct
     from oracle import unet_oracle as O
-    bs = 2
-    x, y = synthetic_ct(bs, size, seed=0)
-    if arch == "classifier":
-        from covidseg_amd.data import synthetic_classification
-        bs = 16
-        x, y = synthetic_classification(bs, size, seed=0)
-        tr = O.ClsOracleTrainer(O.cls_init_weights(0, 1, (size, size)), torch.float32)
-    else:
-        tr = O.OracleTrainer(O.init_weights(seed=0) if arch == "unet" else O.pp_init_weights(seed=0), torch.float32, arch)
-    t0 = time.perf_counter(); tr.train_step(x, y); first = time.perf_counter() - t0     # includes oneDNN warm-up
-    reps = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        tr.train_step(x, y)
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(bs / dt, 4), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{reps} training step(s) of batch {bs} at {size}x{size}x1 fp32 (torch-CPU oracle, {os.cpu_count()} host cpus visible)"}
+    phys = _physical_cores()
+    default_threads = torch.get_num_threads()
+    # algorithmic FLOPs per image of one training step (2 x MAC, convs + ConvTs; SURVEY 8d: 288.65 GFLOP at 512 x 512 for the U-Net), scaled by the pixel count
+    gflop_img = {"unet": 288.652, "unetpp": None, "classifier": None}[arch]
+    gflop_img = gflop_img * (size / 512.0) ** 2 if gflop_img else None
+
+    def make(bs):
+        if arch == "classifier":
+            from covidseg_amd.data import synthetic_classification
+            x, y = synthetic_classification(bs, size, seed=0)
+            return x, y, O.ClsOracleTrainer(O.cls_init_weights(0, 1, (size, size)), torch.float32)
+        x, y = synthetic_ct(bs, size, seed=0)
+        return x, y, O.OracleTrainer(O.init_weights(seed=0) if arch == "unet" else O.pp_init_weights(seed=0), torch.float32, arch)
+
+    t_all = time.perf_counter()
+    best = None
+    try:
+        bs = 16 if arch == "classifier" else 2
+        torch.set_num_threads(phys)
+        x, y, tr = make(bs)
+        t0 = time.perf_counter(); tr.train_step(x, y); first = time.perf_counter() - t0     # includes oneDNN warm-up (primitive creation, weight reorders)
+        t0 = time.perf_counter(); tr.train_step(x, y); probe = (time.perf_counter() - t0) / bs          # seconds per image at the small batch
+        best = (bs / (probe * bs), phys, bs, 1)
+        cands = [(phys, 8)] + ([(max(1, phys // 2), 8)] if phys >= 16 else [])
+        if arch != "unet":
+            cands = []
+        for threads, b in cands:
+            left = seconds_budget - (time.perf_counter() - t_all)
+            if left < 2.5 * probe * b:                         # a warm-up step + a timed one of this batch must fit what is left of the budget
+                b = max(2, int(left / (2.5 * probe)) // 2 * 2)
+                if left < 2.5 * probe * b:
+                    break
+            torch.set_num_threads(threads)
+            x, y, tr = make(b)
+            tr.train_step(x, y)
+            t0 = time.perf_counter(); tr.train_step(x, y); dt = time.perf_counter() - t0
+            if b / dt > best[0]:
+                best = (b / dt, threads, b, 1)
+    finally:
+        torch.set_num_threads(default_threads)
+    v, threads, bs, reps = best
+    rate = f", {v * gflop_img:.0f} GFLOP/s algorithmic" if gflop_img else ""
+    return {"value": round(v, 4), "unit": "images/sec", "cores": int(threads), "kind": "port",
+            "sample": f"{reps} training step of batch {bs} at {size}x{size}x1 fp32 after a warm-up step (torch-CPU oracle: oneDNN convolutions, channels_last memory, "
+                      f"{threads} threads = one per physical core used; {phys} physical cores / {os.cpu_count()} cpus visible, torch's default was {default_threads} threads){rate}"}
 
 
 def _tap_dims(eng, n, name):
@@ -86,6 +129,7 @@ def main():
     ap.add_argument("--no-fit-leg", action="store_true", help="skip the untimed fit_img_s measurement (UNetModel.fit on a host-resident set)")
     ap.add_argument("--fit-steps", type=int, default=20, help="steps per epoch of the fit leg")
     ap.add_argument("--no-sync-bn", action="store_true")
+    ap.add_argument("--no-buckets", action="store_true", help="N > 1 A/B: ONE all-reduce of the whole gradient buffer behind backward (fully exposed) instead of the 5 overlapped buckets")
     ap.add_argument("--small-allreduce", default="device", choices=["device", "rccl"], help="N > 1: BatchNorm / loss sums through the device-side all-reduce (csrc/comm.hip) or through RCCL")
     ap.add_argument("--arch", default="unet", choices=["unet", "unetpp", "classifier"], help="unetpp = the U-Net++ graph (BASELINE "
                     "configs[3], at fp32; --size 256 --batch 32); classifier = the task-2 CNN (configs[4] at the reference's 1-channel fp32; "
@@ -145,7 +189,7 @@ def main():
     reps = (B + len(xs) - 1) // len(xs)
     x = torch.from_numpy(np.concatenate([xs] * reps)[:B]).cuda(); y = torch.from_numpy(np.concatenate([ys] * reps)[:B]).cuda()
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
-                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), small_allreduce=args.small_allreduce, options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) | (json.loads(args.options) if args.options else {}) or None)
+                  arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), small_allreduce=args.small_allreduce, grad_buckets=not args.no_buckets, options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) | (json.loads(args.options) if args.options else {}) or None)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
 
     def settle(seconds):
@@ -236,16 +280,53 @@ def main():
     for _ in range(args.steps):
         last = eng.train_batch(x, y)
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rank_ms = [dt_local / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        rank_ms = [None] * world
+        dist.all_gather_object(rank_ms, dt_local / args.steps * 1e3)
     loss_dice = last.cpu().numpy().tolist()
-    if eng.comm_status() != 0:                 # a device-side all-reduce that timed out: the step's numbers are not a step's
-        raise RuntimeError(f"rank {rank}: device-side all-reduce missed rank {eng.comm_status() - 1}")
+    comm_status = eng.comm_status()
+    if comm_status != 0:                       # a device-side all-reduce that timed out: the step's numbers are not a step's
+        raise RuntimeError(f"rank {rank}: device-side all-reduce missed rank {comm_status - 1}")
+
+    # ---- untimed, behind the measurement (every rank; data-parallel engines only): where the gradient exchange's time goes -- BASELINE.md config 3 asks for "all-reduce time
+    # exposed vs hidden".  COMM_STEPS more steps with event pairs around every gradient all-reduce (on its side stream) and around the compute stream's wait in front of
+    # Adam; per-rank figures are gathered, rank 0 reports its own and the max over ranks.
+    comm = None
+    if eng._dp:
+        COMM_STEPS = 8
+        eng.set_comm_profiling(True)
+        for _ in range(COMM_STEPS):
+            eng.train_batch(x, y)
+        mine = eng.comm_profile()
+        eng.set_comm_profiling(False)
+        mine["comm_status"] = eng.comm_status()
+        every = [mine]
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+        comm = {"world": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "sync_bn": not args.no_sync_bn, "grad_buckets": not args.no_buckets,
+                "small_allreduce_requested": args.small_allreduce,
+                "small_allreduce_in_use": ("device (comm.hip)" if eng._comm is not None else "torch.distributed") if not args.no_sync_bn else None,
+                "small_allreduce_fallback": eng._comm_fallback,          # None, or why the device-side path was asked for and is NOT in use (every rank falls back together)
+                "comm_status": max(e["comm_status"] for e in every),
+                "profiled_steps": mine["steps"], "small_reductions_per_step": mine["small_reductions_per_step"],
+                "buckets_rank0": mine["buckets"],          # launch order = the order backward finishes them; mb = MB of gradients, ms = all-reduce duration on the side stream
+                "buckets_ms_max_over_ranks": [round(max(e["buckets"][i]["ms"] for e in every), 4) for i in range(len(mine["buckets"]))],
+                "allreduce_ms_per_step": {"rank0": mine["allreduce_ms"], "max": max(e["allreduce_ms"] for e in every)},
+                "exposed_ms_per_step": {"rank0": mine["exposed_ms"], "max": max(e["exposed_ms"] for e in every)},          # the compute stream standing in front of Adam (engine._run finish_buckets)
+                "hidden_ms_per_step": {"rank0": mine["hidden_ms"], "min": min(e["hidden_ms"] for e in every)},
+                "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "all": [round(v, 3) for v in rank_ms]},
+                "note": "allreduce = summed duration of a step's gradient all-reduces on their stream; exposed = what the compute stream waited for them in front of the "
+                        "optimizer; hidden = allreduce - exposed (overlapped with backward).  A/B switches: --no-buckets (one exposed all-reduce), --no-sync-bn (no small "
+                        "reductions), --small-allreduce rccl"}
 
     if rank == 0:
         # (conv3x3_dgrad_bn_bwd: the data gradient of a decoder block's first conv with the folded BatchNorm's backward in its epilogue -- the same
@@ -371,6 +452,8 @@ def main():
             out["predict_batch1_ms"] = predict_ms          # median of 20 synchronised model.predict calls at batch 1 (T1:1137): latency, not throughput
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if comm is not None:
+            out["comm"] = comm
     # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which sits in libc's buffer until exit and would
     # land behind an earlier Python print -- flush C stdio on every rank, meet, and only then print (rank 0) and tear the group down
     import ctypes

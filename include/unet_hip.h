@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 14
+#define UNET_ABI_VERSION 15
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -77,16 +77,10 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   HEAD_BWD_FUSED (1)     with HEAD_FUSED and RELU_BITS: dL/d(output of the last conv3x3) = dz_p w_c [y_pc > 0] is never written as a tensor -- unet_head_dzm leaves
  *                          {dz_p, 32 mask bits} per pixel (8 bytes instead of 128) and the last conv's data gradient and weight gradient expand that stream while they
  *                          stage it (-1.5 GB of traffic per step at 512 x 512 x 16); 0 = unet_head_dy writes the fp32 tensor
- *   WGRAD_ATOMIC (0)       fp32 conv3x3 weight gradients on the h2 kernels: 1 = the pixel splits of a layer add their tiles into dw / db with fp32 atomics instead of writing
- *                          per-split slabs that two more launches reduce (75 MB of partial sums per layer, 34 launches per U-Net step); the summation order of the splits is
- *                          then not fixed (never taken in deterministic mode).  Measured 0.04 ms per step SLOWER than the slabs on MI355X, hence opt-in
- *   C1A_RECOMPUTE (0)      fp32 U-Net, one input channel: 1 = the second conv of the first block (T1:860) recomputes the first layer's output (T1:859: 9 multiply-adds per value)
- *                          from a 12 x 36 window of the image while it stages its patch instead of reading the 32-channel tensor (-0.5 GB of reads per training step; the
- *                          inference program then does not run the first layer at all).  Bit-identical results; measured SLOWER on MI355X (that launch 0.286 -> 0.433 ms at
- *                          512 x 512 x 16, more than the first layer's own 0.133 ms), hence opt-in
+ *   (options 11 / 12 of ABI v13-v14 -- WGRAD_ATOMIC, C1A_RECOMPUTE -- were same-box A/B losers and left the library in v15; DESIGN.md keeps the measurements)
  */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,
-       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8, UNET_OPT_POOL_SUMS_FUSED = 9, UNET_OPT_HEAD_BWD_FUSED = 10, UNET_OPT_WGRAD_ATOMIC = 11, UNET_OPT_C1A_RECOMPUTE = 12 };
+       UNET_OPT_HEAD_FUSED = 7, UNET_OPT_SKIP_RAW = 8, UNET_OPT_POOL_SUMS_FUSED = 9, UNET_OPT_HEAD_BWD_FUSED = 10 };
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value);
 int32_t unet_ctx_get_option(unet_ctx* ctx, int32_t option);   /* >= 0: the value; < 0: error */
 
@@ -299,13 +293,6 @@ int32_t unet_conv3x3_head_fwd(unet_ctx*, const float* x, const float* w, const f
  * GLOBAL loss sums; dw_head[32] / db_head[1] += the combination of head_sums. */
 int32_t unet_head_dy(unet_ctx*, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const float* w_head,
                      const void* relu_bits, const float* y, float* dy, float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream);
-/* Replaces: `c1 = Conv2D(32, (3, 3), relu)(inputs)` + `c1 = Conv2D(cout, (3, 3), act)(c1)` T1:859-860 for a ONE-channel input, as one launch that never reads the first
- * layer's output: y[n,h,w,cout] = act(conv3x3(relu(conv3x3(img, w1) + b1), w) + bias), img [n,h,w] fp32, w1 [3][3][1][32], w [3][3][32][cout].  The first layer is
- * recomputed per staged patch with the fmaf order of unet_conv3x3_fwd's one-channel kernel (same bits).  fp32 UNET_ALGO_AUTO kernels, cout = 32 or 16/48-style single block
- * (unet_conv3x3_fwd_c1a_supported); statistics / sign-bit requests as for unet_conv3x3_fwd; w_ws: unet_conv3x3_w_ws_floats(32, cout). */
-int32_t unet_conv3x3_fwd_c1a_supported(unet_ctx*, int32_t algo, int32_t wd, int32_t cout);
-int32_t unet_conv3x3_fwd_c1a(unet_ctx*, const float* img, const float* w1, const float* b1, const float* w, const float* bias, float* y, int32_t n, int32_t h, int32_t wd,
-                             int32_t cout, int32_t act, float* w_ws, void* stream);
 /* The same backward without the fp32 tensor dy: it has ONE fp32 degree of freedom and 32 mask bits per pixel, so unet_head_dzm writes the stream
  * dzm[n,h,w] = {float dz, uint32 mask (bit c = y_c > 0)} (8 bytes per pixel instead of 128; relu_bits required; dw_head / db_head += as unet_head_dy) and the two
  * gradients of the conv in front of the head (`Conv2D(32, (3, 3), relu)`, T1:911) expand it while they stage it:
@@ -526,6 +513,9 @@ int32_t unet_model_tensor_info(const unet_model*, const char* name, int32_t* is_
 int32_t unet_model_bind(unet_model*, float* params, float* grads, float* adam_m, float* adam_v,
                         float* bn_state, void* workspace, size_t workspace_bytes);
 int32_t unet_model_set_io(unet_model*, const float* x, const float* y_true, float* p_out);
+/* loss_out: device float[2] of the caller's that the next forward programs ALSO write (loss, metric) to -- a training loop that collects one pair per step
+ * (model.fit reads them once per epoch, T1:1059) hands in a fresh slot per step instead of copying unet_model_loss_ptr behind every step; NULL = none (ABI v15) */
+int32_t unet_model_set_loss_out(unet_model*, float* loss_out);
 int32_t unet_model_set_dropout(unet_model*, float rate, uint64_t seed);
 /* classifier only: weights of class 0 / class 1 in the loss (Keras class_weight, T2:835); default 1, 1 */
 int32_t unet_model_set_class_weights(unet_model*, float w0, float w1);

@@ -9,13 +9,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 14
+# COVIDSEG_AMD_LIB: another build of the SAME library (the sanitizer build of `make asan`, an A/B build); the default -- and the product -- is the in-tree file
+LIB_PATH = os.environ.get("COVIDSEG_AMD_LIB") or os.path.join(_HERE, "libunet_hip.so")
+ABI_VERSION = 15
 COMM_HANDLE_BYTES, COMM_MAX_WORLD, COMM_MAX_DOUBLES = 64, 8, 2048          # include/unet_hip.h: UNET_COMM_*
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2          # fp16-split h2 kernels where the shape allows / VALU kernels / strict fp32 MFMA kernels
 # unet_ctx_set_option (include/unet_hip.h UNET_OPT_*)
-OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6, "head_fused": 7, "skip_raw": 8, "pool_sums_fused": 9, "head_bwd_fused": 10, "wgrad_atomic": 11, "c1a_recompute": 12}
+OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6, "head_fused": 7, "skip_raw": 8, "pool_sums_fused": 9, "head_bwd_fused": 10}
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
@@ -115,8 +116,6 @@ _PROTOS = {
     "unet_conv3x3_bwd_data_pool_sums": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "unet_head_dy": (i32, [vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "unet_head_bwd_stream_supported": (i32, [vp, i32, i32, i32]),
-    "unet_conv3x3_fwd_c1a_supported": (i32, [vp, i32, i32, i32]),
-    "unet_conv3x3_fwd_c1a": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "unet_head_dzm": (i32, [vp, vp, vp, vp, f64, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_data_dzm": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_dzm": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
@@ -152,6 +151,7 @@ _PROTOS = {
     "unet_model_dtype": (i32, [vp]),
     "unet_model_tap_elem_bytes": (i32, [vp, C.c_char_p, i32]),
     "unet_model_destroy": (None, [vp]),
+    "unet_model_set_loss_out": (C.c_int32, [vp, vp]),
     "unet_model_param_count": (i64, [vp]),
     "unet_model_state_count": (i64, [vp]),
     "unet_model_workspace_bytes": (sz, [vp, i32]),
@@ -200,8 +200,11 @@ def load():
 
 
 class Context:
-    """One unet_ctx per device."""
+    """One unet_ctx per (device, option set), shared by the engines built with them.  A unet_ctx carries mutable host state (slot copies that must be zero between
+    launches, the statistics bookkeeping, the profiling flag, one ConvT image): engines that share a context must be driven from ONE thread on ONE stream at a time
+    -- what every runner of this package does.  An engine that is used from its own thread / stream takes a context of its own (HipUNet(private_context=True))."""
     _cache = {}
+    users = 0                                                  # engines holding this context (retain / release)
 
     def __init__(self, device: int):
         self.lib = load()
@@ -215,10 +218,15 @@ class Context:
         self.device = device
 
     @classmethod
-    def get(cls, device: int, options: dict | None = None) -> "Context":
+    def get(cls, device: int, options: dict | None = None, private: bool = False) -> "Context":
         """The shared default-option context of a device, or -- with options -- a private context carrying them
         (unet_ctx_set_option: a model reads the options when it is created, the op-level entry points when they launch)."""
         key = (device, frozenset((k, int(v)) for k, v in options.items())) if options else device
+        if private:                                            # not cached, not shared: released (and destroyed) by the engine that asked for it
+            ctx = cls(device)
+            for k, v in (options or {}).items():
+                ctx.check(ctx.lib.unet_ctx_set_option(ctx.handle, OPTIONS[k], int(v)), f"set_option({k})")
+            return ctx
         if key not in cls._cache:                              # one context per (device, option set): engines with the same options share it (a context owns 24 MB of device scratch)
             ctx = cls(device)
             for k, v in (options or {}).items():
@@ -226,8 +234,21 @@ class Context:
             cls._cache[key] = ctx
         return cls._cache[key]
 
+    def retain(self):
+        self.users += 1
+        return self
+
+    def release(self):
+        """An engine lets go; a private context is destroyed with its last user, a cached one stays for the next engine (close() frees it explicitly)."""
+        self.users = max(0, self.users - 1)
+        if self.users == 0 and self.handle is not None and not any(v is self for v in type(self)._cache.values()):
+            self.close()
+
     def close(self):
-        """unet_ctx_destroy: frees the context's device scratch (slot copies, ConvT image); the object must not be used afterwards"""
+        """unet_ctx_destroy: frees the context's device scratch (slot copies, ConvT image); the object must not be used afterwards.  Refused while engines other
+        than the caller's still hold the context."""
+        if self.users > 1:
+            raise UNetHipError(f"Context.close(): {self.users} engines still use this context (close them first, or build engines with private_context=True)")
         if self.handle is not None:
             for k in [k for k, v in type(self)._cache.items() if v is self]:
                 del type(self)._cache[k]

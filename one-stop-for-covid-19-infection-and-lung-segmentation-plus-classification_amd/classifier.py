@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 from . import weights as W
-from .keras_like import BatchSource, dp_info, dp_shard
+from .keras_like import BatchSource, check_comm, dp_info, dp_shard
 
 
 # ----------------------------------------------------------------------------------------- sklearn / plot-metric restatements
@@ -220,6 +220,7 @@ class ClassifierModel:
                 xb, yb = src(sel)
                 outs.append(self.backend.train_batch(xb, yb, dropout, **kw)); sizes.append(len(idx))
             vals = np.stack([_host(o) for o in outs])
+            check_comm(self.backend, "fit")
             hist.history["loss"].append(float(np.average(vals[:, 0], weights=sizes))); hist.history["f1"].append(float(vals[:, 1].mean()))
             line = f"Epoch {ep + 1}/{epochs} - loss: {hist.history['loss'][-1]:.4f} - f1: {hist.history['f1'][-1]:.4f}"
             if validation_data is not None:
@@ -261,6 +262,7 @@ class ClassifierModel:
             _, ld = self.backend.predict_batch(x[sel], y[sel], **kw)
             vals.append(ld); sizes.append(min(i + batch_size, len(x)) - i)
         v = np.stack([_host(a) for a in vals])
+        check_comm(self.backend, "evaluate")
         return [float(np.average(v[:, 0], weights=sizes)), float(v[:, 1].mean())]
 
     def predict(self, x, batch_size=32):

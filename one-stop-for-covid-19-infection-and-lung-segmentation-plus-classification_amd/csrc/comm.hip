@@ -9,7 +9,7 @@
 // A value travels as two 8-byte words (sequence number << 32 | half of the double): an aligned 8-byte store is a single-copy atomic on the fabric, so a word whose
 // sequence number matches is complete -- no flag behind the data, no fence, one fabric latency per all-reduce.  Two areas alternate by call parity: a
 // rank can be at most one call ahead of a peer (finishing call k needs the peer's words of call k, which it sends after finishing k - 1).
-// The poll is bounded (timeout_ms): a missing peer sets the communicator's error word instead of hanging the GPU; unet_comm_status reads it.
+// The poll is bounded (timeout_ms): a missing peer sets the communicator's error word and turns the result into NaN instead of hanging the GPU; unet_comm_status reads the word.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -50,7 +50,11 @@ __global__ __launch_bounds__(256) void small_allreduce_kernel(double* __restrict
       a = get(mine + (size_t)s * 2 * MAXD); b = get(mine + (size_t)s * 2 * MAXD + 1);
       if ((unsigned)(a >> 32) == seq && (unsigned)(b >> 32) == seq) break;
       if ((++spins & 63) == 0) {
-        if (wall_clock64() - t0 > timeout_ticks || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicExch(err, 1 + s); return; }
+        if (wall_clock64() - t0 > timeout_ticks || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          // a missing rank: latch 1 + its number AND poison the result -- every value that would have been a cross-rank sum becomes NaN, so a loss / statistic built on
+          // rank-local sums cannot pass for a global one even where nobody reads unet_comm_status (keras_like.check_comm does, once per epoch / evaluate call)
+          atomicExch(err, 1 + s); buf[i] = __longlong_as_double(0x7FF8000000000000ll); return;
+        }
         __builtin_amdgcn_s_sleep(8);
       }
     }

@@ -31,10 +31,6 @@ struct unet_ctx {
   int opt_skip_raw = 1;             // fp32 U-Net: an encoder block's second conv writes straight into the skip half of its concat; the encoder BatchNorm is composed into the folded decoder one
   int opt_head_fused = 1;           // the 1x1 sigmoid head + loss sums + the head's weight-gradient sums in the epilogue of the last conv3x3 (fp32 h2 kernels)
   int opt_head_bwd_fused = 1;       // the head's backward as an 8-byte-per-pixel {dz, mask} stream that the last conv's two gradients expand (no fp32 dY tensor)
-  int opt_wgrad_atomic = 0;         // conv3x3 weight gradients (h2 kernels): the pixel splits add their tiles into the gradient with fp32 atomics instead of writing slabs that two more launches
-                                    // reduce.  Measured +0.04 ms per step (the atomics execute at the memory side): off by default
-  int opt_c1a_recompute = 0;        // fp32 U-Net: the second conv of the first block recomputes the first layer's output (one input channel) while staging instead of reading it.
-                                    // Measured: that launch 0.286 -> 0.433 ms (the step +0.23 ms) -- more than the first layer's own 0.133 ms: opt-in, off by default
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
   int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
@@ -260,6 +256,9 @@ int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx*, const float* dy, const void* wim
 // unet_bn_finalize_train / _infer of a decoder BatchNorm (c = 2 C_enc channels) AND k_bn_compose in one launch
 int32_t k_bn_finalize_compose(unet_ctx*, int training, const double* sums, double count, const float* gamma, const float* beta, float* mm, float* mv, float* bnp, int c,
                               const float* enc_bnp, float* comp, hipStream_t s);
+// unet_loss_finalize / unet_cls_loss_finalize with a second destination (unet_model_set_loss_out; nullptr = none)
+int32_t k_loss_finalize(unet_ctx*, const double* loss_sums, double count, float* loss_out, float* loss_out2, hipStream_t s);
+int32_t k_cls_loss_finalize(unet_ctx*, const double* sums, double count, float* out, float* out2, hipStream_t s);
 int32_t k_bn_compose(unet_ctx*, const float* bnp_dec, const float* bnp_enc, float* comp, int c, hipStream_t s);
 struct h2_head_args { const float* w = nullptr; const float* b = nullptr; float* p = nullptr; const float* t = nullptr; double* slots = nullptr; float aux = 0.0f; };          // (MASK_POOL_SUMS: w = gamma, b = beta, aux = dropout rate)
 bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int M);
@@ -283,19 +282,15 @@ size_t h2_wgrad_c16_ws_bytes(int n, int h, int wd);
 int32_t k_wgrad_c16_gather(unet_ctx*, const float* G, float* dw, float* db, hipStream_t s);
 int32_t k_conv3x3_h2_wgrad_c16(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, hipStream_t s);
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout);
-int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s,
-                           int out_mode /* 0 slabs + reduction, 1 atomics into dw / db zeroed by the call, 2 atomics, the caller zeroed them */);
+int32_t k_conv3x3_h2_wgrad(unet_ctx*, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout, hipStream_t s);
 // the head's backward as a rank-1 stream: k_head_dzm writes dzm[n,h,wd] = {dz, 32 mask bits} (+ the head's own dw / db, accumulated), the two gradients of the
 // last conv3x3 expand it while staging
 int32_t k_head_dzm(unet_ctx*, const float* p, const float* t, const double* loss_sums, double count, const double* head_sums, const unsigned long long* bits, void* dzm, float* dw,
                    float* db, int n, int h, int wd, hipStream_t s);
 bool h2_head_bwd_selected(const unet_ctx* ctx, int algo, int wd, int cin);
-bool h2_c1a_recompute_selected(const unet_ctx* ctx, int algo, int wd, int M);
-int32_t k_conv3x3_h2_fwd_c1a(unet_ctx*, const float* img, const float* w1, const float* b1, const void* wimg, const float* bias, float* y, int ldy, int n, int h, int wd, int M, int act,
-                             hipStream_t s);
 int32_t k_conv3x3_h2_dgrad_dzm(unet_ctx*, const void* dzm, const void* wimg, const float* mask, int mask_mode, float* dx, int n, int h, int wd, int M, hipStream_t s);
 int32_t k_conv3x3_h2_wgrad_dzm(unet_ctx*, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin,
-                               hipStream_t s, int out_mode);
+                               hipStream_t s);
 int32_t k_conv3x3_naive_fwd(unet_ctx*, const float* x, const float* w, const float* bias, const float* mask, int mask_mode,
                             float* y, int n, int h, int wd, int cin, int cout, int act, float rate, uint64_t seed, hipStream_t s);
 bool c1_relu_bits_supported(int wd, int cout);

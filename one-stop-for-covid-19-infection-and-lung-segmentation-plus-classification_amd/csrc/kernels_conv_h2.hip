@@ -156,11 +156,6 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   // the channels it goes to; w_c is a per-contraction-channel factor of the weight image (h2_prep::cs).  K = 32.
   constexpr bool VDY = EPI == 3;
   static_assert(!VDY || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the virtual head gradient feeds the 32-channel data-gradient launch");
-  // EPI 4 (C1A): the general epilogue behind another VIRTUAL input -- the output of the network's first layer, relu(conv3x3(image) + b) with ONE input channel
-  // (T1:859), recomputed from a 12 x 36 window of the image while the patch is staged instead of being fetched (x = the image, ldx = 1; hd.w / hd.b = that layer's
-  // kernel [9][32] and bias).  Same fmaf order as conv3x3_c1x4_kernel: the recomputed values are the stored ones, bit for bit.  K = 32.
-  constexpr bool C1A = EPI == 4;
-  static_assert(!C1A || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the recomputed first layer feeds the 32-channel forward launch");
   static_assert(!HEAD || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the fused head rides on the 32-channel forward kernel");
   static_assert(!POOLS || (MODE == 0 && !GEN), "the pooled sums ride on a plain conv3x3 data-gradient launch");
   if (POOLS) { mask_mode = MASK_POOL_SUMS; act = ACT_NONE; signs = nullptr; }          // (compile-time facts of this instance: the other epilogue forms fall away)
@@ -187,8 +182,6 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   char* const s_in = smem; char* const s_w = smem + IN_BYTES;
   float* const s_amax = reinterpret_cast<float*>(smem + IN_BYTES + W_LDS);
   float* const s_bias = s_amax + 4;                      // [3][NB * 32]: bias (+ the two other coefficient rows of a folded-BatchNorm gradient) of this channel group
-  float* const s_x1 = s_bias + 3 * NB * 32;              // (C1A) [12][36] image window | [9][32] first-layer kernel | [32] its bias
-  float* const s_w1 = s_x1 + 12 * 36;
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,43 +219,11 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     else { gy = y0 + (pix >> 5); gx = x0 + (pix & 31); }
     const bool ok = idx < PPIECES && gy >= 0 && gy < H && gx >= 0 && gx < W;
     if (MODE == 2) poff[k] = ok ? (((2 * gy) * WI + 2 * gx) * ldx + ks * 16 + q * 4) * 4 : UNET_OOB;
-    else if (C1A) poff[k] = ok ? 0 : UNET_OOB;                                             // (only "inside the image": a first-layer output outside it is the zero padding of this conv)
     else if (VDY) poff[k] = ok ? (gy * WI + gx) * 8 : UNET_OOB;                            // (the four pieces of a pixel read the same 8 bytes)
     else poff[k] = ok ? ((gy * WI + gx) * ldx + ks * 16 + q * 4) * 4 : UNET_OOB;          // halo and overhang pieces read 0 (out-of-range buffer offset)
   }
   unet_u32x4 preg[PL], wreg[WL];
   auto issue_loads = [&](int chunk) __attribute__((always_inline)) {
-    if (C1A) {                                               // piece (patch pixel (r, c), channel quad q of this chunk): 9 taps x 4 channels from the image window in LDS
-      const float* wq = s_w1 + chunk * 16 + (tid & 3) * 4;
-      const float4 b4 = *reinterpret_cast<const float4*>(wq + 9 * 32);
-      float4 acc[PL]; int xo[PL];
-#pragma unroll
-      for (int k = 0; k < PL; ++k) {
-        const int pix = (tid >> 2) + k * 64, r = pix / PWD, c = pix - r * PWD;
-        xo[k] = pix < NPIX ? r * 36 + c : 0;                 // window origin = image (y0 - 2 + r, x0 - 2 + c): the 3 x 3 neighbourhood of patch pixel (r, c)
-        acc[k] = b4;
-      }
-      // tap-major: one weight quad in registers at a time (nine of them are 36 registers the 128-register budget of this instance does not have); every accumulator
-      // still sees its taps in the order conv3x3_c1x4_kernel adds them
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const float4 kk = *reinterpret_cast<const float4*>(wq + (a * 3 + b) * 32);
-#pragma unroll
-          for (int k = 0; k < PL; ++k) {
-            const float xv = s_x1[xo[k] + a * 36 + b];
-            acc[k].x = fmaf(xv, kk.x, acc[k].x); acc[k].y = fmaf(xv, kk.y, acc[k].y); acc[k].z = fmaf(xv, kk.z, acc[k].z); acc[k].w = fmaf(xv, kk.w, acc[k].w);
-          }
-        }
-#pragma unroll
-      for (int k = 0; k < PL; ++k) {
-        const bool in = poff[k] == 0;
-        preg[k][0] = in ? __float_as_uint(fmaxf(acc[k].x, 0.f)) : 0u; preg[k][1] = in ? __float_as_uint(fmaxf(acc[k].y, 0.f)) : 0u;
-        preg[k][2] = in ? __float_as_uint(fmaxf(acc[k].z, 0.f)) : 0u; preg[k][3] = in ? __float_as_uint(fmaxf(acc[k].w, 0.f)) : 0u;
-      }
-      return;
-    }
     if (VDY) {                                             // both chunks expand the same {dz, mask} words: fetched once
       if (chunk == 0) {
 #pragma unroll
@@ -364,20 +325,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     s_bias[2 * NB * 32 + tid] = HEAD ? hd.b[0] : coef ? bias[2 * M + ch] : 0.f;
     }
   }
-  if (C1A) {
-    const float* img = x + (long long)n * H * W;
-    for (int i = tid; i < 12 * 36; i += 256) {
-      const int r = i / 36, c = i - r * 36, gy = y0 - 2 + r, gx = x0 - 2 + c;
-      s_x1[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(long long)gy * W + gx] : 0.f;
-    }
-    for (int i = tid; i < 10 * 32; i += 256) s_w1[i] = i < 9 * 32 ? hd.w[i] : hd.b[i - 9 * 32];
-    issue_w_loads(0);
-    __syncthreads();
-    issue_loads(0);
-  } else {
   issue_loads(0);
   issue_w_loads(0);
-  }
   post_amax();
   __syncthreads();
   H2_STAMP(1);
@@ -806,8 +755,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
-  constexpr size_t smem = (size_t)2 * KS * 2 * (NPIX * 16 + (MODE == 0 ? 0 : 64)) + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16 + 3 * NB * 32 * 4 +
-                          (EPI == 4 ? (12 * 36 + 10 * 32) * 4 : 0);
+  constexpr size_t smem = (size_t)2 * KS * 2 * (NPIX * 16 + (MODE == 0 ? 0 : 64)) + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16 + 3 * NB * 32 * 4;
   if (!mask) mask_mode = MASK_NONE;
   const int tiles_x = (wd + 31) / 32, tiles_y = (h + TH - 1) / TH, groups = (M + 32 * NB - 1) / (32 * NB);
   const long long total = (long long)tiles_x * tiles_y * n * groups;
@@ -842,9 +790,6 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
     r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
   } else if (EPI == 2) {
     if (gen || mask_mode != MASK_POOL_SUMS || act != ACT_NONE) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 + pooled sums: a plain data-gradient launch only");
-    r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
-  } else if (EPI == 4) {
-    if (gen || K != 32 || ldx != 1 || !hd.w || !hd.b || mask_mode == MASK_POOL_SUMS || (mask_mode != MASK_NONE && mask_mode != MASK_BIAS_TAB)) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 behind the recomputed first layer: a plain 32-channel forward launch only");
     r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
   } else if (EPI == 3) {
     if (gen || K != 32 || ldx != 2 || act != ACT_NONE || mask_mode == MASK_POOL_SUMS) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 behind the head's {dz, mask} stream: a plain 32-channel data-gradient launch only");
@@ -951,20 +896,6 @@ int32_t k_conv3x3_h2_dgrad_dzm(unet_ctx* ctx, const void* dzm, const void* wimg,
   if (!dzm || !wimg || !dx || h2_nb(M) != 1 || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 dgrad behind the head stream: bad args (M = %d)", M);
   if ((long long)h * wd * std::max(32, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   return launch_h2<0, 1, 2, 4, 3>(ctx, static_cast<const float*>(dzm), 2, static_cast<const unet_bf16*>(wimg), nullptr, mask, mask_mode, dx, M, n, h, wd, 32, M, ACT_NONE, 0.0f, 0, s);
-}
-
-// conv3x3(relu(conv3x3(img, w1) + b1), W) + bias with the first layer (one input channel, 32 outputs: T1:859-860) recomputed while its output is staged: img [n,h,wd] fp32,
-// wimg = the forward image of the second conv (K = 32), y [n,h,wd,M] (pixel stride ldy); statistics / sign-bit requests as for k_conv3x3_h2_fwd
-bool h2_c1a_recompute_selected(const unet_ctx* ctx, int algo, int wd, int M) {
-  return ctx && ctx->opt_c1a_recompute && h2_conv3x3_selected(algo, 32, M) && h2_nb(M) == 1;
-}
-int32_t k_conv3x3_h2_fwd_c1a(unet_ctx* ctx, const float* img_in, const float* w1, const float* b1, const void* wimg, const float* bias, float* y, int ldy, int n, int h, int wd, int M,
-                             int act, hipStream_t s) {
-  if (!img_in || !w1 || !b1 || !wimg || !y || h2_nb(M) != 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 behind the recomputed first layer: bad args (M = %d)", M);
-  if (ldy == 0) ldy = M;
-  if ((long long)h * wd * std::max(32, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
-  h2_head_args hd; hd.w = w1; hd.b = b1;
-  return launch_h2<0, 1, 2, 2, 4>(ctx, img_in, 1, static_cast<const unet_bf16*>(wimg), bias, nullptr, MASK_NONE, y, ldy, n, h, wd, 32, M, act, 0.0f, 0, s, 1 << 30, hd);
 }
 
 // x [n,h,wd,K] dense NHWC fp32, wimg from k_h2_weights (K contraction channels, M output channels), y [n,h,wd,M] fp32

@@ -155,11 +155,12 @@ __global__ __launch_bounds__(TPB) void cls_head_fwd_kernel(const float* __restri
   }
 }
 
-__global__ void cls_loss_finalize_kernel(const double* sums, double count, float* out) {
+__global__ void cls_loss_finalize_kernel(const double* sums, double count, float* out, float* out2) {
   const double eps = 1e-7;                                  // K.epsilon()
   const double prec = sums[1] / (sums[3] + eps), rec = sums[1] / (sums[2] + eps);
-  out[0] = (float)(sums[0] / count);
-  out[1] = (float)(2.0 * (prec * rec) / (prec + rec + eps));
+  const float l = (float)(sums[0] / count), f = (float)(2.0 * (prec * rec) / (prec + rec + eps));
+  out[0] = l; out[1] = f;
+  if (out2) { out2[0] = l; out2[1] = f; }
 }
 
 // single workgroup, N <= 32: thread (o, r) walks batch rows r, r+rows, ...:
@@ -256,11 +257,14 @@ int32_t unet_cls_head_fwd(unet_ctx* ctx, const float* h, const float* w, const f
   return UNET_OK;
 }
 
-int32_t unet_cls_loss_finalize(unet_ctx* ctx, const double* sums, double count, float* out, void* stream) {
+extern "C++" int32_t k_cls_loss_finalize(unet_ctx* ctx, const double* sums, double count, float* out, float* out2, hipStream_t s) {
   if (!ctx || !sums || !out || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "cls_loss_finalize: bad args");
-  hipLaunchKernelGGL(cls_loss_finalize_kernel, dim3(1), dim3(1), 0, as_stream(stream), sums, count, out);
+  hipLaunchKernelGGL(cls_loss_finalize_kernel, dim3(1), dim3(1), 0, s, sums, count, out, out2);
   UNET_CHECK_LAUNCH(ctx, "cls_loss_finalize");
   return UNET_OK;
+}
+int32_t unet_cls_loss_finalize(unet_ctx* ctx, const double* sums, double count, float* out, void* stream) {
+  return k_cls_loss_finalize(ctx, sums, count, out, nullptr, as_stream(stream));
 }
 
 int32_t unet_cls_head_bwd(unet_ctx* ctx, const float* h, const float* w, const float* p, const float* y_true, float class_w0, float class_w1,

@@ -559,10 +559,11 @@ __global__ __launch_bounds__(TPB) void head_fwd_lpp_kernel(const T* __restrict__
   }
 }
 
-__global__ void loss_finalize_kernel(const double* sums, double count, float* out) {
+__global__ void loss_finalize_kernel(const double* sums, double count, float* out, float* out2) {
   double dice = (2.0 * sums[1] + 1.0) / (sums[2] + sums[3] + 1.0);
-  out[0] = (float)(0.5 * (sums[0] / count) + 0.5 * (1.0 - dice));
-  out[1] = (float)dice;
+  const float l = (float)(0.5 * (sums[0] / count) + 0.5 * (1.0 - dice)), d = (float)dice;
+  out[0] = l; out[1] = d;
+  if (out2) { out2[0] = l; out2[1] = d; }                     // (unet_model_set_loss_out: the caller's own copy of this step's pair -- no copy kernel behind the step)
 }
 
 template <typename T>
@@ -1047,10 +1048,13 @@ extern "C++" template <typename T> static int32_t head_fwd_impl(unet_ctx* ctx, c
   UNET_CHECK_LAUNCH(ctx, "head_fwd"); return UNET_OK;
 }
 
-int32_t unet_loss_finalize(unet_ctx* ctx, const double* loss_sums, double count, float* loss_out, void* stream) {
+extern "C++" int32_t k_loss_finalize(unet_ctx* ctx, const double* loss_sums, double count, float* loss_out, float* loss_out2, hipStream_t s) {
   if (!loss_sums || !loss_out || count < 1) UNET_FAIL(ctx, UNET_E_ARG, "loss_finalize: bad args");
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, as_stream(stream), loss_sums, count, loss_out);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, s, loss_sums, count, loss_out, loss_out2);
   UNET_CHECK_LAUNCH(ctx, "loss_finalize"); return UNET_OK;
+}
+int32_t unet_loss_finalize(unet_ctx* ctx, const double* loss_sums, double count, float* loss_out, void* stream) {
+  return k_loss_finalize(ctx, loss_sums, count, loss_out, nullptr, as_stream(stream));
 }
 
 extern "C++" template <typename T> static int32_t head_bwd_impl(unet_ctx* ctx, const T* x, const float* w, const float* p, const float* y_true,

@@ -52,8 +52,7 @@ constexpr int APX = 34;                                       // X pixels per st
 template <int WA, int WB, int WR, int R, bool VDY = false>
 __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ part, int N, int H, int W,
                                                           int CA, int CB, int tiles_b, int strips, int rows_per_chunk, int chunks_per_strip, int nsplit,
-                                                          int npairs, long long pstride, int units, int upb, const float* __restrict__ colscale, float* __restrict__ atom_dw,
-                                                          float* __restrict__ atom_db) {
+                                                          int npairs, long long pstride, int units, int upb, const float* __restrict__ colscale) {
   static_assert(WA * WB * WR == 4 && WR <= R, "4 waves");
   static_assert(!VDY || WB == 1, "the head stream carries one 32-channel tile");
   constexpr int TAPS = 9, AROWS = R + 2;
@@ -321,19 +320,6 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
   if (wr != 0) return;
   const int ar = a0 + wa * 32, bc = b0 + wb * 32 + l31;
   const float cscale = VDY ? (bc < CB ? colscale[bc] : 0.f) : 1.0f;          // (VDY: the operand was dz [y > 0]; the column's head weight comes last)
-  if (atom_dw) {
-    // the splits of a channel-tile pair add their tiles straight into the (zeroed) gradient: fp32 atomics at the memory side instead of nsplit slabs written, read back and
-    // reduced by two more launches per layer (75 MB of partial sums per layer whatever its size: 512 workgroups x 147 KB).  Not taken in deterministic mode.
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (ar + m < CA && bc < CB) atomicAdd(atom_dw + ((long long)t * CA + ar + m) * CB + bc, VDY ? acc[t][r] * cscale : acc[t][r]);
-      }
-    if (wa == 0 && ta == 0 && lane < 32 && bc < CB) atomicAdd(atom_db + bc, VDY ? bsum * cscale : bsum);
-    return;
-  }
   float* P = part + (long long)split * pstride;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
@@ -650,14 +636,8 @@ bool h2_wgrad_selected(int algo, int cin, int cout) {
 }
 size_t h2_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout) { return h2_wgrad_selected(UNET_ALGO_AUTO, cin, cout) ? plan_wgrad_h2(n, h, wd, cin, cout).floats * sizeof(float) : 0; }
 
-// out_mode 0: per-split slabs in ws + the fixed-order reduction; 1: fp32 atomics into dw / db, zeroed here; 2: the same, the caller has zeroed them (one pass over all gradients)
-static int32_t wgrad_zero_out(unet_ctx* ctx, float* dw, float* db, int cin, int cout, hipStream_t s) {
-  if (db == dw + (size_t)9 * cin * cout) return unet_zero(ctx, dw, ((size_t)9 * cin * cout + cout) * sizeof(float), s);
-  int32_t r = unet_zero(ctx, dw, (size_t)9 * cin * cout * sizeof(float), s);
-  return r ? r : unet_zero(ctx, db, (size_t)cout * sizeof(float), s);
-}
 int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin, int cout,
-                           hipStream_t s, int out_mode) {
+                           hipStream_t s) {
   if (cin < 16 || (cin % 16) || cout < 16 || (cout % 16)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2: cin=%d cout=%d unsupported (multiples of 16)", cin, cout);
   if ((long long)h * wd * std::max(cin, cout) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const WgPlanH2 p = plan_wgrad_h2(n, h, wd, cin, cout);
@@ -666,26 +646,22 @@ int32_t k_conv3x3_h2_wgrad(unet_ctx* ctx, const float* x, const float* dy, float
   const long long S = 9LL * cin * cout + cout;
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
-  if (ctx->opt_deterministic) out_mode = 0;
-  if (out_mode == 1) { int32_t r = wgrad_zero_out(ctx, dw, db, cin, cout, s); if (r) return r; }
-  float* adw = out_mode ? dw : nullptr; float* adb = out_mode ? db : nullptr;
 #define UNET_WG(WA_, WB_, WR_) hipLaunchKernelGGL((wgrad_h2_kernel<WA_, WB_, WR_, 2>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, \
-                                                  p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb, (const float*)nullptr, adw, adb)
+                                                  p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb, (const float*)nullptr)
   if (p.WA == 2 && p.WB == 2) UNET_WG(2, 2, 1);
   else if (p.WA == 2) UNET_WG(2, 1, 2);
   else if (p.WB == 2) UNET_WG(1, 2, 2);
   else hipLaunchKernelGGL((wgrad_h2_kernel<1, 1, 4, 4>), grid, dim3(256), 0, s, x, dy, part, n, h, wd, cin, cout, p.tiles_b, p.strips, p.rows_per_chunk, p.chunks_per_strip, p.nsplit, npairs, S,
-                          p.units, p.upb, (const float*)nullptr, adw, adb);
+                          p.units, p.upb, (const float*)nullptr);
 #undef UNET_WG
   UNET_CHECK_LAUNCH(ctx, "wgrad_h2");
-  if (out_mode) return UNET_OK;
   return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
 }
 
 // The weight gradient of the last conv3x3 (cin -> 32, T1:911) from the head's rank-1 stream dzm[n,h,wd] = {dz, 32 mask bits} (k_head_dzm) and the head's weights w_head[32]:
 // dw[3][3][cin][32], db[32] (overwritten); cin = 32 (one channel tile: the kernel form with four row phases)
 int32_t k_conv3x3_h2_wgrad_dzm(unet_ctx* ctx, const float* x, const void* dzm, const float* w_head, float* dw, float* db, void* ws, size_t ws_bytes, int n, int h, int wd, int cin,
-                               hipStream_t s, int out_mode) {
+                               hipStream_t s) {
   const int cout = 32;
   if (!x || !dzm || !w_head || cin != 32) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2 behind the head stream: cin=%d (32)", cin);
   if ((long long)h * wd * 32 * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "wgrad h2: one image must stay below 1 GiB (32-bit buffer offsets)");
@@ -695,12 +671,9 @@ int32_t k_conv3x3_h2_wgrad_dzm(unet_ctx* ctx, const float* x, const void* dzm, c
   const long long S = 9LL * cin * cout + cout;
   const int npairs = p.tiles_a * p.tiles_b;
   const dim3 grid((unsigned)(8 * ((p.nsplit + 7) / 8) * npairs));
-  if (ctx->opt_deterministic) out_mode = 0;
-  if (out_mode == 1) { int32_t r = wgrad_zero_out(ctx, dw, db, cin, cout, s); if (r) return r; }
   hipLaunchKernelGGL((wgrad_h2_kernel<1, 1, 4, 4, true>), grid, dim3(256), 0, s, x, static_cast<const float*>(dzm), part, n, h, wd, cin, cout, p.tiles_b, p.strips, p.rows_per_chunk,
-                     p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb, w_head, out_mode ? dw : nullptr, out_mode ? db : nullptr);
+                     p.chunks_per_strip, p.nsplit, npairs, S, p.units, p.upb, w_head);
   UNET_CHECK_LAUNCH(ctx, "wgrad_h2_dzm");
-  if (out_mode) return UNET_OK;
   return k_wgrad_reduce(ctx, part, p.nslabs, 9, cin, cout, cout, dw, db, s);
 }
 
@@ -735,7 +708,7 @@ int32_t k_conv3x3_h2_wgrad_c16(unet_ctx* ctx, const float* x, const float* dy, f
   if ((wd & 1) || !ws || ws_bytes < h2_wgrad_c16_ws_bytes(n, h, wd)) UNET_FAIL(ctx, UNET_E_ARG, "wgrad h2 (16 channels as pixel pairs): W=%d, workspace %zu < %zu bytes", wd, ws_bytes, h2_wgrad_c16_ws_bytes(n, h, wd));
   const size_t inner = h2_wgrad_ws_bytes(n, h, wd / 2, 32, 32);
   float* G = reinterpret_cast<float*>(static_cast<char*>(ws) + inner);
-  int32_t r = k_conv3x3_h2_wgrad(ctx, x, dy, G, G + 9 * 32 * 32, ws, inner, n, h, wd / 2, 32, 32, s, 0);
+  int32_t r = k_conv3x3_h2_wgrad(ctx, x, dy, G, G + 9 * 32 * 32, ws, inner, n, h, wd / 2, 32, 32, s);
   if (r) return r;
   return k_wgrad_c16_gather(ctx, G, dw, db, s);
 }

@@ -68,8 +68,6 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_SKIP_RAW: return &ctx->opt_skip_raw;
     case UNET_OPT_POOL_SUMS_FUSED: return &ctx->opt_pool_sums_fused;
     case UNET_OPT_HEAD_BWD_FUSED: return &ctx->opt_head_bwd_fused;
-    case UNET_OPT_WGRAD_ATOMIC: return &ctx->opt_wgrad_atomic;
-    case UNET_OPT_C1A_RECOMPUTE: return &ctx->opt_c1a_recompute;
     default: return nullptr;
   }
 }
@@ -136,12 +134,12 @@ static int32_t conv3x3_fwd_dispatch(unet_ctx* ctx, const float* x, const float* 
 }
 
 static int32_t conv3x3_wgrad_dispatch(unet_ctx* ctx, const float* x, const float* dy, float* dw, float* db, void* ws,
-                                      size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s, bool prezeroed = false) {
+                                      size_t ws_bytes, int n, int h, int wd, int cin, int cout, int algo, hipStream_t s) {
   if (algo != UNET_ALGO_NAIVE && mfma_wgrad_supported(cin, cout) && ws && ws_bytes >= mfma_wgrad_ws_bytes(n, h, wd, cin, cout)) {
     if (h2_wgrad_c16_selected(algo, wd, cin, cout) && ws_bytes >= h2_wgrad_c16_ws_bytes(n, h, wd))
       return k_conv3x3_h2_wgrad_c16(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, s);      // pixel pairs as 32 channels: half of the MFMA tile useful instead of a quarter
     if (h2_wgrad_selected(algo, cin, cout) && ws_bytes >= h2_wgrad_ws_bytes(n, h, wd, cin, cout))
-      return k_conv3x3_h2_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s, ctx->opt_wgrad_atomic ? (prezeroed ? 2 : 1) : 0);      // three fp16 MFMA products of the block-scaled two-term split
+      return k_conv3x3_h2_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);      // three fp16 MFMA products of the block-scaled two-term split
     return k_conv3x3_mfma_wgrad(ctx, x, dy, dw, db, ws, ws_bytes, n, h, wd, cin, cout, s);
   }
   if (cin == 1 && algo != UNET_ALGO_NAIVE && (cout % 4) == 0 && 256 % (cout / 4) == 0 && cout <= 256 && ws && ws_bytes >= c1_wgrad_ws_bytes(cout))
@@ -198,15 +196,6 @@ int32_t unet_conv3x3_head_fwd(unet_ctx* ctx, const float* x, const float* w, con
   if (!r && y_true) r = k_head_fold(ctx, loss_sums, head_sums, as_stream(stream));
   return r;
 }
-int32_t unet_conv3x3_fwd_c1a_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cout) { return h2_c1a_recompute_selected(ctx, algo, wd, cout) ? 1 : 0; }
-int32_t unet_conv3x3_fwd_c1a(unet_ctx* ctx, const float* img, const float* w1, const float* b1, const float* w, const float* bias, float* y, int32_t n, int32_t h, int32_t wd, int32_t cout,
-                             int32_t act, float* w_ws, void* stream) {
-  if (!ctx || !img || !w1 || !b1 || !w || !y || !w_ws || n < 1 || h < 1 || wd < 1 || act < 0 || act > ACT_RELU) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd_c1a: bad args");
-  if (!h2_c1a_recompute_selected(ctx, UNET_ALGO_AUTO, wd, cout)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_fwd_c1a: not supported here (unet_conv3x3_fwd_c1a_supported)");
-  int32_t r = k_h2_weights(ctx, w, w_ws, 32, cout, 0, as_stream(stream));
-  if (r) return r;
-  return k_conv3x3_h2_fwd_c1a(ctx, img, w1, b1, w_ws, bias, y, cout, n, h, wd, cout, act, as_stream(stream));
-}
 int32_t unet_head_bwd_stream_supported(unet_ctx* ctx, int32_t algo, int32_t wd, int32_t cin) {
   return ctx && cin == 32 && h2_head_bwd_selected(ctx, algo, wd, cin) && h2_wgrad_selected(algo, cin, 32) ? 1 : 0;
 }
@@ -227,7 +216,7 @@ int32_t unet_conv3x3_bwd_weights_dzm(unet_ctx* ctx, const float* x, const void* 
                                      int32_t wd, int32_t cin, void* stream) {
   if (!ctx || !x || !dzm || !w_head || !dw || !db || n < 1 || h < 1 || wd < 1) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_bwd_weights_dzm: bad args");
   if (!unet_head_bwd_stream_supported(ctx, UNET_ALGO_AUTO, wd, cin)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bwd_weights_dzm: not supported here (unet_head_bwd_stream_supported)");
-  return k_conv3x3_h2_wgrad_dzm(ctx, x, dzm, w_head, dw, db, ws, ws_bytes, n, h, wd, cin, as_stream(stream), ctx->opt_wgrad_atomic ? 1 : 0);
+  return k_conv3x3_h2_wgrad_dzm(ctx, x, dzm, w_head, dw, db, ws, ws_bytes, n, h, wd, cin, as_stream(stream));
 }
 int32_t unet_head_dy(unet_ctx* ctx, const float* p, const float* y_true, const double* loss_sums, double count, const double* head_sums, const float* w_head, const void* relu_bits,
                      const float* y, float* dy, float* dw_head, float* db_head, int32_t n, int32_t h, int32_t wd, void* stream) {
@@ -438,7 +427,7 @@ struct unet_model {
   // bound buffers
   float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *state = nullptr;
   char* ws = nullptr; size_t ws_bytes = 0;
-  const float *x = nullptr, *yt = nullptr; float* pout = nullptr;
+  const float *x = nullptr, *yt = nullptr; float* pout = nullptr; float* loss_out2 = nullptr;
   float drop_rate = 0.0f; uint64_t drop_seed = 0;
   float cw0 = 1.0f, cw1 = 1.0f;                       // classifier: class weights of the loss
   size_t off_dense_ws = 0, dense_ws_bytes = 0;
@@ -454,8 +443,6 @@ struct unet_model {
   // output is never stored (pool reads the raw tensor; the decoder fold composes the two BatchNorms: bn_comp_off = [scale'][shift'][pre_s][pre_t] x 2C per decoder level)
   bool skip_raw = false; std::map<std::string, size_t> bn_comp_off; size_t off_tap_tmp = 0;
   std::set<std::string> pool_sums_fused;          // pooled tensors whose backward sums come out of the data-gradient epilogue (MASK_POOL_SUMS)
-  bool c1a_recompute = false;             // C1A_RECOMPUTE: c1b's forward recomputes c1a's output from the image; the inference program has no c1a op
-  bool grads_prezeroed = false;           // WGRAD_ATOMIC: zero_bwd_sums clears the whole gradient buffer
   bool c9b_virtual = false;               // HEAD_BWD_FUSED with sign bits: the fused head launch does not store c9b's output at all (a tap recomputes it)
   bool head_bwd_fused = false;            // ... and its backward as the {dz, mask} stream the two gradients of c9b expand (HEAD_BWD_FUSED; the stream sits at the start of c9b's gradient buffer)
   size_t off_head_sums = 0; bool head_fused = false;          // U-Net, fp32 h2 kernels: c9b + 1x1 head + loss sums in one launch (kernels_conv_h2.hip, HEAD)
@@ -808,9 +795,6 @@ void build_programs(unet_model* m) {
       const Buf ob = m->act.at(name);
       double fl = 2.0 * 9 * cin * cout * (double)ob.n * ob.h * ob.w;
       double by = eb * (double)ob.n * ob.h * ob.w * (cin + cout) + 4.0 * 9.0 * cin * cout;
-      if (name == "c1a") m->c1a_recompute = !dt && m->in_ch == 1 && m->wprep_f.count("c1b") != 0 && h2_c1a_recompute_selected(ctx, algo, ob.w, 32);
-      if (name == "c1a" && m->c1a_recompute && !training) return;          // inference: nothing reads the first layer's output any more (a tap recomputes it)
-      if (name == "c1b" && m->c1a_recompute) by = eb * (double)ob.n * ob.h * ob.w * (cin / 32.0 + cout) + 4.0 * 9.0 * cin * cout;
       ADD_OP(F, "conv3x3_fwd:" + name, fl, by, {
         if (dt) {
           if (in.empty()) return first_conv_fwd_bf16(ctx, m, name, ob, cout, ACT_RELU, 0.0f, 0, s);
@@ -822,11 +806,7 @@ void build_programs(unet_model* m) {
         const auto so = training ? m->sign_off.find(name) : m->sign_off.end();
         unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
         ctx->signs_req = sg; ctx->signs_done = nullptr;
-        int32_t r;
-        if (name == "c1b" && m->c1a_recompute)                // the first layer's output is recomputed from the image while it is staged (kernels_conv_h2.hip, EPI 4): not read
-          r = k_conv3x3_h2_fwd_c1a(ctx, m->x, m->P("c1a/kernel"), m->P("c1a/bias"), m->wsf(pf->second), m->P(name + "/bias"), m->Aw(name), ob.ld, ob.n, ob.h, ob.w, cout, ACT_RELU, s);
-        else
-        r = conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
+        int32_t r = conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
                                          ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second), ob.ld);          // (ob.ld > cout: c<k>b inside its concat, skip_raw)
         ctx->signs_req = nullptr;
         if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd %s: the launch did not write the ReLU sign bits its data gradient was planned with", name.c_str());
@@ -972,7 +952,7 @@ void build_programs(unet_model* m) {
     SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
     ADD_OP(F, "loss_finalize", 0, 0, {
       if (!m->yt) return UNET_OK;
-      return unet_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsf(m->off_loss_out), s);
+      return k_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsf(m->off_loss_out), m->loss_out2, s);
     });
   }
 
@@ -983,11 +963,9 @@ void build_programs(unet_model* m) {
     for (auto& kv : m->bn_bsum_off) nb = std::max(nb, kv.second);
     size_t bs_bytes = 0;
     for (auto& l : m->layers) if (l.kind == 2) bs_bytes += 2 * (size_t)l.cout * sizeof(double);
-    m->grads_prezeroed = !dt && ctx->opt_wgrad_atomic && !ctx->opt_deterministic;          // WGRAD_ATOMIC: every gradient zeroed once, the conv3x3 weight gradients add into it
     ADD_OP(BW, "zero_bwd_sums", 0, 0, {
       int32_t r = unet_zero(ctx, m->wsf(m->off_bn_bsums), bs_bytes, s);
       if (r) return r;
-      if (m->grads_prezeroed) return unet_zero(ctx, m->grads, (size_t)m->n_params * sizeof(float), s);
       return unet_zero(ctx, m->G("out/kernel"), (size_t)(m->tinfo.at("out/kernel").count + 1) * sizeof(float), s);
     });
     const Buf hb = m->act.at("c9b");
@@ -1039,10 +1017,9 @@ void build_programs(unet_model* m) {
         }
         const float* xin = xsrc.empty() ? m->x : m->A(xsrc);
         if (name == "c9b" && m->head_bwd_fused)               // dy = the head's {dz, mask} stream (head_dzm above)
-          return k_conv3x3_h2_wgrad_dzm(ctx, xin, m->D(name), m->P("out/kernel"), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, s,
-                                        m->grads_prezeroed ? 2 : 0);
+          return k_conv3x3_h2_wgrad_dzm(ctx, xin, m->D(name), m->P("out/kernel"), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes, ob.n, ob.h, ob.w, cin, s);
         return conv3x3_wgrad_dispatch(ctx, xin, m->D(name), m->G(name + "/kernel"), m->G(name + "/bias"), m->wsf(m->off_wgrad_ws), m->wgrad_ws_bytes,
-                                      ob.n, ob.h, ob.w, cin, cout, algo, s, m->grads_prezeroed);
+                                      ob.n, ob.h, ob.w, cin, cout, algo, s);
       });
       if (!xraw.empty()) {
         const size_t go = m->fold_g_off.at(name), bo = m->bnp_off.at(in);
@@ -1498,7 +1475,7 @@ void build_programs_pp(unet_model* m) {
     SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
     ADD_OP(F, "loss_finalize", 0, 0, {
       if (!m->yt) return UNET_OK;
-      return unet_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsf(m->off_loss_out), s);
+      return k_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)hp * gcount, m->wsf(m->off_loss_out), m->loss_out2, s);
     });
   }
 
@@ -1874,7 +1851,7 @@ void build_programs_cls(unet_model* m) {
     SY.push_back({(int)F.size() - 1, 1, true, m->off_loss_sums * 4, 4});
     ADD_OP(F, "loss_finalize", 0, 0, {
       if (!m->yt) return UNET_OK;
-      return unet_cls_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)N * gcount, m->wsf(m->off_loss_out), s);
+      return k_cls_loss_finalize(ctx, m->wsd(m->off_loss_sums), (double)N * gcount, m->wsf(m->off_loss_out), m->loss_out2, s);
     });
   }
 
@@ -2078,6 +2055,12 @@ int32_t unet_model_set_io(unet_model* m, const float* x, const float* y_true, fl
   return UNET_OK;
 }
 
+int32_t unet_model_set_loss_out(unet_model* m, float* loss_out) {
+  if (!m) return UNET_E_ARG;
+  m->loss_out2 = loss_out;
+  return UNET_OK;
+}
+
 int32_t unet_model_set_dropout(unet_model* m, float rate, uint64_t seed) {
   if (!m || rate < 0 || rate >= 1) return UNET_E_ARG;
   m->drop_rate = rate; m->drop_seed = seed;
@@ -2146,12 +2129,6 @@ int32_t unet_model_tap(const unet_model* m, const char* name, int32_t grad, cons
     if (m->fold_c_off.count(conv)) return UNET_E_STATE;
   }
   const std::string nm_ = name;
-  if (!grad && m->c1a_recompute && nm_ == "c1a") {
-    // the inference program does not run the first layer (its consumer recomputes it): a tap does
-    int32_t r = k_conv3x3_c1_fwd(m->ctx, m->x, m->P("c1a/kernel"), m->P("c1a/bias"), const_cast<float*>(m->A("c1a")), b.n, b.h, b.w, b.c, ACT_RELU, 0.0f, 0, nullptr);
-    if (r) return r;
-    if (hipStreamSynchronize(nullptr) != hipSuccess) return UNET_E_HIP;
-  }
   if (!grad && m->c9b_virtual && nm_ == "c9b") {
     // the fused head launch did not store this tensor: a tap recomputes it from c9a with the weight image of the last forward (bias: the current parameter)
     const Buf& xb = m->act.at("c9a");

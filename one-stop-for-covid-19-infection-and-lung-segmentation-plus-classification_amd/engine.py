@@ -30,7 +30,8 @@ class HipUNet:
 
     def __init__(self, h: int, w: int, in_ch: int = 1, device: int | None = None, conv_algo: int = _lib.ALGO_AUTO,
                  process_group=None, sync_bn: bool = True, dropout_rate: float = 0.25, seed: int = 0, lr: float = ADAM_LR,
-                 arch: str = "unet", dtype: str = "fp32", force_dp: bool = False, options: dict | None = None, small_allreduce: str = "device"):
+                 arch: str = "unet", dtype: str = "fp32", force_dp: bool = False, options: dict | None = None, small_allreduce: str = "device",
+                 comm_timeout_ms: int = 60000, private_context: bool = False, grad_buckets: bool = True):
         torch = _torch()
         self.lib = _lib.load()
         # dtype "bf16": activations / activation gradients stored as bf16 in the workspace (BASELINE.json configs[3], [4]); image,
@@ -43,7 +44,8 @@ class HipUNet:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.dev = torch.device("cuda", self.device_index)
         # options: {"deterministic": 1, "bn_fold": 0, ...} (_lib.OPTIONS; include/unet_hip.h UNET_OPT_*) -> a private context carrying them
-        self.ctx = _lib.Context.get(self.device_index, options)
+        # (engines with equal options share one context -- single thread, single stream; private_context=True: a context of this engine's own, _lib.Context)
+        self.ctx = _lib.Context.get(self.device_index, options, private=private_context).retain()
         self.h, self.w, self.in_ch, self.algo = h, w, in_ch, conv_algo
         self.arch = arch                       # "unet" (T1:853-916) or "unetpp" (task1_unet_plus_plus.py:858-950; its dropout
         self._arch_id = {"unet": _lib.ARCH_UNET, "unetpp": _lib.ARCH_UNETPP, "classifier": _lib.ARCH_CLASSIFIER}[arch]   # rates fixed: >0 = on
@@ -73,7 +75,8 @@ class HipUNet:
         self._ws = None
         self._infer_ready = None               # the plan (by identity) whose inference-only preparation -- split weight images, moving-statistics scale / shift, folded tables -- is current
         self._pinned = {}                      # _to_dev: pinned staging rings by element count
-        self._idx_pin, self._idx_i = [None] * 4, 0
+        self._idx_pin, self._idx_ev, self._idx_i = [None] * 8, [None] * 8, 0
+        self._loss_chunk, self._loss_i = None, 0
         # flat buffers sized from a probe plan
         probe = self._create_plan(1)
         self.n_params = self.lib.unet_model_param_count(probe)
@@ -96,7 +99,15 @@ class HipUNet:
         # peers' IPC-mapped receive areas; falls back to RCCL, loudly and on every rank together, if the areas cannot be mapped or a self-test fails);
         # "rccl" = torch.distributed all-reduces, inline or on the side stream.  Gradient buckets are RCCL either way.
         assert small_allreduce in ("device", "rccl"), small_allreduce
+        # comm_timeout_ms: how long a device-side reduction polls for a peer before it latches the error word and returns NaN sums (keras_like.check_comm raises at
+        # the next epoch / evaluate boundary).  A rank may legitimately lag (checkpoint writes, a new plan): raise it for slow filesystems, or take "rccl", which waits.
+        self._comm_timeout_ms = int(comm_timeout_ms)
+        self._comm_fallback = None             # why the device-side all-reduce was asked for but is not in use (None: in use, or never asked for)
         self._comm = self._make_comm() if (self._dp and small_allreduce == "device") else None
+        # grad_buckets False (an A/B switch, bench.py --no-buckets): ONE all-reduce of the whole gradient buffer on the compute stream behind the backward program --
+        # nothing overlaps it, so its whole duration is exposed (what the 5 overlapped buckets are measured against)
+        self.grad_buckets = bool(grad_buckets)
+        self._comm_prof = None                 # set_comm_profiling: event pairs of the gradient all-reduces and of the compute stream's wait in front of Adam
 
     # ------------------------------------------------------------------ plans / buffers
     def _create_plan(self, n, replicated=False):
@@ -240,11 +251,18 @@ class HipUNet:
         sf = int(np.prod(ds.shape[1:]))
         if sf % 4:
             return ds[torch.from_numpy(idx).to(self.dev)]
-        k = self._idx_i % 4; self._idx_i += 1                                        # four pinned index buffers in rotation (a step outlives the host by < 3 batches)
+        if len(idx) == 0:
+            return torch.empty((0,) + tuple(ds.shape[1:]), dtype=torch.float32, device=self.dev)
+        # eight pinned index buffers in rotation; a buffer is rewritten only after the H2D copy that read it has finished (an event per buffer, as in
+        # _to_dev): fit() syncs the host once per epoch, so the host can queue many batches ahead of a GPU-bound step
+        k = self._idx_i % 8; self._idx_i += 1
+        if self._idx_ev[k] is not None:
+            self._idx_ev[k].synchronize()
         if self._idx_pin[k] is None or self._idx_pin[k].numel() < len(idx):
             self._idx_pin[k] = torch.empty(max(len(idx), 256), dtype=torch.int64).pin_memory()
         self._idx_pin[k][:len(idx)].copy_(torch.from_numpy(idx))
         di = self._idx_pin[k][:len(idx)].to(self.dev, non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.dev)); self._idx_ev[k] = ev
         out = torch.empty((len(idx),) + tuple(ds.shape[1:]), dtype=torch.float32, device=self.dev)
         self.ctx.check(self.lib.unet_gather_samples(self.ctx.handle, ds.data_ptr(), di.data_ptr(), out.data_ptr(), len(idx), sf, self._stream()), "gather_samples")
         return out
@@ -284,7 +302,7 @@ class HipUNet:
                 ok, why = False, f"self-test: nothing from rank {err.value - 1} within 10 s"
             elif not torch.equal(t.cpu(), torch.arange(1, 301, dtype=torch.float64) * (world * (world + 1) // 2)):
                 ok, why = False, "self-test: wrong sums"
-            lib.unet_comm_set_timeout_ms(comm, 60000)
+            lib.unet_comm_set_timeout_ms(comm, self._comm_timeout_ms)
         if world > 1:                                      # all ranks or none
             flags = [None] * world
             dist.all_gather_object(flags, (ok, why), group=self.pg)
@@ -295,6 +313,7 @@ class HipUNet:
             if comm:
                 lib.unet_comm_destroy(comm)
             warnings.warn(f"covidseg_amd: device-side small all-reduce unavailable ({why}); BatchNorm / loss sums go through torch.distributed instead", RuntimeWarning)
+            self._comm_fallback = why or "unavailable"
             return None
         return comm
 
@@ -306,11 +325,43 @@ class HipUNet:
         self.ctx.check(self.lib.unet_comm_status(self._comm, C.byref(err), self._stream()), "comm_status")
         return err.value
 
+    def set_comm_profiling(self, on: bool):
+        """Data-parallel engines: bracket every gradient all-reduce (events on the side stream) and the compute stream's wait in front of Adam with timing events.
+        comm_profile() turns what has been collected into per-step figures.  Off by default (a few event records per step)."""
+        self._comm_prof = {"buckets": [], "waits": [], "small": 0, "steps0": self.step} if (on and self._dp) else None
+
+    def comm_profile(self):
+        """{"steps", "buckets": [{"mb", "ms"} in launch order], "allreduce_ms", "exposed_ms", "hidden_ms", "small_reductions_per_step"} averaged over the steps since
+        set_comm_profiling(True): allreduce_ms = summed duration of a step's gradient all-reduces on their stream; exposed_ms = what the compute stream waited for them in
+        front of the optimizer; hidden_ms = the rest (overlapped with backward).  Synchronises the device."""
+        torch = _torch()
+        pr = self._comm_prof
+        if pr is None:
+            return None
+        torch.cuda.synchronize(self.dev)
+        steps = max(1, self.step - pr["steps0"])
+        per = max(1, len(pr["buckets"]) // steps)              # buckets per step, in launch order
+        ms = [0.0] * per; mb = [0.0] * per
+        for i, (nbytes, e0, e1) in enumerate(pr["buckets"][:per * steps]):
+            ms[i % per] += e0.elapsed_time(e1) / steps; mb[i % per] = nbytes / 1e6
+        exposed = sum(w0.elapsed_time(w1) for w0, w1 in pr["waits"]) / steps
+        total = sum(ms)
+        return {"steps": steps, "buckets": [{"mb": round(b, 2), "ms": round(m, 4)} for b, m in zip(mb, ms)], "allreduce_ms": round(total, 4), "exposed_ms": round(exposed, 4),
+                "hidden_ms": round(max(total - exposed, 0.0), 4), "small_reductions_per_step": round(pr["small"] / steps, 1)}
+
     def close(self):
         if getattr(self, "_comm", None):
             self.lib.unet_comm_destroy(self._comm); self._comm = None
+        for p in getattr(self, "_plans", {}).values():
+            self.lib.unet_model_destroy(p["m"])
+        self._plans = {}
+        if getattr(self, "ctx", None) is not None:
+            self.ctx.release(); self.ctx = None
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():                            # (interpreter teardown: the HIP runtime may be gone already -- the process's memory goes with it)
+            return
         try:
             self.close()
         except Exception:
@@ -363,12 +414,28 @@ class HipUNet:
             else:
                 self._all_reduce(self._ws_view_f64(ptr, count))
 
+        prof = self._comm_prof
+
         def reduce_bucket(ptr, count):
             off = (ptr - self.grads.data_ptr()) // 4
             ev = torch.cuda.Event(); ev.record(cur)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
+                if prof is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(self._comm_stream)
                 self._all_reduce(self.grads[off:off + count], self.pg_grad)
+                if prof is not None:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(self._comm_stream)
+                    prof["buckets"].append((count * 4, e0, e1))
+
+        def finish_buckets():
+            # the compute stream meets the side stream in front of Adam: the time it stands here is the EXPOSED part of the gradient exchange
+            if prof is not None:
+                w0 = torch.cuda.Event(enable_timing=True); w0.record(cur)
+            cur.wait_stream(self._comm_stream)
+            if prof is not None:
+                w1 = torch.cuda.Event(enable_timing=True); w1.record(cur)
+                prof["waits"].append((w0, w1))
 
         def reduce_small_async(ptr, count):
             # the reduction runs on its own stream behind everything launched so far; the compute stream goes on with the independent op(s) the program
@@ -380,16 +447,36 @@ class HipUNet:
                 done = torch.cuda.Event(); done.record(self._small_stream)
             return done
 
-        kinds = (0, 1, 2, 3) if self.sync_bn else (3,)
+        kinds = ((0, 1, 2) if self.sync_bn else ()) + ((3,) if self.grad_buckets else ())
+        if prof is not None:
+            prof["small"] += sum(1 for sp in plan["sync"][prog] if sp[1] in kinds and sp[1] != 3)
         # (device-side reductions cost one small kernel: they run inline even where the program leaves room for a side stream)
         dp.run_program(run_range, nops, plan["sync"][prog], reduce_small, reduce_bucket,
-                       lambda: cur.wait_stream(self._comm_stream), kinds, None if self._comm is not None else reduce_small_async, lambda done: cur.wait_event(done))
+                       finish_buckets, kinds, None if self._comm is not None else reduce_small_async, lambda done: cur.wait_event(done))
+        if prog == _lib.PROG_BWD and not self.grad_buckets:
+            if prof is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record(cur)
+            self._all_reduce(self.grads, self.pg_grad)
+            if prof is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record(cur)
+                prof["buckets"].append((self.grads.numel() * 4, e0, e1)); prof["waits"].append((e0, e1))
 
     def _loss_tensor(self, plan):
         torch = _torch()
         ptr = self.lib.unet_model_loss_ptr(plan["m"])
         off = ptr - self._ws.data_ptr()
         return self._ws[off:off + 8].view(torch.float32)
+
+    def _loss_slot(self, plan):
+        """A fresh [loss, metric] slot that the coming forward's loss_finalize writes besides the workspace pair (unet_model_set_loss_out): the per-step result a
+        caller keeps (fit() reads one pair per step at the end of the epoch) with no copy kernel behind the step.  Slots are cut from 4096-pair chunks; a chunk
+        lives as long as a slot of it does."""
+        torch = _torch()
+        if self._loss_chunk is None or self._loss_i >= self._loss_chunk.shape[0]:
+            self._loss_chunk, self._loss_i = torch.zeros((4096, 2), dtype=torch.float32, device=self.dev), 0
+        slot = self._loss_chunk[self._loss_i]; self._loss_i += 1
+        self.ctx.check(self.lib.unet_model_set_loss_out(plan["m"], slot.data_ptr()), "set_loss_out")
+        return slot
 
     def forward_backward(self, x, y, training_dropout=True, replicated=False):
         """fwd (training mode) + loss + bwd on one batch; gradients land in self.grads.
@@ -409,9 +496,10 @@ class HipUNet:
         self._drop_calls += 1
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr(), self._p_train.data_ptr()), "set_io")
         self._keep = (xd, yd)
+        slot = self._loss_slot(plan)
         self._run(plan, _lib.PROG_FWD_TRAIN, replicated)
         self._run(plan, _lib.PROG_BWD, replicated)
-        return self._loss_tensor(plan)
+        return slot
 
     def adam_step(self, replicated=False):
         self.step += 1
@@ -424,7 +512,7 @@ class HipUNet:
 
     def train_batch(self, x, y, training_dropout=True, replicated=False):
         """One optimizer step (model.fit inner loop, T1:1059).  Returns device tensor [loss, dice]."""
-        out = self.forward_backward(x, y, training_dropout, replicated) + 0.0      # a copy made by a kernel (clone() takes the D2D-copy path: ~20 us bubble)
+        out = self.forward_backward(x, y, training_dropout, replicated)          # (its own slot, written by the forward's loss_finalize: no copy behind the step)
         self.adam_step(replicated)
         return out
 
@@ -440,8 +528,11 @@ class HipUNet:
         yd = self._to_dev(y) if y is not None else None
         self.ctx.check(self.lib.unet_model_set_io(plan["m"], xd.data_ptr(), yd.data_ptr() if yd is not None else None, p.data_ptr()), "set_io")
         self._keep = (xd, yd)
+        slot = self._loss_slot(plan) if yd is not None else None
+        if yd is None:
+            self.ctx.check(self.lib.unet_model_set_loss_out(plan["m"], None), "set_loss_out")
         self._run(plan, _lib.PROG_FWD_INFER, replicated)
-        return p, (self._loss_tensor(plan) + 0.0 if yd is not None else None)
+        return p, slot
 
     def threshold_sums(self, p, y, thresholds, replicated=False):
         """[T,3] float64 (sum gt*pr, sum pr, sum gt) with pr = p > t  (sm.metrics, T1:1206-1207); summed over the ranks' shards under data parallelism."""

@@ -40,6 +40,16 @@ def dp_info(backend):
     return (int(backend.world), int(backend.rank)) if getattr(backend, "_dp", False) else (1, 0)
 
 
+def check_comm(backend, where):
+    """A device-side all-reduce that timed out (csrc/comm.hip: a rank more than the timeout behind) leaves the BatchNorm / loss sums rank-local from then on --
+    sync-BN training would silently turn into unsynchronised statistics.  Read the communicator's sticky error word wherever the host synchronises anyway
+    (per epoch in fit, per call in evaluate) and fail loudly.  Backends without the hook (CPU test backends) have nothing to check."""
+    st = backend.comm_status() if hasattr(backend, "comm_status") else 0
+    if st:
+        raise RuntimeError(f"{where}: a device-side all-reduce did not receive rank {st - 1}'s contribution within the timeout; the BatchNorm / loss sums of this "
+                           f"run are not the global batch's (HipUNet(small_allreduce='rccl') waits instead of timing out)")
+
+
 def dp_shard(idx, world, rank):
     """How one global mini-batch is run on `world` ranks so that the step equals the single-process step on the whole batch
     (the engine reduces BatchNorm sums, Dice sums and gradients over the ranks, engine.py): a batch whose size divides by the world size
@@ -220,6 +230,7 @@ class UNetModel:
                 outs.append(self.backend.train_batch(xb, yb, dropout, **kw))                  # [loss, dice_coeff] of the WHOLE batch on every rank
                 sizes.append(len(idx))
             vals = np.stack([_host(o) for o in outs])                     # one host sync per epoch
+            check_comm(self.backend, "fit")
             hist.history["loss"].append(float(np.average(vals[:, 0], weights=sizes)))
             hist.history["dice_coeff"].append(float(vals[:, 1].mean()))
             line = f"Epoch {ep + 1}/{epochs} - loss: {hist.history['loss'][-1]:.4f} - dice_coeff: {hist.history['dice_coeff'][-1]:.4f}"
@@ -252,7 +263,7 @@ class UNetModel:
         (the reference re-compiles and re-runs evaluate per threshold, T1:1205-1211)."""
         losses, dices, sizes, per_batch = [], [], [], []
         world, rank = dp_info(self.backend)
-        src = _source if _source is not None else BatchSource(self.backend, x, y, device_resident=device_resident)
+        src = _source if _source is not None else self._eval_source(x, y, device_resident)
         for i in range(0, len(x), batch_size):
             sel, kw = dp_shard(np.arange(i, min(i + batch_size, len(x))), world, rank)
             xb, yb = src(sel)
@@ -261,12 +272,35 @@ class UNetModel:
             if thresholds is not None and len(thresholds):
                 per_batch.append(self.backend.threshold_sums(p, yb, thresholds, **kw))
         vals = np.stack([_host(v) for v in losses])
+        check_comm(self.backend, "evaluate")
         out = {"loss": float(np.average(vals[:, 0], weights=sizes)), "dice_coeff": float(vals[:, 1].mean())}
         if per_batch:
             sc = [sm_scores(s[:, 0], s[:, 1], s[:, 2]) for s in (_host(b) for b in per_batch)]
             for k in ("dice", "iou", "precision", "recall"):
                 out[k] = np.mean([b[k] for b in sc], axis=0)
         return out
+
+    def _eval_source(self, x, y, device_resident):
+        """The BatchSource of an evaluate() call, kept while the SAME arrays come back (the runners sweep thresholds / call evaluate repeatedly on one hold-out
+        set, T1:1196-1330): the set is uploaded to HBM once, not per call.  Keyed by object identity + a strided content sample, held through weak references where the type allows."""
+        import weakref
+
+        def probe(a):                                          # (a strided sample of the contents: an array edited in place between two calls is uploaded again)
+            if not isinstance(a, np.ndarray) or a.size == 0:
+                return None
+            f = a.reshape(-1)
+            return hash(f[::max(1, f.size // 4096)].tobytes())
+        key = (id(x), id(y), device_resident, probe(x), probe(y))
+        c = getattr(self, "_eval_cache", None)
+        if c is not None and c[0] == key and all(r() is o for r, o in zip(c[1], (x, y))):
+            return c[2]
+        try:
+            refs = (weakref.ref(x), weakref.ref(y))
+        except TypeError:
+            return BatchSource(self.backend, x, y, device_resident=device_resident)          # (lists etc.: no identity to hold on to)
+        src = BatchSource(self.backend, x, y, device_resident=device_resident)
+        self._eval_cache = (key, refs, src)
+        return src
 
     def intermediate_output(self, layer_name, x, batch_size=32):
         """Model(inputs=model.input, outputs=model.get_layer(layer_name).output).predict(x)  (T1:1385-1387, layer 'conv2d_9' = the

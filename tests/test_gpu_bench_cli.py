@@ -30,7 +30,26 @@ def _check(out, n):
     assert d["value"] > 0 and abs(d["value"] - 2 * n * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]          # whole-job images / the max-over-ranks time
     assert d["unit"] == "images/sec" and "roofline" in d and "cpu_baseline" not in d                        # (the CPU baseline is an N = 1 leg)
     assert all(v == v for v in d["config"]["last_loss_dice"])
+    _check_comm(d, n)
     return d
+
+
+def _check_comm(d, n, buckets=True, sync_bn=True):
+    """the N > 1 line explains itself (all-reduce time exposed vs hidden)"""
+    c = d["comm"]
+    assert c["world"] == n and c["comm_status"] == 0 and c["sync_bn"] is sync_bn and c["grad_buckets"] is buckets
+    assert c["small_allreduce_in_use"] in (("device (comm.hip)", "torch.distributed") if sync_bn else (None,))
+    assert (c["small_allreduce_fallback"] is None) == (c["small_allreduce_in_use"] != "torch.distributed" or c["small_allreduce_requested"] == "rccl")
+    nb = 5 if buckets else 1
+    assert len(c["buckets_rank0"]) == nb == len(c["buckets_ms_max_over_ranks"])
+    assert abs(sum(b["mb"] for b in c["buckets_rank0"]) - 7762401 * 4 / 1e6) < 0.1                           # the five buckets are the whole gradient buffer
+    assert all(b["ms"] > 0 for b in c["buckets_rank0"])
+    ar, ex, hid = c["allreduce_ms_per_step"], c["exposed_ms_per_step"], c["hidden_ms_per_step"]
+    assert ar["max"] >= ar["rank0"] > 0 and ex["max"] >= ex["rank0"] >= 0 and hid["rank0"] >= 0
+    assert abs(ar["rank0"] - ex["rank0"] - hid["rank0"]) < 1e-3 or hid["rank0"] == 0
+    assert c["small_reductions_per_step"] == (17 if sync_bn else 0)
+    r = c["rank_ms_per_step"]
+    assert len(r["all"]) == n and r["min"] <= r["max"] <= d["ms_per_step"] * 1.001 + 1e-3
 
 
 def test_bench_two_ranks_as_the_driver_launches_it():
@@ -55,3 +74,20 @@ def test_bench_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--batch", "2", "--steps", "1", "--warmup", "0"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_comm_object_at_world_one_and_the_ab_switches():
+    """UNET_BENCH_FORCE_PG=1 walks the data-parallel program (RCCL backend) at world 1: the line carries the same `comm` object; --no-buckets is ONE all-reduce whose whole
+    duration is exposed, --no-sync-bn has no small reductions"""
+    env = _env(); env.pop("UNET_BENCH_BACKEND"); env["UNET_BENCH_FORCE_PG"] = "1"
+    for extra, kw in (([], {}), (["--no-buckets"], {"buckets": False}), (["--no-sync-bn"], {"sync_bn": False})):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "64", "--batch", "2", "--steps", "2", "--warmup", "1", "--settle", "0", "--no-cpu-baseline", "--no-strict-leg",
+               "--no-fit-leg"] + extra
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.strip().splitlines() if l.strip()][-1])
+        assert d["n_gpus"] == 1
+        _check_comm(d, 1, **kw)
+        if extra == ["--no-buckets"]:
+            c = d["comm"]
+            assert abs(c["exposed_ms_per_step"]["rank0"] - c["allreduce_ms_per_step"]["rank0"]) < 1e-6 and c["hidden_ms_per_step"]["rank0"] == 0

@@ -421,7 +421,7 @@ def test_context_options_select_the_graph_forms_in_one_process():
     for nm in ("bn1", "bn3", "c2b", "p2", "bn9", "c9a"):
         assert relerr(ref.tap(2, nm), off.tap(2, nm)) < 2e-6, nm
     for opts, expect_fwd, expect_bwd in (({"bn_fold": 0}, "bn_apply:bn9", "bn_bwd_apply:bn9"), ({"bn_fold": 1}, None, "bn_bwd_apply:bn9"), ({"head_fused": 0}, "head_fwd", "head_bwd"),
-                                         ({"head_fused": 1, "relu_bits": 0}, "conv3x3_fwd_head:c9b", "head_dy"), ({"skip_raw": 0}, None, None), ({"pool_sums_fused": 0}, None, "pool_bwd_sums:p1"), ({"head_bwd_fused": 0}, None, "head_dy"), ({"wgrad_atomic": 1}, None, None), ({"c1a_recompute": 1}, None, None),
+                                         ({"head_fused": 1, "relu_bits": 0}, "conv3x3_fwd_head:c9b", "head_dy"), ({"skip_raw": 0}, None, None), ({"pool_sums_fused": 0}, None, "pool_bwd_sums:p1"), ({"head_bwd_fused": 0}, None, "head_dy"),
                                          ({"enc_bn_fused": 0}, None, "pool_bwd_bnstats:p1"), ({"relu_bits": 0}, None, None),
                                          ({"bn_concat_analytic": 0, "bn_fuse_stats": 0}, None, None), ({"deterministic": 1}, None, None)):
         eng = make(64, 96, dropout_rate=0.0, options=opts); eng.set_weights(wts); eng.forward_backward(x, y)

@@ -385,52 +385,6 @@ def test_conv3x3_head_fused_fwd_and_dy(ops, shape):
     assert abs(s3n[0] - sn[0]) < 0.5                                # (the BCE sum: the separate kernel takes the logit from p -- 0.39 (1 - t) off on the one pixel with z = 15.55, above)
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 24, 32), (1, 40, 72, 32), (3, 9, 8, 32), (1, 6, 104, 16), (2, 70, 33, 32)])
-def test_second_conv_recomputes_the_one_channel_first_layer_while_staging(ops, shape):
-    """unet_conv3x3_fwd_c1a: Conv2D(32, relu)(1-channel image) -> Conv2D(cout, relu) (T1:859-860) as one launch that never reads the first layer's output.  The recompute
-    uses the fmaf order of the one-channel kernel, so the result equals the two-launch form IN EVERY BIT (tiles at the image border, widths that are not a multiple of
-    the 32-pixel tile, a 16-channel second conv); and both stay within the op tolerance of float64."""
-    from gpu_util import relerr
-    n, h, w, co = shape
-    from covidseg_amd import _lib
-    assert ops.lib.unet_conv3x3_fwd_c1a_supported(ops.h, 0, w, co) == 0          # opt-in (measured slower than the two launches on MI355X: DESIGN.md, A/B log of round 4)
-    ops.ck(ops.lib.unet_ctx_set_option(ops.h, _lib.OPTIONS["c1a_recompute"], 1), "opt in")
-    try:
-        _c1a_recompute_case(ops, n, h, w, co)
-    finally:
-        ops.ck(ops.lib.unet_ctx_set_option(ops.h, _lib.OPTIONS["c1a_recompute"], 0), "opt out")
-
-
-def _c1a_recompute_case(ops, n, h, w, co):
-    from gpu_util import relerr
-    assert ops.lib.unet_conv3x3_fwd_c1a_supported(ops.h, 0, w, co) == 1 and ops.lib.unet_conv3x3_fwd_c1a_supported(ops.h, 0, w, 64) == 0 and ops.lib.unet_conv3x3_fwd_c1a_supported(ops.h, 1, w, co) == 0
-    rng = np.random.default_rng(h + w)
-    img = rng.random((n, h, w, 1)).astype(np.float32)
-    w1 = (rng.standard_normal((3, 3, 1, 32)) * 0.5).astype(np.float32); b1 = (rng.standard_normal(32) * 0.2).astype(np.float32)
-    k2 = (rng.standard_normal((3, 3, 32, co)) * (2.0 / (9 * 32)) ** 0.5).astype(np.float32); b2 = (rng.standard_normal(co) * 0.1).astype(np.float32)
-    y1 = ops.z(n, h, w, 32); y2 = ops.z(n, h, w, co); yf = ops.z(n, h, w, co)
-    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(img).data_ptr(), ops.d(w1).data_ptr(), ops.d(b1).data_ptr(), y1.data_ptr(), n, h, w, 1, 32, 1, 0.0, 0, 0, ops.wws(1, 32), ops.s), "first layer")
-    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, y1.data_ptr(), ops.d(k2).data_ptr(), ops.d(b2).data_ptr(), y2.data_ptr(), n, h, w, 32, co, 1, 0.0, 0, 0, ops.wws(32, co), ops.s), "second conv")
-    ops.ck(ops.lib.unet_conv3x3_fwd_c1a(ops.h, ops.d(img).data_ptr(), ops.d(w1).data_ptr(), ops.d(b1).data_ptr(), ops.d(k2).data_ptr(), ops.d(b2).data_ptr(), yf.data_ptr(), n, h, w, co, 1,
-                                        ops.wws(32, co), ops.s), "fused")
-    assert torch.equal(yf, y2) and float(yf.abs().sum()) > 0
-    want = O.conv3x3_bias_relu(O.conv3x3_bias_relu(T64(img), T64(w1), T64(b1)), T64(k2), T64(b2)).numpy()
-    assert relerr(yf.cpu().numpy(), want) < 2e-6
-    # with sign bits of the output requested (the mask of the next data gradient) and no activation
-    bits = torch.zeros(max(n * h * w * co // 64, 1), dtype=torch.int64, device="cuda"); bits2 = torch.zeros_like(bits)
-    if co == 32 and w % 8 == 0:
-        ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits.data_ptr()), "arm")
-        ops.ck(ops.lib.unet_conv3x3_fwd_c1a(ops.h, ops.d(img).data_ptr(), ops.d(w1).data_ptr(), ops.d(b1).data_ptr(), ops.d(k2).data_ptr(), ops.d(b2).data_ptr(), yf.data_ptr(), n, h, w, co, 1,
-                                            ops.wws(32, co), ops.s), "fused + bits")
-        ops.ck(ops.lib.unet_request_relu_bits(ops.h, bits2.data_ptr()), "arm")
-        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, y1.data_ptr(), ops.d(k2).data_ptr(), ops.d(b2).data_ptr(), y2.data_ptr(), n, h, w, 32, co, 1, 0.0, 0, 0, ops.wws(32, co), ops.s), "second conv + bits")
-        assert torch.equal(bits, bits2) and torch.equal(yf, y2)
-    ops.ck(ops.lib.unet_conv3x3_fwd_c1a(ops.h, ops.d(img).data_ptr(), ops.d(w1).data_ptr(), ops.d(b1).data_ptr(), ops.d(k2).data_ptr(), ops.d(b2).data_ptr(), yf.data_ptr(), n, h, w, co, 0,
-                                        ops.wws(32, co), ops.s), "fused, linear")
-    ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, y1.data_ptr(), ops.d(k2).data_ptr(), ops.d(b2).data_ptr(), y2.data_ptr(), n, h, w, 32, co, 0, 0.0, 0, 0, ops.wws(32, co), ops.s), "second conv, linear")
-    assert torch.equal(yf, y2)
-
-
 @pytest.mark.parametrize("shape", [(2, 16, 24), (1, 40, 72), (3, 9, 8), (1, 6, 104)])
 def test_head_backward_as_a_stream_expanded_by_the_last_convs_gradients(ops, shape):
     """dL/d(output of the last conv3x3) = dz_p w_c [y_pc > 0] (T1:911-913 backwards) has one fp32 degree of freedom and 32 mask bits per pixel: unet_head_dzm writes that
