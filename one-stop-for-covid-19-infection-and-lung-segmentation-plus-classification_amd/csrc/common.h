@@ -16,6 +16,7 @@
 // Deterministic mode (UNET_OPT_DETERMINISTIC): UNET_BN_SLOTS_DET copies, every workgroup of a reduction kernel owns ONE copy (grids are capped at the copy
 // count), so each atomic lands on a zero it alone writes, and the fold kernel sums the copies in index order: bit-identical reruns.
 constexpr int UNET_BN_SLOTS = 64, UNET_BN_SLOTS_DET = 1024, UNET_BN_SLOT_DOUBLES = 2048;
+constexpr int UNET_CUS = 256;                              // compute units of an MI355X (8 XCDs x 32): what a launch must out-number to fill the chip
 constexpr int UNET_HEAD_SUMS = 100;          // doubles behind the loss sums: the per-channel sums of a fused head's weight gradient (k_head_fold)
 struct unet_ctx {
   int device = 0;
@@ -88,6 +89,45 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// (a sc, b sc) as packed fp16 pairs h, m with x sc ~ h + m: h = RN_f16(x sc), m = RN_f16(x sc - h) -- the two-term split of the h2 kernels with the block scale folded in.
+// v_fma_mixlo / mixhi_f16 take fp32 and fp16 sources in one fused multiply-add and round ONCE to fp16: h is the product itself (exact in fp32: sc is a power of two),
+// m the exact difference -- the same bits as scale, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_fma, v_cvt_pk (six VALU instructions per pair) in four.
+__device__ __forceinline__ void split2_scaled(float a, float b, float sc, unsigned& h, unsigned& m) {
+  unsigned hh, mm;
+#ifdef H2_AB_OLD_SPLIT
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  a *= sc; b *= sc;
+  const f16x2_ h2 = __builtin_convertvector((f32x2_){a, b}, f16x2_);
+  const f16x2_ m2 = __builtin_convertvector((f32x2_){a - (float)h2[0], b - (float)h2[1]}, f16x2_);
+  h = __builtin_bit_cast(unsigned, h2); m = __builtin_bit_cast(unsigned, m2);
+  return;
+#endif
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(a), "v"(sc));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(b), "v"(sc));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(mm) : "v"(a), "v"(sc), "v"(hh));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(mm) : "v"(b), "v"(sc), "v"(hh));
+  h = hh; m = mm;
+}
+
+// Maximum over the wave of a NON-NEGATIVE float (a block's max |x|), returned wave-uniform in a scalar register: four DPP steps inside each row of 16 lanes (the
+// operands ride on the v_max instructions: no LDS round trip) + one v_readlane per row.  Non-negative floats order like their bit patterns, so the maxima are integer
+// ones (no NaN canonicalisation; a NaN input wins and poisons the block, which it does anyway).  Replaces six dependent ds_bpermute exchanges (~600 cycles of LDS
+// latency on the critical path of every staged chunk of the h2 kernels).
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+#ifdef H2_AB_OLD_AMAX
+  for (int o = 32; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  return x;
+#endif
+  unsigned v = __float_as_uint(x);
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));           // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));           // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));          // row_half_mirror: the other quad of the 8
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));          // row_mirror: the other 8 of the 16
+  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16), r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return __uint_as_float(max(max(r0, r1), max(r2, r3)));
 }
 
 // Branch-free guarded 16-byte load: the hardware range check of a buffer descriptor returns 0 for byte offsets >= the record

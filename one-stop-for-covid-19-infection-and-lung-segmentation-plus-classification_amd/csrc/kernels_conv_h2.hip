@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
                                                            int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs,
-                                                           int mask_climit, h2_head_args hd) {
+                                                           int mask_climit, h2_head_args hd, int img_nb) {
   constexpr bool HEAD = EPI == 1, POOLS = EPI == 2;          // EPI: 0 the general epilogue, 1 + the 1x1 sigmoid head (below), 2 + the pooled-path sums of an encoder tail (MASK_POOL_SUMS)
   // EPI 3 (VDY): the general epilogue behind a VIRTUAL input -- the gradient of the last conv3x3's output, dy[p][c] = dz_p w_c [y_pc > 0] (T1:911-913 backwards), staged from
   // the 8-byte-per-pixel stream {dz_p, 32 mask bits} of head_dzm_kernel (x = that stream, ldx = 2): one value is scaled and split per staged piece, the mask bits pick
@@ -239,12 +239,17 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   };
   // the weight slab of a chunk: 27-36 KB that every workgroup of the channel group reads -- L2 hits (~250 cycles).  It is requested AFTER the chunk's MFMAs
   // (behind the barrier), so its staging registers share the MFMA operand registers, and lands while the patch is scaled and split
+  // img_nb > NB (NB = 1 only): the image was built for img_nb 32-channel blocks per workgroup (h2_nb(M) = 2; 4 for a ConvT forward) and this launch runs ONE block per
+  // workgroup because the wider grid would leave CUs idle (batch-1 inference, the deep levels of small batches): group g is block g % img_nb of the image's group
+  // g / img_nb, whose slab holds [tap | k-step][block][plane][half][32] pieces -- 128 consecutive pieces per (tap, block), the taps img_nb * 128 pieces apart
+  const bool wide_img = NB == 1 && img_nb > 1;
   auto issue_w_loads = [&](int chunk) __attribute__((always_inline)) {
-    const int wsoff = (g * nchunks + chunk) * W_BYTES;
+    const int wsoff = wide_img ? ((g / img_nb) * nchunks + chunk) * (img_nb * W_BYTES) + (g % img_nb) * 2048 : (g * nchunks + chunk) * W_BYTES;
 #pragma unroll
     for (int k = 0; k < WL; ++k) {
       const int idx = tid + k * 256;
-      wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, idx < WPIECES ? idx * 16 : UNET_OOB, wsoff, 0);
+      const int po = wide_img ? ((idx >> 7) * img_nb * 128 + (idx & 127)) * 16 : idx * 16;
+      wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, idx < WPIECES ? po : UNET_OOB, wsoff, 0);
     }
   };
   // max |x| of the pieces this wave holds -> s_amax[wave]
@@ -256,8 +261,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(__uint_as_float(preg[k][j])));
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_nonneg(mx);
     if (lane == 0) s_amax[wave] = mx;
   };
   int e_run = 120;                                           // running exponent of the activation operand: staged values are x * 2^e_run
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
           const unsigned k01 = h2_pair_mask(nib, 0), k23 = h2_pair_mask(nib, 2);
           h0 = hh & k01; h1 = hh & k23; m0 = mm & k01; m1 = mm & k23;
         } else {
-        split2(__uint_as_float(preg[k][0]) * sc, __uint_as_float(preg[k][1]) * sc, h0, m0);
-        split2(__uint_as_float(preg[k][2]) * sc, __uint_as_float(preg[k][3]) * sc, h1, m1);
+        split2_scaled(__uint_as_float(preg[k][0]), __uint_as_float(preg[k][1]), sc, h0, m0);
+        split2_scaled(__uint_as_float(preg[k][2]), __uint_as_float(preg[k][3]), sc, h1, m1);
         }
         const int q = tid & 3, pp = (tid >> 2) + k * 64;                // (k * 64 / NPIX is a compile-time constant in the ConvT modes: NPIX % 64 == 0 there)
         const int ks = MODE == 0 ? 0 : (k * 64) / NPIX;
@@ -751,8 +755,10 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 
 template <int MODE, int NB, int RW, int WPS, int EPI = 0>
 int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd,
-                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30, h2_head_args hd = h2_head_args()) {
+                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30, h2_head_args hd = h2_head_args(), int img_nb = 0) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
+  if (img_nb == 0) img_nb = NB;                              // (the image's blocks per group: NB unless a one-block launch reads a two-block image, conv_h2_kernel)
+  if (img_nb != NB && !(MODE != 2 && NB == 1 && (img_nb == 2 || img_nb == 4) && (M % (32 * img_nb)) == 0 && EPI == 0)) UNET_FAIL(ctx, UNET_E_ARG, "conv h2: image of %d blocks per group on a %d-block launch", img_nb, NB);
   constexpr int TH = 4 * RW;
   constexpr int NPIX = MODE == 0 ? (TH + 2) * 34 : TH * 32;
   constexpr size_t smem = (size_t)2 * KS * 2 * (NPIX * 16 + (MODE == 0 ? 0 : 64)) + (NB != 1 || MODE != 0 ? (size_t)((KS * T * NB * 2 * 2 * 32 + 255) / 256) * 256 * 16 : (size_t)KS * T * NB * 2 * 2 * 32 * 16) + 16 + 3 * NB * 32 * 4;
@@ -781,7 +787,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
-                       stats_c, signs, mask_climit, hd);
+                       stats_c, signs, mask_climit, hd, img_nb);
     return UNET_OK;
   };
   int32_t r;
@@ -907,7 +913,14 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
   if (mask_climit < M && ((mask_climit % 32) || mask_mode < MASK_BN_BWD)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2: mask_climit %d must be a whole number of 32-channel blocks of a folded-BatchNorm gradient", mask_climit);
-  if (h2_nb(M) == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
+  // Grids that leave CUs idle (batch-1 inference below 256 x 256, the 32 x 32 level of small batches) trade tile size for workgroups, on the SAME weight image:
+  //   fewer than two two-block 8-row tiles per CU -> ONE 32-channel block per workgroup (twice the workgroups, half the MFMAs per staged chunk; the patch is staged twice,
+  //   which an idle CU does for free); still fewer than one workgroup per CU -> 4-row tiles (one row per wave) on top of that
+  const int inb = h2_nb(M);
+  const long long t8 = (long long)((wd + 31) / 32) * ((h + 7) / 8) * n;
+  if (t8 * ((M + 31) / 32) < UNET_CUS) return launch_h2<0, 1, 1, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), inb);
+  if (inb == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
+  if (t8 * ((M + 63) / 64) < 2 * UNET_CUS) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), 2);
   // 16-row tiles (twice the MFMAs per staged chunk, 7 spilled registers at two workgroups per CU) measured 3-5 % faster on the 64 x 64 ... 128 x 128 layers when
   // they still fill the 512 resident slots, 2-4 % slower on the 256 / 512 pixel layers (fewer, longer workgroups) and much slower when the grid falls below one round
   const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
@@ -967,6 +980,9 @@ int32_t k_convT_h2_fwd(unet_ctx* ctx, const float* x, const float* w, const floa
     prepared = ctx->convt_img;
   }
   const unet_bf16* img = static_cast<const unet_bf16*>(prepared);
+  // (fewer than one four-block workgroup per CU -- the 32 x 32 and 64 x 64 inputs of batch-1 inference --: one block per workgroup on the same four-block image)
+  if ((long long)((wd + 31) / 32) * ((h + 7) / 8) * n * ((4 * cout + 127) / 128) < UNET_CUS && (cout % 32) == 0)
+    return launch_h2<1, 1, 2, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s, 1 << 30, h2_head_args(), 4);
   return launch_h2<1, 4, 2, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
 }
 

@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
 #pragma unroll
         for (int j = 0; j < 4; ++j) mb = fmaxf(mb, fabsf(__uint_as_float(breg[k][j])));
       }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+      ma = wave_max_nonneg(ma); mb = wave_max_nonneg(mb);
       if (lane == 0) { s_amax[0][wave] = ma; s_amax[1][wave] = mb; }
     };
     auto store_lds = [&](int ys, int base, int j0) __attribute__((always_inline)) {
@@ -198,8 +197,8 @@ __global__ __launch_bounds__(256, (R == 4 && WA * WB > 1) ? 1 : 2) void wgrad_h2
       const float sa = pow2f(e_a), sb = pow2f(e_b);
       auto put = [&](char* dst, const unet_u32x4& v, float sc) __attribute__((always_inline)) {
         unsigned h0, m0, h1, m1;
-        split2(__uint_as_float(v[0]) * sc, __uint_as_float(v[1]) * sc, h0, m0);
-        split2(__uint_as_float(v[2]) * sc, __uint_as_float(v[3]) * sc, h1, m1);
+        split2_scaled(__uint_as_float(v[0]), __uint_as_float(v[1]), sc, h0, m0);
+        split2_scaled(__uint_as_float(v[2]), __uint_as_float(v[3]), sc, h1, m1);
         *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(dst + STAGE1) = make_uint2(m0, m1);
       };
@@ -434,8 +433,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
       for (int k = 0; k < NB_; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mb = fmaxf(mb, fabsf(__uint_as_float(breg[k][j])));
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+      ma = wave_max_nonneg(ma); mb = wave_max_nonneg(mb);
       if (lane == 0) { s_amax[0][wave] = ma; s_amax[1][wave] = mb; }
     };
     auto store_lds = [&]() __attribute__((always_inline)) {
@@ -462,8 +460,8 @@ __global__ __launch_bounds__(256, 2) void wgradT_h2_kernel(const float* __restri
       const float sa = pow2f(e_a), sb = pow2f(e_b);
       auto put = [&](char* dst, const unet_u32x4& v, float sc) __attribute__((always_inline)) {
         unsigned h0, m0, h1, m1;
-        split2(__uint_as_float(v[0]) * sc, __uint_as_float(v[1]) * sc, h0, m0);
-        split2(__uint_as_float(v[2]) * sc, __uint_as_float(v[3]) * sc, h1, m1);
+        split2_scaled(__uint_as_float(v[0]), __uint_as_float(v[1]), sc, h0, m0);
+        split2_scaled(__uint_as_float(v[2]), __uint_as_float(v[3]), sc, h1, m1);
         *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(dst + STAGE1) = make_uint2(m0, m1);
       };

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import sys
 from collections import OrderedDict
 
 import numpy as np
@@ -359,8 +360,7 @@ class HipUNet:
             self.ctx.release(); self.ctx = None
 
     def __del__(self):
-        import sys
-        if sys.is_finalizing():                            # (interpreter teardown: the HIP runtime may be gone already -- the process's memory goes with it)
+        if sys is None or sys.is_finalizing():                            # (interpreter teardown: the HIP runtime may be gone already -- the process's memory goes with it)
             return
         try:
             self.close()

@@ -766,9 +766,11 @@ def test_copy_and_accum_slices(ops):
     assert np.allclose(dst.cpu().numpy(), g1[..., 32:64] + g2, atol=1e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 512, 512, 32, 32), (2, 256, 256, 64, 64), (4, 32, 32, 256, 512), (1, 224, 224, 16, 32)])
+@pytest.mark.parametrize("shape", [(2, 512, 512, 32, 32), (2, 256, 256, 64, 64), (4, 32, 32, 256, 512), (1, 224, 224, 16, 32), (16, 128, 128, 64, 64), (16, 32, 32, 128, 128)])
 def test_h2_matches_strict_fp32_mfma_at_full_size(ops, shape):
-    """BASELINE-size layers (too big for the CPU oracle in a unit test): the fp16-split h2 kernels (forward, data gradient, weight gradient; algo 0)
+    """(the three launch forms of the 64-channel-group kernel: 8-row tiles at 256 x 256, 16-row tiles at 16 x 128 x 128, and -- grids below two workgroups per CU, 4 x 32 x 32 -- one
+    32-channel block per workgroup on the two-block weight image)
+    BASELINE-size layers (too big for the CPU oracle in a unit test): the fp16-split h2 kernels (forward, data gradient, weight gradient; algo 0)
     against the strict fp32 MFMA kernels (algo 2: exact fp32 multiply-add) on the same device buffers -- two independent kernel families, relative
     L2 difference <= 1e-5."""
     from gpu_util import relerr

@@ -1,13 +1,16 @@
 #!/bin/bash
-# Host-side sanitizer run: the ASan + UBSan build of libunet_hip.so (`make -C <package>/csrc asan`, host objects only) loaded into python with the
-# sanitizer runtime preloaded; builds the three graphs (plans of two batch sizes, all option sets of the options test), runs training steps, inference, taps, the DP program
+# Host-side sanitizer run: the UBSan + libstdc++-assertions build of libunet_hip.so (`make -C <package>/csrc ubsan`, host objects only; default) or,
+# with `asan` as the first argument, the ASan + UBSan build with the sanitizer runtime preloaded (which the HIP runtime of this image does not survive: its HSA allocation
+# interceptor fails at the first device allocation -- profiles/r05_sanitizer.txt); builds the three graphs (plans of two batch sizes, all option sets of the options test), runs training steps, inference, taps, the DP program
 # at world 1 and tears everything down.  Any ASan / UBSan report goes to gpurun_out/asan/report.* and fails the script.
 set -u
 cd "$(dirname "$0")/../.."
 OUT=gpurun_out/asan; mkdir -p $OUT; rm -f $OUT/report.*
-RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
-LIB=$PWD/build/asan/libunet_hip_asan.so
-[ -f "$LIB" ] || make -C one-stop-*/csrc asan -j8 >/dev/null || exit 1
+MODE=${1:-ubsan}
+RT=""
+if [ "$MODE" = asan ]; then RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1); fi
+LIB=$PWD/build/$MODE/libunet_hip_$MODE.so
+[ -f "$LIB" ] || make -C one-stop-*/csrc $MODE -j8 >/dev/null || exit 1
 export COVIDSEG_AMD_LIB=$LIB
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=0:log_path=$PWD/$OUT/report:abort_on_error=0
 export UBSAN_OPTIONS=print_stacktrace=1:log_path=$PWD/$OUT/report
@@ -49,4 +52,4 @@ tail -5 $OUT/run.log
 n=$(ls $OUT/report.* 2>/dev/null | wc -l)
 echo "exit $rc, sanitizer report files: $n"
 if [ $rc -ne 0 ] || [ $n -ne 0 ] || ! grep -q ASAN_RUN_DONE $OUT/run.log; then head -60 $OUT/report.* 2>/dev/null; exit 1; fi
-echo "asan_check: clean"
+echo "sanitizer check ($MODE): clean"
