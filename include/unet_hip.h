@@ -64,11 +64,14 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   ENC_BN_FUSED (1)       encoder tail backward without a statistics pass (sums from the pooled tensors + closed-form skip term, one fused apply pass)
  *   BN_CONCAT_ANALYTIC (1) decoder BatchNorm statistics: skip half from the encoder layer's sums, only the upsampled half measured
  *   BN_FUSE_STATS (1)      BatchNorm statistics accumulated by the producing conv's epilogue (unet_request_bn_stats honoured)
- *   DETERMINISTIC (0)      1 = every reduction in a fixed order: no floating-point atomics anywhere (BatchNorm / loss / metric sums through per-workgroup
- *                          slots folded in index order; statistics by their own pass), so reruns are bit-identical; costs ~6 % of the step
+ *   DETERMINISTIC (0)      1 = no floating-point atomics anywhere, so reruns are bit-identical: the reductions of the stand-alone passes go through per-workgroup slots
+ *                          folded in index order; the sums a kernel EPILOGUE takes (BatchNorm statistics, the fused head's loss / gradient sums, the pooled sums -- launches
+ *                          with far more workgroups than slots) leave as exact integer window sums, four 64-bit words per value, whose addition is associative
+ *                          (ABI v15: the same fused graph as the default mode; 1.6 % of the step, 9 % before).  Domain of an epilogue partial sum: |t| < 2^39,
+ *                          bits below 2^-80 dropped; outside it (and for Inf / NaN) the folded value is NaN
  *   HEAD_FUSED (1)         fp32 U-Net, h2 kernels: the 1x1 sigmoid head (T1:913), the loss sums and the per-channel sums of the head's weight gradient come out of
  *                          the epilogue of the last conv3x3 (no pass over its 32-channel output in forward; backward writes dL/d(conv output) from p, the labels
- *                          and one bit per element); 0 = the separate head_fwd / head_bwd passes (always taken in deterministic mode)
+ *                          and one bit per element); 0 = the separate head_fwd / head_bwd passes
  *   SKIP_RAW (1)           fp32 U-Net with BN_FOLD >= 2, ENC_BN_FUSED and BN_CONCAT_ANALYTIC: the second conv of an encoder block (T1:860) writes straight into the skip half
  *                          of its concat (T1:908) and the encoder BatchNorm's output is never stored: max-pool reads the raw tensor, the folded decoder BatchNorm is
  *                          composed with the encoder one (two affine maps in a row are one).  -1 GB of writes per step at 512 x 512 x 16.  0 = the normalised copy is stored

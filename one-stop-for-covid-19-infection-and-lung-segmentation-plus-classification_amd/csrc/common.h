@@ -43,6 +43,7 @@ struct unet_ctx {
   int stats_req_c = 0;              // channels of the BatchNorm (0 = not armed)
   const void* stats_in_slots = nullptr;
   int stats_in_slots_c = 0;
+  bool stats_in_slots_xs = false;   // ... as exact window sums (deterministic mode, xsum_add below) instead of doubles
   // one-shot: the next h2 conv3x3 forward with a ReLU epilogue also writes the sign bits of what it stores (MASK_RELU_BITS layout) here and leaves the
   // address in signs_done; the data gradients that would re-read the fp32 tensor as their mask read 1/32 of the bytes
   unsigned long long* signs_req = nullptr;
@@ -89,6 +90,43 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// ---- deterministic mode: sums taken in a kernel EPILOGUE (thousands of workgroups per launch, far more than there are slot copies) as exact, order-independent
+// window sums.  A float t is an integer multiple of 2^(e - 23); four 64-bit integer accumulators per value with least-significant bits 2^-80, 2^-48, 2^-16, 2^16
+// take it without rounding: q = t / lsb(w) of the window below its lowest bit (56 bits at most), its low 32 bits into window w, the rest into window w + 1.
+// Integer addition is associative, so the atomics may land in any order and on any number of slot copies: the folded value is the same bits on every run -- and
+// exact, where the fp64 atomics of the default mode round.  Domain: 2^-57 <= |t| < 2^39 (below: the bits under 2^-80 are dropped, the same ones on every run;
+// above, Inf, NaN: the value is poisoned and folds to NaN, as a floating-point sum would be).  A slot row holds UNET_BN_SLOT_DOUBLES / 4 such values.
+constexpr int UNET_XW = 4;
+__device__ __forceinline__ void xsum_add(double* row, int idx, float t) {
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(row) + (size_t)UNET_XW * idx;
+  const int eb = (int)((__float_as_uint(t) >> 23) & 0xFF);
+  if (eb == 0) return;                                       // zero (a denormal: below every window)
+  const int e = eb - 127;
+  if (e >= 39) { atomicMax(reinterpret_cast<long long*>(acc + 3), 1LL << 62); return; }          // out of the domain / Inf / NaN: poison
+  const int w = min(max((e - 23 + 80) >> 5, 0), 2);
+  const double sc = __longlong_as_double((long long)(1023 + 80 - 32 * w) << 52);          // 2^(80 - 32 w)
+  const long long q = __double2ll_rd((double)t * sc);
+  atomicAdd(acc + w, (unsigned long long)(q & 0xFFFFFFFFll));
+  atomicAdd(acc + w + 1, (unsigned long long)(q >> 32));
+}
+// the value of index idx summed over the first nslots slot copies (row stride UNET_BN_SLOT_DOUBLES); the words are cleared for the next launch
+__device__ __forceinline__ double xsum_take(double* slots, int idx, int nslots) {
+  long long S0 = 0, S1 = 0, S2 = 0, S3 = 0; bool bad = false;
+  for (int k0 = 0; k0 < nslots; k0 += 8) {                    // (nslots is a multiple of 8) eight copies' 32 bytes in flight; integer sums: no order to keep
+    longlong2 a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      longlong2* p = reinterpret_cast<longlong2*>(slots + (size_t)(k0 + k) * UNET_BN_SLOT_DOUBLES + (size_t)UNET_XW * idx);
+      a[k] = p[0]; b[k] = p[1];
+      p[0] = make_longlong2(0, 0); p[1] = make_longlong2(0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { S0 += a[k].x; S1 += a[k].y; S2 += b[k].x; S3 += b[k].y; bad |= b[k].y >= (1LL << 61); }
+  }
+  const double r = ((double)S3 * 65536.0 + (double)S2 * (1.0 / 65536.0)) + ((double)S1 * __longlong_as_double((long long)(1023 - 48) << 52) + (double)S0 * __longlong_as_double((long long)(1023 - 80) << 52));
+  return bad ? __longlong_as_double(0x7FF8000000000000ll) : r;
 }
 
 // (a sc, b sc) as packed fp16 pairs h, m with x sc ~ h + m: h = RN_f16(x sc), m = RN_f16(x sc - h) -- the two-term split of the h2 kernels with the block scale folded in.
@@ -286,7 +324,7 @@ int32_t k_conv3x3_h2_fwd(unet_ctx*, const float* x, const void* wimg, const floa
 // pre = (s_enc, t_enc) (x_dec = pre_s x_raw + pre_t: what the decoder BatchNorm's backward sums are taken over); the upsampled half keeps (s_dec, t_dec), pre = (1, 0)
 // the data gradient of the conv behind an encoder tail with the tail's BatchNorm-backward sums in its epilogue (MASK_POOL_SUMS): dy [n,h,wd,K] -> dx [n,h,wd,M], pooled = the
 // forward's max-pool + dropout output [n,h,wd,M]; sums[2 M] += (folded out of the slot copies behind the launch)
-int32_t k_slot_fold(unet_ctx*, double* sums, int count, hipStream_t s);          // sums[i] += the slot copies' entries i (cleared), in index order (kernels_pointwise.hip)
+int32_t k_slot_fold(unet_ctx*, double* sums, int count, hipStream_t s, bool xs = false);          // xs: the slots hold exact window sums (xsum_add), UNET_BN_SLOTS copies          // sums[i] += the slot copies' entries i (cleared), in index order (kernels_pointwise.hip)
 // the pooled sums a MASK_POOL_SUMS launch left in the slot copies -> sums[2 c] (+=), + the closed-form skip term (unet_bn_bwd_skip_term) + the BatchNorm's parameter gradients: one launch
 int32_t k_enc_tail_finish(unet_ctx*, double* sums, const double* dec_sum_dyxhat, const float* dec_invstd, const float* dec_gamma, const float* gamma, float* dgamma, float* dbeta, int c,
                           double frac, hipStream_t s);

@@ -375,8 +375,8 @@ int32_t launch_conv_bf16(unet_ctx* ctx, const unet_bf16* x, int ldx, const unet_
   if (MODE != 2 && ctx->stats_req_c > 0) {
     const int c = ctx->stats_req_c; ctx->stats_req_c = 0;
     if ((mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots && smem >= 4 * 32 * 80 + 4 * NB * 64 * 4 &&
-        (M % 32) == 0) {          // (a half-padded 16-channel block pays more in this epilogue than its statistics pass costs: classifier c1b 0.28 -> 0.39 ms)
-      stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c;
+        (M % 32) == 0 && !ctx->opt_deterministic) {          // (deterministic mode: the bf16 kernels leave the statistics to their own fixed-order pass)          // (a half-padded 16-channel block pays more in this epilogue than its statistics pass costs: classifier c1b 0.28 -> 0.39 ms)
+      stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; ctx->stats_in_slots_xs = false;
     }
   }
   auto go = [&](auto kern) -> int32_t {

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
                                                            int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs,
-                                                           int mask_climit, h2_head_args hd, int img_nb) {
+                                                           int mask_climit, h2_head_args hd, int img_nb, int xs) {
   constexpr bool HEAD = EPI == 1, POOLS = EPI == 2;          // EPI: 0 the general epilogue, 1 + the 1x1 sigmoid head (below), 2 + the pooled-path sums of an encoder tail (MASK_POOL_SUMS)
   // EPI 3 (VDY): the general epilogue behind a VIRTUAL input -- the gradient of the last conv3x3's output, dy[p][c] = dz_p w_c [y_pc > 0] (T1:911-913 backwards), staged from
   // the 8-byte-per-pixel stream {dz_p, 32 mask bits} of head_dzm_kernel (x = that stream, ldx = 2): one value is scaled and split per staged piece, the mask bits pick
@@ -550,7 +550,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       __syncthreads();
       if (tid < 103) {                                     // [0, 96): the three per-channel sums; 96..99: bce, t p, t, p; 100..102: sum a, sum t q, sum q
         const float t = (s_hsum[tid] + s_hsum[104 + tid]) + (s_hsum[208 + tid] + s_hsum[312 + tid]);
-        atomicAdd(hd.slots + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + tid, (double)t);
+        double* const row = hd.slots + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES;
+        if (xs) xsum_add(row, tid, t); else atomicAdd(row + tid, (double)t);          // (xs: deterministic mode -- exact window sums, common.h)
       }
     }
     H2_STAMP(8);
@@ -742,7 +743,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         for (int wv = 0; wv < 4; ++wv) t += s_stat[((wv * NB + nb) * 2 + kind) * 32 + c32];
         int ch = mb + c32;
         if (MODE == 1) ch = ch % (M >> 2);                 // ConvT: the four (a, b) planes of a channel
-        atomicAdd(stats + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES + (kind ? stats_c : 0) + ch, (double)t);
+        double* const row = stats + (size_t)(blockIdx.x % UNET_BN_SLOTS) * UNET_BN_SLOT_DOUBLES;
+        if (xs) xsum_add(row, (kind ? stats_c : 0) + ch, t); else atomicAdd(row + (kind ? stats_c : 0) + ch, (double)t);
       }
     }
   }
@@ -772,10 +774,14 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   double* stats = nullptr; int stats_c = 0;
   if (MODE != 2 && ctx->stats_req_c > 0) {
     const int c = ctx->stats_req_c; ctx->stats_req_c = 0;
-    if ((mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && 2 * c <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots) { stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; }
+    // (deterministic mode: the sums leave as exact window sums, four words per value -- xsum_add, common.h)
+    const int xw = ctx->opt_deterministic ? UNET_XW : 1;
+    if ((mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && 2 * c * xw <= UNET_BN_SLOT_DOUBLES && c == (MODE == 1 ? M / 4 : M) && ctx->bn_slots) {
+      stats = ctx->bn_slots; stats_c = c; ctx->stats_in_slots = y; ctx->stats_in_slots_c = c; ctx->stats_in_slots_xs = ctx->opt_deterministic != 0;
+    }
   }
   if (mask_mode == MASK_POOL_SUMS) {
-    if (MODE != 0 || !ctx->bn_slots || 2 * M > UNET_BN_SLOT_DOUBLES || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "conv h2: the pooled-sums epilogue is a conv3x3 data-gradient launch (M = %d)", M);
+    if (MODE != 0 || !ctx->bn_slots || 2 * M * (ctx->opt_deterministic ? UNET_XW : 1) > UNET_BN_SLOT_DOUBLES) UNET_FAIL(ctx, UNET_E_ARG, "conv h2: the pooled-sums epilogue is a conv3x3 data-gradient launch (M = %d)", M);
     stats = ctx->bn_slots; stats_c = M;
   }
   if (mask_mode == MASK_RELU_BITS && ((M & 31) || (wd & 7))) UNET_FAIL(ctx, UNET_E_SHAPE, "conv h2: the bit mask needs M %% 32 == 0 and W %% 8 == 0 (M=%d W=%d)", M, wd);
@@ -787,7 +793,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
-                       stats_c, signs, mask_climit, hd, img_nb);
+                       stats_c, signs, mask_climit, hd, img_nb, ctx->opt_deterministic ? 1 : 0);
     return UNET_OK;
   };
   int32_t r;
@@ -930,7 +936,7 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
 
 bool h2_pool_sums_selected(const unet_ctx* ctx, int algo, int wd, int K, int M) {
   (void)wd;
-  return ctx && ctx->opt_pool_sums_fused && !ctx->opt_deterministic && ctx->bn_slots && h2_conv3x3_selected(algo, K, M) && (M % 32) == 0 && 2 * M <= UNET_BN_SLOT_DOUBLES;
+  return ctx && ctx->opt_pool_sums_fused && ctx->bn_slots && h2_conv3x3_selected(algo, K, M) && (M % 32) == 0 && 2 * M * (ctx->opt_deterministic ? UNET_XW : 1) <= UNET_BN_SLOT_DOUBLES;
 }
 int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx* ctx, const float* dy, const void* wimg, const float* pooled, const float* gamma, const float* beta, float rate, float* dx, double* sums,
                                      int n, int h, int wd, int K, int M, hipStream_t s) {
@@ -944,14 +950,14 @@ int32_t k_conv3x3_h2_dgrad_pool_sums(unet_ctx* ctx, const float* dy, const void*
   else if (h <= 128 && wgs16 >= 512) r = launch_h2<0, 2, 4, 2, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
   else r = launch_h2<0, 2, 2, 2, 2>(ctx, dy, K, img, nullptr, pooled, MASK_POOL_SUMS, dx, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, hd);
   if (r || !sums) return r;
-  return k_slot_fold(ctx, sums, 2 * M, s);
+  return k_slot_fold(ctx, sums, 2 * M, s, ctx->opt_deterministic != 0);
 }
 
 // The network's last conv3x3 + its 1x1 sigmoid head (T1:911-913) in one launch: y = relu(conv(x)) [n,h,wd,32], p = sigmoid(y . wh + bh) [n,h,wd]; with labels t:
 // the slot copies `ctx->bn_slots` receive [0,96) sum_p a y_c | sum_p t q y_c | sum_p q y_c, [96,100) sum bce, sum t p, sum t, sum p, [100,103) sum a, sum t q, sum q
 // (a = dBCE/dz, q = p (1 - p)): k_head_fold moves them out; the head's weight gradient is a combination of them once the batch-global Dice sums are known
 bool h2_conv3x3_head_selected(const unet_ctx* ctx, int algo, int wd, int K, int M) {
-  return ctx && !ctx->opt_deterministic && ctx->opt_head_fused && ctx->bn_slots && h2_conv3x3_selected(algo, K, M) && M == 32 && (wd & 7) == 0;
+  return ctx && ctx->opt_head_fused && ctx->bn_slots && h2_conv3x3_selected(algo, K, M) && M == 32 && (wd & 7) == 0;
 }
 int32_t k_conv3x3_h2_head_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, float* y, const float* wh, const float* bh, float* p, const float* t,
                               int n, int h, int wd, int K, hipStream_t s) {

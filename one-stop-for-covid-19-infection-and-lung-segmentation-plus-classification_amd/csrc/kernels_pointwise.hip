@@ -391,10 +391,12 @@ __global__ void bn_bwd_skip_term_kernel(double* __restrict__ sums, const double*
 // bn_slot_fold + bn_bwd_skip_term + bn_bwd_param_grads of an encoder tail in ONE launch (the pooled sums sit in the slot copies, left there by a data-gradient epilogue)
 __global__ void enc_tail_finish_kernel(double* __restrict__ slots, double* __restrict__ sums, const double* __restrict__ dec_s2, const float* __restrict__ dec_istd,
                                        const float* __restrict__ dec_gamma, const float* __restrict__ gamma, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, double frac,
-                                       float eps, int nslots) {
+                                       float eps, int nslots, int xs) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= C) return;
   double s1 = 0.0, s2 = 0.0;
+  if (xs) { s1 = xsum_take(slots, j, nslots); s2 = xsum_take(slots, C + j, nslots); }
+  else
   for (int k0 = 0; k0 < nslots; k0 += 8) {                  // eight independent load pairs in flight, summed in index order
     double v1[8], v2[8];
 #pragma unroll
@@ -623,10 +625,12 @@ __global__ __launch_bounds__(TPB) void head_bwd_kernel(const T* __restrict__ x, 
 
 // ---- the fused head (kernels_conv_h2.hip: conv_h2_kernel<..., HEAD>) -------------------------------------------------
 // fold of the 103 sums it left in the slot copies (cleared for the next launch): [96, 100) -> loss_sums, the rest -> head_sums[99]
-__global__ void head_fold_kernel(double* __restrict__ slots, double* __restrict__ loss_sums, double* __restrict__ head_sums, int nslots) {
+__global__ void head_fold_kernel(double* __restrict__ slots, double* __restrict__ loss_sums, double* __restrict__ head_sums, int nslots, int xs) {
   const int i = threadIdx.x;
   if (i >= 103) return;
   double s = 0.0;
+  if (xs) s = xsum_take(slots, i, nslots);
+  else
   for (int k0 = 0; k0 < nslots; k0 += 16) {
     double v[16];
 #pragma unroll
@@ -810,9 +814,10 @@ __global__ __launch_bounds__(TPB) void zero_kernel(float4* __restrict__ p, long 
 // sums[i] += sum over the slot copies IN INDEX ORDER; the copies are cleared for the next launch.  OUT = double (statistics) or float (the head's
 // weight gradient in deterministic mode)
 template <typename OUT>
-__global__ void bn_slot_fold_kernel(double* __restrict__ slots, OUT* __restrict__ sums, int n2c, int nslots) {
+__global__ void bn_slot_fold_kernel(double* __restrict__ slots, OUT* __restrict__ sums, int n2c, int nslots, int xs = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n2c) return;
+  if (xs) { sums[i] += (OUT)xsum_take(slots, i, nslots); return; }          // (exact window sums left by a kernel epilogue in deterministic mode, common.h)
   double s = 0.0;
   for (int k0 = 0; k0 < nslots; k0 += 16) {                 // (nslots is a multiple of 16) sixteen independent loads in flight, summed in index order
     double v[16];
@@ -829,10 +834,12 @@ __global__ void bn_slot_fold_kernel(double* __restrict__ slots, OUT* __restrict_
 // without reading the tensor.  Thread i < c_up folds the measured sums of the up half out of the slot copies (as bn_slot_fold_kernel), thread
 // c_up + j writes the analytic pair of skip channel j.  Layout of `sums`: [c_up + c_skip sums][c_up + c_skip sums of squares].
 __global__ void bn_fold_concat_kernel(double* __restrict__ slots, double* __restrict__ sums, int c_up, int c_skip, const double* __restrict__ src_sums,
-                                      double src_count, const float* __restrict__ src_gamma, const float* __restrict__ src_beta, double pixels, float eps, int nslots) {
+                                      double src_count, const float* __restrict__ src_gamma, const float* __restrict__ src_beta, double pixels, float eps, int nslots, int xs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int c2 = c_up + c_skip;
-  if (i < c_up) {
+  if (i < c_up && xs) {
+    sums[i] += xsum_take(slots, i, nslots); sums[c2 + i] += xsum_take(slots, c_up + i, nslots);
+  } else if (i < c_up) {
     double s1 = 0.0, s2 = 0.0;
     for (int k0 = 0; k0 < nslots; k0 += 8) {                // eight independent load pairs in flight, summed in index order
       double v1[8], v2[8];
@@ -874,8 +881,9 @@ extern "C++" template <typename T> static int32_t bn_stats_impl(unet_ctx* ctx, c
     int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
     hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c, ctx->bn_nslots());
   }
+  const bool xs = ctx->stats_in_slots && ctx->stats_in_slots_xs;          // (left by a conv epilogue in deterministic mode: exact window sums in the first UNET_BN_SLOTS copies)
   ctx->stats_in_slots = nullptr;                           // (else: the conv that wrote x left them there -- fold only)
-  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c, ctx->bn_nslots());
+  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((2 * c + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, 2 * c, xs ? UNET_BN_SLOTS : ctx->bn_nslots(), xs ? 1 : 0);
   UNET_CHECK_LAUNCH(ctx, "bn_stats"); return UNET_OK;
 }
 
@@ -893,9 +901,10 @@ extern "C++" template <typename T> static int32_t bn_stats_concat_impl(unet_ctx*
     int grid = (int)std::min<int64_t>(cdiv64(pixels, (int64_t)ppb * 16), BN_STATS_BLOCKS); if (grid < 1) grid = 1;
     hipLaunchKernelGGL((bn_stats_kernel<0, T>), dim3(grid), dim3(TPB), 0, as_stream(stream), x_up, ldx, (const T*)nullptr, 0, nullptr, ctx->bn_slots, (long long)pixels, c_up, ctx->bn_nslots());
   }
+  const bool xs = ctx->stats_in_slots && ctx->stats_in_slots_xs;
   ctx->stats_in_slots = nullptr;                           // (else: the ConvT that wrote the up half left its sums there)
   hipLaunchKernelGGL(bn_fold_concat_kernel, dim3((c_up + c_skip + 127) / 128), dim3(128), 0, as_stream(stream), ctx->bn_slots, sums, c_up, c_skip, src_sums, src_count, src_gamma,
-                     src_beta, (double)pixels, 1e-3f, ctx->bn_nslots());
+                     src_beta, (double)pixels, 1e-3f, xs ? UNET_BN_SLOTS : ctx->bn_nslots(), xs ? 1 : 0);
   UNET_CHECK_LAUNCH(ctx, "bn_stats_concat"); return UNET_OK;
 }
 
@@ -1071,14 +1080,15 @@ extern "C++" template <typename T> static int32_t head_bwd_impl(unet_ctx* ctx, c
   UNET_CHECK_LAUNCH(ctx, "head_bwd"); return UNET_OK;
 }
 
-extern "C++" int32_t k_slot_fold(unet_ctx* ctx, double* sums, int count, hipStream_t s) {
-  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((count + 127) / 128), dim3(128), 0, s, ctx->bn_slots, sums, count, ctx->bn_nslots());
+extern "C++" int32_t k_slot_fold(unet_ctx* ctx, double* sums, int count, hipStream_t s, bool xs) {
+  hipLaunchKernelGGL(bn_slot_fold_kernel<double>, dim3((count + 127) / 128), dim3(128), 0, s, ctx->bn_slots, sums, count, xs ? UNET_BN_SLOTS : ctx->bn_nslots(), xs ? 1 : 0);
   UNET_CHECK_LAUNCH(ctx, "slot_fold"); return UNET_OK;
 }
 extern "C++" int32_t k_enc_tail_finish(unet_ctx* ctx, double* sums, const double* dec_sum_dyxhat, const float* dec_invstd, const float* dec_gamma, const float* gamma, float* dgamma,
                                        float* dbeta, int c, double frac, hipStream_t s) {
-  if (!sums || !dec_sum_dyxhat || !dec_invstd || !dec_gamma || !gamma || !dgamma || !dbeta || c < 1 || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "enc_tail_finish: bad args");
-  hipLaunchKernelGGL(enc_tail_finish_kernel, dim3((c + 127) / 128), dim3(128), 0, s, ctx->bn_slots, sums, dec_sum_dyxhat, dec_invstd, dec_gamma, gamma, dgamma, dbeta, c, frac, 1e-3f, UNET_BN_SLOTS);
+  if (!sums || !dec_sum_dyxhat || !dec_invstd || !dec_gamma || !gamma || !dgamma || !dbeta || c < 1) UNET_FAIL(ctx, UNET_E_ARG, "enc_tail_finish: bad args");
+  hipLaunchKernelGGL(enc_tail_finish_kernel, dim3((c + 127) / 128), dim3(128), 0, s, ctx->bn_slots, sums, dec_sum_dyxhat, dec_invstd, dec_gamma, gamma, dgamma, dbeta, c, frac, 1e-3f, UNET_BN_SLOTS,
+                     ctx->opt_deterministic ? 1 : 0);
   UNET_CHECK_LAUNCH(ctx, "enc_tail_finish"); return UNET_OK;
 }
 extern "C++" int32_t k_bn_finalize_compose(unet_ctx* ctx, int training, const double* sums, double count, const float* gamma, const float* beta, float* mm, float* mv, float* bnp, int c,
@@ -1089,8 +1099,8 @@ extern "C++" int32_t k_bn_finalize_compose(unet_ctx* ctx, int training, const do
   UNET_CHECK_LAUNCH(ctx, "bn_finalize_compose"); return UNET_OK;
 }
 extern "C++" int32_t k_head_fold(unet_ctx* ctx, double* loss_sums, double* head_sums, hipStream_t s) {
-  if (!loss_sums || !head_sums || ctx->opt_deterministic) UNET_FAIL(ctx, UNET_E_ARG, "head_fold: bad args");
-  hipLaunchKernelGGL(head_fold_kernel, dim3(1), dim3(128), 0, s, ctx->bn_slots, loss_sums, head_sums, UNET_BN_SLOTS);
+  if (!loss_sums || !head_sums) UNET_FAIL(ctx, UNET_E_ARG, "head_fold: bad args");
+  hipLaunchKernelGGL(head_fold_kernel, dim3(1), dim3(128), 0, s, ctx->bn_slots, loss_sums, head_sums, UNET_BN_SLOTS, ctx->opt_deterministic ? 1 : 0);
   UNET_CHECK_LAUNCH(ctx, "head_fold"); return UNET_OK;
 }
 

@@ -152,7 +152,7 @@ extern "C" {
 // Conv2D / Conv2DTranspose -> BatchNormalization in training mode (T1:860-861, 886-888): see common.h (unet_ctx::stats_req_c)
 int32_t unet_request_bn_stats(unet_ctx* ctx, int32_t c) {
   if (!ctx || c < 0) UNET_FAIL(ctx, UNET_E_ARG, "request_bn_stats: bad args");
-  ctx->stats_req_c = (ctx->opt_bn_fuse_stats && !ctx->opt_deterministic) ? c : 0;          // (deterministic mode: statistics by their own fixed-order pass)
+  ctx->stats_req_c = ctx->opt_bn_fuse_stats ? c : 0;          // (deterministic mode: the h2 kernels leave exact window sums -- common.h xsum_add --, the bf16 ones decline)
   return UNET_OK;
 }
 

@@ -889,6 +889,55 @@ def test_conv_epilogue_bn_statistics_equal_the_statistics_pass(ops, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 72, 32, 32), (4, 128, 128, 32, 64), (2, 16, 32, 128, 128), (2, 8, 8, 256, 256)])
+def test_conv_epilogue_statistics_in_deterministic_mode_are_exact_window_sums(ops, shape):
+    """UNET_OPT_DETERMINISTIC keeps the epilogue statistics (round 5): a launch has far more workgroups than there are slot copies, so the partial sums leave as EXACT
+    integer window sums (common.h xsum_add: four 64-bit words per value, associative addition) -- any arrival order folds to the same bits.  Checked: two runs agree
+    in every bit; the fold equals the float64 sum of the per-workgroup float partials to double round-off (here: of the stored tensor, to the fp32 round-off of the
+    in-tile partial sums, 1e-6); accumulation into non-zero sums; tiny and huge magnitudes inside the domain; a NaN in the tensor poisons the sum."""
+    from gpu_util import relerr
+    from covidseg_amd import _lib
+    n, h, w, ci, co = shape
+    ctx = _lib.Context.get(0, {"deterministic": 1}, private=True)
+    try:
+        rng = np.random.default_rng(ci + co + h)
+        for scale in (1.0, 3e-7, 2e3):
+            x = (rng.standard_normal((n, h, w, ci)) * scale).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+            b = (rng.standard_normal(co) * 0.3 * scale).astype(np.float32)
+            xd, kd, bd = ops.d(x), ops.d(k), ops.d(b)
+            pixels = n * h * w
+            outs = []
+            for rep in range(2):
+                y = ops.z(n, h, w, co); fused = ops.z(2 * co, dtype=torch.float64)
+                ctx.check(ops.lib.unet_request_bn_stats(ctx.handle, co), "arm")
+                ctx.check(ops.lib.unet_conv3x3_fwd(ctx.handle, xd.data_ptr(), kd.data_ptr(), bd.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, ops.wws(ci, co), ops.s), "conv")
+                ctx.check(ops.lib.unet_bn_stats(ctx.handle, y.data_ptr(), co, fused.data_ptr(), pixels, co, ops.s), "fold")
+                outs.append(fused.cpu().numpy().copy())
+            assert np.array_equal(outs[0], outs[1])                                 # bit for bit
+            y64 = y.cpu().numpy().astype(np.float64).reshape(-1, co)
+            want = np.concatenate([y64.sum(0), (y64 * y64).sum(0)])
+            assert relerr(outs[0], want) < 1e-6, scale
+            plain = ops.z(2 * co, dtype=torch.float64)
+            ctx.check(ops.lib.unet_bn_stats(ctx.handle, y.data_ptr(), co, plain.data_ptr(), pixels, co, ops.s), "plain pass: nothing armed, slots clean")
+            assert relerr(plain.cpu().numpy(), want) < 1e-6
+            ctx.check(ops.lib.unet_request_bn_stats(ctx.handle, co), "arm again")   # accumulates
+            ctx.check(ops.lib.unet_conv3x3_fwd(ctx.handle, xd.data_ptr(), kd.data_ptr(), bd.data_ptr(), y.data_ptr(), n, h, w, ci, co, 1, 0.0, 0, 0, ops.wws(ci, co), ops.s), "conv")
+            ctx.check(ops.lib.unet_bn_stats(ctx.handle, y.data_ptr(), co, fused.data_ptr(), pixels, co, ops.s), "fold")
+            assert np.array_equal(fused.cpu().numpy(), outs[1] + outs[1])
+        x[0, h // 2, w // 2, 0] = np.nan
+        y = ops.z(n, h, w, co); fused = ops.z(2 * co, dtype=torch.float64)
+        ctx.check(ops.lib.unet_request_bn_stats(ctx.handle, co), "arm")
+        ctx.check(ops.lib.unet_conv3x3_fwd(ctx.handle, ops.d(x).data_ptr(), kd.data_ptr(), bd.data_ptr(), y.data_ptr(), n, h, w, ci, co, 0, 0.0, 0, 0, ops.wws(ci, co), ops.s), "conv (linear: a ReLU would clip the NaN)")
+        ctx.check(ops.lib.unet_bn_stats(ctx.handle, y.data_ptr(), co, fused.data_ptr(), pixels, co, ops.s), "fold")
+        assert np.isnan(fused.cpu().numpy()).all()
+        clean = ops.z(2 * co, dtype=torch.float64)
+        ctx.check(ops.lib.unet_bn_stats(ctx.handle, ops.d(np.ones((n, h, w, co), np.float32)).data_ptr(), co, clean.data_ptr(), pixels, co, ops.s), "the slots are clean again")
+        assert np.array_equal(clean.cpu().numpy(), np.full(2 * co, float(pixels)))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 12, 20, 64, 32), (1, 9, 33, 128, 64), (2, 8, 8, 512, 256)])
 def test_convT_epilogue_bn_statistics_of_the_up_half(ops, shape):
     """Conv2DTranspose -> concatenate -> BatchNormalization (T1:886-888): the armed ConvT adds the statistics of the half it writes into the concat;
