@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   // touches 32 cache lines with 32 B each.  Transposed through a 4.5-KB per-wave staging row (the patch planes are dead), eight consecutive lanes write one
   // full 128-B line: 1/4 of the write requests (measured with the placement faked: -5...-20 % per launch).
   __syncthreads();                                         // (every wave is past its last fragment read: the planes may be overwritten)
+  H2_STAMP(11);
   char* const s_out = smem + wave * (32 * OUT_PS);
   float* const s_stat = reinterpret_cast<float*>(smem + 4 * 32 * OUT_PS);          // [wave][nb][sum | sum of squares][32 channels]
 
@@ -511,10 +512,14 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(s_out + out_cell(l31, hi * 4 + q)) = make_float4(acc[r][0][q * 4], acc[r][0][q * 4 + 1], acc[r][0][q * 4 + 2], acc[r][0][q * 4 + 3]);
+      float4 t4s[4];                                       // (the four reads together, as in the general epilogue below)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t4s[j] = *reinterpret_cast<const float4*>(s_out + out_cell(j * 8 + (lane >> 3), lane & 7));
+      asm volatile("" :: "v"(t4s[0].x), "v"(t4s[1].x), "v"(t4s[2].x), "v"(t4s[3].x));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pj = j * 8 + (lane >> 3), cj = lane & 7, pxj = x0 + pj;
-        const float4 t4 = *reinterpret_cast<const float4*>(s_out + out_cell(pj, cj));
+        const float4 t4 = t4s[j];
         const long long oj = (((long long)n * H + py) * W + pxj) * ldy;
         if (signs) {                                       // (wave-uniform) sign bits of the stored values: the mask of the head's own backward
           const bool vld = pxj < W;
@@ -684,10 +689,17 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(s_out + out_cell(l31, hi * 4 + q)) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
       // (LDS executes a wave's instructions in order: the reads below see the writes above, the next row's writes come after these reads)
+      // The four line-layout reads are issued TOGETHER, in front of the (branchy) store code: read - wait - store per line meant four dependent LDS round trips per
+      // (row, block) behind the other workgroup's fragment reads -- ~650 cycles per store instruction, 23-44 % of a tile's lifetime at the 256 / 512 pixel levels
+      // (profiles/r05_h2_timeline.txt)
+      float4 t4s[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t4s[j] = *reinterpret_cast<const float4*>(s_out + out_cell(j * 8 + (lane >> 3), lane & 7));
+      asm volatile("" :: "v"(t4s[0].x), "v"(t4s[1].x), "v"(t4s[2].x), "v"(t4s[3].x));          // (all four have landed here: nothing sinks a read back to its use)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pj = j * 8 + (lane >> 3), cj = lane & 7, pxj = x0 + pj;
-        const float4 t4 = *reinterpret_cast<const float4*>(s_out + out_cell(pj, cj));
+        const float4 t4 = t4s[j];
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
         else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
@@ -732,6 +744,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
     }
   }
+  H2_STAMP(12);
   if (MODE != 2 && stats) {
     __syncthreads();
     if (tid < NB * 64) {

@@ -53,6 +53,9 @@ def main():
     for i, nm in enumerate(names):
         d = t[:, i + 1] - t[:, i]
         print(f"  {nm:62s} median {np.median(d):8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f} cycles")
+    for nm, a, b in (("  of the epilogue: barrier in front of it (slowest wave's last MFMAs)", 7, 11), ("  of the epilogue: coefficient reads, LDS transposes, stores issued", 11, 12), ("  of the epilogue: statistics barrier + atomics", 12, 8)):
+        d = t[:, b] - t[:, a]
+        print(f"  {nm:62s} median {np.median(d):8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f} cycles")
     tot = t[:, 8] - t[:, 0]
     print(f"  {'workgroup lifetime':62s} median {np.median(tot):8.0f}  p10 {np.percentile(tot, 10):8.0f}  p90 {np.percentile(tot, 90):8.0f} cycles")
     xcc = t[:, 10] & 0xF
