@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define UNET_ABI_VERSION 15
+#define UNET_ABI_VERSION 16
 
 typedef struct unet_ctx unet_ctx;
 typedef struct unet_model unet_model;
@@ -124,6 +124,12 @@ int32_t unet_request_bn_stats(unet_ctx*, int32_t c);
 int32_t unet_relu_bits_supported(int32_t algo, int32_t h, int32_t wd, int32_t cin, int32_t cout);
 size_t unet_relu_bits_bytes(int32_t n, int32_t h, int32_t wd, int32_t c);
 int32_t unet_request_relu_bits(unet_ctx*, void* bits);
+/* Inference on one slice (T1:1136-1137: `model.predict` on a single 512 x 512 image) leaves the deep levels with fewer workgroups than the chip has CUs, each walking a long
+ * chain of dependent loads over its contraction.  unet_allow_k_slices arms the NEXT unet_conv3x3_fwd / unet_conv3x3_bwd_data on this context (no dropout, no mask, no armed
+ * statistics / sign bits, fp32 h2 kernels) to contract 2-4 slices of K side by side into context-owned slabs and add them -- with the bias and the ReLU -- in a second pass,
+ * where its grid is that small (fewer than 1.5 workgroups per CU, K >= 256); any other launch ignores it.  Same result up to the order of the fp32 additions, which then
+ * follows the grid size: training programs (whose data-parallel ranks must add in the order of the whole batch) never arm it, and a deterministic-mode context ignores it. */
+int32_t unet_allow_k_slices(unet_ctx*);
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
                          int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
                          int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, float* w_ws, void* stream);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # COVIDSEG_AMD_LIB: another build of the SAME library (the sanitizer build of `make asan`, an A/B build); the default -- and the product -- is the in-tree file
 LIB_PATH = os.environ.get("COVIDSEG_AMD_LIB") or os.path.join(_HERE, "libunet_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 COMM_HANDLE_BYTES, COMM_MAX_WORLD, COMM_MAX_DOUBLES = 64, 8, 2048          # include/unet_hip.h: UNET_COMM_*
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2          # fp16-split h2 kernels where the shape allows / VALU kernels / strict fp32 MFMA kernels
@@ -51,6 +51,7 @@ _PROTOS = {
     "unet_relu_bits_supported": (i32, [i32, i32, i32, i32, i32]),
     "unet_relu_bits_bytes": (sz, [i32, i32, i32, i32]),
     "unet_request_relu_bits": (i32, [vp, vp]),
+    "unet_allow_k_slices": (i32, [vp]),
     "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, i32, vp, vp]),
     "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, i32, f32, u64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),

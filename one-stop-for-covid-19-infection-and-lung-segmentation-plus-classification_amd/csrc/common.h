@@ -37,6 +37,9 @@ struct unet_ctx {
   int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
   void* convt_img = nullptr;        // device scratch for the split fp16 weight image of a ConvT launch (kernels_conv_h2.hip); launches on one stream only
   size_t convt_img_bytes = 0;
+  int k_slices_ok = 0;              // one-shot (unet_allow_k_slices): the next h2 conv3x3 launch may slice its contraction (inference programs arm it)
+  void* splitk_ws = nullptr;        // device scratch for the partial-sum slabs of a K-sliced conv3x3 launch (kernels_conv_h2.hip: SPLITK); launches on one stream only
+  size_t splitk_ws_bytes = 0;
   // Conv2D / Conv2DTranspose -> BatchNormalization (T1:860-861, 886-888): unet_request_bn_stats() arms the next forward launch; a kernel that can
   // (kernels_conv_h2.hip) adds the per-channel (sum y, sum y^2) of what it writes to bn_slots and leaves the tensor's address in stats_in_slots,
   // and the unet_bn_stats / unet_bn_stats_concat call on that tensor folds the slots without reading it

@@ -72,12 +72,17 @@ struct h2_prep_list { h2_prep item[UNET_PREP_MAX]; int n; };          // passed 
 __global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {          // grid (H2_MAXB, layers)
   const h2_prep& p = L.item[blockIdx.y];
   float mx = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.nw4; i += (long long)gridDim.x * 256) {
+  auto one = [&](long long i) __attribute__((always_inline)) {
     const float4 v = reinterpret_cast<const float4*>(p.w)[i];
     float m4 = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     if (p.cs && !p.cs_bound) m4 *= fabsf(p.cs[(int)((i * 4 / p.cs_div) % p.cs_mod)]);          // (the four elements of a float4 share their input channel: cs_div is a multiple of 4)
-    mx = fmaxf(mx, m4);
-  }
+    return m4;
+  };
+  // (four independent loads per thread and round: with one, the 2.4 M weights of a 512 -> 512 layer were 48 dependent round trips per thread -- 23 us per launch)
+  const long long st = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * st < p.nw4; i += 4 * st) mx = fmaxf(fmaxf(mx, fmaxf(one(i), one(i + st))), fmaxf(one(i + 2 * st), one(i + 3 * st)));
+  for (; i < p.nw4; i += st) mx = fmaxf(mx, one(i));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   __shared__ float s_m[4];
@@ -144,12 +149,16 @@ __device__ __forceinline__ int out_cell(int p, int c) { return p * 128 + ((c ^ (
 //         (pixel stride ldx) that is staged
 // HEAD (the network's last conv3x3, T1:911-913): the 1x1 sigmoid head, the four loss sums and the three per-channel sums the head's weight gradient is a
 // combination of are taken from the output tile while it is in registers / LDS (h2_head_args; one channel group of 32, ReLU, no mask)
-template <int MODE, int NB, int RW, bool GEN, int WPS, int EPI = 0>
+// SPLITK (conv3x3 launches that leave most CUs idle -- the 32 x 32 ... 128 x 128 levels of batch-1 inference, T1:1137): blockIdx.y = a slice of `kcps` staged chunks of the
+// contraction; the slice's partial sums (no bias, no activation) go to slab blockIdx.y of `y` (slabs `y_split` floats apart) and h2_splitk_finish_kernel adds the slabs,
+// the bias / border-class table and the ReLU.  A tile's K loop is a chain of dependent global loads (~1.7 us per chunk with one workgroup per CU and 27 MFMAs a chunk):
+// the slices run it in parallel
+template <int MODE, int NB, int RW, bool GEN, int WPS, int EPI = 0, bool SPLITK = false>
 __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restrict__ x, int ldx, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
                                                            const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int K, int M, int act,
                                                            int mask_mode, float rate, unsigned long long seed, int tiles_x, int tiles_y, int groups,
                                                            int total_blocks, double* __restrict__ stats, int stats_c, unsigned long long* __restrict__ signs,
-                                                           int mask_climit, h2_head_args hd, int img_nb, int xs) {
+                                                           int mask_climit, h2_head_args hd, int img_nb, int xs, int kcps, long long y_split) {
   constexpr bool HEAD = EPI == 1, POOLS = EPI == 2;          // EPI: 0 the general epilogue, 1 + the 1x1 sigmoid head (below), 2 + the pooled-path sums of an encoder tail (MASK_POOL_SUMS)
   // EPI 3 (VDY): the general epilogue behind a VIRTUAL input -- the gradient of the last conv3x3's output, dy[p][c] = dz_p w_c [y_pc > 0] (T1:911-913 backwards), staged from
   // the 8-byte-per-pixel stream {dz_p, 32 mask bits} of head_dzm_kernel (x = that stream, ldx = 2): one value is scaled and split per staged piece, the mask bits pick
@@ -158,6 +167,7 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   static_assert(!VDY || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the virtual head gradient feeds the 32-channel data-gradient launch");
   static_assert(!HEAD || (MODE == 0 && NB == 1 && RW == 2 && !GEN), "the fused head rides on the 32-channel forward kernel");
   static_assert(!POOLS || (MODE == 0 && !GEN), "the pooled sums ride on a plain conv3x3 data-gradient launch");
+  static_assert(!SPLITK || (MODE == 0 && EPI == 0 && !GEN), "K slices: plain conv3x3 launches");
   if (POOLS) { mask_mode = MASK_POOL_SUMS; act = ACT_NONE; signs = nullptr; }          // (compile-time facts of this instance: the other epilogue forms fall away)
   if (HEAD) { mask_mode = MASK_NONE; act = ACT_RELU; stats = nullptr; }
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;          // taps; 16-channel k-steps per staged chunk
@@ -196,6 +206,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
   const int x0 = tx * 32, y0 = ty * TH;
   const int HI = MODE == 2 ? 2 * H : H, WI = MODE == 2 ? 2 * W : W;          // the staged tensor's image size
   const int nchunks = K / (16 * KS);
+  const int cbeg = SPLITK ? (int)blockIdx.y * kcps : 0, cend = SPLITK ? min(cbeg + kcps, nchunks) : nchunks;          // the staged chunks this workgroup contracts over
+  if (SPLITK) y += (long long)blockIdx.y * y_split;
   const unet_bf16* const wimg = wimg_hdr + H2_HEADER / 2;
   const float w_unscale = *reinterpret_cast<const float*>(wimg_hdr);          // 2^-e_w of the layer
 
@@ -329,8 +341,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     s_bias[2 * NB * 32 + tid] = HEAD ? hd.b[0] : coef ? bias[2 * M + ch] : 0.f;
     }
   }
-  issue_loads(0);
-  issue_w_loads(0);
+  issue_loads(cbeg);
+  issue_w_loads(cbeg);
   post_amax();
   __syncthreads();
   H2_STAMP(1);
@@ -391,19 +403,19 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       }
     }
   };
-  for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
+  for (int chunk = cbeg; chunk + 1 < cend; ++chunk) {
     issue_loads(chunk + 1);
     __builtin_amdgcn_s_setprio(2);                           // (the wave feeding the matrix pipe goes ahead of the co-resident workgroups' staging / epilogue: 0.3 % of the step)
     mfma_chunk();
     __builtin_amdgcn_s_setprio(0);
-    if (chunk == 0) H2_STAMP(3);
+    if (chunk == cbeg) H2_STAMP(3);
     issue_w_loads(chunk + 1);                              // (behind this wave's last MFMA issue: the operand registers are free)
     post_amax();
     __syncthreads();                                       // every wave is done reading this chunk's planes; the four partial maxima are visible
-    if (chunk == 0) H2_STAMP(4);
+    if (chunk == cbeg) H2_STAMP(4);
     store_lds();
     __syncthreads();
-    if (chunk == 0) H2_STAMP(5);
+    if (chunk == cbeg) H2_STAMP(5);
   }
   H2_STAMP(6);
   // ---- last chunk: what the epilogue reads per output element (the ReLU / ELU mask of a data gradient, x of a folded-BatchNorm gradient) is requested
@@ -768,9 +780,11 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
 #endif
 }
 
+// splits > 1 (MODE 0, EPI 0, no statistics / sign bits / mask / dropout): `splits` slices of the contraction into the slabs y + i * n * h * wd * ldy (SPLITK above)
 template <int MODE, int NB, int RW, int WPS, int EPI = 0>
 int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd,
-                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30, h2_head_args hd = h2_head_args(), int img_nb = 0) {
+                  int K, int M, int act, float rate, unsigned long long seed, hipStream_t s, int mask_climit = 1 << 30, h2_head_args hd = h2_head_args(), int img_nb = 0,
+                  int splits = 1) {
   constexpr int T = MODE == 0 ? 9 : 1, KS = MODE == 0 ? 1 : 2;
   if (img_nb == 0) img_nb = NB;                              // (the image's blocks per group: NB unless a one-block launch reads a two-block image, conv_h2_kernel)
   if (img_nb != NB && !(MODE != 2 && NB == 1 && (img_nb == 2 || img_nb == 4) && (M % (32 * img_nb)) == 0 && EPI == 0)) UNET_FAIL(ctx, UNET_E_ARG, "conv h2: image of %d blocks per group on a %d-block launch", img_nb, NB);
@@ -803,13 +817,23 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
     unsigned long long* q = ctx->signs_req; ctx->signs_req = nullptr;
     if (act == ACT_RELU && rate == 0.0f && (mask_mode == MASK_NONE || mask_mode == MASK_BIAS_TAB) && !(M & 31) && !(wd & 7)) { signs = q; ctx->signs_done = q; }
   }
+  const int nchunks_ = K / (16 * KS), kcps = (nchunks_ + splits - 1) / splits;
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x, tiles_y, groups, (int)total, stats,
-                       stats_c, signs, mask_climit, hd, img_nb, ctx->opt_deterministic ? 1 : 0);
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)((nchunks_ + kcps - 1) / kcps)), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x,
+                       tiles_y, groups, (int)total, stats, stats_c, signs, mask_climit, hd, img_nb, ctx->opt_deterministic ? 1 : 0, kcps, (long long)n * h * wd * ldy);
     return UNET_OK;
   };
   int32_t r;
+  if (splits > 1) {
+    if constexpr (MODE == 0 && EPI == 0 && NB == 1 && WPS == 4) {
+      if (gen || stats || signs || mask_mode != MASK_NONE || bias || act != ACT_NONE || rate != 0.0f) UNET_FAIL(ctx, UNET_E_ARG, "conv h2: K slices go with a plain partial-sum launch");
+      r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI, true>);
+      if (r) return r;
+      UNET_CHECK_LAUNCH(ctx, "conv_h2 (K slices)");
+      return UNET_OK;
+    } else UNET_FAIL(ctx, UNET_E_ARG, "conv h2: K slices exist for the one-block conv3x3 launches");
+  }
   if (EPI == 1) {
     if (gen || mask_mode != MASK_NONE || act != ACT_RELU || M != 32 || stats) UNET_FAIL(ctx, UNET_E_ARG, "conv h2 + head: a plain 32-channel ReLU forward launch only");
     r = go(conv_h2_kernel<MODE, NB, RW, false, WPS, EPI>);
@@ -824,6 +848,29 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   if (r) return r;
   UNET_CHECK_LAUNCH(ctx, "conv_h2");
   return UNET_OK;
+}
+
+// the slabs of a K-sliced launch (SPLITK) -> y = act(sum of the slabs + bias): bias[c], or for a folded-BatchNorm forward (MASK_BIAS_TAB) row `border class of the pixel` of the
+// table [16][M]; one float4 per thread, slabs dense [n,h,w,M], y with pixel stride ldy
+__global__ __launch_bounds__(256) void h2_splitk_finish_kernel(const float* __restrict__ part, int splits, long long stride, const float* __restrict__ bias, int tab, int act,
+                                                               float* __restrict__ y, int ldy, int H, int W, int M, long long total4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int m4 = M >> 2, c4 = (int)(i % m4);
+  const long long pix = i / m4;
+  float4 a = *reinterpret_cast<const float4*>(part + i * 4);
+  for (int k = 1; k < splits; ++k) {
+    const float4 b = *reinterpret_cast<const float4*>(part + (long long)k * stride + i * 4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  if (bias) {
+    int cls = 0;
+    if (tab) { const int px = (int)(pix % W), py = (int)((pix / W) % H); cls = (((py == 0) | ((py == H - 1) << 1)) << 2) | ((px == 0) | ((px == W - 1) << 1)); }
+    const float4 b = *reinterpret_cast<const float4*>(bias + (long long)cls * M + c4 * 4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  if (act == ACT_RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  *reinterpret_cast<float4*>(y + pix * ldy + c4 * 4) = a;
 }
 
 }  // namespace
@@ -937,6 +984,34 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   //   which an idle CU does for free); still fewer than one workgroup per CU -> 4-row tiles (one row per wave) on top of that
   const int inb = h2_nb(M);
   const long long t8 = (long long)((wd + 31) / 32) * ((h + 7) / 8) * n;
+  // K slices: fewer than 1.5 one-block workgroups per CU and a contraction of sixteen or more staged chunks (batch-1 inference from the 128 x 128 level down): four slices of
+  // the K loop side by side, then one pass that adds the slabs, the bias and the ReLU.  Only where the caller allowed it for this launch (unet_allow_k_slices: the inference
+  // programs do -- the slicing follows the grid, i.e. the batch, and a data-parallel rank's share of a batch must add up in the order of the whole batch), not for launches
+  // that carry statistics / sign bits / a per-element mask / dropout, and not in deterministic mode
+  {
+    const bool small8 = t8 * ((M + 31) / 32) < UNET_CUS;          // (the 4-row tiles below)
+    const long long wgs = (small8 ? (long long)((wd + 31) / 32) * ((h + 3) / 4) * n : t8) * ((M + 31) / 32);
+    const int nchunks = K / 16;
+    const bool armed = ctx->k_slices_ok != 0; ctx->k_slices_ok = 0;          // (one-shot: unet_allow_k_slices)
+    const bool plain = armed && (!mask || mask_mode == MASK_BIAS_TAB) && rate == 0.0f && (act == ACT_NONE || act == ACT_RELU) && !ctx->stats_req_c && !ctx->signs_req && !ctx->opt_deterministic;
+    // (measured per launch at batch 1, 512 x 512: 16 chunks and more gain -- c5b 54 -> 27 us, c5a 29 -> 19, c6a 59 -> 43 with the finish pass --, 8 chunks do not)
+    if (plain && ctx->splitk_ws && nchunks >= 16 && 2 * wgs < 3 * UNET_CUS && (inb == 1 || small8 || t8 * ((M + 63) / 64) < 2 * UNET_CUS) && (M % 32) == 0) {
+      const int splits = std::min(4, nchunks / 4);
+      const size_t slab = (size_t)n * h * wd * M;
+      if (splits >= 2 && (size_t)splits * slab * sizeof(float) <= ctx->splitk_ws_bytes) {
+        float* part = static_cast<float*>(ctx->splitk_ws);
+        int32_t r;
+        if (small8) r = launch_h2<0, 1, 1, 4>(ctx, x, K, img, nullptr, nullptr, MASK_NONE, part, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, h2_head_args(), inb, splits);
+        else r = launch_h2<0, 1, 2, 4>(ctx, x, K, img, nullptr, nullptr, MASK_NONE, part, M, n, h, wd, K, M, ACT_NONE, 0.0f, 0, s, 1 << 30, h2_head_args(), inb, splits);
+        if (r) return r;
+        const long long total4 = (long long)slab / 4;
+        hipLaunchKernelGGL(h2_splitk_finish_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, part, splits, (long long)slab, bias, mask && mask_mode == MASK_BIAS_TAB ? 1 : 0, act,
+                           y, ldy, h, wd, M, total4);
+        UNET_CHECK_LAUNCH(ctx, "conv_h2 (K slices: finish)");
+        return UNET_OK;
+      }
+    }
+  }
   if (t8 * ((M + 31) / 32) < UNET_CUS) return launch_h2<0, 1, 1, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), inb);
   if (inb == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
   if (t8 * ((M + 63) / 64) < 2 * UNET_CUS) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), 2);

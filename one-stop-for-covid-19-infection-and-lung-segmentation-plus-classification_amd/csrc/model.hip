@@ -43,6 +43,8 @@ int32_t unet_ctx_create(int32_t device_id, unet_ctx** out) {
       hipMemset(c->bn_slots, 0, sb) != hipSuccess) { (void)hipSetDevice(prev); delete c; return UNET_E_HIP; }
   c->convt_img_bytes = (size_t)8 << 20;             // ConvT weight images up to cin * cout = 512 K (u6 of the U-Net: 128 K)
   if (hipMalloc(&c->convt_img, c->convt_img_bytes) != hipSuccess) { c->convt_img = nullptr; c->convt_img_bytes = 0; }
+  c->splitk_ws_bytes = (size_t)32 << 20;            // K-sliced launches have < 384 workgroups of <= 8 x 32 x 32 outputs: 4 slices x 12 MB at most
+  if (hipMalloc(&c->splitk_ws, c->splitk_ws_bytes) != hipSuccess) { c->splitk_ws = nullptr; c->splitk_ws_bytes = 0; }
   (void)hipSetDevice(prev);
   *out = c;
   return UNET_OK;
@@ -51,6 +53,7 @@ int32_t unet_ctx_create(int32_t device_id, unet_ctx** out) {
 void unet_ctx_destroy(unet_ctx* ctx) {
   if (ctx && ctx->bn_slots) (void)hipFree(ctx->bn_slots);
   if (ctx && ctx->convt_img) (void)hipFree(ctx->convt_img);
+  if (ctx && ctx->splitk_ws) (void)hipFree(ctx->splitk_ws);
   delete ctx;
 }
 const char* unet_last_error(const unet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
@@ -166,6 +169,11 @@ size_t unet_relu_bits_bytes(int32_t n, int32_t h, int32_t wd, int32_t c) { retur
 int32_t unet_request_relu_bits(unet_ctx* ctx, void* bits) {
   if (!ctx) return UNET_E_ARG;
   ctx->signs_req = static_cast<unsigned long long*>(bits); ctx->signs_done = nullptr;
+  return UNET_OK;
+}
+int32_t unet_allow_k_slices(unet_ctx* ctx) {
+  if (!ctx) return UNET_E_ARG;
+  ctx->k_slices_ok = 1;
   return UNET_OK;
 }
 
@@ -788,7 +796,11 @@ void build_programs(unet_model* m) {
   for (int training = 1; training >= 0; --training) {
     auto& F = training ? FT : FI;
     auto& SY = m->syncref[training ? UNET_PROG_FWD_TRAIN : UNET_PROG_FWD_INFER];
-    ADD_OP(F, "zero_sums", 0, 0, { return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s); });
+    const int tr_ = training;
+    ADD_OP(F, "zero_sums", 0, 0, {
+      if (!tr_ && !m->yt) return UNET_OK;          // (inference without labels: no statistics, no loss sums -- nothing adds into them)
+      return unet_zero(ctx, m->wsf(m->off_bn_sums), sums_bytes, s);
+    });
     if (!dt) ADD_OP(F, "weight_images:fwd", 0, 0, { return prep_weights(0, s); });       // all split weight images of the program in one batch of launches
     else ADD_OP(F, "weight_images:fwd", 0, 0, { return prep_weights_bf16(0, s); });
     auto conv = [&](const std::string& name, const std::string& in, int cin, int cout) {
@@ -806,6 +818,7 @@ void build_programs(unet_model* m) {
         const auto so = training ? m->sign_off.find(name) : m->sign_off.end();
         unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
         ctx->signs_req = sg; ctx->signs_done = nullptr;
+        ctx->k_slices_ok = training ? 0 : 1;          // (inference: a launch that leaves most CUs idle may slice its contraction -- kernels_conv_h2.hip, SPLITK)
         int32_t r = conv3x3_fwd_dispatch(ctx, xin, m->P(name + "/kernel"), m->P(name + "/bias"), nullptr, MASK_NONE, m->Aw(name), ob.n, ob.h, ob.w, cin, cout,
                                          ACT_RELU, 0.0f, 0, algo, s, m->wsf(m->off_wt), 0, pf == m->wprep_f.end() ? nullptr : m->wsf(pf->second), ob.ld);          // (ob.ld > cout: c<k>b inside its concat, skip_raw)
         ctx->signs_req = nullptr;
@@ -910,6 +923,7 @@ void build_programs(unet_model* m) {
           const auto so = training ? m->sign_off.find(cn) : m->sign_off.end();
           unsigned long long* sg = so == m->sign_off.end() ? nullptr : reinterpret_cast<unsigned long long*>(m->wsf(so->second));
           ctx->signs_req = sg; ctx->signs_done = nullptr;
+          ctx->k_slices_ok = training ? 0 : 1;
           int32_t r = k_conv3x3_h2_fwd(ctx, m->A(xn), m->wsf(uo), tab, tab, MASK_BIAS_TAB, m->Aw(cn), ob.n, ob.h, ob.w, cin, cout, ACT_RELU, 0.0f, 0, s);
           ctx->signs_req = nullptr;
           if (!r && sg && ctx->signs_done != sg) UNET_FAIL(ctx, UNET_E_STATE, "conv3x3_fwd %s: the launch did not write the ReLU sign bits its data gradient was planned with", cn.c_str());

@@ -30,6 +30,40 @@ CONV_SHAPES = [(2, 9, 13, 3, 5), (1, 16, 16, 1, 32), (2, 16, 16, 32, 32), (2, 12
                (2, 32, 32, 64, 64), (1, 28, 28, 32, 32), (1, 7, 30, 16, 64), (2, 9, 20, 8, 96)]
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 32, 256, 512), (1, 64, 64, 512, 256), (1, 128, 128, 256, 128), (2, 16, 16, 256, 96), (1, 64, 64, 256, 256)])
+def test_conv3x3_k_slices_on_small_grids(ops, shape):
+    """The deep levels of batch-1 inference (T1:1137: predict on one 512 x 512 slice -> 32 x 32 ... 128 x 128 tensors with 128-512 channels) leave most CUs without a
+    workgroup, and a tile's K loop is a chain of dependent loads: such launches contract 2-4 slices of K side by side and a second pass adds the slabs, the bias and the
+    ReLU (kernels_conv_h2.hip: SPLITK).  Against float64 with the per-element bound of every other conv test, with and without ReLU, and against the same launch on a
+    deterministic-mode context (which never slices) in tests/test_gpu_model.py's predict tests."""
+    from gpu_util import relerr, conv_abs_sums, elem_ratio
+    n, h, w, ci, co = shape
+    rng = np.random.default_rng(ci + co + h)
+    x = np.maximum(rng.standard_normal((n, h, w, ci)), 0).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    for relu in (1, 0):
+        y = ops.z(n, h, w, co); y0 = ops.z(n, h, w, co)
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y0.data_ptr(), n, h, w, ci, co, relu, 0.0, 0, 0, ops.wws(ci, co), ops.s), "conv fwd")
+        ops.ck(ops.lib.unet_allow_k_slices(ops.h), "arm")
+        ops.ck(ops.lib.unet_conv3x3_fwd(ops.h, ops.d(x).data_ptr(), ops.d(k).data_ptr(), ops.d(b).data_ptr(), y.data_ptr(), n, h, w, ci, co, relu, 0.0, 0, 0, ops.wws(ci, co), ops.s), "conv fwd")
+        want = O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=bool(relu)).numpy()
+        assert relerr(y.cpu().numpy(), want) < TOL
+        d01 = np.abs(y.cpu().numpy() - y0.cpu().numpy()).max()
+        assert 0 < d01 < 1e-5 * np.abs(want).max(), d01          # the armed launch DID add in another order (it sliced), and only that
+        if relu == 0:
+            a = conv_abs_sums(x, k, np.zeros((n, h, w, co), np.float32), with_floor=False)
+            r = elem_ratio(y.cpu().numpy(), want, a["y_a1"] + np.abs(b)[None, None, None, :])
+            assert r <= 1.0, (shape, r)
+    # the data gradient of the same layer without a mask runs through the same dispatch (flipped image)
+    dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
+    dx = ops.z(n, h, w, ci)
+    ops.ck(ops.lib.unet_allow_k_slices(ops.h), "arm")
+    ops.ck(ops.lib.unet_conv3x3_bwd_data(ops.h, ops.d(dy).data_ptr(), ops.d(k).data_ptr(), None, 0, 0.0, 0, dx.data_ptr(), ops.wws(ci, co), n, h, w, ci, co, 0, ops.s), "conv dgrad")
+    xt = T64(x).requires_grad_(True)
+    O.conv3x3_bias_relu(xt, T64(k), T64(b), relu=False).backward(T64(dy))
+    assert relerr(dx.cpu().numpy(), xt.grad.numpy()) < TOL
+
+
 @pytest.mark.parametrize("algo", [0, 1, 2])          # the fp16-split h2 family (where the shape allows) / VALU / strict fp32 MFMA
 @pytest.mark.parametrize("shape", CONV_SHAPES)
 def test_conv3x3_fwd(ops, shape, algo):

@@ -180,7 +180,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in unet_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert _lib.load().unet_abi_version() == _lib.ABI_VERSION == 15
+    assert _lib.load().unet_abi_version() == _lib.ABI_VERSION == 16
 
 
 def test_product_fails_loudly_without_gpu():
