@@ -409,7 +409,8 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
     mfma_chunk();
     __builtin_amdgcn_s_setprio(0);
     if (chunk == cbeg) H2_STAMP(3);
-    issue_w_loads(chunk + 1);                              // (behind this wave's last MFMA issue: the operand registers are free)
+    issue_w_loads(chunk + 1);                              // (behind this wave's last MFMA issue: the operand registers are free; requested BEFORE the MFMAs into registers of
+                                                           //  its own -- the two-block 8-row kernels have 60 to spare -- it measured +0.10 ms per step: profiles/r05_ab_early_weight_slab.txt)
     post_amax();
     __syncthreads();                                       // every wave is done reading this chunk's planes; the four partial maxima are visible
     if (chunk == cbeg) H2_STAMP(4);
