@@ -260,7 +260,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- untimed setup 4 (rank 0, N=1): latency of model.predict(x.reshape(1,H,W,1)) (T1:1137) -- inference forward at batch 1, synchronised per call
-    predict_ms = None
+    predict_ms = predict_cold_ms = None
     if rank == 0 and world == 1 and args.arch == "unet":
         x1 = x[:1].contiguous()
         for _ in range(3):
@@ -269,6 +269,11 @@ def main():
         for _ in range(20):
             ts = time.perf_counter(); eng.predict_batch(x1); torch.cuda.synchronize(); lat.append((time.perf_counter() - ts) * 1e3)
         predict_ms = round(sorted(lat)[len(lat) // 2], 3)
+        lat = []                                   # ... and with the per-weight preparation (weight images, inference BatchNorm tables) redone every call: the first predict after a weight change
+        for _ in range(10):
+            eng._infer_ready = None
+            ts = time.perf_counter(); eng.predict_batch(x1); torch.cuda.synchronize(); lat.append((time.perf_counter() - ts) * 1e3)
+        predict_cold_ms = round(sorted(lat)[len(lat) // 2], 3)
 
     # ---- untimed setup 5 (rank 0, N=1, U-Net): the REAL model.fit path (T1:1059-1061) -- a host-resident float64 set, as the reference's runner holds it,
     # through keras_like.UNetModel.fit: upload once (pinned staging), per step a device-side gather of the shuffled batch, per epoch one host sync
@@ -474,6 +479,7 @@ def main():
             out.update(fit_stats)
         if predict_ms is not None:
             out["predict_batch1_ms"] = predict_ms          # median of 20 synchronised model.predict calls at batch 1 (T1:1137): latency, not throughput
+            out["predict_batch1_cold_ms"] = predict_cold_ms          # the same with the weight preparation redone per call (first predict after set_weights / a training step)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if comm is not None:

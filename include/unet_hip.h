@@ -130,6 +130,9 @@ int32_t unet_request_relu_bits(unet_ctx*, void* bits);
  * where its grid is that small (fewer than 1.5 workgroups per CU, K >= 256); any other launch ignores it.  Same result up to the order of the fp32 additions, which then
  * follows the grid size: training programs (whose data-parallel ranks must add in the order of the whole batch) never arm it, and a deterministic-mode context ignores it. */
 int32_t unet_allow_k_slices(unet_ctx*);
+/* Largest private segment (register-spill scratch, bytes per lane) among the h2 conv3x3 / ConvT kernels this context has launched so far: a build whose register-heavy
+ * instances fell over their spill cliff shows here (and nowhere in the numerics) -- the GPU test suite holds it under a bound. */
+int32_t unet_ctx_max_kernel_scratch_bytes(unet_ctx*);
 int32_t unet_conv3x3_fwd(unet_ctx*, const float* x, const float* w, const float* bias, float* y,
                          int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cout,
                          int32_t act, float drop_rate, uint64_t drop_seed, int32_t algo, float* w_ws, void* stream);

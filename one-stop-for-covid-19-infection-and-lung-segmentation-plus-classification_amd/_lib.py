@@ -52,6 +52,7 @@ _PROTOS = {
     "unet_relu_bits_bytes": (sz, [i32, i32, i32, i32]),
     "unet_request_relu_bits": (i32, [vp, vp]),
     "unet_allow_k_slices": (i32, [vp]),
+    "unet_ctx_max_kernel_scratch_bytes": (i32, [vp]),
     "unet_conv3x3_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, u64, i32, vp, vp]),
     "unet_conv3x3_bwd_data": (i32, [vp, vp, vp, vp, i32, f32, u64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "unet_conv3x3_bwd_weights_ws_bytes": (sz, [i32, i32, i32, i32, i32]),

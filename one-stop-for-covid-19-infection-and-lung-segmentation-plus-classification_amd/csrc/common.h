@@ -52,6 +52,8 @@ struct unet_ctx {
   unsigned long long* signs_req = nullptr;
   const void* signs_done = nullptr;
   std::set<const void*> big_lds_kernels;   // kernels already opted in to > 64 KiB of dynamic LDS on this context's device
+  std::set<const void*> noted_kernels;     // h2 kernels whose private-segment size has been looked up (unet_note_kernel)
+  int max_scratch_bytes = 0;               // the largest private segment (spill scratch) among the h2 conv kernels this context has launched: unet_ctx_max_kernel_scratch_bytes
   std::string err;
 };
 
@@ -82,6 +84,15 @@ static inline int32_t unet_big_lds(unet_ctx* ctx, const void* kernel, size_t byt
   if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) UNET_FAIL(ctx, UNET_E_HIP, "%s: cannot reserve %zu bytes of LDS", what, bytes);
   ctx->big_lds_kernels.insert(kernel);
   return UNET_OK;
+}
+// The register-heavy kernels live a few registers from their spill cliff (the ELU / dropout instances of conv_h2_kernel: 32-40 spilled VGPRs, 36-80 B of scratch per lane as
+// built); a change that pushes one over it does not fail any numerics test -- it made U-Net++ 2.6x slower once (round 5: 640 B of scratch).  Every launch site notes its
+// kernel's private-segment size once per context; tests/test_gpu_unetpp.py holds the maximum under a bound.
+static inline void unet_note_kernel(unet_ctx* ctx, const void* kernel) {
+  if (ctx->noted_kernels.count(kernel)) return;
+  ctx->noted_kernels.insert(kernel);
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, kernel) == hipSuccess && (int)at.localSizeBytes > ctx->max_scratch_bytes) ctx->max_scratch_bytes = (int)at.localSizeBytes;
 }
 #define UNET_BIG_LDS(ctx, kern, bytes, what) do { int32_t _r = unet_big_lds(ctx, reinterpret_cast<const void*>(kern), bytes, what); if (_r) return _r; } while (0)
 

@@ -705,14 +705,17 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
       // The four line-layout reads are issued TOGETHER, in front of the (branchy) store code: read - wait - store per line meant four dependent LDS round trips per
       // (row, block) behind the other workgroup's fragment reads -- ~650 cycles per store instruction, 23-44 % of a tile's lifetime at the 256 / 512 pixel levels
       // (profiles/r05_h2_timeline.txt)
+      // (not in the ELU / dropout instances: U-Net++'s kernels sit at their register limit -- twelve more live registers there cost 72 spilled scalars and 6x the launch time)
       float4 t4s[4];
+      if (!GEN) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) t4s[j] = *reinterpret_cast<const float4*>(s_out + out_cell(j * 8 + (lane >> 3), lane & 7));
-      asm volatile("" :: "v"(t4s[0].x), "v"(t4s[1].x), "v"(t4s[2].x), "v"(t4s[3].x));          // (all four have landed here: nothing sinks a read back to its use)
+        for (int j = 0; j < 4; ++j) t4s[j] = *reinterpret_cast<const float4*>(s_out + out_cell(j * 8 + (lane >> 3), lane & 7));
+        asm volatile("" :: "v"(t4s[0].x), "v"(t4s[1].x), "v"(t4s[2].x), "v"(t4s[3].x));          // (all four have landed here: nothing sinks a read back to its use)
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int pj = j * 8 + (lane >> 3), cj = lane & 7, pxj = x0 + pj;
-        const float4 t4 = t4s[j];
+        const float4 t4 = GEN ? *reinterpret_cast<const float4*>(s_out + out_cell(pj, cj)) : t4s[j];
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
         else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
@@ -821,6 +824,7 @@ int32_t launch_h2(unet_ctx* ctx, const float* x, int ldx, const unet_bf16* wimg,
   const int nchunks_ = K / (16 * KS), kcps = (nchunks_ + splits - 1) / splits;
   auto go = [&](auto kern) -> int32_t {
     if (smem > 65536) UNET_BIG_LDS(ctx, kern, smem, "conv_h2");
+    unet_note_kernel(ctx, reinterpret_cast<const void*>(kern));
     hipLaunchKernelGGL(kern, dim3(grid, (unsigned)((nchunks_ + kcps - 1) / kcps)), dim3(256), smem, s, x, ldx, wimg, bias, mask, y, ldy, n, h, wd, K, M, act, mask_mode, rate, seed, tiles_x,
                        tiles_y, groups, (int)total, stats, stats_c, signs, mask_climit, hd, img_nb, ctx->opt_deterministic ? 1 : 0, kcps, (long long)n * h * wd * ldy);
     return UNET_OK;

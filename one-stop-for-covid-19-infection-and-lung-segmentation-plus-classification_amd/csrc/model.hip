@@ -171,6 +171,7 @@ int32_t unet_request_relu_bits(unet_ctx* ctx, void* bits) {
   ctx->signs_req = static_cast<unsigned long long*>(bits); ctx->signs_done = nullptr;
   return UNET_OK;
 }
+int32_t unet_ctx_max_kernel_scratch_bytes(unet_ctx* ctx) { return ctx ? ctx->max_scratch_bytes : -1; }
 int32_t unet_allow_k_slices(unet_ctx* ctx) {
   if (!ctx) return UNET_E_ARG;
   ctx->k_slices_ok = 1;
