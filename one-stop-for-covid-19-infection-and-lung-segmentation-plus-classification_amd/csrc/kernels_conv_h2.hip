@@ -727,7 +727,14 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
             signs[((((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * (M >> 5) + (g * NB + nb)) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
         }
         if (pxj < W && mb0 + cj * 4 < M) {
-          *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;
+          // The output leaves with the streaming (nontemporal) hint: at the 256 x 256 / 512 x 512 levels it is 0.25-1 GB, far beyond what the 256-MB memory-side cache can
+          // keep for the next launch, and written normally it pushes out what that launch is about to read.  Same-box A/B: 15.145 -> 14.986, 15.380 -> 15.260, 15.252 ->
+          // 15.163 ms on three boxes (the readers of the 512 x 512 tensors 9-20 % faster; batch-1 inference unchanged).  Only the 8-row instances streaming: half the gain;
+          // decided per launch by output size behind a branch: +0.2 ms (profiles/r05_ab_streaming_stores.txt)
+          {
+            float* const q = y + oj + cj * 4;
+            __builtin_nontemporal_store(t4.x, q); __builtin_nontemporal_store(t4.y, q + 1); __builtin_nontemporal_store(t4.z, q + 2); __builtin_nontemporal_store(t4.w, q + 3);
+          }
           if (POOLS) {
             // the stored gradient g and the pooled activation p of the same elements (line layout both): st1 += g ks, st2 += g ks (p (1 - rate) - beta) / gamma
             const float4 pv = MPF ? mpre[MPF ? nb : 0][MPF ? r : 0][j] : *reinterpret_cast<const float4*>(mask + oj + cj * 4);
