@@ -391,20 +391,20 @@ def main():
         # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE): collected OFFLINE at this exact workload
         # (tools/collect_r03_profiles.sh, calibration inside the file), not in this run -- only quoted for the configuration it was measured on
         traffic, tname = None, None
-        for tname in (("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if args.dtype == "fp32" else ("r03_pmc_traffic_bf16.json", "r01_pmc_traffic_bf16.json")):
+        for tname in (("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json") if args.dtype == "fp32" else ("r03_pmc_traffic_bf16.json", "r01_pmc_traffic_bf16.json")):
             tfile = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tfile) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet":
                 traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
                 break
         step_traffic = None
-        tf4 = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        tf4 = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
         if os.path.exists(tf4) and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet" and args.dtype == "fp32":
             t4 = json.load(open(tf4))
             if "hbm_bytes_per_step_all_kernels" in t4:
                 sb = float(t4["hbm_bytes_per_step_all_kernels"])
                 step_traffic = {"hbm_bytes_per_step_all_kernels": round(sb), "vs_survey_54.3GB": round(sb / 54.300299148e9, 3),
                                 "vs_op_model": round(sb / max(sum(o[2] for o in ops), 1.0), 3),
-                                "source": "profiles/r04_pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of one step, counter-only rocprofv3 passes; offline, this workload)"}
+                                "source": "profiles/r05_pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of one step, counter-only rocprofv3 passes; offline, this workload)"}
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
         H2R = 3.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
         n_h2 = sum(int(abs(exec_ratio(o[0]) - H2R) < 1e-9) for o in dom)
