@@ -125,6 +125,40 @@ def cpu_baseline(size, seconds_budget=28.0, arch="unet"):
                       f"cpu quota {quota if quota else 'none'}, torch's default was {default_threads} threads){rate}"}
 
 
+def live_traffic(timeout_s=150):
+    """HBM bytes of THIS build's step from the PMC counters, measured now: two counter-only rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- separate runs, no tracing, as
+    MI355X_MICROARCH.md prescribes) over two training steps of tools/profile_ops.py in a child process; FETCH_SIZE (KB) x 2 (gfx950 tallies 128-B requests at 64 B) +
+    WRITE_SIZE (KB), per launch of the conv3x3 forward / data-gradient family and summed over every kernel of a step.  None if rocprofv3 is not there or anything fails
+    (the line then quotes the offline figure of profiles/)."""
+    import collections, csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="unet_pmc_", dir="/tmp")
+    try:
+        tot = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            subprocess.run(["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", os.path.join(tmp, c), "--", sys.executable, os.path.join(ROOT, "tools", "profile_ops.py"),
+                            "--reps", "1", "--warm", "1"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            agg = collections.defaultdict(lambda: [0.0, 0])
+            for f in glob.glob(os.path.join(tmp, c, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == c:
+                        a = agg[r["Kernel_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+            tot[c] = agg
+        steps = sum(n for k, (v, n) in tot["FETCH_SIZE"].items() if "adam_kernel" in k)
+        dom = [k for k in tot["FETCH_SIZE"] if "conv_h2_kernel<0" in k]
+        launches = sum(tot["FETCH_SIZE"][k][1] for k in dom)
+        if steps < 1 or launches < 1:
+            return None
+        rd = sum(tot["FETCH_SIZE"][k][0] for k in dom) * 2048.0; wr = sum(tot["WRITE_SIZE"][k][0] for k in dom if k in tot["WRITE_SIZE"]) * 1024.0
+        all_b = sum(v for v, n in tot["FETCH_SIZE"].values()) * 2048.0 + sum(v for v, n in tot["WRITE_SIZE"].values()) * 1024.0
+        return {"per_launch": (rd + wr) / launches, "launches_per_step": launches / steps, "per_step_all_kernels": all_b / steps, "steps": steps}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _tap_dims(eng, n, name):
     import ctypes as C
     from covidseg_amd import _lib
@@ -150,6 +184,8 @@ def main():
     ap.add_argument("--options", default="", help='context options as JSON, e.g. {"head_fused": 0} (same-box A/B of graph forms; _lib.OPTIONS)')
     ap.add_argument("--settle", type=float, default=2.0, help="seconds of untimed steps ahead of the warm-up (clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic-leg", action="store_true", help="skip the live PMC measurement of roofline.traffic / step_traffic (two counter-only rocprofv3 passes in a child process, ~20 s; "
+                                                                  "the line then quotes the offline figure of profiles/)")
     ap.add_argument("--no-fit-leg", action="store_true", help="skip the untimed fit_img_s measurement (UNetModel.fit on a host-resident set)")
     ap.add_argument("--fit-steps", type=int, default=20, help="steps per epoch of the fit leg")
     ap.add_argument("--no-sync-bn", action="store_true")
@@ -405,6 +441,18 @@ def main():
                 step_traffic = {"hbm_bytes_per_step_all_kernels": round(sb), "vs_survey_54.3GB": round(sb / 54.300299148e9, 3),
                                 "vs_op_model": round(sb / max(sum(o[2] for o in ops), 1.0), 3),
                                 "source": "profiles/r05_pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of one step, counter-only rocprofv3 passes; offline, this workload)"}
+        traffic_unit = f"HBM bytes per launch, rocprofv3 PMC collected offline on this workload (profiles/{tname}); not measured in this run"
+        # ... and measured NOW where the default workload runs on one GPU (the timed region is over: nothing here touches `value`)
+        live = None
+        if world == 1 and not args.no_traffic_leg and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet" and args.dtype == "fp32" and not args.options and not args.deterministic:
+            live = live_traffic()
+        if live is not None:
+            traffic = round(live["per_launch"])
+            traffic_unit = (f"HBM bytes per launch of this kernel family, MEASURED IN THIS RUN: two counter-only rocprofv3 passes (FETCH_SIZE x 2 [gfx950 tallies 128-B requests at 64 B] + WRITE_SIZE) "
+                            f"over {live['steps']} training steps in a child process, {live['launches_per_step']:.1f} launches per step")
+            sb = live["per_step_all_kernels"]
+            step_traffic = {"hbm_bytes_per_step_all_kernels": round(sb), "vs_survey_54.3GB": round(sb / 54.300299148e9, 3), "vs_op_model": round(sb / max(sum(o[2] for o in ops), 1.0), 3),
+                            "source": "measured in this run (the same two counter passes, summed over every kernel of a step)"}
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
         H2R = 3.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
         n_h2 = sum(int(abs(exec_ratio(o[0]) - H2R) < 1e-9) for o in dom)
@@ -430,7 +478,7 @@ def main():
                     "note": "achieved = ALGORITHMIC (direct-convolution, SURVEY 8d) FLOPs of these launches / their time, against the fp32 MFMA peak",
                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         roof.update({"traffic": traffic,
-                     "traffic_unit": f"HBM bytes per launch, rocprofv3 PMC collected offline on this workload (profiles/{tname}); not measured in this run",
+                     "traffic_unit": traffic_unit,
                      "algorithmic_bytes_per_launch": round(alg_bytes),
                      "launches_per_step": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                      "avg_launch_gflop": round(fl / max(launches, 1) / 1e9, 3),

@@ -11,7 +11,7 @@ for r in $(seq "$R"); do
   for v in A B; do
     src="$A"; [ "$v" = B ] && src="$B"
     cp "$src" "$LIB"
-    python bench.py --no-cpu-baseline --no-strict-leg "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'])" >> "$out"
+    python bench.py --no-cpu-baseline --no-strict-leg --no-traffic-leg "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'])" >> "$out"
   done
 done
 cp /tmp/_keep.so "$LIB"

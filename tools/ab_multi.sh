@@ -10,7 +10,7 @@ out="${AB_OUT:-gpurun_out/ab_multi.txt}"; mkdir -p "$(dirname "$out")"; : > "$ou
 for r in $(seq "$R"); do
   for src in $LIBS; do
     cp "$src" "$LIB"
-    python bench.py --no-cpu-baseline --no-strict-leg --no-fit-leg "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$src', d['value'], d['ms_per_step'], d.get('predict_batch1_ms'))" >> "$out"
+    python bench.py --no-cpu-baseline --no-strict-leg --no-fit-leg --no-traffic-leg "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$src', d['value'], d['ms_per_step'], d.get('predict_batch1_ms'))" >> "$out"
   done
 done
 cp /tmp/_keep.so "$LIB"
