@@ -185,7 +185,7 @@ int32_t unet_conv3x3_fwd(unet_ctx* ctx, const float* x, const float* w, const fl
     UNET_FAIL(ctx, UNET_E_ARG, "conv3x3_fwd: bad args");
   const void* armed = ctx->signs_req;
   int32_t r = conv3x3_fwd_dispatch(ctx, x, w, bias, nullptr, MASK_NONE, y, n, h, wd, cin, cout, act, drop_rate, drop_seed, algo, as_stream(stream), w_ws, 0);
-  ctx->signs_req = nullptr;
+  ctx->signs_req = nullptr; ctx->k_slices_ok = 0;
   if (!r && armed && ctx->signs_done != armed) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_fwd: armed with unet_request_relu_bits but this launch cannot write them (unet_relu_bits_supported, act = ReLU, no dropout)");
   return r;
 }
@@ -266,8 +266,10 @@ int32_t unet_conv3x3_bwd_data(unet_ctx* ctx, const float* dy, const float* w, co
   if (mask_mode == MASK_RELU_BITS && !unet_relu_bits_supported(algo, h, wd, cout, cin))
     UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3_bwd_data: no bit-mask form for h=%d w=%d cin=%d cout=%d algo=%d (unet_relu_bits_supported(algo, h, w, cout, cin))", h, wd, cin, cout, algo);
   // data gradient = 3x3 convolution of dy (cout channels) with the flipped/transposed kernel -> cin channels
-  return conv3x3_fwd_dispatch(ctx, dy, w, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
-                              as_stream(stream), wt_ws, 1);
+  const int32_t r = conv3x3_fwd_dispatch(ctx, dy, w, nullptr, mask_src, mask_mode, dx, n, h, wd, cout, cin, ACT_NONE, mask_rate, mask_seed, algo,
+                                         as_stream(stream), wt_ws, 1);
+  ctx->k_slices_ok = 0;          // (one-shot: a launch that did not run on the h2 kernels must not leave the arm for a later one)
+  return r;
 }
 
 // the data gradient behind an encoder tail (MaxPooling2D + Dropout, T1:862-863) with that tail's pooled-path BatchNorm-backward sums in the epilogue (include/unet_hip.h)
@@ -2111,7 +2113,7 @@ int32_t unet_model_run(unet_model* m, int32_t prog, int32_t begin, int32_t end, 
   // (weight gradients on a second stream beside the data-gradient chain were measured 1-3 % SLOWER on this chip -- two matrix kernels sharing the CUs
   //  cost each other more than their gaps are worth; round 4: even the ~25 tiny launches of the split weight images, forked onto a side stream beside the
   //  HBM-bound first-layer kernel, cost 0.05 ms per step (same-box A/B 16.56 -> 16.61 ms) -- so every launch of a model stays on the caller's stream)
-  if (begin == 0 && prog != UNET_PROG_BWD) { ctx->stats_req_c = 0; ctx->stats_in_slots = nullptr; ctx->stats_in_slots_c = 0; ctx->signs_req = nullptr; }   // a program starts clean whatever an aborted run left armed
+  if (begin == 0 && prog != UNET_PROG_BWD) { ctx->stats_req_c = 0; ctx->stats_in_slots = nullptr; ctx->stats_in_slots_c = 0; ctx->signs_req = nullptr; ctx->k_slices_ok = 0; }   // a program starts clean whatever an aborted run left armed
   for (int i = begin; i < end; ++i) {
     if (ctx->profiling) UNET_HIP(ctx, hipEventRecord(e0, s));
     const int32_t r = P[i].run(s);
