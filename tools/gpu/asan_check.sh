@@ -22,6 +22,7 @@ from covidseg_amd.engine import HipUNet
 from covidseg_amd import weights as W, _lib
 print("library:", _lib.LIB_PATH)
 x, y = synthetic_ct(3, 64, seed=1)
+first = {}
 for arch, opts in (("unet", None), ("unet", {"deterministic": 1}), ("unet", {"bn_fold": 0}), ("unet", {"head_fused": 0, "skip_raw": 0}), ("unet", {"relu_bits": 0, "pool_sums_fused": 0}),
                    ("unetpp", None), ("classifier", None)):
     eng = HipUNet(64, 64, 1, device=0, arch=arch, options=opts, dropout_rate=0.25 if arch == "unet" else 0.2, private_context=True)
@@ -33,7 +34,11 @@ for arch, opts in (("unet", None), ("unet", {"deterministic": 1}), ("unet", {"bn
         eng.predict_batch(xc[:2], yc[:2])
     else:
         for n in (3, 2):
-            print(arch, opts, n, eng.train_batch(x[:n], y[:n]).cpu().numpy())
+            ld = eng.train_batch(x[:n], y[:n]).cpu().numpy()
+            print(arch, opts, n, ld)
+            # the instrumented library must compute what the product computes: a finite BCE + Dice loss of an untrained net on 11 % foreground, a Dice coefficient in (0, 1)
+            assert np.isfinite(ld).all() and 0.3 < ld[0] < 2.0 and 0.0 < ld[1] < 0.9, (arch, opts, n, ld)
+            if arch == "unet": first.setdefault(n, ld); assert np.abs(ld - first[n]).max() < 2e-2, (opts, n, ld, first[n])          # every U-Net graph form starts from the same weights
         p, ld = eng.predict_batch(x[:1], y[:1]); eng.predict_batch(x[:1])
         eng.tap(1, "c9b" if arch == "unet" else "x1_4b"); eng.tap(1, "bn1")
         eng.get_grads(); eng.get_weights()
