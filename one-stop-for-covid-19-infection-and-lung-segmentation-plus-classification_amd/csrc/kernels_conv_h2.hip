@@ -69,7 +69,8 @@ constexpr int H2_MAXB = 48;                                  // workgroups per l
 struct h2_prep { const float* w; const float* cs; unet_bf16* img; long long tap_stride, sk, sm, total, nw4; int T, KS, nb, nchunks, flip, m, cs_div, cs_mod, max_only, cs_bound; };
 struct h2_prep_list { h2_prep item[UNET_PREP_MAX]; int n; };          // passed by value as a kernel argument (3.4 KiB)
 
-__global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {          // grid (H2_MAXB, layers)
+constexpr int H2_MAXT = 1024;                                // threads per workgroup of the max pass: 16 waves per partial maximum keep a 2.4 M-weight layer at 3 rounds of loads per thread
+__global__ __launch_bounds__(H2_MAXT) void h2_wmax_kernel(h2_prep_list L) {          // grid (H2_MAXB, layers)
   const h2_prep& p = L.item[blockIdx.y];
   float mx = 0.f;
   auto one = [&](long long i) __attribute__((always_inline)) {
@@ -79,16 +80,21 @@ __global__ __launch_bounds__(256) void h2_wmax_kernel(h2_prep_list L) {         
     return m4;
   };
   // (four independent loads per thread and round: with one, the 2.4 M weights of a 512 -> 512 layer were 48 dependent round trips per thread -- 23 us per launch)
-  const long long st = (long long)gridDim.x * 256;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long st = (long long)gridDim.x * H2_MAXT;
+  long long i = (long long)blockIdx.x * H2_MAXT + threadIdx.x;
   for (; i + 3 * st < p.nw4; i += 4 * st) mx = fmaxf(fmaxf(mx, fmaxf(one(i), one(i + st))), fmaxf(one(i + 2 * st), one(i + 3 * st)));
   for (; i < p.nw4; i += st) mx = fmaxf(mx, one(i));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  __shared__ float s_m[4];
+  __shared__ float s_m[H2_MAXT / 64];
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) reinterpret_cast<float*>(p.img)[8 + blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  if (threadIdx.x == 0) {
+    float m = s_m[0];
+#pragma unroll
+    for (int k = 1; k < H2_MAXT / 64; ++k) m = fmaxf(m, s_m[k]);
+    reinterpret_cast<float*>(p.img)[8 + blockIdx.x] = m;
+  }
 }
 
 __global__ __launch_bounds__(256) void h2_wimg_kernel(h2_prep_list L, int maxb) {          // blockIdx.y = layer
@@ -945,7 +951,7 @@ int32_t k_h2_prep_multi(unet_ctx* ctx, const float* const* w, const float* const
     if (cs && cs[k] && kind[k] == 1) { L.item[k].cs_bound = 1; L.item[k].cs_mod = cout[k]; }
     most = std::max(most, L.item[k].total);
   }
-  hipLaunchKernelGGL(h2_wmax_kernel, dim3(H2_MAXB, (unsigned)count), dim3(256), 0, s, L);
+  hipLaunchKernelGGL(h2_wmax_kernel, dim3(H2_MAXB, (unsigned)count), dim3(H2_MAXT), 0, s, L);
   hipLaunchKernelGGL(h2_wimg_kernel, dim3((unsigned)std::min<long long>((most + 255) / 256, 256), (unsigned)count), dim3(256), 0, s, L, (int)H2_MAXB);
   UNET_CHECK_LAUNCH(ctx, "h2_prep_multi");
   return UNET_OK;
