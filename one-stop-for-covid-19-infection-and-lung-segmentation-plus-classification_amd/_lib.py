@@ -16,7 +16,7 @@ COMM_HANDLE_BYTES, COMM_MAX_WORLD, COMM_MAX_DOUBLES = 64, 8, 2048          # inc
 
 ALGO_AUTO, ALGO_NAIVE, ALGO_MFMA = 0, 1, 2          # fp16-split h2 kernels where the shape allows / VALU kernels / strict fp32 MFMA kernels
 # unet_ctx_set_option (include/unet_hip.h UNET_OPT_*)
-OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6, "head_fused": 7, "skip_raw": 8, "pool_sums_fused": 9, "head_bwd_fused": 10}
+OPTIONS = {"relu_bits": 1, "bn_fold": 2, "enc_bn_fused": 3, "bn_concat_analytic": 4, "bn_fuse_stats": 5, "deterministic": 6, "head_fused": 7, "skip_raw": 8, "pool_sums_fused": 9, "head_bwd_fused": 10, "conv_pp": 13}
 ARCH_UNET, ARCH_UNETPP, ARCH_CLASSIFIER = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2

@@ -32,6 +32,7 @@ struct unet_ctx {
   int opt_skip_raw = 1;             // fp32 U-Net: an encoder block's second conv writes straight into the skip half of its concat; the encoder BatchNorm is composed into the folded decoder one
   int opt_head_fused = 1;           // the 1x1 sigmoid head + loss sums + the head's weight-gradient sums in the epilogue of the last conv3x3 (fp32 h2 kernels)
   int opt_head_bwd_fused = 1;       // the head's backward as an 8-byte-per-pixel {dz, mask} stream that the last conv's two gradients expand (no fp32 dY tensor)
+  int opt_conv_pp = 0;              // shallow conv3x3 forward / data-gradient launches on the persistent two-half schedule (kernels_conv_pp.hip)
   int opt_deterministic = 0;        // fixed-order reductions everywhere (no floating-point atomics): bit-identical reruns
   double* bn_slots = nullptr;       // device, UNET_BN_SLOTS_DET x UNET_BN_SLOT_DOUBLES (16 MB), all zero between launches
   int bn_nslots() const { return opt_deterministic ? UNET_BN_SLOTS_DET : UNET_BN_SLOTS; }
@@ -321,6 +322,10 @@ constexpr int UNET_PREP_MAX = 36;          // layers per batched weight-preparat
 // fp32 conv3x3 / ConvT on the fp16 matrix cores through the block-scaled 2-term fp16 split (kernels_conv_h2.hip, kernels_wgrad_h2.hip): three fp16 MFMA products per
 // multiply.  The family of UNET_ALGO_AUTO wherever the channel counts allow; K = contraction channels, M = output channels of a launch
 bool h2_conv3x3_selected(int algo, int K, int M);
+// the persistent two-half schedule of the shallow levels (kernels_conv_pp.hip): same weight image, same epilogue contract as k_conv3x3_h2_fwd for the launches it takes
+bool pp_conv3x3_selected(const unet_ctx* ctx, int K, int M, int n, int h, int wd, const float* mask, int mask_mode, int act, float rate, int ldy);
+int32_t k_conv3x3_pp_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd, int K, int M,
+                         int act, hipStream_t s);
 size_t h2_wimg_bytes(int K, int M);
 // (cs: optional per-input-channel factor of a forward image -- the scale of a BatchNorm folded into the conv; the scaled weights are never materialised)
 int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s, const float* cs = nullptr);

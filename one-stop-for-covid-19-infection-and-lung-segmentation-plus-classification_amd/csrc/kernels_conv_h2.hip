@@ -996,6 +996,7 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   if (K < 16 || (K % 16) || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: K=%d M=%d (multiples of 16)", K, M);
   if ((long long)h * wd * std::max(K, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
   const unet_bf16* img = static_cast<const unet_bf16*>(wimg);
+  if (mask_climit >= M && pp_conv3x3_selected(ctx, K, M, n, h, wd, mask, mask_mode, act, rate, ldy)) return k_conv3x3_pp_fwd(ctx, x, wimg, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, s);
   if (mask_climit < M && ((mask_climit % 32) || mask_mode < MASK_BN_BWD)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 h2: mask_climit %d must be a whole number of 32-channel blocks of a folded-BatchNorm gradient", mask_climit);
   // Grids that leave CUs idle (batch-1 inference below 256 x 256, the 32 x 32 level of small batches) trade tile size for workgroups, on the SAME weight image:
   //   fewer than two two-block 8-row tiles per CU -> ONE 32-channel block per workgroup (twice the workgroups, half the MFMAs per staged chunk; the patch is staged twice,

@@ -71,13 +71,14 @@ static int* ctx_option(unet_ctx* ctx, int32_t option) {
     case UNET_OPT_SKIP_RAW: return &ctx->opt_skip_raw;
     case UNET_OPT_POOL_SUMS_FUSED: return &ctx->opt_pool_sums_fused;
     case UNET_OPT_HEAD_BWD_FUSED: return &ctx->opt_head_bwd_fused;
+    case UNET_OPT_CONV_PP: return &ctx->opt_conv_pp;
     default: return nullptr;
   }
 }
 int32_t unet_ctx_set_option(unet_ctx* ctx, int32_t option, int32_t value) {
   if (!ctx) return UNET_E_ARG;
   int* p = ctx_option(ctx, option);
-  const int hi = option == UNET_OPT_BN_FOLD ? 3 : 1;
+  const int hi = option == UNET_OPT_BN_FOLD ? 3 : option == UNET_OPT_CONV_PP ? 2 : 1;          // (CONV_PP 2: also the launches too small to fill the persistent grid -- tests)
   if (!p || value < 0 || value > hi) UNET_FAIL(ctx, UNET_E_ARG, "ctx_set_option: option %d value %d", option, value);
   *p = value;
   return UNET_OK;
