@@ -80,9 +80,10 @@ int32_t unet_ctx_set_profiling(unet_ctx* ctx, int32_t on);
  *   HEAD_BWD_FUSED (1)     with HEAD_FUSED and RELU_BITS: dL/d(output of the last conv3x3) = dz_p w_c [y_pc > 0] is never written as a tensor -- unet_head_dzm leaves
  *                          {dz_p, 32 mask bits} per pixel (8 bytes instead of 128) and the last conv's data gradient and weight gradient expand that stream while they
  *                          stage it (-1.5 GB of traffic per step at 512 x 512 x 16); 0 = unet_head_dy writes the fp32 tensor
- *   CONV_PP (13)           the conv3x3 forward / data-gradient launches of the shallow levels (K = 32 -> 32 channels) on the persistent two-half schedule of
+ *   CONV_PP (13; default 1) the conv3x3 forward / data-gradient launches of the shallow levels (K = 32 -> 32 channels) on the persistent two-half schedule of
  *                          kernels_conv_pp.hip: one 512-thread workgroup per CU, the layer's split weight image resident in LDS, one half's MFMAs over the other half's
- *                          loads, split and stores.  Same arithmetic as the h2 kernels (one block exponent per 8 x 32 pixel tile).  0 = conv_h2_kernel everywhere
+ *                          loads, split and stores.  Same arithmetic as the h2 kernels (one block exponent per 8 x 32 pixel tile); taken by launches of at least four tiles per
+ *                          half-workgroup (2048 tiles: 512 x 512 from batch 2 up).  0 = conv_h2_kernel everywhere; 2 = also smaller launches (tests)
  *   (options 11 / 12 of ABI v13-v14 -- WGRAD_ATOMIC, C1A_RECOMPUTE -- were same-box A/B losers and left the library in v15; DESIGN.md keeps the measurements)
  */
 enum { UNET_OPT_RELU_BITS = 1, UNET_OPT_BN_FOLD = 2, UNET_OPT_ENC_BN_FUSED = 3, UNET_OPT_BN_CONCAT_ANALYTIC = 4, UNET_OPT_BN_FUSE_STATS = 5, UNET_OPT_DETERMINISTIC = 6,

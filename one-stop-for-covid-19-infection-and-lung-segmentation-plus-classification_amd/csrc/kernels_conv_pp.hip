@@ -22,7 +22,7 @@
 #define PP_TRACE 0
 #endif
 #ifndef PP_MID
-#define PP_MID 4            // the step behind which the MFMA phase has its middle barrier (P3 = steps 0 .. PP_MID: as long as the other half's P1)
+#define PP_MID 2            // the step behind which the MFMA phase has its middle barrier (P3 = steps 0 .. PP_MID: as long as the other half's P1)
 #endif
 #ifndef PP_STORE_AUX
 #define PP_STORE_AUX 2          // nontemporal
