@@ -183,6 +183,13 @@ __device__ __forceinline__ float wave_max_nonneg(float x) {
   return __uint_as_float(max(max(r0, r1), max(r2, r3)));
 }
 
+// v[lane `l`] = s (v_writelane_b32: the lane select must be an immediate beside a scalar source -- one constant-bus operand; `l` folds after unrolling)
+__device__ __forceinline__ void unet_writelane(int& v, unsigned s, int l) {
+#define UNET_WL(L) case L: asm("s_nop 1\n\tv_writelane_b32 %0, %1, " #L : "+v"(v) : "s"(s)); break;          // (s_nop: a VALU-written scalar needs two wait states in front of a VALU read on gfx950 -- nothing pads an asm statement)
+  switch (l) { UNET_WL(0) UNET_WL(1) UNET_WL(2) UNET_WL(3) UNET_WL(4) UNET_WL(5) UNET_WL(6) UNET_WL(7) UNET_WL(8) UNET_WL(9) UNET_WL(10) UNET_WL(11) UNET_WL(12) UNET_WL(13) UNET_WL(14) UNET_WL(15) default: break; }
+#undef UNET_WL
+}
+
 // Branch-free guarded 16-byte load: the hardware range check of a buffer descriptor returns 0 for byte offsets >= the record
 // count, so halo / overhang lanes simply carry an out-of-range offset (no exec-mask branch, no select).  Tensors addressed this
 // way must be smaller than 1 GiB (COL_OOB + a valid row offset must still be out of range).
@@ -325,7 +332,7 @@ bool h2_conv3x3_selected(int algo, int K, int M);
 // the persistent two-half schedule of the shallow levels (kernels_conv_pp.hip): same weight image, same epilogue contract as k_conv3x3_h2_fwd for the launches it takes
 bool pp_conv3x3_selected(const unet_ctx* ctx, int K, int M, int n, int h, int wd, const float* mask, int mask_mode, int act, float rate, int ldy);
 int32_t k_conv3x3_pp_fwd(unet_ctx*, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd, int K, int M,
-                         int act, hipStream_t s);
+                         int act, hipStream_t s, bool vdy = false);          // (vdy: x = the head's {dz, mask} stream [n,h,wd] of 8 bytes, K = 32: k_conv3x3_h2_dgrad_dzm)
 size_t h2_wimg_bytes(int K, int M);
 // (cs: optional per-input-channel factor of a forward image -- the scale of a BatchNorm folded into the conv; the scaled weights are never materialised)
 int32_t k_h2_weights(unet_ctx*, const float* w, void* img, int cin, int cout, int flip, hipStream_t s, const float* cs = nullptr);

@@ -541,11 +541,14 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         const float4 t4 = t4s[j];
         const long long oj = (((long long)n * H + py) * W + pxj) * ldy;
         if (signs) {                                       // (wave-uniform) sign bits of the stored values: the mask of the head's own backward
-          const bool vld = pxj < W;
-          const unsigned long long b0 = __builtin_amdgcn_ballot_w64(vld && t4.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(vld && t4.y > 0.f);
-          const unsigned long long b2 = __builtin_amdgcn_ballot_w64(vld && t4.z > 0.f), b3 = __builtin_amdgcn_ballot_w64(vld && t4.w > 0.f);
+          // (W % 8 == 0: an 8-pixel cell is inside the image or not at all; the four words of a cell go to lanes 0..3 of a register pair by v_writelane -- a select chain
+          //  per lane compiled to nested exec-mask branches, ~35 instructions per cell)
+          const unsigned long long bb[4] = {__builtin_amdgcn_ballot_w64(t4.x > 0.f), __builtin_amdgcn_ballot_w64(t4.y > 0.f), __builtin_amdgcn_ballot_w64(t4.z > 0.f), __builtin_amdgcn_ballot_w64(t4.w > 0.f)};
+          int slo = 0, shi = 0;
+          unet_writelane(slo, (unsigned)bb[0], 0); unet_writelane(shi, (unsigned)(bb[0] >> 32), 0); unet_writelane(slo, (unsigned)bb[1], 1); unet_writelane(shi, (unsigned)(bb[1] >> 32), 1);
+          unet_writelane(slo, (unsigned)bb[2], 2); unet_writelane(shi, (unsigned)(bb[2] >> 32), 2); unet_writelane(slo, (unsigned)bb[3], 3); unet_writelane(shi, (unsigned)(bb[3] >> 32), 3);
           if (lane < 4 && x0 + j * 8 < W)
-            signs[(((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+            signs[(((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * 4 + lane] = ((unsigned long long)(unsigned)shi << 32) | (unsigned)slo;
         }
         if (pxj < W) {
           if (y) *reinterpret_cast<float4*>(y + oj + cj * 4) = t4;          // (y null: nothing downstream reads the tensor -- p, the sums and the sign bits are all the backward takes)
@@ -725,12 +728,14 @@ __global__ __launch_bounds__(256, WPS) void conv_h2_kernel(const float* __restri
         long long oj;
         if (MODE == 1) oj = (((long long)n * 2 * H + 2 * py + (ab >> 1)) * (2 * W) + 2 * pxj + (ab & 1)) * ldy + (oc - hi * 16);
         else oj = (((long long)n * H + py) * W + pxj) * ldy + (mb - hi * 16);
-        if (MODE == 0 && signs) {                          // (wave-uniform) sign bits of the stored values: four ballots per 8 pixels x 32 channels
-          const bool vld = pxj < W && mb0 + cj * 4 < M;
-          const unsigned long long b0 = __builtin_amdgcn_ballot_w64(vld && t4.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(vld && t4.y > 0.f);
-          const unsigned long long b2 = __builtin_amdgcn_ballot_w64(vld && t4.z > 0.f), b3 = __builtin_amdgcn_ballot_w64(vld && t4.w > 0.f);
+        if (MODE == 0 && !GEN && signs) {                  // (wave-uniform; never with ELU / dropout) sign bits of the stored values: four ballots per 8 pixels x 32 channels
+          // (signs are written only for M % 32 == 0 and W % 8 == 0: every lane of a cell inside the image is valid; the four words -> lanes 0..3 by v_writelane)
+          const unsigned long long bb[4] = {__builtin_amdgcn_ballot_w64(t4.x > 0.f), __builtin_amdgcn_ballot_w64(t4.y > 0.f), __builtin_amdgcn_ballot_w64(t4.z > 0.f), __builtin_amdgcn_ballot_w64(t4.w > 0.f)};
+          int slo = 0, shi = 0;
+          unet_writelane(slo, (unsigned)bb[0], 0); unet_writelane(shi, (unsigned)(bb[0] >> 32), 0); unet_writelane(slo, (unsigned)bb[1], 1); unet_writelane(shi, (unsigned)(bb[1] >> 32), 1);
+          unet_writelane(slo, (unsigned)bb[2], 2); unet_writelane(shi, (unsigned)(bb[2] >> 32), 2); unet_writelane(slo, (unsigned)bb[3], 3); unet_writelane(shi, (unsigned)(bb[3] >> 32), 3);
           if (lane < 4 && x0 + j * 8 < W)
-            signs[((((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * (M >> 5) + (g * NB + nb)) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+            signs[((((long long)n * H + py) * (W >> 3) + (x0 >> 3) + j) * (M >> 5) + (g * NB + nb)) * 4 + lane] = ((unsigned long long)(unsigned)shi << 32) | (unsigned)slo;
         }
         if (pxj < W && mb0 + cj * 4 < M) {
           // The output leaves with the streaming (nontemporal) hint: at the 256 x 256 / 512 x 512 levels it is 0.25-1 GB, far beyond what the 256-MB memory-side cache can
@@ -985,6 +990,7 @@ bool h2_head_bwd_selected(const unet_ctx* ctx, int algo, int wd, int cin) {
 int32_t k_conv3x3_h2_dgrad_dzm(unet_ctx* ctx, const void* dzm, const void* wimg, const float* mask, int mask_mode, float* dx, int n, int h, int wd, int M, hipStream_t s) {
   if (!dzm || !wimg || !dx || h2_nb(M) != 1 || M < 16 || (M % 16)) UNET_FAIL(ctx, UNET_E_ARG, "conv3x3 dgrad behind the head stream: bad args (M = %d)", M);
   if ((long long)h * wd * std::max(32, M) * 4 >= (1LL << 30)) UNET_FAIL(ctx, UNET_E_SHAPE, "conv3x3 h2: one image must stay below 1 GiB (32-bit buffer offsets)");
+  if (pp_conv3x3_selected(ctx, 32, M, n, h, wd, mask, mask_mode, ACT_NONE, 0.0f, M)) return k_conv3x3_pp_fwd(ctx, static_cast<const float*>(dzm), wimg, nullptr, mask, mask_mode, dx, M, n, h, wd, 32, M, ACT_NONE, s, true);
   return launch_h2<0, 1, 2, 4, 3>(ctx, static_cast<const float*>(dzm), 2, static_cast<const unet_bf16*>(wimg), nullptr, mask, mask_mode, dx, M, n, h, wd, 32, M, ACT_NONE, 0.0f, 0, s);
 }
 

@@ -51,7 +51,10 @@ __device__ __forceinline__ f16x8 pp_frag(const char* p) { return *reinterpret_ca
 __device__ __forceinline__ int pp_cell(int p, int c) { return p * 128 + ((c ^ (p & 7)) << 4); }
 
 // KC = 16-channel chunks of the contraction (K = 16 KC); one 32-channel output block per workgroup (M = 32)
-template <int KC, bool BITS>
+// BITS: the data-gradient instance, `mask` = one-bit ReLU mask of the output (MASK_RELU_BITS).  VDY: the input is VIRTUAL -- the gradient of the last conv3x3's output,
+// dy[p][c] = dz_p w_c [y_pc > 0] (T1:911-913 backwards), staged from the 8-byte-per-pixel stream {dz_p, 32 mask bits} of head_dzm_kernel (x = that stream): one value is
+// scaled and split per piece, the mask bits pick the channels it goes to; w_c is a per-contraction-channel factor of the weight image (kernels_conv_h2.hip: EPI 3)
+template <int KC, bool BITS, bool VDY>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict__ x, const unet_bf16* __restrict__ wimg_hdr, const float* __restrict__ bias,
                                                          const float* __restrict__ mask, float* __restrict__ y, int ldy, int N, int H, int W, int act, int mask_mode,
                                                          int tiles_x, int tiles_y, int total_tiles, double* __restrict__ stats, int stats_c,
@@ -90,11 +93,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
 #pragma unroll
   for (int k = 0; k < PL; ++k) {
     const int pix = pix0 + k * (256 / PPC), r = pix / PWD, col = pix - r * PWD;
-    rel[k] = pix < NPIX ? ((r * W + col) * K + pc * 4) * 4 : UNET_OOB;          // relative to pixel (y0 - 1, x0 - 1)
+    rel[k] = pix < NPIX ? (VDY ? (r * W + col) * 8 : ((r * W + col) * K + pc * 4) * 4) : UNET_OOB;          // relative to pixel (y0 - 1, x0 - 1); VDY: the 8 pieces of a pixel read the same 8 bytes
   }
   // the descriptor starts one row + one pixel in front of the tensor (never dereferenced there: halo pieces carry an out-of-range offset and read 0)
-  const long long lead = (long long)(W + 1) * K;
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x - lead, ((long long)N * H * W * K + lead) * 4);
+  constexpr int XPP = VDY ? 2 : K;                          // floats per pixel of the staged tensor
+  const long long lead = (long long)(W + 1) * XPP;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x - lead, ((long long)N * H * W * XPP + lead) * 4);
   // the output rows leave as full 128-B lines: lane -> (pixel lane / 8 of an 8-pixel group, channel quad lane % 8); a (row, group) is a scalar offset
   const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(y, (((long long)N * H * W - 1) * ldy + M) * 4);
   const int st_lane = ((lane >> 3) * ldy + (lane & 7) * 4) * 4;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
     return p;
   };
   auto issue_loads = [&](pos p, unet_u32x4 (&preg)[PL]) __attribute__((always_inline)) {
-    const int soff = (((p.n * H + p.y0) * W + p.x0) * K) * 4;          // + lead - (W + 1) K: the tile's pixel (y0 - 1, x0 - 1)
+    const int soff = (((p.n * H + p.y0) * W + p.x0) * XPP) * 4;          // + lead - (W + 1) XPP: the tile's pixel (y0 - 1, x0 - 1)
     // ONE sequence of requests behind an offset select: two arms that both define the registers made the compiler copy all 44 of them behind a vmcnt(0) -- the
     // whole HBM round trip of the patch in front of the epilogue
     int off[PL];
@@ -131,7 +135,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
       }
     }
 #pragma unroll
-    for (int k = 0; k < PL; ++k) { asm volatile("" : "+v"(off[k])); preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off[k], soff, 0); }
+    for (int k = 0; k < PL; ++k) {
+      asm volatile("" : "+v"(off[k]));
+      if (VDY) { const unet_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, off[k], soff, 0); preg[k][0] = v[0]; preg[k][1] = v[1]; }
+      else preg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off[k], soff, 0);
+    }
   };
 
   // ---- once per workgroup: the weight image of the layer and the bias row
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
   unsigned mpre[BITS ? RW : 1][4];
   const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(mask, BITS ? (long long)N * H * (W >> 3) * 32 : 0);
   float4 t4s[4];
+  int sg_lo = 0, sg_hi = 0;                                  // the sign words of a row: word (cell jj, k) in lane 4 jj + k
 
   // ---- the epilogue of the previous tile in 18 slices, one behind the MFMAs of each step of the current tile: the CU's store path takes one 1-KB store instruction per
   // ~110 cycles (measured: 32 KB per tile in ~3500 cycles whatever else runs) -- a wave that issues its eight stores back to back sits in front of a full queue for
@@ -192,12 +201,21 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
       const int jj = (q - 2) >> 1;
       const int pxj = px0 + jj * 8 + (lane >> 3);
       const float4 t4 = t4s[jj];
-      if (signs) {                                         // (wave-uniform) sign bits of the stored values: four ballots per 8 pixels x 32 channels (MASK_RELU_BITS layout)
-        const bool vld = pxj < W;
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(vld && t4.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(vld && t4.y > 0.f);
-        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(vld && t4.z > 0.f), b3 = __builtin_amdgcn_ballot_w64(vld && t4.w > 0.f);
-        if (lane < 4 && px0 + jj * 8 < W)
-          signs[(((long long)pn * H + py) * (W >> 3) + (px0 >> 3) + jj) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+      if (signs) {
+        // (wave-uniform) sign bits of the stored values (MASK_RELU_BITS layout: u64 words [n][y][x / 8][4], word k bit (pixel % 8) * 8 + channel / 4 for channel % 4 == k):
+        // in the line layout a compare's lane mask IS word k of the 8-pixel cell.  The 16 words of a row are collected in lanes 0..15 of a register pair (v_writelane:
+        // no select chains, no exec-mask branches) and leave as ONE 128-B store behind the row's last cell (W % 8 == 0: a cell is inside the image or not at all)
+        const unsigned long long b[4] = {__builtin_amdgcn_ballot_w64(t4.x > 0.f), __builtin_amdgcn_ballot_w64(t4.y > 0.f), __builtin_amdgcn_ballot_w64(t4.z > 0.f), __builtin_amdgcn_ballot_w64(t4.w > 0.f)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          unet_writelane(sg_lo, (unsigned)b[k], jj * 4 + k);
+          unet_writelane(sg_hi, (unsigned)(b[k] >> 32), jj * 4 + k);
+        }
+        if (jj == 3) {
+          const int cells = min(4, (W - px0) >> 3);
+          if (lane < 4 * cells)
+            signs[(((long long)pn * H + py) * (W >> 3) + (px0 >> 3)) * 4 + lane] = ((unsigned long long)(unsigned)sg_hi << 32) | (unsigned)sg_lo;
+        }
       }
       // one full 128-B line per 8 lanes, streaming (nontemporal: kernels_conv_h2.hip, profiles/r05_ab_streaming_stores.txt); columns past the image: out-of-range offset
       const bool ok = pxj < W;
@@ -273,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
       float mx = 0.f;
 #pragma unroll
       for (int k = 0; k < PL; ++k) {
+        if (VDY) { mx = fmaxf(mx, preg[k][1] ? fabsf(__uint_as_float(preg[k][0])) : 0.f); continue; }
         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mx) : "v"(preg[k][0]), "v"(preg[k][1]));
         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mx) : "v"(preg[k][2]), "v"(preg[k][3]));
       }
@@ -337,8 +356,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
       for (int k = 0; k < PL; ++k) {
         if (pix0 + k * (256 / PPC) < NPIX) {               // (only the last k is partial)
           unsigned h0, m0, h1, m1;
+          if (VDY) {
+            unsigned hh, mm;
+            split2_scaled(__uint_as_float(preg[k][0]), __uint_as_float(preg[k][0]), sc, hh, mm);
+            const unsigned nib = preg[k][1] >> (pc * 4);   // bits 0..3: this piece's four channels (piece pc of the pixel = channels 4 pc .. 4 pc + 3)
+            const unsigned k01 = h2_pair_mask(nib, 0), k23 = h2_pair_mask(nib, 2);
+            h0 = hh & k01; h1 = hh & k23; m0 = mm & k01; m1 = mm & k23;
+          } else {
           split2_scaled(__uint_as_float(preg[k][0]), __uint_as_float(preg[k][1]), sc, h0, m0);
           split2_scaled(__uint_as_float(preg[k][2]), __uint_as_float(preg[k][3]), sc, h1, m1);
+          }
           *reinterpret_cast<uint2*>(s_in + dst0 + k * (256 / PPC) * 16) = make_uint2(h0, h1);
           *reinterpret_cast<uint2*>(s_in + dst0 + k * (256 / PPC) * 16 + PLANE) = make_uint2(m0, m1);
         }
@@ -417,7 +444,7 @@ bool pp_conv3x3_selected(const unet_ctx* ctx, int K, int M, int n, int h, int wd
 }
 
 int32_t k_conv3x3_pp_fwd(unet_ctx* ctx, const float* x, const void* wimg, const float* bias, const float* mask, int mask_mode, float* y, int ldy, int n, int h, int wd, int K, int M,
-                         int act, hipStream_t s) {
+                         int act, hipStream_t s, bool vdy) {
   if (K != 32 || M != 32) UNET_FAIL(ctx, UNET_E_SHAPE, "conv pp: K=%d M=%d", K, M);
   constexpr int KC = 2;
   if (!mask) mask_mode = MASK_NONE;
@@ -439,7 +466,9 @@ int32_t k_conv3x3_pp_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   }
   constexpr int NPIX = 340, CHUNK = 4 * NPIX * 16 + 32;
   constexpr size_t smem = (size_t)KC * 9 * 2048 + 2 * (size_t)KC * CHUNK + 4 * 4096 + 32 + 128 + 8 * 2 * 32 * 4 + 16 * 32 * 4;
-  auto kern = mask_mode == MASK_RELU_BITS ? conv_pp_kernel<KC, true> : conv_pp_kernel<KC, false>;
+  if (vdy && (stats || signs || bias || act != ACT_NONE || mask_mode == MASK_BIAS_TAB)) UNET_FAIL(ctx, UNET_E_ARG, "conv pp behind the head's {dz, mask} stream: a plain data-gradient launch only");
+  auto kern = vdy ? (mask_mode == MASK_RELU_BITS ? conv_pp_kernel<KC, true, true> : conv_pp_kernel<KC, false, true>)
+                  : (mask_mode == MASK_RELU_BITS ? conv_pp_kernel<KC, true, false> : conv_pp_kernel<KC, false, false>);
   UNET_BIG_LDS(ctx, kern, smem, "conv_pp");
   unet_note_kernel(ctx, reinterpret_cast<const void*>(kern));
   const unsigned grid = (unsigned)(ctx->num_cu & ~7);

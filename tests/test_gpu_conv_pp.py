@@ -124,3 +124,35 @@ def test_pp_full_size_launch_takes_the_schedule_by_itself():
     p1.ck(p1.lib.unet_conv3x3_fwd(p1.h, p1.d(x).data_ptr(), p1.d(k).data_ptr(), p1.d(b).data_ptr(), y.data_ptr(), n, h, w, c, c, 1, 0.0, 0, 0, p1.wws(c, c), p1.s), "conv fwd")
     want = O.conv3x3_bias_relu(T64(x), T64(k), T64(b), relu=True).numpy()
     assert relerr(y.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32), (3, 33, 72), (1, 64, 48)])
+def test_pp_data_gradient_behind_the_heads_stream(pp, shape):
+    """The last conv3x3's data gradient from the 8-byte-per-pixel stream {dz, 32 mask bits} (T1:911-913 backwards; unet_conv3x3_bwd_data_dzm) on the persistent schedule:
+    against float64 from the same stream, and against conv_h2_kernel's EPI 3 instance."""
+    from gpu_util import relerr, Ops
+    n, h, w = shape
+    c = 32
+    rng = np.random.default_rng(11 + h + w)
+    k3 = (rng.standard_normal((3, 3, c, c)) * 0.2).astype(np.float32); kh = rng.standard_normal(c).astype(np.float32)
+    dz = (rng.standard_normal((n, h, w)) * 1e-7).astype(np.float32); mbits = rng.integers(0, 2 ** 32, (n, h, w), dtype=np.uint64).astype(np.uint32)
+    st = np.stack([dz.view(np.uint32), mbits], -1).reshape(-1).copy()
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    pos = (x > 0).reshape(n, h, w // 8, 8, 1, 8, 4)
+    words = np.zeros((n, h, w // 8, 1, 4), np.uint64)
+    for p in range(8):
+        for q in range(8):
+            words |= pos[:, :, :, p, :, q, :].astype(np.uint64) << np.uint64(p * 8 + q)
+    bits_in = torch.from_numpy(words.view(np.int64).reshape(-1)).cuda()
+    dy = dz[..., None].astype(np.float64) * kh[None, None, None, :].astype(np.float64) * ((mbits[..., None] >> np.arange(c, dtype=np.uint32)) & 1)
+    xt = T64(x).requires_grad_(True)
+    O.conv3x3_bias_relu(xt, T64(k3), torch.zeros(c, dtype=torch.float64), relu=False).backward(T64(dy))
+    want = xt.grad.numpy() * (x > 0)
+    dzm = torch.from_numpy(st.view(np.int32)).cuda()
+    dx = pp.z(n, h, w, c)
+    pp.ck(pp.lib.unet_conv3x3_bwd_data_dzm(pp.h, dzm.data_ptr(), pp.d(k3).data_ptr(), pp.d(kh).data_ptr(), bits_in.data_ptr(), dx.data_ptr(), pp.wws(c, c), n, h, w, c, pp.s), "dgrad of the stream (pp)")
+    assert relerr(dx.cpu().numpy(), want) < TOL
+    b0 = PPOps(0)
+    dx0 = b0.z(n, h, w, c)
+    b0.ck(b0.lib.unet_conv3x3_bwd_data_dzm(b0.h, dzm.data_ptr(), b0.d(k3).data_ptr(), b0.d(kh).data_ptr(), bits_in.data_ptr(), dx0.data_ptr(), b0.wws(c, c), n, h, w, c, b0.s), "dgrad of the stream (h2)")
+    assert relerr(dx.cpu().numpy(), dx0.cpu().numpy()) < 2e-6
