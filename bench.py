@@ -33,6 +33,51 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense v_mfma_f32_32x32x16_bf16
 HBM_PEAK_GBS = 8000.0
 
 
+class _SmiSampler:
+    """Shader clock and socket power of THIS rank's GPU sampled from a side thread (amdsmi, ~0.4 ms per read) while a region runs: the pool's boxes differ by ~7 % in what
+    the same library measures, and the chip runs against its power cap -- the bench line says which kind of box / operating point it was.  Best effort: any
+    failure leaves the fields null."""
+    def __init__(self, index=0, period_s=0.01):
+        self.clk, self.pw, self._stop, self._thr, self.ok = [], [], False, None, False
+        self.period = period_s
+        try:
+            import amdsmi
+            self._smi = amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self._h = hs[index if index < len(hs) else 0]
+            self.ok = True
+        except Exception:
+            self.ok = False
+
+    def _run(self):
+        while not self._stop:
+            try:
+                m = self._smi.amdsmi_get_gpu_metrics_info(self._h)
+                cl = [c for c in m.get("current_gfxclks", []) if isinstance(c, (int, float)) and 0 < c < 10000]
+                if cl:
+                    self.clk.append(sum(cl) / len(cl))
+                pw = m.get("current_socket_power")
+                if isinstance(pw, (int, float)) and pw > 0:
+                    self.pw.append(float(pw))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def start(self):
+        if self.ok:
+            import threading
+            self._stop = False
+            self._thr = threading.Thread(target=self._run, daemon=True); self._thr.start()
+        return self
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop = True; self._thr.join(); self._thr = None
+        import statistics as st
+        return {"sclk_mhz": round(st.median(self.clk), 1) if self.clk else None, "power_w": round(st.median(self.pw), 1) if self.pw else None, "samples": len(self.clk)}
+
+
 def _physical_cores():
     """Physical cores this process may run on: distinct (package, core) pairs of the cpus in the affinity mask (hyper-thread siblings counted once)."""
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
@@ -125,7 +170,7 @@ def cpu_baseline(size, seconds_budget=28.0, arch="unet"):
                       f"cpu quota {quota if quota else 'none'}, torch's default was {default_threads} threads){rate}"}
 
 
-def live_traffic(timeout_s=150):
+def live_traffic(timeout_s=90):
     """HBM bytes of THIS build's step from the PMC counters, measured now: two counter-only rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- separate runs, no tracing, as
     MI355X_MICROARCH.md prescribes) over two training steps of tools/profile_ops.py in a child process; FETCH_SIZE (KB) x 2 (gfx950 tallies 128-B requests at 64 B) +
     WRITE_SIZE (KB), per launch of the conv3x3 forward / data-gradient family and summed over every kernel of a step.  None if rocprofv3 is not there or anything fails
@@ -146,7 +191,7 @@ def live_traffic(timeout_s=150):
                         a = agg[r["Kernel_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
             tot[c] = agg
         steps = sum(n for k, (v, n) in tot["FETCH_SIZE"].items() if "adam_kernel" in k)
-        dom = [k for k in tot["FETCH_SIZE"] if "conv_h2_kernel<0" in k]
+        dom = [k for k in tot["FETCH_SIZE"] if "conv_h2_kernel<0" in k or "conv_pp_kernel<" in k]          # (conv3x3 forward / data gradient: both schedules)
         launches = sum(tot["FETCH_SIZE"][k][1] for k in dom)
         if steps < 1 or launches < 1:
             return None
@@ -272,11 +317,13 @@ def main():
     for _ in range(2):
         eng.train_batch(x, y)                # first-touch: plans, workspace, weight images
     settle(args.settle)                      # (a cold chip runs these launches ~40 % slower than the timed region does: the per-op times would not be the step's)
+    smi_prof = _SmiSampler(0).start() if rank == 0 else None          # (the per-op leg serialises the ops: its own operating point)
     eng.set_profiling(True, B)
     for _ in range(PROF_STEPS):
         eng.train_batch(x, y)
     torch.cuda.synchronize()
     eng.set_profiling(False)
+    smi_prof = smi_prof.stop() if smi_prof is not None else None
     ops = eng.op_profile(B, 0) + eng.op_profile(B, 1)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S))); eng.reset_optimizer()
 
@@ -341,11 +388,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    smi = _SmiSampler(int(os.environ.get("LOCAL_RANK", "0")) if not os.environ.get("UNET_BENCH_ONE_DEVICE") else 0).start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = eng.train_batch(x, y)
     torch.cuda.synchronize()
-    dt_local = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others)
+    dt_local = time.perf_counter() - t0
+    smi_timed = smi.stop() if smi is not None else None          # this rank's own K steps (before it waits for the others)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -445,14 +494,16 @@ def main():
         # ... and measured NOW where the default workload runs on one GPU (the timed region is over: nothing here touches `value`)
         live = None
         if world == 1 and not args.no_traffic_leg and B == 16 and S == 512 and args.algo == 0 and args.arch == "unet" and args.dtype == "fp32" and not args.options and not args.deterministic:
+            t_leg = time.perf_counter()
             live = live_traffic()
+            t_leg = time.perf_counter() - t_leg
         if live is not None:
             traffic = round(live["per_launch"])
             traffic_unit = (f"HBM bytes per launch of this kernel family, MEASURED IN THIS RUN: two counter-only rocprofv3 passes (FETCH_SIZE x 2 [gfx950 tallies 128-B requests at 64 B] + WRITE_SIZE) "
                             f"over {live['steps']} training steps in a child process, {live['launches_per_step']:.1f} launches per step")
             sb = live["per_step_all_kernels"]
             step_traffic = {"hbm_bytes_per_step_all_kernels": round(sb), "vs_survey_54.3GB": round(sb / 54.300299148e9, 3), "vs_op_model": round(sb / max(sum(o[2] for o in ops), 1.0), 3),
-                            "source": "measured in this run (the same two counter passes, summed over every kernel of a step)"}
+                            "source": "measured in this run (the same two counter passes, summed over every kernel of a step)", "leg_seconds": round(t_leg, 1)}
         alg_bytes = sum(o[2] for o in dom) / max(launches, 1)
         H2R = 3.0 * FP32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
         n_h2 = sum(int(abs(exec_ratio(o[0]) - H2R) < 1e-9) for o in dom)
@@ -460,7 +511,7 @@ def main():
         if n_h2 == launches and launches:
             # every launch of the dominant family runs on the fp16 matrix pipe (three products per fp32 multiply): price the products it EXECUTES against that pipe's dense peak
             prod = 3.0 * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_h2_kernel (fp32 in / out, block-scaled two-term fp16 split, 3 v_mfma_f32_32x32x16_f16 products "
+            roof = {"bound": "mfma", "kernel": f"conv3x3 fwd + data-gradient launches: conv_h2_kernel / conv_pp_kernel (fp32 in / out, block-scaled two-term fp16 split, 3 v_mfma_f32_32x32x16_f16 products "
                                                f"per multiply, {n_h2} launches)",
                     "achieved": round(prod, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(prod / BF16_MFMA_PEAK_TFLOPS, 4),
                     "effective_tflops": round(effective, 2),
@@ -521,6 +572,14 @@ def main():
                        "deterministic": bool(args.deterministic), "bn_fold": 3 if args.fold16 else 2, "dropout": {"unet": 0.25, "unetpp": "0.2/0.4 (fused in the conv epilogue)", "classifier": 0.4}[args.arch], "last_loss_dice": [round(v, 5) for v in loss_dice]},
             "roofline": roof,
         }
+        # the operating point of the timed region (median of ~100 Hz amdsmi samples on rank 0's GPU: mean shader clock over the 8 XCDs, socket power) -- the pool's boxes
+        # differ by ~7 % on the same library; a slow BENCH line with a low clock is a slow box, not a regression
+        if smi_timed is not None:
+            out["sclk_mhz"] = smi_timed["sclk_mhz"]; out["power_w"] = smi_timed["power_w"]; out["smi_samples"] = smi_timed["samples"]
+        if smi_prof is not None and smi_prof["sclk_mhz"] and isinstance(roof, dict) and roof.get("bound") == "mfma":
+            # the dominant family's fraction against the matrix peak AT THE CLOCK THE PER-OP LEG RAN AT (peak scales with the shader clock: 2400 MHz nominal)
+            roof["sclk_mhz_per_op_leg"] = smi_prof["sclk_mhz"]; roof["power_w_per_op_leg"] = smi_prof["power_w"]
+            roof["frac_at_observed_clock"] = round(roof["achieved"] / (roof["peak"] * smi_prof["sclk_mhz"] / 2400.0), 4)
         if strict is not None:
             out["fp32_strict_img_s"] = strict
         if fit_stats is not None:

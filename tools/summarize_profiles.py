@@ -37,7 +37,7 @@ def collect(counter):
 
 
 def family(name):
-    if "conv_mfma_kernel<0" in name or "conv_bf16_kernel<0" in name or "conv_h2_kernel<0" in name:
+    if "conv_mfma_kernel<0" in name or "conv_bf16_kernel<0" in name or "conv_h2_kernel<0" in name or "conv_pp_kernel<" in name:
         return "dom"
     if "bn_apply_kernel" in name:
         return "bn_apply"          # fp32: 8 B per element, bf16 storage: 4 B
