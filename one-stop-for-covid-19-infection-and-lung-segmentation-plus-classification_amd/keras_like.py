@@ -130,7 +130,8 @@ class BatchSource:
                 a = np.asarray(a)
                 if a.dtype != np.float32:
                     a = a.astype(np.float32)                              # once, not per batch (the reference feeds float64, T1:520)
-            self.dev.append((d, a))
+            self.dev.append((d, a if d is None else True))          # (a device copy: the host array is not held -- the caller's reference is the only one)
+        self.all_resident = all(d is not None for d, a in self.dev if a is not None)
 
     def __call__(self, idx):
         out = []
@@ -282,24 +283,39 @@ class UNetModel:
 
     def _eval_source(self, x, y, device_resident):
         """The BatchSource of an evaluate() call, kept while the SAME arrays come back (the runners sweep thresholds / call evaluate repeatedly on one hold-out
-        set, T1:1196-1330): the set is uploaded to HBM once, not per call.  Keyed by object identity + a strided content sample, held through weak references where the type allows."""
+        set, T1:1196-1330): the set is uploaded to HBM once, not per call.  Reused only for NumPy arrays whose identity AND whole contents are unchanged (a 64-bit
+        hash of every byte -- ~10 GB/s, cheap next to the upload it saves; an in-place edit between two calls is always seen); anything else (torch tensors, lists)
+        gets a fresh source.  The cached set is released as soon as either array dies."""
         import weakref
 
-        def probe(a):                                          # (a strided sample of the contents: an array edited in place between two calls is uploaded again)
-            if not isinstance(a, np.ndarray) or a.size == 0:
-                return None
-            f = a.reshape(-1)
-            return hash(f[::max(1, f.size // 4096)].tobytes())
-        key = (id(x), id(y), device_resident, probe(x), probe(y))
+        def digest(a):
+            buf = memoryview(np.ascontiguousarray(a)).cast("B")
+            try:
+                import xxhash
+                return xxhash.xxh3_64_intdigest(buf)
+            except ImportError:
+                import zlib
+                return (zlib.crc32(buf) << 32) | zlib.adler32(buf)
+        if not (isinstance(x, np.ndarray) and isinstance(y, np.ndarray)) or x.size == 0:
+            return BatchSource(self.backend, x, y, device_resident=device_resident)
+        key = (id(x), id(y), device_resident, x.shape, y.shape, str(x.dtype), str(y.dtype), digest(x), digest(y))
         c = getattr(self, "_eval_cache", None)
         if c is not None and c[0] == key and all(r() is o for r, o in zip(c[1], (x, y))):
             return c[2]
+        self._eval_cache = None
+        selfref = weakref.ref(self)
+
+        def drop(_):                                           # (either array is gone: the device copy goes with it)
+            m = selfref()
+            if m is not None:
+                m._eval_cache = None
         try:
-            refs = (weakref.ref(x), weakref.ref(y))
+            refs = (weakref.ref(x, drop), weakref.ref(y, drop))
         except TypeError:
-            return BatchSource(self.backend, x, y, device_resident=device_resident)          # (lists etc.: no identity to hold on to)
+            return BatchSource(self.backend, x, y, device_resident=device_resident)
         src = BatchSource(self.backend, x, y, device_resident=device_resident)
-        self._eval_cache = (key, refs, src)
+        if src.all_resident:                                   # (a host-side source saves no upload and would keep the arrays alive)
+            self._eval_cache = (key, refs, src)
         return src
 
     def intermediate_output(self, layer_name, x, batch_size=32):

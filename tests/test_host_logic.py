@@ -108,6 +108,34 @@ def test_evaluate_is_mean_of_batch_metrics_and_weighted_loss():
     np.testing.assert_allclose(sm_scores(s[:, 0], s[:, 1], s[:, 2])["iou"], O.sm_scores(s[:, 0], s[:, 1], s[:, 2])["iou"])
 
 
+def test_evaluate_reuses_its_uploaded_set_only_while_every_byte_is_unchanged():
+    """evaluate() keeps the BatchSource of the arrays it was last given (the runners call it once per threshold sweep on one hold-out set, T1:1196-1330).  The reuse is
+    keyed by identity AND a hash of the whole buffers: ANY in-place edit between two calls -- one mask pixel, far from any sampling stride -- is scored, not the stale copy;
+    the cached set goes when the arrays die."""
+    import gc
+    x, y = synthetic_ct(5, 16, seed=4)
+    m = small_model()
+    be = m.backend
+    uploads = []
+    be.resident = lambda a, max_fraction=0.5: (uploads.append(id(a)), np.array(a, np.float32))[1]          # a backend with a resident set: the "device" copy
+    be.take = lambda d, idx: d[np.asarray(idx)]
+    a = m.evaluate(x, y, batch_size=2)
+    src = m._eval_cache[2]
+    assert m.evaluate(x, y, batch_size=2) == a and m._eval_cache[2] is src and len(uploads) == 2          # same bytes: the same source, nothing uploaded again
+    y[3, 7, 9, 0] = 1.0 - y[3, 7, 9, 0]                                              # one element edited in place
+    b = m.evaluate(x, y, batch_size=2)
+    assert m._eval_cache[2] is not src and b["loss"] != a["loss"] and len(uploads) == 4
+    ref = O.OracleTrainer(m.get_weights()).evaluate(x, y, batch_size=2)
+    assert b["loss"] == pytest.approx(ref["loss"], rel=1e-6)
+    m.evaluate(list(x), list(y), batch_size=2)                                       # (no array identity to hold on to: a fresh source)
+    del x, y; gc.collect()
+    assert m._eval_cache is None                                                     # the arrays died: the resident copy is released with them
+    del be.resident, be.take
+    x, y = synthetic_ct(5, 16, seed=4)
+    m.evaluate(x, y, batch_size=2)
+    assert m._eval_cache is None                                                     # a host-side source is not kept (it would save nothing and hold the arrays)
+
+
 def test_weight_file_roundtrip_and_keras_names(tmp_path):
     w = W.init_weights(3)
     f = str(tmp_path / "unet_0.8954_cosine_annealer.h5")          # reference file name T1:1079
