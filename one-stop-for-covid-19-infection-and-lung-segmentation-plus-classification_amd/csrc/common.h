@@ -111,15 +111,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 // window sums.  A float t is an integer multiple of 2^(e - 23); four 64-bit integer accumulators per value with least-significant bits 2^-80, 2^-48, 2^-16, 2^16
 // take it without rounding: q = t / lsb(w) of the window below its lowest bit (56 bits at most), its low 32 bits into window w, the rest into window w + 1.
 // Integer addition is associative, so the atomics may land in any order and on any number of slot copies: the folded value is the same bits on every run -- and
-// exact, where the fp64 atomics of the default mode round.  Domain: 2^-57 <= |t| < 2^39 (below: the bits under 2^-80 are dropped, the same ones on every run;
-// above, Inf, NaN: the value is poisoned and folds to NaN, as a floating-point sum would be).  A slot row holds UNET_BN_SLOT_DOUBLES / 4 such values.
+// exact, where the fp64 atomics of the default mode round.  Domain: 2^-57 <= |t| < 2^60 (below: the bits under 2^-80 are dropped, the same ones on every run; from 2^39 on a
+// float is a whole multiple of 2^16 and goes into the top window as ONE integer -- the sum of y^2 over a 256-pixel tile stays in the domain for |y| up to ~6e7; above 2^60,
+// Inf, NaN: the value is poisoned and folds to NaN, as a floating-point sum would be).  A slot row holds UNET_BN_SLOT_DOUBLES / 4 such values.
 constexpr int UNET_XW = 4;
 __device__ __forceinline__ void xsum_add(double* row, int idx, float t) {
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(row) + (size_t)UNET_XW * idx;
   const int eb = (int)((__float_as_uint(t) >> 23) & 0xFF);
   if (eb == 0) return;                                       // zero (a denormal: below every window)
   const int e = eb - 127;
-  if (e >= 39) { atomicMax(reinterpret_cast<long long*>(acc + 3), 1LL << 62); return; }          // out of the domain / Inf / NaN: poison
+  if (e >= 60) { atomicMax(reinterpret_cast<long long*>(acc + 3), 1LL << 62); return; }          // out of the domain / Inf / NaN: poison
+  if (e >= 39) {                                             // lsb(t) = 2^(e - 23) >= 2^16: t / 2^16 is an integer below 2^44 -- exact in the top window (1024 of them stay below 2^61)
+    atomicAdd(acc + 3, (unsigned long long)__double2ll_rd((double)t * (1.0 / 65536.0)));
+    return;
+  }
   const int w = min(max((e - 23 + 80) >> 5, 0), 2);
   const double sc = __longlong_as_double((long long)(1023 + 80 - 32 * w) << 52);          // 2^(80 - 32 w)
   const long long q = __double2ll_rd((double)t * sc);

@@ -935,7 +935,7 @@ def test_conv_epilogue_statistics_in_deterministic_mode_are_exact_window_sums(op
     ctx = _lib.Context.get(0, {"deterministic": 1}, private=True)
     try:
         rng = np.random.default_rng(ci + co + h)
-        for scale in (1.0, 3e-7, 2e3):
+        for scale in (1.0, 3e-7, 2e3, 1e6):          # (1e6: per-tile sums of y^2 around 2^48 -- beyond the 2^39 the windows take in two pieces, inside the top window's integer range)
             x = (rng.standard_normal((n, h, w, ci)) * scale).astype(np.float32); k = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
             b = (rng.standard_normal(co) * 0.3 * scale).astype(np.float32)
             xd, kd, bd = ops.d(x), ops.d(k), ops.d(b)
