@@ -16,7 +16,6 @@
 // Deterministic mode (UNET_OPT_DETERMINISTIC): UNET_BN_SLOTS_DET copies, every workgroup of a reduction kernel owns ONE copy (grids are capped at the copy
 // count), so each atomic lands on a zero it alone writes, and the fold kernel sums the copies in index order: bit-identical reruns.
 constexpr int UNET_BN_SLOTS = 64, UNET_BN_SLOTS_DET = 1024, UNET_BN_SLOT_DOUBLES = 2048;
-constexpr int UNET_CUS = 256;                              // compute units of an MI355X (8 XCDs x 32): what a launch must out-number to fill the chip
 constexpr int UNET_HEAD_SUMS = 100;          // doubles behind the loss sums: the per-channel sums of a fused head's weight gradient (k_head_fold)
 struct unet_ctx {
   int device = 0;

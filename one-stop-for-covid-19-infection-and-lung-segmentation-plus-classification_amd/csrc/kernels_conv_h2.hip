@@ -1014,13 +1014,13 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
   // programs do -- the slicing follows the grid, i.e. the batch, and a data-parallel rank's share of a batch must add up in the order of the whole batch), not for launches
   // that carry statistics / sign bits / a per-element mask / dropout, and not in deterministic mode
   {
-    const bool small8 = t8 * ((M + 31) / 32) < UNET_CUS;          // (the 4-row tiles below)
+    const bool small8 = t8 * ((M + 31) / 32) < ctx->num_cu;          // (the 4-row tiles below)
     const long long wgs = (small8 ? (long long)((wd + 31) / 32) * ((h + 3) / 4) * n : t8) * ((M + 31) / 32);
     const int nchunks = K / 16;
     const bool armed = ctx->k_slices_ok != 0; ctx->k_slices_ok = 0;          // (one-shot: unet_allow_k_slices)
     const bool plain = armed && (!mask || mask_mode == MASK_BIAS_TAB) && rate == 0.0f && (act == ACT_NONE || act == ACT_RELU) && !ctx->stats_req_c && !ctx->signs_req && !ctx->opt_deterministic;
     // (measured per launch at batch 1, 512 x 512: 16 chunks and more gain -- c5b 54 -> 27 us, c5a 29 -> 19, c6a 59 -> 43 with the finish pass --, 8 chunks do not)
-    if (plain && ctx->splitk_ws && nchunks >= 16 && 2 * wgs < 3 * UNET_CUS && (inb == 1 || small8 || t8 * ((M + 63) / 64) < 2 * UNET_CUS) && (M % 32) == 0) {
+    if (plain && ctx->splitk_ws && nchunks >= 16 && 2 * wgs < 3 * ctx->num_cu && (inb == 1 || small8 || t8 * ((M + 63) / 64) < 2 * ctx->num_cu) && (M % 32) == 0) {
       const int splits = std::min(4, nchunks / 4);
       const size_t slab = (size_t)n * h * wd * M;
       if (splits >= 2 && (size_t)splits * slab * sizeof(float) <= ctx->splitk_ws_bytes) {
@@ -1037,9 +1037,9 @@ int32_t k_conv3x3_h2_fwd(unet_ctx* ctx, const float* x, const void* wimg, const 
       }
     }
   }
-  if (t8 * ((M + 31) / 32) < UNET_CUS) return launch_h2<0, 1, 1, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), inb);
+  if (t8 * ((M + 31) / 32) < ctx->num_cu) return launch_h2<0, 1, 1, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), inb);
   if (inb == 1) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit);
-  if (t8 * ((M + 63) / 64) < 2 * UNET_CUS) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), 2);
+  if (t8 * ((M + 63) / 64) < 2 * ctx->num_cu) return launch_h2<0, 1, 2, 4>(ctx, x, K, img, bias, mask, mask_mode, y, ldy, n, h, wd, K, M, act, rate, seed, s, mask_climit, h2_head_args(), 2);
   // 16-row tiles (twice the MFMAs per staged chunk, 7 spilled registers at two workgroups per CU) measured 3-5 % faster on the 64 x 64 ... 128 x 128 layers when
   // they still fill the 512 resident slots, 2-4 % slower on the 256 / 512 pixel layers (fewer, longer workgroups) and much slower when the grid falls below one round
   const long long wgs16 = (long long)((wd + 31) / 32) * ((h + 15) / 16) * n * ((M + 63) / 64);
@@ -1100,7 +1100,7 @@ int32_t k_convT_h2_fwd(unet_ctx* ctx, const float* x, const float* w, const floa
   }
   const unet_bf16* img = static_cast<const unet_bf16*>(prepared);
   // (fewer than one four-block workgroup per CU -- the 32 x 32 and 64 x 64 inputs of batch-1 inference --: one block per workgroup on the same four-block image)
-  if ((long long)((wd + 31) / 32) * ((h + 7) / 8) * n * ((4 * cout + 127) / 128) < UNET_CUS && (cout % 32) == 0)
+  if ((long long)((wd + 31) / 32) * ((h + 7) / 8) * n * ((4 * cout + 127) / 128) < ctx->num_cu && (cout % 32) == 0)
     return launch_h2<1, 1, 2, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s, 1 << 30, h2_head_args(), 4);
   return launch_h2<1, 4, 2, 2>(ctx, x, cin, img, bias, nullptr, MASK_NONE, y, ldy, n, h, wd, cin, 4 * cout, ACT_NONE, 0.0f, 0, s);
 }
