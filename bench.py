@@ -216,6 +216,8 @@ def _tap_dims(eng, n, name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--comm-selftest", action="store_true", help="N > 1 first contact: build the data-parallel engine (process group, IPC mapping of the device-side small all-reduce and its "
+                    "self-test), run 1000 small all-reduces through either path and ten of the whole gradient buffer, print ONE JSON line with the per-call times of every rank, exit")
     ap.add_argument("--steps", type=int, default=40)     # the chip needs ~1 s of load to settle its clocks
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16 (configs[1]) or 8 (--config 2)")
@@ -296,6 +298,21 @@ def main():
     eng = HipUNet(S, S, 1, device=local, conv_algo=args.algo, process_group=pg, sync_bn=not args.no_sync_bn, dropout_rate=0.25, seed=rank,
                   arch=args.arch, dtype=args.dtype, force_dp=bool(os.environ.get("UNET_BENCH_FORCE_PG")), small_allreduce=args.small_allreduce, grad_buckets=not args.no_buckets, options=({"deterministic": 1} if args.deterministic else {}) | ({"bn_fold": 3} if args.fold16 else {}) | (json.loads(args.options) if args.options else {}) or None)
     eng.set_weights(W.init_weights(0, 1, args.arch, (S, S)))       # identical replicas
+    if args.comm_selftest:
+        # a diagnosis that needs no training step: if the first minute on an 8-GPU node fails, this line still says which exchange path works and how fast it is
+        mine = eng.comm_selftest()
+        every = [mine]
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+        if rank == 0:
+            keys = [k for k in ("device_us_per_call", "torch_distributed_us_per_call", "gradient_allreduce_ms") if k in mine]
+            print(json.dumps({"comm_selftest": {"world": world, "backend": backend, "rank0": mine, "max_over_ranks": {k: max(e[k] for e in every) for k in keys},
+                                                "all_exact": all(e.get("device_exact", True) and e.get("torch_distributed_exact", True) for e in every),
+                                                "statuses": [e.get("device_status", 0) for e in every]}}), flush=True)
+        if pg is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
 
     def settle(seconds):
         ts = time.perf_counter()

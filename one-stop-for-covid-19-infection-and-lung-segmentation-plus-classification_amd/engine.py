@@ -318,6 +318,49 @@ class HipUNet:
             return None
         return comm
 
+    def comm_selftest(self, calls=1000, doubles=1024):
+        """First-contact diagnosis of the exchange paths of a data-parallel engine, without a training step (bench.py --comm-selftest): `calls` back-to-back small all-reduces
+        of `doubles` float64 through the device-side communicator (csrc/comm.hip; exactness checked on every rank) and through torch.distributed, ten all-reduces of the whole
+        gradient buffer through the bucket communicator -- microseconds per call by events on the stream each runs on."""
+        import torch.distributed as dist
+        torch = _torch()
+        out = {"world": self.world, "rank": self.rank, "small_allreduce": "device (comm.hip)" if self._comm is not None else "torch.distributed", "fallback": self._comm_fallback}
+        if not self._dp:
+            return out
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        t = torch.ones(doubles, dtype=torch.float64, device=self.dev) * (self.rank + 1)
+        if self._comm is not None:
+            e0, e1 = ev(), ev()
+            ok = True
+            e0.record()
+            for _ in range(calls):
+                t.fill_(self.rank + 1.0)
+                ok = ok and self.lib.unet_comm_allreduce_f64(self._comm, t.data_ptr(), t.numel(), self._stream()) == 0
+            e1.record(); torch.cuda.synchronize(self.dev)
+            out["device_us_per_call"] = round(e0.elapsed_time(e1) * 1e3 / calls, 2)          # (incl. the fill kernel in front of each call)
+            out["device_exact"] = bool(ok and torch.all(t == self.world * (self.world + 1) / 2).item())
+            out["device_status"] = self.comm_status()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(calls):
+            t.fill_(self.rank + 1.0)
+            dist.all_reduce(t, group=self.pg)
+        e1.record(); torch.cuda.synchronize(self.dev)
+        out["torch_distributed_us_per_call"] = round(e0.elapsed_time(e1) * 1e3 / calls, 2)
+        out["torch_distributed_exact"] = bool(torch.all(t == self.world * (self.world + 1) / 2).item())
+        g = torch.ones_like(self.grads)
+        dist.all_reduce(g, group=self.pg_grad if getattr(self, "pg_grad", None) is not None else self.pg)
+        torch.cuda.synchronize(self.dev)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(g, group=self.pg_grad if getattr(self, "pg_grad", None) is not None else self.pg)
+        e1.record(); torch.cuda.synchronize(self.dev)
+        ms = e0.elapsed_time(e1) / 10
+        out["gradient_buffer_mb"] = round(g.numel() * 4 / 1e6, 2); out["gradient_allreduce_ms"] = round(ms, 3)
+        out["gradient_allreduce_busbw_gbs"] = round(2 * (self.world - 1) / self.world * g.numel() * 4 / (ms * 1e-3) / 1e9, 1) if self.world > 1 and ms > 0 else None
+        return out
+
     def comm_status(self):
         """0, or 1 + the rank whose contribution to a device-side all-reduce did not arrive in time (sticky; synchronises the stream)"""
         if self._comm is None:

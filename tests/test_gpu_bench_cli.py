@@ -62,6 +62,36 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     _check(r.stdout, 2)
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_four_and_eight_ranks_on_the_one_gpu(n):
+    """The world sizes the driver's scaling run uses beyond 2 (8 ranks): bucket order, `comm` keys, per-rank spread and the whole-job value at
+    4 and 8 ranks -- every rank on cuda:0, gloo for the buckets, the device-side small all-reduce through IPC between 4 / 8 processes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--size", "64", "--batch", "2", "--steps", "2", "--warmup", "1", "--settle", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _check(r.stdout, n)
+    assert len(d["comm"]["rank_ms_per_step"]["all"]) == n
+
+
+def test_bench_comm_selftest_prints_a_diagnosis_without_a_training_step():
+    """bench.py --comm-selftest (4 ranks on the one GPU): IPC mapping + self-test of the device-side small all-reduce, 1000 calls through either path (exact on every
+    rank), ten all-reduces of the 31 MB gradient buffer -- one JSON line, no step."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "64", "--batch", "2", "--comm-selftest"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.strip()][-1])["comm_selftest"]
+    assert d["world"] == 4 and d["all_exact"] is True and d["statuses"] == [0, 0, 0, 0]
+    r0 = d["rank0"]
+    assert r0["small_allreduce"] == "device (comm.hip)" and r0["device_us_per_call"] > 0 and r0["torch_distributed_us_per_call"] > 0
+    assert abs(r0["gradient_buffer_mb"] - 7762401 * 4 / 1e6) < 0.1 and r0["gradient_allreduce_ms"] > 0 and set(d["max_over_ranks"]) == {"device_us_per_call", "torch_distributed_us_per_call", "gradient_allreduce_ms"}
+
+
 def test_bench_bare_gpus_flag_relaunches_itself_under_torchrun():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--batch", "2", "--steps", "2", "--warmup", "1", "--settle", "0"]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
