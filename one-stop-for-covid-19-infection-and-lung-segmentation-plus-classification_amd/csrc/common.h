@@ -153,15 +153,6 @@ __device__ __forceinline__ double xsum_take(double* slots, int idx, int nslots) 
 // m the exact difference -- the same bits as scale, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_fma, v_cvt_pk (six VALU instructions per pair) in four.
 __device__ __forceinline__ void split2_scaled(float a, float b, float sc, unsigned& h, unsigned& m) {
   unsigned hh, mm;
-#ifdef H2_AB_OLD_SPLIT
-  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
-  typedef float f32x2_ __attribute__((ext_vector_type(2)));
-  a *= sc; b *= sc;
-  const f16x2_ h2 = __builtin_convertvector((f32x2_){a, b}, f16x2_);
-  const f16x2_ m2 = __builtin_convertvector((f32x2_){a - (float)h2[0], b - (float)h2[1]}, f16x2_);
-  h = __builtin_bit_cast(unsigned, h2); m = __builtin_bit_cast(unsigned, m2);
-  return;
-#endif
   asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(a), "v"(sc));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(b), "v"(sc));
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(mm) : "v"(a), "v"(sc), "v"(hh));
@@ -174,10 +165,6 @@ __device__ __forceinline__ void split2_scaled(float a, float b, float sc, unsign
 // ones (no NaN canonicalisation; a NaN input wins and poisons the block, which it does anyway).  Replaces six dependent ds_bpermute exchanges (~600 cycles of LDS
 // latency on the critical path of every staged chunk of the h2 kernels).
 __device__ __forceinline__ float wave_max_nonneg(float x) {
-#ifdef H2_AB_OLD_AMAX
-  for (int o = 32; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
-  return x;
-#endif
   unsigned v = __float_as_uint(x);
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));           // quad_perm [1,0,3,2]
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));           // quad_perm [2,3,0,1]
