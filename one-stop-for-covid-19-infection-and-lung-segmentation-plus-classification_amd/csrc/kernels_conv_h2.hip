@@ -28,6 +28,7 @@
 #ifndef H2_EXPERIMENT
 #define H2_EXPERIMENT 0
 #endif
+
 #if H2_EXPERIMENT == 5
 // measurement build only (tools/h2_timeline.py): wave 0 of every workgroup stamps s_memtime at its phase boundaries
 __device__ unsigned long long h2_trace[16384 * 16];

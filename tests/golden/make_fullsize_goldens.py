@@ -27,7 +27,37 @@ import fullsize_cases as FC                  # noqa: E402
 P_STRIDE = 1009
 
 
+def bf16_round(a):
+    """round-to-nearest-even to bf16, returned as float32 (what the engine's bf16-storage mode does to the conv / ConvT kernels when it lays them out)"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+def main_bf16store(names):
+    """--store bf16: the same step with bf16 STORAGE emulated in the float64 oracle (oracle.store_bf16 at every activation / activation gradient the engine materialises,
+    conv / ConvT kernels rounded to bf16 as the engine lays them out) -> fullsize_<case>_bf16store.npz.  U-Net cases only (the oracle emulates the storage points of that
+    graph).  tests/test_gpu_fullsize.py measures the engine's bf16-storage step against BOTH this fixture and the plain float64 one."""
+    for name in names:
+        arch, w, x, y = FC.build(name)
+        assert arch == "unet", "storage emulation exists for the U-Net graph"
+        for k in w:
+            if k.endswith("/kernel") and k not in ("c1a/kernel", "out/kernel"):
+                w[k] = bf16_round(w[k])
+        t0 = time.time()
+        r = O.loss_and_grads(w, x, y, dtype=torch.float64, ckpt=True, store=O.store_bf16)
+        arrs = dict(loss=np.float64(r["loss"]), metric=np.float64(r["dice"]), p_sample=r["p"].reshape(-1)[::P_STRIDE].astype(np.float32), p_mean=np.float64(r["p"].mean()))
+        for k, g in r["grads"].items():
+            arrs["gnorm/" + k] = np.float64(np.linalg.norm(g)); arrs["gsum/" + k] = np.float64(g.sum())
+        for k in FC.FULL_GRADS[arch]:
+            arrs["grad/" + k] = r["grads"][k].astype(np.float32)
+        out = os.path.join(HERE, f"fullsize_{name}_bf16store.npz")
+        np.savez_compressed(out, **arrs)
+        print(f"{name} (bf16 storage emulated): {time.time() - t0:.0f} s, loss {r['loss']:.9f}, dice {r['dice']:.9f}, wrote {out} ({os.path.getsize(out)} bytes)", flush=True)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--store" and sys.argv[2] == "bf16":
+        return main_bf16store(sys.argv[3:] or ["unet_512_bs16"])
     for name in (sys.argv[1:] or list(FC.CASES)):
         arch, w, x, y = FC.build(name)
         t0 = time.time()
