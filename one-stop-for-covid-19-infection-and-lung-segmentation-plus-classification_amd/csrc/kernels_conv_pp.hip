@@ -284,8 +284,53 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
   auto body = [&](const int it, unet_u32x4 (&preg)[PL]) __attribute__((always_inline)) {
     const int t_cur = t0 + it * slots, t_next = t_cur + slots, t_prev = t_cur - slots;
     const bool have_cur = it < iters && t_cur < t_end, have_next = it + 1 < iters && t_next < t_end, have_prev = it >= 1 && t_prev < t_end;
-    // ---- P1: the patch of this iteration's tile has landed: its max |x| (this wave's pieces) -> LDS; the previous tile's accumulators -> its output values (bias, activation,
-    // the one-bit mask of a data gradient), which the epilogue slices of P3 / P4 store
+    // the previous tile's accumulators -> its output values (bias / border-class table, activation, the one-bit mask of a data gradient), which the epilogue slices of P3 / P4 store
+    auto output_values = [&]() __attribute__((always_inline)) {
+    {
+        // lane (l31, hi) holds, for pixel column l31 of each of its RW rows, channels hi * 16 + 0..15 of the previous tile
+        const int py0 = p_prev.y0, px0 = p_prev.x0;
+        const float unscale = pp_pow2f(-e_prev) * w_unscale;
+        const int px_ = px0 + l31;
+        const bool border = tab_mask && (py0 == 0 || py0 + TH >= H || px0 == 0 || px0 + 32 >= W);
+        float bv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *reinterpret_cast<const float4*>(s_bias + hi * 16 + q * 4);
+          bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int py = py0 + wave * RW + r;
+          if (border && (py == 0 || py == H - 1 || px_ == 0 || px_ == W - 1)) {
+            // forward of a conv whose input BatchNorm is folded into it: border pixels see fewer taps of the shift -- the bias vector of their border class (`mask` = table [16][M])
+            const int cls = (((py == 0) | ((py == H - 1) << 1)) << 2) | ((px_ == 0) | ((px_ == W - 1) << 1));
+            const float* tb = s_tab + cls * M + hi * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 b4 = *reinterpret_cast<const float4*>(tb + q * 4);
+              vprev[r][q * 4] = fmaf(acc[r][q * 4], unscale, b4.x); vprev[r][q * 4 + 1] = fmaf(acc[r][q * 4 + 1], unscale, b4.y);
+              vprev[r][q * 4 + 2] = fmaf(acc[r][q * 4 + 2], unscale, b4.z); vprev[r][q * 4 + 3] = fmaf(acc[r][q * 4 + 3], unscale, b4.w);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vprev[r][i] = fmaf(acc[r][i], unscale, bv[i]);
+          }
+          if (act == ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vprev[r][i] = fmaxf(vprev[r][i], 0.f);
+          }
+          if (bits_mask) {
+            // this lane's bits of word k: ((pixel % 4) * 8 + hi * 4 + q) for channel quad q -- a sign-extended one-bit field IS the AND mask of the value
+            const unsigned sh = (l31 & 3) * 8 + hi * 4;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) vprev[r][qq * 4 + k] = __uint_as_float(__float_as_uint(vprev[r][qq * 4 + k]) & (unsigned)__builtin_amdgcn_sbfe((int)mpre[BITS ? r : 0][k], sh + qq, 1u));
+          }
+        }
+      }
+    };
+    // ---- P1: the patch of this iteration's tile has landed: its max |x| (this wave's pieces) -> LDS
     PP_STAMP(0);
     if (have_cur) {
       float mx = 0.f;
@@ -298,54 +343,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
       mx = wave_max_nonneg(mx);
       if (lane == 0) s_amax[wave] = mx;
     }
-    if (have_prev) {
-      // lane (l31, hi) holds, for pixel column l31 of each of its RW rows, channels hi * 16 + 0..15 of the previous tile
-      const int py0 = p_prev.y0, px0 = p_prev.x0;
-      const float unscale = pp_pow2f(-e_prev) * w_unscale;
-      const int px_ = px0 + l31;
-      const bool border = tab_mask && (py0 == 0 || py0 + TH >= H || px0 == 0 || px0 + 32 >= W);
-      float bv[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + hi * 16 + q * 4);
-        bv[q * 4] = b4.x; bv[q * 4 + 1] = b4.y; bv[q * 4 + 2] = b4.z; bv[q * 4 + 3] = b4.w;
-      }
-#pragma unroll
-      for (int r = 0; r < RW; ++r) {
-        const int py = py0 + wave * RW + r;
-        if (border && (py == 0 || py == H - 1 || px_ == 0 || px_ == W - 1)) {
-          // forward of a conv whose input BatchNorm is folded into it: border pixels see fewer taps of the shift -- the bias vector of their border class (`mask` = table [16][M])
-          const int cls = (((py == 0) | ((py == H - 1) << 1)) << 2) | ((px_ == 0) | ((px_ == W - 1) << 1));
-          const float* tb = s_tab + cls * M + hi * 16;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 b4 = *reinterpret_cast<const float4*>(tb + q * 4);
-            vprev[r][q * 4] = fmaf(acc[r][q * 4], unscale, b4.x); vprev[r][q * 4 + 1] = fmaf(acc[r][q * 4 + 1], unscale, b4.y);
-            vprev[r][q * 4 + 2] = fmaf(acc[r][q * 4 + 2], unscale, b4.z); vprev[r][q * 4 + 3] = fmaf(acc[r][q * 4 + 3], unscale, b4.w);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) vprev[r][i] = fmaf(acc[r][i], unscale, bv[i]);
-        }
-        if (act == ACT_RELU) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) vprev[r][i] = fmaxf(vprev[r][i], 0.f);
-        }
-        if (bits_mask) {
-          // this lane's bits of word k: ((pixel % 4) * 8 + hi * 4 + q) for channel quad q -- a sign-extended one-bit field IS the AND mask of the value
-          const unsigned sh = (l31 & 3) * 8 + hi * 4;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) vprev[r][qq * 4 + k] = __uint_as_float(__float_as_uint(vprev[r][qq * 4 + k]) & (unsigned)__builtin_amdgcn_sbfe((int)mpre[BITS ? r : 0][k], sh + qq, 1u));
-        }
-      }
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP_STAMP(1);
     __builtin_amdgcn_s_barrier();
     PP_STAMP(2);
-    // ---- P2: scale + split the patch into this half's planes; request the next tile's patch
+    // ---- P2: scale + split the patch into this half's planes; request the next tile's patch; the previous tile's output values (a data gradient's in front: its mask words
+    // are overwritten by this tile's request; otherwise behind the requests, where the staging half has slack and the other half's P3 does not wait for it)
+    if (BITS && have_prev) output_values();
     if (have_cur) {
       const float4 m4 = *reinterpret_cast<const float4*>(s_amax);
       const float mx = fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w));
@@ -387,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const float* __restrict
     if (have_next && (PP_EXP & 2) == 0) issue_loads(p_next, preg);
     __builtin_amdgcn_sched_barrier(0);
     PP_STAMP(4);
+    if (!BITS && have_prev) output_values();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP_STAMP(5);
     __builtin_amdgcn_s_barrier();

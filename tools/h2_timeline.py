@@ -62,12 +62,9 @@ def main():
     hw = t[:, 9]
     cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
     key = xcc * 1000 + se * 100 + sh * 20 + cu
-    spans = []
+    # (no per-XCC kernel span: s_memtime is a per-XCC counter -- stamps of different XCDs are not on one time base, and round 5's line compared unrelated numbers;
+    #  the per-CU figures below only combine stamps of one CU)
     conc = []
-    for kx in np.unique(xcc):
-        m = xcc == kx
-        spans.append(t[m, 8].max() - t[m, 0].min())
-    print(f"  kernel span per XCC (cycles of the 100 MHz-independent shader clock): {[int(v) for v in spans]}")
     for kk in np.unique(key)[:400]:
         m = key == kk
         a, bb = t[m, 0], t[m, 8]

@@ -41,8 +41,7 @@ def main():
         for i, nm in enumerate(names):
             d = (tt[:, :, i + 1] - tt[:, :, i]).reshape(-1)
             print(f"   {nm:36s} median {np.median(d):7.0f}  p10 {np.percentile(d, 10):7.0f}  p90 {np.percentile(d, 90):7.0f}")
-    span = t[:, :, iters, 10].max() - t[:, :, 0, 0].min()
-    print(f"kernel span (first stamp to last) {span} cycles; per block lifetimes median {np.median(t[:, 0, iters, 10] - t[:, 0, 0, 0]):.0f}")
+    print(f"per block lifetimes median {np.median(t[:, 0, iters, 10] - t[:, 0, 0, 0]):.0f} cycles (stamps of different XCDs are not on one time base: no chip-wide span)")
 
 
 if __name__ == "__main__":

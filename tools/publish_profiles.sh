@@ -12,4 +12,5 @@ cp $O/pmc_matrix_summary.json profiles/${R}_pmc_matrix_summary.json
 for c in FETCH_SIZE WRITE_SIZE; do f=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f profiles/${R}_pmc_${c}_counter_collection.csv; done
 grep -v amdgpu.ids $O/predict_batch1.txt > profiles/${R}_predict_batch1.txt
 f=$(find $O/predict_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/${R}_predict_kernel_stats.csv
+for f in ab_conv_pp_ops ab_conv_pp_model pp_timeline; do [ -f $O/$f.txt ] && grep -v amdgpu.ids $O/$f.txt > profiles/${R}_$f.txt; done
 ls -la profiles/${R}_*
