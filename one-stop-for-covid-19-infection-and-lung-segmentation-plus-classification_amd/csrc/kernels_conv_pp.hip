@@ -1,19 +1,19 @@
-// fp32 3x3 convolution (forward + data gradient) of the SHALLOW levels (K <= 64 contraction channels, 32 output channels per workgroup, T1:859-860, 910-911):
-// the arithmetic of kernels_conv_h2.hip -- three fp16 MFMA products of a block-scaled two-term split -- in a different schedule.
+// fp32 3x3 convolution (forward + data gradient) of the 32 -> 32-channel launches of the 512 x 512 level (T1:860, 911: c1b forward, the data gradients of c1b and c9b):
+// the arithmetic of kernels_conv_h2.hip -- three fp16 MFMA products of a block-scaled two-term split -- in a different schedule (DESIGN.md section 4j).
 //
-// conv_h2_kernel leaves the overlap of one tile's loads / split / stores with another tile's MFMAs to the CU's two to four independent workgroups, which drift into
-// the same phase (profiles/r05_h2_timeline.txt: a tile waits 9-23 % of its life for its first loads and 23-44 % in its epilogue while the matrix pipe is 34-44 % busy),
-// re-fetches the layer's weight slab from the L2 per chunk and tile, and pays two barriers and ~400 instructions of index arithmetic per 54 MFMAs.  Here:
+// conv_h2_kernel leaves the overlap of one tile's loads / split / stores with another tile's MFMAs to the CU's two to four independent workgroups, re-fetches the layer's
+// weight slab from the L2 per chunk and tile, and pays two barriers and ~400 instructions of index arithmetic per 54 MFMAs.  Here:
 //   * ONE persistent 512-thread workgroup per CU walks the tiles of its XCD; its two 4-wave halves work on tiles of their own, two barrier intervals apart
-//     (half 1 enters the loop two barriers late): while one half issues a tile's MFMAs the other scales / splits its next tile into LDS, requests the tile after
-//     that and stores its previous tile -- every SIMD holds one wave of each half, so a matrix stream always runs beside a memory stream;
-//   * the layer's whole split weight image (36 B per weight: 36 / 72 KB) is copied into LDS once per workgroup;
-//   * a tile's whole contraction (K = 32: both 16-channel chunks) is staged at once: one exponent per tile from the max |x| of its patch, no accumulator rescaling;
+//     (half 1 enters the loop two barriers late): every SIMD holds one wave of each half, so a matrix stream always runs beside a staging stream;
+//   * the layer's whole split weight image (36 B per weight: 36 KB) is copied into LDS once per workgroup;
+//   * a tile's whole contraction (both 16-channel chunks) is staged at once: one exponent per tile from the max |x| of its patch, no accumulator rescaling;
 //   * a tile's patch travels global -> registers one full MFMA phase ahead of its use; per-thread offsets are computed once per kernel, a tile is a scalar offset;
+//   * the MFMA phase requests the operands of step s + 1 before the MFMAs of step s, and carries the previous tile's epilogue in 18 slices (one store every other step);
 //   * BatchNorm statistics are kept per lane across all tiles of the workgroup and folded once at the end of the kernel.
-// Barrier intervals of an iteration, per half:   P1 max |x| of the landed patch -> LDS     P2 split -> planes; request the next patch; epilogue of the previous tile
-//                                                 P3 first 18 MFMAs                          P4 the other MFMAs
+// Barrier intervals of an iteration, per half:   P1 max |x| of the landed patch -> LDS     P2 split -> planes; request the next patch; the previous tile's output values
+//                                                 P3 MFMA steps 0 .. 2 (+ slices)            P4 MFMA steps 3 .. 17 (+ slices)
 // (half 0 in P1 / P2 while half 1 is in P3 / P4 and vice versa; the P1 / P3 interval exists only to make the four partial maxima of a half visible to its waves).
+// What bounds it (measured: tools/pp_timeline.py, profiles/r06_pp_timeline.txt): the CU's vector-memory pipeline takes ~12 B per cycle -- 151 KB per tile pair in 12.3 k cycles.
 #include <type_traits>
 
 #include "common.h"
